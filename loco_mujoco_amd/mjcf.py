@@ -1,0 +1,564 @@
+"""
+MJCF reader + "mini-compiler" (host side, cold path).
+
+The reference builds its models with two third-party packages that are not part of this
+framework: ``dm_control.mjcf`` (XML object model used for model surgery, e.g.
+``loco_mujoco/environments/quadrupeds/unitreeA1.py:756-776``) and ``mujoco.MjModel.from_xml_string``
+(the MuJoCo model compiler, invoked by mushroom-rl from ``loco_mujoco/environments/base.py:109-111``).
+This module replaces both for the subset of MJCF the BASELINE models use:
+
+* default classes (nested ``<default class=...>``, ``childclass``), ``autolimits``,
+* bodies with hinge/slide joints, explicit ``<inertial>`` (``diaginertia``+``quat`` or ``fullinertia``),
+* primitive geoms (plane, sphere, capsule, cylinder, box; ``fromto``), sites,
+* ``<motor>`` actuators with joint transmission,
+* ``<option>`` timestep / cone / impratio / integrator / iterations / tolerance.
+
+The result is a :class:`CompiledModel`: flat numpy arrays (body tree, joints/dofs, geoms, actuators,
+options) plus the ``qpos0``-derived constants the constraint regulariser needs
+(``dof_invweight0``, ``body_invweight0``).
+
+Everything here is fp64 numpy; nothing here is on the hot path.
+"""
+
+import copy
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# geom types (numbering is private to this framework; shared with csrc/ and oracle/ via the blob)
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 4, 5
+GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE,
+              "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}
+JNT_SLIDE, JNT_HINGE = 0, 1
+CONE_PYRAMIDAL, CONE_ELLIPTIC = 0, 1
+INT_EULER, INT_RK4 = 0, 1
+
+_DEFAULT_SOLREF = (0.02, 1.0)
+_DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
+
+
+# --------------------------------------------------------------------------------------
+# small math helpers
+# --------------------------------------------------------------------------------------
+
+def _floats(s, n=None):
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None:
+        assert len(v) == n, (s, n)
+    return v
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw])
+
+
+def quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def axis_angle_quat(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    n = np.linalg.norm(axis)
+    if n < 1e-300:
+        return np.array([1.0, 0, 0, 0])
+    s = np.sin(0.5 * angle) / n
+    return np.array([np.cos(0.5 * angle), axis[0] * s, axis[1] * s, axis[2] * s])
+
+
+def z_to_quat(vec):
+    """Quaternion that rotates the z-axis onto ``vec`` (shortest arc)."""
+    vec = np.asarray(vec, dtype=np.float64)
+    vec = vec / np.linalg.norm(vec)
+    z = np.array([0.0, 0.0, 1.0])
+    axis = np.cross(z, vec)
+    s = np.linalg.norm(axis)
+    c = vec[2]
+    if s < 1e-10:
+        if c > 0:
+            return np.array([1.0, 0, 0, 0])
+        return np.array([0.0, 1.0, 0, 0])
+    ang = np.arctan2(s, c)
+    return axis_angle_quat(axis / s, ang)
+
+
+# --------------------------------------------------------------------------------------
+# XML object model (what the reference gets from dm_control.mjcf)
+# --------------------------------------------------------------------------------------
+
+class MjcfHandle:
+    """
+    A thin mutable handle on an MJCF document, with the few operations the reference's environment
+    classes perform through ``dm_control.mjcf`` (``find``, ``add``, remove): see
+    ``unitreeA1.py:768-774``, ``base_humanoid.py:86-127``, ``atlas.py:338-364``.
+    """
+
+    def __init__(self, root):
+        self.root = root
+
+    @classmethod
+    def from_path(cls, path):
+        return cls(ET.parse(str(path)).getroot())
+
+    @classmethod
+    def from_string(cls, s):
+        return cls(ET.fromstring(s))
+
+    def copy(self):
+        return MjcfHandle(copy.deepcopy(self.root))
+
+    def find(self, tag, name):
+        for el in self.root.iter(tag):
+            if el.get("name") == name:
+                return el
+        return None
+
+    def find_all(self, tag):
+        return list(self.root.iter(tag))
+
+    def add(self, parent, tag, **attrs):
+        el = ET.SubElement(parent, tag)
+        for k, v in attrs.items():
+            el.set(k, v if isinstance(v, str) else " ".join(repr(float(x)) for x in np.atleast_1d(v)))
+        return el
+
+    def remove(self, el):
+        for parent in self.root.iter():
+            if el in list(parent):
+                parent.remove(el)
+                return True
+        return False
+
+    def to_xml_string(self):
+        return ET.tostring(self.root, encoding="unicode")
+
+
+# --------------------------------------------------------------------------------------
+# compiled model
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class CompiledModel:
+    # options
+    timestep: float = 0.002
+    gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+    cone: int = CONE_PYRAMIDAL
+    impratio: float = 1.0
+    integrator: int = INT_EULER
+    iterations: int = 100
+    tolerance: float = 1e-8
+    # sizes
+    nbody: int = 0
+    njnt: int = 0
+    nv: int = 0
+    ngeom: int = 0
+    nu: int = 0
+    nsite: int = 0
+    # names
+    body_names: list = field(default_factory=list)
+    jnt_names: list = field(default_factory=list)
+    geom_names: list = field(default_factory=list)
+    act_names: list = field(default_factory=list)
+    site_names: list = field(default_factory=list)
+    # arrays are attached dynamically (see compile_mjcf)
+
+    def jnt_id(self, name):
+        return self.jnt_names.index(name)
+
+    def act_id(self, name):
+        return self.act_names.index(name)
+
+    def body_id(self, name):
+        return self.body_names.index(name)
+
+
+class _Defaults:
+    """Resolved ``<default>`` tree: class name -> {tag -> attribute dict}."""
+
+    def __init__(self, root):
+        self.classes = {"main": {}}
+        self.parent = {"main": None}
+        for d in root.findall("default"):
+            self._walk(d, "main", top=True)
+
+    def _walk(self, el, parent_cls, top=False):
+        if top:
+            cls = el.get("class", "main")
+        else:
+            cls = el.get("class")
+            assert cls is not None, "nested <default> needs a class"
+        if cls not in self.classes:
+            self.classes[cls] = copy.deepcopy(self.classes[parent_cls]) if cls != parent_cls else {}
+            self.parent[cls] = parent_cls if cls != parent_cls else None
+        table = self.classes[cls]
+        for child in el:
+            if child.tag == "default":
+                continue
+            table.setdefault(child.tag, {}).update(child.attrib)
+        for child in el.findall("default"):
+            self._walk(child, cls)
+
+    def resolve(self, tag, el, childclass):
+        cls = el.get("class", childclass if childclass is not None else "main")
+        attrs = dict(self.classes.get(cls, {}).get(tag, {}))
+        attrs.update({k: v for k, v in el.attrib.items() if k != "class"})
+        return attrs
+
+
+def _inertia_from_inertial(attrs):
+    """Returns (mass, ipos, 3x3 inertia tensor expressed in the BODY frame, about the COM)."""
+    mass = float(attrs["mass"])
+    ipos = _floats(attrs.get("pos", "0 0 0"), 3)
+    if "fullinertia" in attrs:
+        f = _floats(attrs["fullinertia"], 6)
+        inertia = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+    else:
+        d = _floats(attrs["diaginertia"], 3)
+        q = _floats(attrs.get("quat", "1 0 0 0"), 4)
+        q = q / np.linalg.norm(q)
+        r = quat_to_mat(q)
+        inertia = r @ np.diag(d) @ r.T
+    return mass, ipos, inertia
+
+
+def compile_mjcf(handle, timestep=None):
+    """
+    Compile an :class:`MjcfHandle` into a :class:`CompiledModel`.
+
+    ``timestep`` overrides ``<option timestep>`` like the reference does (``base.py:33,109-111``).
+    """
+    root = handle.root
+    comp = root.find("compiler")
+    comp = comp.attrib if comp is not None else {}
+    assert comp.get("angle", "degree") == "radian", "only angle=radian models are supported"
+    assert comp.get("coordinate", "local") == "local"
+    autolimits = comp.get("autolimits", "false") == "true"
+
+    m = CompiledModel()
+    opt = root.find("option")
+    opt = opt.attrib if opt is not None else {}
+    m.timestep = float(opt.get("timestep", 0.002)) if timestep is None else float(timestep)
+    m.cone = CONE_ELLIPTIC if opt.get("cone", "pyramidal") == "elliptic" else CONE_PYRAMIDAL
+    m.impratio = float(opt.get("impratio", 1.0))
+    m.integrator = {"Euler": INT_EULER, "RK4": INT_RK4}[opt.get("integrator", "Euler")]
+    m.iterations = int(opt.get("iterations", 100))
+    m.tolerance = float(opt.get("tolerance", 1e-8))
+    assert opt.get("solver", "Newton") == "Newton"
+    if "gravity" in opt:
+        m.gravity = _floats(opt["gravity"], 3)
+
+    defaults = _Defaults(root)
+
+    bodies = [dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mass=0.0,
+                   ipos=np.zeros(3), inertia=np.zeros((3, 3)), jntadr=-1, jntnum=0)]
+    joints, geoms, sites = [], [], []
+
+    def walk_body(el, parent_id, childclass):
+        if el.tag == "worldbody":
+            bid = 0
+        else:
+            cc = el.get("childclass", childclass)
+            childclass = cc
+            q = _floats(el.get("quat", "1 0 0 0"), 4)
+            b = dict(name=el.get("name", "body%d" % len(bodies)), parent=parent_id,
+                     pos=_floats(el.get("pos", "0 0 0"), 3), quat=q / np.linalg.norm(q),
+                     mass=0.0, ipos=np.zeros(3), inertia=np.zeros((3, 3)), jntadr=-1, jntnum=0)
+            bodies.append(b)
+            bid = len(bodies) - 1
+            inertial = el.find("inertial")
+            if inertial is not None:
+                b["mass"], b["ipos"], b["inertia"] = _inertia_from_inertial(inertial.attrib)
+            for j in el.findall("joint"):
+                a = defaults.resolve("joint", j, childclass)
+                jt = a.get("type", "hinge")
+                assert jt in ("hinge", "slide"), "joint type %s not supported" % jt
+                axis = _floats(a.get("axis", "0 0 1"), 3)
+                axis = axis / np.linalg.norm(axis)
+                has_range = "range" in a
+                rng = _floats(a.get("range", "0 0"), 2)
+                if "limited" in a and a["limited"] in ("true", "false"):
+                    limited = a["limited"] == "true"
+                else:
+                    limited = has_range and autolimits
+                assert float(a.get("ref", 0)) == 0.0 and float(a.get("springref", 0)) == 0.0
+                jd = dict(name=a.get("name", "jnt%d" % len(joints)), type=JNT_HINGE if jt == "hinge" else JNT_SLIDE,
+                          body=bid, pos=_floats(a.get("pos", "0 0 0"), 3), axis=axis,
+                          limited=limited, range=rng, stiffness=float(a.get("stiffness", 0)),
+                          damping=float(a.get("damping", 0)), armature=float(a.get("armature", 0)),
+                          frictionloss=float(a.get("frictionloss", 0)), margin=float(a.get("margin", 0)),
+                          solref_limit=_floats(a.get("solreflimit", "%g %g" % _DEFAULT_SOLREF), 2),
+                          solimp_limit=_pad_solimp(a.get("solimplimit")),
+                          solref_friction=_floats(a.get("solreffriction", "%g %g" % _DEFAULT_SOLREF), 2),
+                          solimp_friction=_pad_solimp(a.get("solimpfriction")))
+                if b["jntnum"] == 0:
+                    b["jntadr"] = len(joints)
+                b["jntnum"] += 1
+                joints.append(jd)
+        for g in el.findall("geom"):
+            a = defaults.resolve("geom", g, childclass)
+            gt = GEOM_TYPES[a.get("type", "sphere")]
+            size = np.zeros(3)
+            sz = _floats(a["size"]) if "size" in a else np.zeros(0)
+            size[:len(sz)] = sz
+            pos = _floats(a.get("pos", "0 0 0"), 3)
+            q = _floats(a.get("quat", "1 0 0 0"), 4)
+            q = q / np.linalg.norm(q)
+            if "fromto" in a and gt in (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX):
+                ft = _floats(a["fromto"], 6)
+                vec = ft[0:3] - ft[3:6]
+                half = 0.5 * np.linalg.norm(vec)
+                pos = 0.5 * (ft[0:3] + ft[3:6])
+                q = z_to_quat(vec)
+                if gt == GEOM_BOX:
+                    size = np.array([size[0], size[0], half])
+                else:
+                    size = np.array([size[0], half, 0.0])
+            fr = np.array([1.0, 0.005, 0.0001])
+            if "friction" in a:
+                f = _floats(a["friction"])
+                fr[:len(f)] = f
+            geoms.append(dict(name=a.get("name", ""), type=gt, body=bid, pos=pos, quat=q, size=size,
+                              contype=int(a.get("contype", 1)), conaffinity=int(a.get("conaffinity", 1)),
+                              condim=int(a.get("condim", 3)), priority=int(a.get("priority", 0)),
+                              friction=fr, solmix=float(a.get("solmix", 1.0)),
+                              solref=_floats(a.get("solref", "%g %g" % _DEFAULT_SOLREF), 2),
+                              solimp=_pad_solimp(a.get("solimp")),
+                              margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)),
+                              mesh=a.get("mesh")))
+        for s in el.findall("site"):
+            a = defaults.resolve("site", s, childclass)
+            pos = _floats(a.get("pos", "0 0 0"), 3)
+            q = _floats(a.get("quat", "1 0 0 0"), 4)
+            if "fromto" in a:
+                ft = _floats(a["fromto"], 6)
+                pos = 0.5 * (ft[0:3] + ft[3:6])
+                q = z_to_quat(ft[0:3] - ft[3:6])
+            sites.append(dict(name=a.get("name", ""), body=bid, pos=pos, quat=q / np.linalg.norm(q)))
+        for child in el.findall("body"):
+            walk_body(child, bid, childclass)
+
+    walk_body(root.find("worldbody"), 0, None)
+
+    # ---------------- bodies
+    m.nbody = len(bodies)
+    m.body_names = [b["name"] for b in bodies]
+    m.body_parent = np.array([b["parent"] for b in bodies], dtype=np.int32)
+    m.body_pos = np.array([b["pos"] for b in bodies])
+    m.body_quat = np.array([b["quat"] for b in bodies])
+    m.body_mass = np.array([b["mass"] for b in bodies])
+    m.body_ipos = np.array([b["ipos"] for b in bodies])
+    m.body_inertia = np.array([b["inertia"] for b in bodies])          # (nbody,3,3) body frame, about COM
+    m.body_jntadr = np.array([b["jntadr"] for b in bodies], dtype=np.int32)
+    m.body_jntnum = np.array([b["jntnum"] for b in bodies], dtype=np.int32)
+    # weld id: the nearest ancestor-or-self that has joints (0 = welded to the world)
+    weld = np.zeros(m.nbody, dtype=np.int32)
+    for i in range(1, m.nbody):
+        weld[i] = i if bodies[i]["jntnum"] > 0 else weld[bodies[i]["parent"]]
+    m.body_weldid = weld
+
+    # ---------------- joints / dofs (all joints are 1-dof, so dof id == joint id)
+    m.njnt = m.nv = len(joints)
+    m.jnt_names = [j["name"] for j in joints]
+    m.jnt_type = np.array([j["type"] for j in joints], dtype=np.int32)
+    m.jnt_body = np.array([j["body"] for j in joints], dtype=np.int32)
+    m.jnt_pos = np.array([j["pos"] for j in joints]).reshape(-1, 3)
+    m.jnt_axis = np.array([j["axis"] for j in joints]).reshape(-1, 3)
+    m.jnt_limited = np.array([j["limited"] for j in joints], dtype=np.int32)
+    m.jnt_range = np.array([j["range"] for j in joints]).reshape(-1, 2)
+    m.jnt_stiffness = np.array([j["stiffness"] for j in joints])
+    m.jnt_margin = np.array([j["margin"] for j in joints])
+    m.jnt_solref = np.array([j["solref_limit"] for j in joints]).reshape(-1, 2)
+    m.jnt_solimp = np.array([j["solimp_limit"] for j in joints]).reshape(-1, 5)
+    m.dof_damping = np.array([j["damping"] for j in joints])
+    m.dof_armature = np.array([j["armature"] for j in joints])
+    m.dof_frictionloss = np.array([j["frictionloss"] for j in joints])
+    m.dof_solref = np.array([j["solref_friction"] for j in joints]).reshape(-1, 2)
+    m.dof_solimp = np.array([j["solimp_friction"] for j in joints]).reshape(-1, 5)
+    # dof parent: previous dof in the same body, else last dof of the nearest jointed ancestor
+    dof_parent = -np.ones(m.nv, dtype=np.int32)
+    body_lastdof = -np.ones(m.nbody, dtype=np.int32)
+    for i in range(1, m.nbody):
+        last = body_lastdof[bodies[i]["parent"]]
+        for k in range(bodies[i]["jntnum"]):
+            d = bodies[i]["jntadr"] + k
+            dof_parent[d] = last
+            last = d
+        body_lastdof[i] = last
+    m.dof_parent = dof_parent
+    m.qpos0 = np.zeros(m.nv)
+
+    # ---------------- geoms (drop purely visual ones: contype == conaffinity == 0)
+    geoms = [g for g in geoms if (g["contype"] != 0 or g["conaffinity"] != 0)]
+    for g in geoms:
+        assert g["type"] != GEOM_MESH, "collidable mesh geoms need the convex-hull path (not built yet)"
+    m.ngeom = len(geoms)
+    m.geom_names = [g["name"] for g in geoms]
+    m.geom_type = np.array([g["type"] for g in geoms], dtype=np.int32)
+    m.geom_body = np.array([g["body"] for g in geoms], dtype=np.int32)
+    m.geom_pos = np.array([g["pos"] for g in geoms]).reshape(-1, 3)
+    m.geom_quat = np.array([g["quat"] for g in geoms]).reshape(-1, 4)
+    m.geom_size = np.array([g["size"] for g in geoms]).reshape(-1, 3)
+    m.geom_contype = np.array([g["contype"] for g in geoms], dtype=np.int32)
+    m.geom_conaffinity = np.array([g["conaffinity"] for g in geoms], dtype=np.int32)
+    m.geom_condim = np.array([g["condim"] for g in geoms], dtype=np.int32)
+    m.geom_priority = np.array([g["priority"] for g in geoms], dtype=np.int32)
+    m.geom_friction = np.array([g["friction"] for g in geoms]).reshape(-1, 3)
+    m.geom_solmix = np.array([g["solmix"] for g in geoms])
+    m.geom_solref = np.array([g["solref"] for g in geoms]).reshape(-1, 2)
+    m.geom_solimp = np.array([g["solimp"] for g in geoms]).reshape(-1, 5)
+    m.geom_margin = np.array([g["margin"] for g in geoms])
+    m.geom_gap = np.array([g["gap"] for g in geoms])
+
+    # ---------------- sites
+    m.nsite = len(sites)
+    m.site_names = [s["name"] for s in sites]
+    m.site_body = np.array([s["body"] for s in sites], dtype=np.int32)
+    m.site_pos = np.array([s["pos"] for s in sites]).reshape(-1, 3)
+    m.site_quat = np.array([s["quat"] for s in sites]).reshape(-1, 4)
+
+    # ---------------- actuators (motors on joints)
+    acts = []
+    act_root = root.find("actuator")
+    if act_root is not None:
+        for a_el in act_root:
+            assert a_el.tag == "motor", "actuator type %s not supported" % a_el.tag
+            a = defaults.resolve("motor", a_el, None)
+            gear = _floats(a.get("gear", "1"))[0]
+            cr = _floats(a.get("ctrlrange", "0 0"), 2)
+            if "ctrllimited" in a and a["ctrllimited"] in ("true", "false"):
+                cl = a["ctrllimited"] == "true"
+            else:
+                cl = ("ctrlrange" in a) and autolimits
+            acts.append(dict(name=a.get("name", ""), dof=m.jnt_names.index(a["joint"]), gear=gear,
+                             ctrlrange=cr, ctrllimited=cl))
+    m.nu = len(acts)
+    m.act_names = [a["name"] for a in acts]
+    m.act_dof = np.array([a["dof"] for a in acts], dtype=np.int32)
+    m.act_gear = np.array([a["gear"] for a in acts])
+    m.act_ctrlrange = np.array([a["ctrlrange"] for a in acts]).reshape(-1, 2)
+    m.act_ctrllimited = np.array([a["ctrllimited"] for a in acts], dtype=np.int32)
+
+    _set_const(m)
+    return m
+
+
+def _pad_solimp(s):
+    v = np.array(_DEFAULT_SOLIMP)
+    if s is not None:
+        f = _floats(s)
+        v[:len(f)] = f
+    return v
+
+
+# --------------------------------------------------------------------------------------
+# qpos0-derived constants
+# --------------------------------------------------------------------------------------
+
+def forward_kinematics(m, qpos):
+    """
+    Plain numpy forward kinematics (cold path; used for model constants and host-side checks).
+    Joint composition rule: the joints of one body act in declaration order, each about its own
+    body-local axis through its anchor.
+
+    Returns dict with xpos (nbody,3), xmat (nbody,3,3), xipos (nbody,3), xanchor (nv,3), xaxis (nv,3).
+    """
+    xpos = np.zeros((m.nbody, 3))
+    xquat = np.zeros((m.nbody, 4))
+    xquat[0] = [1, 0, 0, 0]
+    xanchor = np.zeros((m.nv, 3))
+    xaxis = np.zeros((m.nv, 3))
+    for i in range(1, m.nbody):
+        p = m.body_parent[i]
+        rp = quat_to_mat(xquat[p])
+        pos = xpos[p] + rp @ m.body_pos[i]
+        quat = quat_mul(xquat[p], m.body_quat[i])
+        for k in range(m.body_jntnum[i]):
+            j = m.body_jntadr[i] + k
+            r = quat_to_mat(quat)
+            xanchor[j] = pos + r @ m.jnt_pos[j]
+            xaxis[j] = r @ m.jnt_axis[j]
+            if m.jnt_type[j] == JNT_SLIDE:
+                pos = pos + xaxis[j] * (qpos[j] - m.qpos0[j])
+            else:
+                quat = quat_mul(quat, axis_angle_quat(m.jnt_axis[j], qpos[j] - m.qpos0[j]))
+                pos = xanchor[j] - quat_to_mat(quat) @ m.jnt_pos[j]
+        quat = quat / np.linalg.norm(quat)
+        xpos[i], xquat[i] = pos, quat
+    xmat = np.array([quat_to_mat(q) for q in xquat])
+    xipos = xpos + np.einsum("bij,bj->bi", xmat, m.body_ipos)
+    return dict(xpos=xpos, xquat=xquat, xmat=xmat, xipos=xipos, xanchor=xanchor, xaxis=xaxis)
+
+
+def _dof_affects_body(m):
+    """bool (nbody, nv): dof d moves body b."""
+    aff = np.zeros((m.nbody, m.nv), dtype=bool)
+    for b in range(1, m.nbody):
+        a = b
+        while a != 0:
+            for k in range(m.body_jntnum[a]):
+                aff[b, m.body_jntadr[a] + k] = True
+            a = m.body_parent[a]
+    return aff
+
+
+def body_jacobians(m, kin, point):
+    """6 x nv Jacobians (translational rows 0:3 at ``point[b]``, rotational rows 3:6) for every body."""
+    aff = _dof_affects_body(m)
+    jac = np.zeros((m.nbody, 6, m.nv))
+    for b in range(1, m.nbody):
+        for d in range(m.nv):
+            if not aff[b, d]:
+                continue
+            ax = kin["xaxis"][d]
+            if m.jnt_type[d] == JNT_SLIDE:
+                jac[b, 0:3, d] = ax
+            else:
+                jac[b, 0:3, d] = np.cross(ax, point[b] - kin["xanchor"][d])
+                jac[b, 3:6, d] = ax
+    return jac
+
+
+def mass_matrix(m, qpos):
+    kin = forward_kinematics(m, qpos)
+    jac = body_jacobians(m, kin, kin["xipos"])
+    mm = np.zeros((m.nv, m.nv))
+    for b in range(1, m.nbody):
+        jp, jr = jac[b, 0:3], jac[b, 3:6]
+        iw = kin["xmat"][b] @ m.body_inertia[b] @ kin["xmat"][b].T
+        mm += m.body_mass[b] * jp.T @ jp + jr.T @ iw @ jr
+    mm[np.diag_indices(m.nv)] += m.dof_armature
+    return mm, kin, jac
+
+
+def _set_const(m):
+    """
+    ``dof_invweight0`` / ``body_invweight0`` at ``qpos0`` (what MuJoCo's model compiler stores and its
+    constraint regulariser reads): diagonal of M^-1 per dof, and for every
+    moving body the mean diagonal of the translational / rotational 3x3 blocks of J M^-1 J^T with J taken
+    at the body's centre of mass.
+    """
+    if m.nv == 0:
+        m.dof_invweight0 = np.zeros(0)
+        m.body_invweight0 = np.zeros((m.nbody, 2))
+        m.meaninertia = 1.0
+        return
+    mm, kin, jac = mass_matrix(m, m.qpos0)
+    minv = np.linalg.inv(mm)
+    m.dof_invweight0 = np.diag(minv).copy()
+    biw = np.zeros((m.nbody, 2))
+    for b in range(1, m.nbody):
+        if m.body_weldid[b] == 0:
+            continue
+        a = jac[b] @ minv @ jac[b].T
+        biw[b, 0] = (a[0, 0] + a[1, 1] + a[2, 2]) / 3.0
+        biw[b, 1] = (a[3, 3] + a[4, 4] + a[5, 5]) / 3.0
+    m.body_invweight0 = biw
+    m.meaninertia = float(np.trace(mm) / m.nv)

@@ -1,0 +1,57 @@
+/*
+ * oracle.h — C interface of the fp64 CPU oracle (TEST INFRASTRUCTURE ONLY; see oracle.c header).
+ * Loaded with ctypes by oracle/pyoracle.py from tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg. Never linked into the product library.
+ */
+#ifndef LMO_ORACLE_H
+#define LMO_ORACLE_H
+
+#define LMO_MAXBODY 40
+#define LMO_MAXV 32
+#define LMO_MAXGEOM 160
+#define LMO_MAXPAIR 8192
+#define LMO_MAXCON 96
+#define LMO_MAXEFC 400
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmo_model lmo_model;
+
+typedef struct {
+  double dist, pos[3], frame[9], includemargin, margin, friction[5], solref[2], solimp[5], mu;
+  int dim, geom1, geom2, efc_address;
+} lmo_contact;
+
+typedef struct {
+  int ncon, nefc, solver_iter_total, solver_iter_max, unhandled_pairs;
+} lmo_stats;
+
+typedef struct {
+  /* caller-provided buffers (any may be NULL) */
+  double *M, *bias, *passive, *actuator, *qacc_smooth, *qacc, *qfrc_constraint, *xpos, *xmat, *geom_xpos;
+  lmo_contact* contacts; int max_con;
+  double *efc_J, *efc_aref, *efc_R, *efc_force; int* efc_type; int max_efc;
+  /* outputs */
+  int ncon, nefc, solver_iter, unhandled_pairs;
+} lmo_forward_out;
+
+lmo_model* lmo_model_create(const double* blob, long n);
+void lmo_model_destroy(lmo_model* m);
+/* what: 0 = disable self collision (value!=0), 1 = solver iterations, 2 = solver tolerance */
+void lmo_set_option(lmo_model* m, int what, double value);
+int lmo_nv(const lmo_model* m);
+int lmo_nu(const lmo_model* m);
+
+/* advance (qpos,qvel) by nsub physics substeps under constant ctrl; warmstart (nv) may be NULL */
+int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl, double* warmstart, int nsub,
+             lmo_stats* stats);
+/* one forward-dynamics pass with intermediate results */
+int lmo_forward(const lmo_model* m, const double* qpos, const double* qvel, const double* ctrl,
+                const double* warmstart, lmo_forward_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+"""
+ctypes binding of the fp64 CPU oracle (oracle/oracle.c). TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never by loco_mujoco_amd/.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liblmoracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liblmoracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class Contact(C.Structure):
+    _fields_ = [("dist", C.c_double), ("pos", C.c_double * 3), ("frame", C.c_double * 9),
+                ("includemargin", C.c_double), ("margin", C.c_double), ("friction", C.c_double * 5),
+                ("solref", C.c_double * 2), ("solimp", C.c_double * 5), ("mu", C.c_double),
+                ("dim", C.c_int), ("geom1", C.c_int), ("geom2", C.c_int), ("efc_address", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter_total", C.c_int),
+                ("solver_iter_max", C.c_int), ("unhandled_pairs", C.c_int)]
+
+
+_DP = C.POINTER(C.c_double)
+
+
+class ForwardOut(C.Structure):
+    _fields_ = [(n, _DP) for n in ("M", "bias", "passive", "actuator", "qacc_smooth", "qacc", "qfrc_constraint",
+                                   "xpos", "xmat", "geom_xpos")] + \
+               [("contacts", C.POINTER(Contact)), ("max_con", C.c_int)] + \
+               [(n, _DP) for n in ("efc_J", "efc_aref", "efc_R", "efc_force")] + \
+               [("efc_type", C.POINTER(C.c_int)), ("max_efc", C.c_int),
+                ("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter", C.c_int), ("unhandled_pairs", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.lmo_model_create.restype = C.c_void_p
+        _lib.lmo_model_create.argtypes = [_DP, C.c_long]
+        _lib.lmo_model_destroy.argtypes = [C.c_void_p]
+        _lib.lmo_set_option.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        _lib.lmo_step.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
+        _lib.lmo_forward.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.POINTER(ForwardOut)]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_DP)
+
+
+class Oracle:
+    MAX_CON, MAX_EFC = 96, 400
+
+    def __init__(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float64)
+        self._h = lib().lmo_model_create(_p(blob), len(blob))
+        if not self._h:
+            raise ValueError("oracle rejected the model blob")
+        self.nv = int(blob[3])
+        self.nu = int(blob[5])
+        self.nbody = int(blob[2])
+        self.ngeom = int(blob[4])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().lmo_model_destroy(self._h)
+            self._h = None
+
+    def set_option(self, what, value):
+        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2}[what], float(value))
+
+    def step(self, qpos, qvel, ctrl, nsub=1, warmstart=None):
+        """Returns new (qpos, qvel, warmstart, stats-dict). Inputs are not modified."""
+        q = np.array(qpos, dtype=np.float64)
+        v = np.array(qvel, dtype=np.float64)
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        w = np.zeros(self.nv) if warmstart is None else np.array(warmstart, dtype=np.float64)
+        st = Stats()
+        lib().lmo_step(self._h, _p(q), _p(v), _p(c), _p(w), int(nsub), C.byref(st))
+        return q, v, w, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def forward(self, qpos, qvel, ctrl, warmstart=None):
+        nv = self.nv
+        q = np.ascontiguousarray(qpos, dtype=np.float64)
+        v = np.ascontiguousarray(qvel, dtype=np.float64)
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        w = np.zeros(nv) if warmstart is None else np.ascontiguousarray(warmstart, dtype=np.float64)
+        res = dict(M=np.zeros((nv, nv)), bias=np.zeros(nv), passive=np.zeros(nv), actuator=np.zeros(nv),
+                   qacc_smooth=np.zeros(nv), qacc=np.zeros(nv), qfrc_constraint=np.zeros(nv),
+                   xpos=np.zeros((self.nbody, 3)), xmat=np.zeros((self.nbody, 9)), geom_xpos=np.zeros((self.ngeom, 3)),
+                   efc_J=np.zeros((self.MAX_EFC, nv)), efc_aref=np.zeros(self.MAX_EFC), efc_R=np.zeros(self.MAX_EFC),
+                   efc_force=np.zeros(self.MAX_EFC))
+        out = ForwardOut()
+        for k, a in res.items():
+            setattr(out, k, _p(a))
+        cons = (Contact * self.MAX_CON)()
+        etype = np.zeros(self.MAX_EFC, dtype=np.int32)
+        out.contacts = cons
+        out.max_con = self.MAX_CON
+        out.efc_type = etype.ctypes.data_as(C.POINTER(C.c_int))
+        out.max_efc = self.MAX_EFC
+        lib().lmo_forward(self._h, _p(q), _p(v), _p(c), _p(w), C.byref(out))
+        ne, nc = out.nefc, out.ncon
+        for k in ("efc_J", "efc_aref", "efc_R", "efc_force"):
+            res[k] = res[k][:ne]
+        res["efc_type"] = etype[:ne]
+        res["contacts"] = [dict(dist=cons[i].dist, pos=np.array(cons[i].pos), frame=np.array(cons[i].frame).reshape(3, 3),
+                                dim=cons[i].dim, geom1=cons[i].geom1, geom2=cons[i].geom2, mu=cons[i].mu,
+                                friction=np.array(cons[i].friction), efc_address=cons[i].efc_address)
+                           for i in range(nc)]
+        res.update(ncon=nc, nefc=ne, solver_iter=out.solver_iter, unhandled_pairs=out.unhandled_pairs)
+        return res
