@@ -1,0 +1,115 @@
+/*
+ * locohip.h — C-ABI of the MI355X batched locomotion step ("liblocohip.so").
+ *
+ * The reference has no C boundary on this path: LocoEnv.step() is mushroom-rl's MuJoCo.step, which
+ * calls into the MuJoCo C library through its pybind module. The entry points
+ * below are what a loco-mujoco maintainer would bind with ctypes to replace, for
+ * a whole batch of environments at once:
+ *
+ *   lm_model_create     <- MjModel.from_xml_string + MultiMuJoCo.__init__ bookkeeping
+ *                          (/root/reference/loco_mujoco/environments/base.py:109-126;
+ *                           obs/action spec unitreeA1.py:778-854)
+ *   lm_batch_create     <- mujoco.MjData(model), one per environment (base.py:185)
+ *   lm_set_state        <- LocoEnv.set_sim_state: data.joint(name).qpos/qvel = value (base.py:478-497)
+ *                          after mj_resetData (base.py:180): also clears the solver warm start
+ *   lm_get_state        <- data.qpos / data.qvel reads (ObservationHelper._build_obs, base.py:202)
+ *   lm_set_goal         <- per-episode goal written into the observation
+ *                          (unitreeA1.py:288-291 set_goal, :454-476 _create_observation)
+ *   lm_step             <- MuJoCo.step: _preprocess_action (base.py:606-621) -> ctrl ->
+ *                          mujoco.mj_step(model, data, n_substeps) -> _create_observation
+ *                          (base.py:584-604, unitreeA1.py:454-476) -> is_absorbing/_has_fallen
+ *                          (base.py:243-255, unitreeA1.py:503-536) -> reward (base.py:170-176,
+ *                          utils/reward.py:66-117, evaluated on the previous observation)
+ *   lm_set_reset_table  <- Trajectory.reset_trajectory + set_sim_state for finished episodes
+ *                          (utils/trajectory.py:236-273, base.py:178-203), done on the device
+ *   lm_rollout          <- the user's `for step in range(n): env.step(a)` loop
+ *                          (tests/test_environments.py:15-38), kept on the device for benchmarking
+ *   lm_forward_debug    <- mujoco.mj_forward (base.py:362) with intermediate results, for parity tests
+ *
+ * All arrays at the boundary are caller-owned HOST buffers, row-major [n_envs][dim], float32.
+ * Device memory lives behind the opaque handles. Functions return 0 on success, non-zero on error;
+ * lm_last_error() returns a message for the calling thread. One handle = one GPU; handles are not
+ * thread-safe (one host thread per handle), calls on a handle are stream-ordered.
+ */
+#ifndef LOCOHIP_H
+#define LOCOHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lm_model lm_model;
+typedef struct lm_batch lm_batch;
+
+typedef struct {
+  int nq, nv, nu, nobs, ngoal, n_substeps, n_chains, max_chain_dofs;
+} lm_dims;
+
+typedef struct {
+  double env_steps;        /* control steps executed, summed over environments */
+  double episodes;         /* episodes finished (absorbing or horizon) */
+  double reward_sum;       /* sum of rewards */
+  double nan_resets;       /* environments reset because their state became non-finite */
+  double solver_iters;     /* Newton iterations, summed over environments and substeps */
+  double overflow_contacts;/* contacts dropped because a per-chain contact slot budget was exceeded */
+  double unhandled_geoms;  /* substeps in which a geom without a device collider came within margin */
+  double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
+} lm_stats;
+
+typedef struct {
+  /* all optional (NULL = skip); [n_envs][...] row-major float32 */
+  float* M;            /* [nv*nv]  joint-space inertia */
+  float* qfrc_bias;    /* [nv] */
+  float* qfrc_smooth;  /* [nv]  passive - bias + actuator */
+  float* qacc_smooth;  /* [nv] */
+  float* qacc;         /* [nv]  after the constraint solve */
+  float* qfrc_constraint; /* [nv] */
+  int* ncon;           /* [1] active contacts */
+  int* solver_iter;    /* [1] */
+} lm_forward_out;
+
+int lm_device_count(void);
+const char* lm_last_error(void);
+
+/* model_blob / task_blob: float64 arrays laid out as in lm_model_blob.h */
+int lm_model_create(const double* model_blob, size_t n_model, const double* task_blob, size_t n_task,
+                    int device, lm_model** out);
+void lm_model_destroy(lm_model* m);
+int lm_model_dims(const lm_model* m, lm_dims* out);
+
+int lm_batch_create(lm_model* m, int n_envs, lm_batch** out);
+void lm_batch_destroy(lm_batch* b);
+
+/* mask: [n_envs] bytes, NULL = all environments. Setting a state clears that env's warm start. */
+int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask);
+int lm_get_state(lm_batch* b, float* qpos, float* qvel);
+int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask);
+
+/* one control step for every environment. action in [-1,1] (normalised, base.py:606-621).
+   obs [n_envs][nobs], reward [n_envs], done [n_envs] may each be NULL. Synchronous. */
+int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t* done);
+
+/* device-side episode handling: rows = [qpos(nq) | qvel(nv) | goal(ngoal)]; when enabled, an
+   environment whose step ended absorbing (or reached `horizon` control steps, 0 = never) restarts
+   from a row drawn with a counter-based RNG keyed by (seed, global env id, episode count) and the
+   observation returned for that step is the fresh one. */
+int lm_set_reset_table(lm_batch* b, const float* rows, int n_rows, uint64_t seed, int64_t global_env_offset);
+int lm_set_auto_reset(lm_batch* b, int enabled, int horizon);
+
+/* n_steps control steps entirely on the device. action_mode 0: zero action; 1: a ~ U(-1,1)^nu from
+   the counter-based RNG. Accumulates into *stats (may be NULL). */
+int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stats* stats);
+
+/* one forward-dynamics pass at the current state with `action`, without advancing it */
+int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out);
+
+int lm_get_stats(lm_batch* b, lm_stats* out, int reset);
+int lm_sync(lm_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,206 @@
+"""
+ctypes loader for ``liblocohip.so`` (C-ABI: ``include/locohip.h``) — the ONLY physics path of the
+product. There is no CPU fallback: if the library or a GPU is missing this module raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblocohip.so")
+
+_F = C.POINTER(C.c_float)
+_U8 = C.POINTER(C.c_uint8)
+_D = C.POINTER(C.c_double)
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nq", "nv", "nu", "nobs", "ngoal", "n_substeps", "n_chains", "max_chain_dofs")]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("env_steps", "episodes", "reward_sum", "nan_resets", "solver_iters",
+                                          "overflow_contacts", "unhandled_geoms", "kernel_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ForwardOut(C.Structure):
+    _fields_ = [(n, _F) for n in ("M", "qfrc_bias", "qfrc_smooth", "qacc_smooth", "qacc", "qfrc_constraint")] + \
+               [("ncon", C.POINTER(C.c_int)), ("solver_iter", C.POINTER(C.c_int))]
+
+
+EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
+           "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_goal", "lm_step",
+           "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_forward_debug", "lm_get_stats", "lm_sync"]
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load liblocohip.so and declare its prototypes. Raises BackendError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError("HIP library not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C loco_mujoco_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.lm_device_count.restype = C.c_int
+    lib.lm_last_error.restype = C.c_char_p
+    lib.lm_model_create.argtypes = [_D, C.c_size_t, _D, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    lib.lm_model_destroy.argtypes = [C.c_void_p]
+    lib.lm_model_destroy.restype = None
+    lib.lm_model_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
+    lib.lm_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.lm_batch_destroy.argtypes = [C.c_void_p]
+    lib.lm_batch_destroy.restype = None
+    lib.lm_set_state.argtypes = [C.c_void_p, _F, _F, _U8]
+    lib.lm_get_state.argtypes = [C.c_void_p, _F, _F]
+    lib.lm_set_goal.argtypes = [C.c_void_p, _F, _U8]
+    lib.lm_step.argtypes = [C.c_void_p, _F, _F, _F, _U8]
+    lib.lm_set_reset_table.argtypes = [C.c_void_p, _F, C.c_int, C.c_uint64, C.c_int64]
+    lib.lm_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.lm_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(Stats)]
+    lib.lm_forward_debug.argtypes = [C.c_void_p, _F, C.POINTER(ForwardOut)]
+    lib.lm_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    lib.lm_sync.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BackendError("liblocohip: %s (code %d)" % (load_library().lm_last_error().decode(), rc))
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(_F)
+
+
+def _mask(mask, n):
+    if mask is None:
+        return None, None
+    m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(n)
+    return m, m.ctypes.data_as(_U8)
+
+
+class HipModel:
+    def __init__(self, model_blob, task_blob, device=0):
+        lib = load_library()
+        if lib.lm_device_count() <= 0:
+            raise BackendError("no HIP device visible: the batched simulator needs an MI355X (no CPU fallback)")
+        mb = np.ascontiguousarray(model_blob, dtype=np.float64)
+        tb = np.ascontiguousarray(task_blob, dtype=np.float64)
+        h = C.c_void_p()
+        _check(lib.lm_model_create(mb.ctypes.data_as(_D), len(mb), tb.ctypes.data_as(_D), len(tb), device, C.byref(h)))
+        self._h = h
+        d = Dims()
+        _check(lib.lm_model_dims(h, C.byref(d)))
+        self.dims = d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().lm_model_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class HipBatch:
+    """A batch of ``n_envs`` lock-step environments resident on one GPU."""
+
+    def __init__(self, model, n_envs):
+        self.model = model
+        self.n = int(n_envs)
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.lm_batch_create(model._h, self.n, C.byref(h)))
+        self._h = h
+        d = model.dims
+        self.nq, self.nv, self.nu, self.nobs, self.ngoal = d.nq, d.nv, d.nu, d.nobs, d.ngoal
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lm_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_state(self, qpos, qvel, mask=None):
+        q, v = _f32(qpos, (self.n, self.nq)), _f32(qvel, (self.n, self.nv))
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_set_state(self._h, _fp(q), _fp(v), mp))
+
+    def get_state(self):
+        q = np.empty((self.n, self.nq), dtype=np.float32)
+        v = np.empty((self.n, self.nv), dtype=np.float32)
+        _check(self._lib.lm_get_state(self._h, _fp(q), _fp(v)))
+        return q, v
+
+    def set_goal(self, goal, mask=None):
+        if self.ngoal == 0:
+            return
+        g = _f32(goal, (self.n, self.ngoal))
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_set_goal(self._h, _fp(g), mp))
+
+    def step(self, action):
+        a = _f32(action, (self.n, self.nu))
+        obs = np.empty((self.n, self.nobs), dtype=np.float32)
+        rew = np.empty(self.n, dtype=np.float32)
+        done = np.empty(self.n, dtype=np.uint8)
+        _check(self._lib.lm_step(self._h, _fp(a), _fp(obs), _fp(rew), done.ctypes.data_as(_U8)))
+        return obs, rew, done.astype(bool)
+
+    def set_reset_table(self, rows, seed=0, global_env_offset=0):
+        r = _f32(rows)
+        assert r.ndim == 2 and r.shape[1] == self.nq + self.nv + self.ngoal
+        _check(self._lib.lm_set_reset_table(self._h, _fp(r), r.shape[0], int(seed), int(global_env_offset)))
+
+    def set_auto_reset(self, enabled, horizon=0):
+        _check(self._lib.lm_set_auto_reset(self._h, int(bool(enabled)), int(horizon)))
+
+    def rollout(self, n_steps, action_mode=0, seed=0):
+        st = Stats()
+        _check(self._lib.lm_rollout(self._h, int(n_steps), int(action_mode), int(seed), C.byref(st)))
+        return st.as_dict()
+
+    def forward_debug(self, action):
+        a = _f32(action, (self.n, self.nu))
+        nv = self.nv
+        res = dict(M=np.zeros((self.n, nv, nv), np.float32), qfrc_bias=np.zeros((self.n, nv), np.float32),
+                   qfrc_smooth=np.zeros((self.n, nv), np.float32), qacc_smooth=np.zeros((self.n, nv), np.float32),
+                   qacc=np.zeros((self.n, nv), np.float32), qfrc_constraint=np.zeros((self.n, nv), np.float32))
+        ncon = np.zeros(self.n, np.int32)
+        it = np.zeros(self.n, np.int32)
+        out = ForwardOut()
+        for k, arr in res.items():
+            setattr(out, k, _fp(arr))
+        out.ncon = ncon.ctypes.data_as(C.POINTER(C.c_int))
+        out.solver_iter = it.ctypes.data_as(C.POINTER(C.c_int))
+        _check(self._lib.lm_forward_debug(self._h, _fp(a), C.byref(out)))
+        res["ncon"], res["solver_iter"] = ncon, it
+        return res
+
+    def stats(self, reset=False):
+        st = Stats()
+        _check(self._lib.lm_get_stats(self._h, C.byref(st), int(reset)))
+        return st.as_dict()
+
+    def sync(self):
+        _check(self._lib.lm_sync(self._h))

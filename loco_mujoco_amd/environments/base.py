@@ -1,0 +1,474 @@
+"""
+``LocoEnv`` — host-side mirror of the reference's ``loco_mujoco/environments/base.py`` for the
+``step()``/``reset()`` hot path, batched over ``n_envs`` lock-step environments that live on one
+MI355X behind the C-ABI (``include/locohip.h``).
+
+What stays identical to the reference (for ``n_envs=1``): ``LocoEnv.make(task_id, **kw)``,
+``reset(obs=None) -> obs``, ``step(action) -> (obs, reward, absorbing, info)``, ``info.observation_space``
+/ ``info.action_space`` (actions normalised to [-1, 1], ``base.py:122-126``), ``create_dataset()``,
+``load_trajectory()``, the ``np.random`` draw order of ``reset`` (``base.py:187-191``,
+``trajectory.py:253,259``) and float64 NumPy outputs of shape ``(nobs,)``.
+With ``n_envs=N`` every array gains a leading batch dimension.
+
+What is different by design: the physics, observation gather, reward and termination of ``step()``
+run inside one HIP kernel launch per control step (``csrc/``); this class only converts dtypes and
+keeps the episode bookkeeping. There is no CPU physics path in the product.
+"""
+
+import copy
+import warnings
+from itertools import product
+
+import numpy as np
+
+from ..model_blob import pack_model, pack_task
+from ..utils.reward import (CustomReward, NoReward, PosReward, TargetVelocityReward)
+from ..utils.trajectory import Trajectory
+from .observation import Box, MDPInfo, ObservationHelper, ObservationType
+
+
+class _HostState:
+    """Host copy of one environment's simulation state, used to assemble the reset observation."""
+
+    def __init__(self, nq, nv):
+        self.qpos = np.zeros(nq)
+        self.qvel = np.zeros(nv)
+        self.site_xmat = {}
+
+
+class LocoEnv:
+    """Base class of all locomotion environments (reference ``base.py:25``)."""
+
+    _registered_envs = dict()
+
+    def __init__(self, model, action_spec, observation_spec, collision_groups=None, gamma=0.99, horizon=1000,
+                 n_substeps=10, reward_type=None, reward_params=None, traj_params=None, random_start=True,
+                 init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
+                 use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
+                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, **viewer_params):
+        if use_foot_forces:
+            raise NotImplementedError("use_foot_forces=True (ground-reaction-force observations, reference "
+                                      "base.py:94-98,623-631) is not built yet")
+        if domain_randomization_config is not None:
+            raise NotImplementedError("domain randomization (reference utils/domain_randomization.py) is not "
+                                      "built yet")
+        self._model = model
+        assert abs(model.timestep - timestep) < 1e-12, "compile the model with the environment's timestep"
+        self._timestep = timestep
+        self._n_substeps = n_substeps
+        self._n_intermediate_steps = 1
+        self.n_envs = int(n_envs)
+        self._device = device
+
+        # ---- observation / action bookkeeping (what mushroom-rl's MuJoCo.__init__ does)
+        self.obs_helper = ObservationHelper(observation_spec, model)
+        self._action_spec = list(action_spec) if action_spec else list(model.act_names)
+        self._action_indices = np.array([model.act_id(n) for n in self._action_spec], dtype=np.int64)
+        low = model.act_ctrlrange[self._action_indices, 0].copy()
+        high = model.act_ctrlrange[self._action_indices, 1].copy()
+        action_space = Box(low, high)
+        observation_space = Box(*self.obs_helper.get_obs_limits())
+        self._mdp_info = MDPInfo(observation_space, action_space, gamma, horizon, dt=self.dt)
+
+        self._reward_function = self._get_reward_function(reward_type, reward_params)
+        self._use_foot_forces = False
+        self.info.observation_space = Box(*self._get_observation_space())
+
+        # actions are normalised to [-1, 1] (reference base.py:122-126)
+        self.norm_act_mean = (high + low) / 2.0
+        self.norm_act_delta = (high - low) / 2.0
+        self.info.action_space.low[:] = -1.0
+        self.info.action_space.high[:] = 1.0
+
+        self._dataset = None
+        self.trajectories = None
+        if traj_params:
+            self.load_trajectory(traj_params)
+        self._random_start = random_start
+        self._init_step_no = init_step_no
+        self._use_absorbing_states = use_absorbing_states
+
+        # ---- simulation state
+        self._host = [_HostState(model.nv, model.nv) for _ in range(self.n_envs)]
+        self._obs = None
+        self._backend = None           # created on first use (needs a GPU)
+        self._pending_state = False
+        self._auto_reset = False
+        self._n_models = 1
+        self._random_env_reset = True
+
+    # ------------------------------------------------------------------ registry / factory
+    @classmethod
+    def register(cls):
+        LocoEnv._registered_envs.setdefault(cls.__name__, cls)
+
+    @staticmethod
+    def list_registered_loco_mujoco():
+        return list(LocoEnv._registered_envs.keys())
+
+    @staticmethod
+    def make(env_name, *args, **kwargs):
+        """``LocoEnv.make("UnitreeA1.simple.real", **kw)`` -> ``UnitreeA1.generate("simple", "real", **kw)``."""
+        parts = env_name.split(".")
+        name, gen_args = parts[0], parts[1:]
+        if name not in LocoEnv._registered_envs:
+            raise ValueError("Environment '%s' is not registered. Available: %s"
+                             % (name, LocoEnv.list_registered_loco_mujoco()))
+        return LocoEnv._registered_envs[name].generate(*gen_args, *args, **kwargs)
+
+    @classmethod
+    def get_all_task_names(cls):
+        names = []
+        for e, env in cls._registered_envs.items():
+            for conf in env.valid_task_confs.get_all_combinations():
+                names.append(".".join([e] + list(conf.values())))
+        return names
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def info(self):
+        return self._mdp_info
+
+    @property
+    def dt(self):
+        return self._timestep * self._n_intermediate_steps * self._n_substeps
+
+    @property
+    def backend(self):
+        """The device batch (``HipBatch``). Created lazily; raises if the HIP library/GPU is missing."""
+        if self._backend is None:
+            from ..backend import HipBatch, HipModel
+            self._hip_model = HipModel(pack_model(self._model), self._make_task_blob(), self._device)
+            self._backend = HipBatch(self._hip_model, self.n_envs)
+        return self._backend
+
+    # ------------------------------------------------------------------ trajectories / datasets
+    def load_trajectory(self, traj_params, warn=True):
+        if self.trajectories is not None:
+            warnings.warn("New trajectories loaded, which overrides the old ones.", RuntimeWarning)
+        self.trajectories = Trajectory(keys=self.get_all_observation_keys(),
+                                       low=self.info.observation_space.low,
+                                       high=self.info.observation_space.high,
+                                       joint_pos_idx=self.obs_helper.joint_pos_idx,
+                                       interpolate_map=self._interpolate_map,
+                                       interpolate_remap=self._interpolate_remap,
+                                       interpolate_map_params=self._get_interpolate_map_params(),
+                                       interpolate_remap_params=self._get_interpolate_remap_params(),
+                                       warn=warn, **traj_params)
+
+    def create_dataset(self, ignore_keys=None):
+        if self._dataset is None:
+            if self.trajectories is None:
+                raise ValueError("No trajectory was passed to the environment. "
+                                 "To create a dataset pass a trajectory first.")
+            dataset = self.trajectories.create_dataset(ignore_keys=ignore_keys)
+            for state in dataset["states"]:
+                has_fallen, msg = self._has_fallen(state, return_err_msg=True)
+                if has_fallen:
+                    raise ValueError("Some of the states in the created dataset are terminal states. "
+                                     "This should not happen.\n\nViolations:\n" + msg)
+            self._dataset = copy.deepcopy(dataset)
+            return dataset
+        return copy.deepcopy(self._dataset)
+
+    def get_all_observation_keys(self):
+        return [k for k, _, _ in self.obs_helper.observation_spec]
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, obs=None):
+        """
+        Start new episodes in ALL environments (reference ``base.py:178-203``). RNG draw order per
+        environment: model index, trajectory number, step in trajectory [, yaw]. Returns the initial
+        observation(s), computed on the host in float64 exactly like the reference (no physics call).
+        """
+        rows = []
+        for e in range(self.n_envs):
+            self._reset_one(e, obs)
+            rows.append(self._create_observation(self.obs_helper._build_obs(self._host[e])))
+        self._pending_state = True
+        self._obs = np.stack(rows)
+        return self._out(self._obs)
+
+    def _reset_one(self, e, obs):
+        h = self._host[e]
+        h.qpos[:] = self._model.qpos0          # mj_resetData
+        h.qvel[:] = 0.0
+        if self._random_env_reset:
+            np.random.randint(0, self._n_models)
+        self._cur_env = e
+        self.setup(obs)
+
+    def setup(self, obs):
+        """Initial state of the current environment (reference ``base.py:205-241``)."""
+        self._reward_function.reset_state()
+        if obs is not None:
+            self._init_sim_from_obs(obs)
+            return
+        self._check_start_mode()
+        if self.trajectories is not None:
+            self.set_sim_state(self._sample_start())
+
+    def _check_start_mode(self):
+        if not self.trajectories and self._random_start:
+            raise ValueError("Random start not possible without trajectory data.")
+        elif not self.trajectories and self._init_step_no is not None:
+            raise ValueError("Setting an initial step is not possible without trajectory data.")
+        elif self._init_step_no is not None and self._random_start:
+            raise ValueError("Either use a random start or set an initial step, not both.")
+
+    def _sample_start(self):
+        if self._random_start:
+            return self.trajectories.reset_trajectory()
+        if self._init_step_no is not None:
+            traj_len = self.trajectories.trajectory_length
+            n_traj = self.trajectories.number_of_trajectories
+            assert self._init_step_no <= traj_len * n_traj
+            return self.trajectories.reset_trajectory(int(self._init_step_no % traj_len),
+                                                      int(self._init_step_no / traj_len))
+        return self.trajectories.reset_trajectory(substep_no=0)
+
+    def set_sim_state(self, sample):
+        """Write a trajectory sample into the simulation state, entry by entry, by NAME (``base.py:478-497``)."""
+        spec = self.obs_helper.observation_spec
+        assert len(sample) == len(spec)
+        h = self._host[self._cur_env]
+        for (key, name, ot), value in zip(spec, sample):
+            if ot == ObservationType.JOINT_POS:
+                h.qpos[self._model.jnt_id(name)] = np.asarray(value).reshape(-1)[0]
+            elif ot == ObservationType.JOINT_VEL:
+                h.qvel[self._model.jnt_id(name)] = np.asarray(value).reshape(-1)[0]
+            else:
+                h.site_xmat[name] = np.asarray(value, dtype=np.float64).reshape(9).copy()
+
+    def _init_sim_from_obs(self, obs):
+        assert len(obs.shape) == 1
+        obs = np.concatenate([[0.0, 0.0], obs])
+        spec = self.obs_helper.observation_spec
+        assert len(obs) >= len(spec)
+        self.set_sim_state(obs[:len(spec)])
+
+    # ------------------------------------------------------------------ step
+    def step(self, action):
+        """
+        One control step (= ``n_substeps`` physics steps) for every environment; the whole reference
+        sequence of SURVEY.md §3.3 — un-normalise action, physics, observation, absorbing, reward on the
+        previous observation — runs in one kernel launch on the device.
+        """
+        if self._obs is None:
+            raise RuntimeError("call reset() before step()")
+        b = self.backend
+        if self._pending_state:
+            self._upload_state()
+        a = np.asarray(action, dtype=np.float64).reshape(self.n_envs, -1)
+        prev_obs = self._obs
+        obs32, rew32, done = b.step(a)
+        obs = obs32.astype(np.float64)
+        if self._reward_function.device_spec() is None:
+            reward = np.asarray(self.reward(prev_obs, a, obs, done), dtype=np.float64) * np.ones(self.n_envs)
+        else:
+            reward = rew32.astype(np.float64)
+        self._obs = obs
+        if self.n_envs == 1:
+            return obs[0].copy(), float(reward[0]), bool(done[0]), {}
+        return obs.copy(), reward, done, {}
+
+    def _upload_state(self):
+        qpos = np.stack([h.qpos for h in self._host])
+        qvel = np.stack([h.qvel for h in self._host])
+        self._backend.set_state(qpos, qvel)
+        goal = self._goal_rows()
+        if goal is not None:
+            self._backend.set_goal(goal)
+        self._pending_state = False
+
+    def _goal_rows(self):
+        """(n_envs, n_goal) constants appended to the device observation, or None."""
+        return None
+
+    def enable_auto_reset(self, seed=0, horizon=None, global_env_offset=0):
+        """
+        Device-side episode handling for batched rollouts: finished environments restart from a random
+        trajectory sample inside the step kernel (counter-based RNG keyed by global env id, so results
+        do not depend on how environments are sharded over GPUs).
+        """
+        if self.trajectories is None:
+            raise ValueError("auto reset needs trajectory data")
+        b = self.backend
+        b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset)
+        b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)
+        self._auto_reset = True
+
+    def _reset_table(self):
+        """Rows [qpos | qvel | goal] for every trajectory sample."""
+        tab = self.trajectories.as_state_table()
+        spec = self.obs_helper.observation_spec
+        nv = self._model.nv
+        rows = np.zeros((tab.shape[0], 2 * nv))
+        col = 0
+        for key, name, ot in spec:
+            if ot == ObservationType.JOINT_POS:
+                rows[:, self._model.jnt_id(name)] = tab[:, col]
+                col += 1
+            elif ot == ObservationType.JOINT_VEL:
+                rows[:, nv + self._model.jnt_id(name)] = tab[:, col]
+                col += 1
+            else:
+                col += 9
+        return rows
+
+    # ------------------------------------------------------------------ hooks (same names as the reference)
+    def _preprocess_action(self, action):
+        return np.asarray(action) * self.norm_act_delta + self.norm_act_mean
+
+    def _create_observation(self, obs):
+        return np.asarray(obs)[2:].copy()
+
+    def is_absorbing(self, obs):
+        return self._has_fallen(obs) if self._use_absorbing_states else False
+
+    def reward(self, state, action, next_state, absorbing):
+        return self._reward_function(state, action, next_state, absorbing)
+
+    def _has_fallen(self, obs, return_err_msg=False):
+        raise NotImplementedError
+
+    def _termination_spec(self):
+        """[(obs index, low, high)]: absorbing iff any listed entry leaves [low, high]."""
+        raise NotImplementedError
+
+    def _get_observation_space(self):
+        return self.info.observation_space.low[2:], self.info.observation_space.high[2:]
+
+    def _get_reward_function(self, reward_type, reward_params):
+        if reward_type == "custom":
+            return CustomReward(**reward_params)
+        elif reward_type == "target_velocity":
+            idx = self.get_obs_idx("dq_pelvis_tx")
+            assert len(idx) == 1
+            return TargetVelocityReward(x_vel_idx=idx[0], **reward_params)
+        elif reward_type == "x_pos":
+            idx = self.get_obs_idx("q_pelvis_tx")
+            assert len(idx) == 1
+            return PosReward(pos_idx=idx[0])
+        elif reward_type is None:
+            return NoReward()
+        raise NotImplementedError("The specified reward has not been implemented: %s" % reward_type)
+
+    def get_obs_idx(self, key):
+        return [i - 2 for i in self.obs_helper.obs_idx_map[key]]
+
+    def _get_idx(self, keys):
+        if not isinstance(keys, list):
+            keys = [keys]
+        return np.concatenate([self.obs_helper.obs_idx_map[k] for k in keys]) - 2
+
+    def _get_from_obs(self, obs, keys):
+        obs = np.concatenate([[0.0, 0.0], obs])
+        if not isinstance(keys, list):
+            keys = [keys]
+        return np.concatenate([self.obs_helper.get_from_obs(obs, k) for k in keys])
+
+    def get_kinematic_obs_mask(self):
+        return np.arange(len(self.obs_helper.observation_spec) - 2)
+
+    def _len_qpos_qvel(self):
+        keys = self.get_all_observation_keys()
+        return len([k for k in keys if k.startswith("q_")]), len([k for k in keys if k.startswith("dq_")])
+
+    def _get_interpolate_map_params(self):
+        return None
+
+    def _get_interpolate_remap_params(self):
+        return None
+
+    @staticmethod
+    def _interpolate_map(traj, **interpolate_map_params):
+        return np.array(traj)
+
+    @staticmethod
+    def _interpolate_remap(traj, **interpolate_remap_params):
+        return [obs for obs in traj]
+
+    # ------------------------------------------------------------------ task description for the device
+    def _n_goal(self):
+        return 0
+
+    def _make_task_blob(self):
+        qpos_idx, qvel_idx = [], []
+        for key, name, ot in self.obs_helper.observation_spec[2:]:
+            if ot == ObservationType.JOINT_POS:
+                qpos_idx.append(self._model.jnt_id(name))
+            elif ot == ObservationType.JOINT_VEL:
+                qvel_idx.append(self._model.jnt_id(name))
+        n_goal = self._n_goal()
+        nobs = len(qpos_idx) + len(qvel_idx) + n_goal
+        assert nobs == self.info.observation_space.shape[0], "device observation layout does not match the space"
+        spec = self._reward_function.device_spec()
+        rtype, rparams = spec if spec is not None else (0, [])
+        term = self._termination_spec() if self._use_absorbing_states else []
+        return pack_task(nobs, qpos_idx, qvel_idx, n_goal, self._action_indices, self.norm_act_mean,
+                         self.norm_act_delta, [t[0] for t in term], [t[1] for t in term], [t[2] for t in term],
+                         rtype, rparams, self._n_substeps)
+
+    # ------------------------------------------------------------------ misc surface
+    def _out(self, obs):
+        return obs[0].copy() if self.n_envs == 1 else obs.copy()
+
+    def render(self, record=False):
+        raise NotImplementedError("rendering is out of scope of the headless batched simulator (SURVEY.md §2 row 22)")
+
+    def stop(self):
+        pass
+
+    def seed(self, seed=None):
+        np.random.seed(seed)
+
+    def play_trajectory(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
+        """Kinematic replay of the loaded trajectory (reference ``base.py:314-386``): yields the observation
+        of every replayed sample; no dynamics, no rendering."""
+        assert self.trajectories is not None
+        out = []
+        sample = self.trajectories.reset_trajectory(substep_no=1)
+        self._cur_env = 0
+        n_episodes = 1 if n_episodes is None else n_episodes
+        for _ in range(n_episodes):
+            steps = 0
+            while sample is not None and (n_steps_per_episode is None or steps < n_steps_per_episode):
+                self.set_sim_state(sample)
+                out.append(self._create_observation(self.obs_helper._build_obs(self._host[0])))
+                sample = self.trajectories.get_next_sample()
+                steps += 1
+            sample = self.trajectories.reset_trajectory(substep_no=1)
+        return np.array(out)
+
+
+class ValidTaskConf:
+    """Valid (task, mode, dataset type) combinations of an environment (reference ``base.py:972-1041``)."""
+
+    def __init__(self, tasks=None, modes=None, data_types=None, non_combinable=None):
+        self.tasks, self.modes, self.data_types, self.non_combinable = tasks, modes, data_types, non_combinable
+        for nc in (non_combinable or []):
+            assert len(nc) == 3
+
+    def get_all(self):
+        return (copy.deepcopy(self.tasks), copy.deepcopy(self.modes), copy.deepcopy(self.data_types),
+                copy.deepcopy(self.non_combinable))
+
+    def get_all_combinations(self):
+        confs = []
+        for t, m, dt in product(self.tasks or [None], self.modes or [None], self.data_types or [None]):
+            conf = {}
+            if t is not None:
+                conf["task"] = t
+            if m is not None:
+                conf["mode"] = m
+            if dt is not None:
+                conf["data_type"] = dt
+            if self.non_combinable is None:
+                confs.append(conf)
+                continue
+            for bad_t, bad_m, bad_dt in self.non_combinable:
+                if not ((bad_t is None or t == bad_t) and (bad_m is None or m == bad_m)
+                        and (bad_dt is None or dt == bad_dt)):
+                    confs.append(conf)
+        return confs

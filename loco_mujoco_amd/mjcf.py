@@ -170,6 +170,31 @@ class CompiledModel:
     site_names: list = field(default_factory=list)
     # arrays are attached dynamically (see compile_mjcf)
 
+    _SCALARS = ("timestep", "cone", "impratio", "integrator", "iterations", "tolerance", "nbody", "njnt", "nv",
+                "ngeom", "nu", "nsite", "meaninertia")
+    _NAMES = ("body_names", "jnt_names", "geom_names", "act_names", "site_names")
+
+    def save(self, path):
+        """Serialise to an ``.npz`` (arrays + a JSON header); see :meth:`load`."""
+        import json
+        arrays = {k: v for k, v in self.__dict__.items() if isinstance(v, np.ndarray)}
+        meta = {k: getattr(self, k) for k in self._SCALARS}
+        meta.update({k: list(getattr(self, k)) for k in self._NAMES})
+        np.savez_compressed(path, __meta__=np.array(json.dumps(meta)), **arrays)
+
+    @classmethod
+    def load(cls, path):
+        import json
+        m = cls()
+        with np.load(path, allow_pickle=False) as f:
+            meta = json.loads(str(f["__meta__"]))
+            for k in f.files:
+                if k != "__meta__":
+                    setattr(m, k, f[k])
+        for k, v in meta.items():
+            setattr(m, k, v)
+        return m
+
     def jnt_id(self, name):
         return self.jnt_names.index(name)
 

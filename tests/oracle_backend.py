@@ -1,0 +1,64 @@
+"""
+TEST-ONLY stand-in for ``loco_mujoco_amd.backend.HipBatch`` built on the fp64 CPU oracle, so that the
+host logic of ``LocoEnv`` (reset, observation assembly, action un-normalisation, termination, reward)
+can be checked end-to-end against the reference's golden rollouts on a machine without a GPU.
+Never imported by the product.
+"""
+
+import numpy as np
+
+from loco_mujoco_amd.model_blob import pack_model
+from oracle.pyoracle import Oracle
+
+
+class OracleBatch:
+    def __init__(self, env):
+        self.env = env
+        self.oracle = Oracle(pack_model(env._model))
+        self.n = env.n_envs
+        self.qpos = np.zeros((self.n, env._model.nv))
+        self.qvel = np.zeros((self.n, env._model.nv))
+        self.warm = np.zeros((self.n, env._model.nv))
+        self.goal = None
+        self.prev_obs = None
+        self.stats_log = []
+
+    def set_state(self, qpos, qvel, mask=None):
+        self.qpos[:] = qpos
+        self.qvel[:] = qvel
+        self.warm[:] = 0
+
+    def set_goal(self, goal, mask=None):
+        self.goal = np.array(goal, dtype=np.float64)
+
+    def _obs(self, e):
+        env = self.env
+        qi = [env._model.jnt_id(n) for k, n, t in env.obs_helper.observation_spec[2:] if k.startswith("q_")]
+        vi = [env._model.jnt_id(n) for k, n, t in env.obs_helper.observation_spec[2:] if k.startswith("dq_")]
+        parts = [self.qpos[e, qi], self.qvel[e, vi]]
+        if self.goal is not None:
+            parts.append(self.goal[e])
+        return np.concatenate(parts)
+
+    def step(self, action):
+        env = self.env
+        if self.prev_obs is None:
+            self.prev_obs = np.stack([self._obs(e) for e in range(self.n)])
+        obs, rew, done = [], [], []
+        for e in range(self.n):
+            ctrl = np.zeros(env._model.nu)
+            ctrl[env._action_indices] = env._preprocess_action(action[e])
+            q, v, w, st = self.oracle.step(self.qpos[e], self.qvel[e], ctrl, env._n_substeps, self.warm[e])
+            self.qpos[e], self.qvel[e], self.warm[e] = q, v, w
+            self.stats_log.append(st)
+            o = self._obs(e)
+            obs.append(o)
+            done.append(bool(env.is_absorbing(o)))
+            rew.append(env.reward(self.prev_obs[e], action[e], o, done[-1]))
+        self.prev_obs = np.stack(obs)
+        return np.stack(obs), np.array(rew, dtype=np.float64), np.array(done)
+
+
+def attach(env):
+    env._backend = OracleBatch(env)
+    return env

@@ -1,0 +1,139 @@
+"""Host-side surface of the drop-in (no GPU): task registry, spaces, reset row 0, datasets, rewards."""
+
+import numpy as np
+import pytest
+
+import loco_mujoco_amd
+from loco_mujoco_amd import LocoEnv, mjcf
+from loco_mujoco_amd.environments import gymnasium as lm_gym
+from loco_mujoco_amd.utils.reward import TargetVelocityReward, VelocityVectorReward
+
+GOLD = np.load(__file__.replace("test_host_logic.py", "golden/reference_rollouts.npz"))
+
+
+@pytest.fixture(scope="module")
+def env():
+    np.random.seed(0)
+    return LocoEnv.make("UnitreeA1.simple", debug=True)
+
+
+def test_task_names_and_errors():
+    names = loco_mujoco_amd.get_all_task_names()
+    assert "UnitreeA1.simple.real" in names and "UnitreeA1.hard.perfect" in names
+    with pytest.raises(ValueError):
+        LocoEnv.make("UnitreeA1.fast")
+    with pytest.raises(ValueError):
+        LocoEnv.make("NoSuchRobot.walk")
+
+
+def test_spaces_match_reference(env):
+    assert env.info.observation_space.shape == (37,)
+    assert env.info.action_space.shape == (12,)
+    assert np.all(env.info.action_space.low == -1) and np.all(env.info.action_space.high == 1)
+    assert np.allclose(env.norm_act_mean, 0) and np.allclose(env.norm_act_delta, 1)
+    low, high = env.info.observation_space.low, env.info.observation_space.high
+    assert low[0] == -np.inf and np.isclose(low[4], -0.802851) and np.isclose(high[6], -0.916298)
+    assert list(low[-3:]) == [-1, -1, -np.inf] and list(high[-3:]) == [1, 1, np.inf]
+    assert abs(env.dt - 0.01) < 1e-15 and env.info.horizon == 1000 and env.info.gamma == 0.99
+
+
+def test_reset_row0_reproduces_golden():
+    """seed(0) -> (model 0, traj 0, step 47) -> golden row 0 to 1e-12 (reference reset needs no physics)."""
+    np.random.seed(0)
+    e = LocoEnv.make("UnitreeA1.simple", debug=True)
+    obs = e.reset()
+    assert obs.dtype == np.float64 and obs.shape == (37,)
+    assert np.abs(obs - GOLD["UnitreeA1.simple.real"][0]).max() < 1e-12
+    assert e.trajectories.traj_no == 0 and e.trajectories.subtraj_step_no == 47
+
+
+def test_gym_wrapper_reset():
+    np.random.seed(0)
+    w = lm_gym.make("LocoMujoco", env_name="UnitreeA1.simple", debug=True)
+    obs, info = w.reset()
+    assert info == {} and np.abs(obs - GOLD["UnitreeA1.simple.real"][0]).max() < 1e-12
+    assert w.observation_space.shape == (37,) and w.action_space.shape == (12,)
+
+
+def test_batched_reset_draw_order():
+    np.random.seed(0)
+    e = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=3)
+    obs = e.reset()
+    assert obs.shape == (3, 37)
+    assert np.abs(obs[0] - GOLD["UnitreeA1.simple.real"][0]).max() < 1e-12
+    assert not np.allclose(obs[0], obs[1])
+
+
+def test_has_fallen_thresholds(env):
+    g = GOLD["UnitreeA1.simple.real"]
+    assert [bool(env._has_fallen(r)) for r in g] == [False] * 17 + [True]
+    o = g[0].copy()
+    o[1] = 0.28
+    assert env._has_fallen(o)
+    o = g[0].copy()
+    o[2] = -0.2
+    assert env._has_fallen(o)
+    spec = env._termination_spec()
+    for row in g:
+        dev = any(row[i] < lo or row[i] > hi for i, lo, hi in spec)
+        assert dev == bool(env._has_fallen(row))
+
+
+def test_rewards_formulas(env):
+    g = GOLD["UnitreeA1.simple.real"]
+    r = env.reward(g[3], None, g[4], False)
+    v = g[3][[16, 17]]
+    want = np.exp(-5 * np.linalg.norm(v - g[3][36] * g[3][[34, 35]]))
+    assert np.isclose(r, want)
+    assert isinstance(env._reward_function, VelocityVectorReward)
+    batch = env._reward_function(g[:5], None, None, None)
+    assert batch.shape == (5,) and np.isclose(batch[3], want)
+    tv = TargetVelocityReward(2.5, 17)
+    assert np.isclose(tv(g[0], None, None, None), np.exp(-(g[0][17] - 2.5) ** 2))
+
+
+def test_create_dataset(env):
+    d = env.create_dataset()
+    assert d["states"].shape == (3 * 99, 37) and d["next_states"].shape == (3 * 99, 37)
+    assert d["absorbing"].sum() == 0 and d["last"].sum() == 3
+    assert np.allclose(d["states"][1:99], d["next_states"][0:98])
+    d2 = env.create_dataset()
+    assert np.array_equal(d["states"], d2["states"])
+
+
+def test_reset_table_rows_equal_reset_samples(env):
+    tab = env._reset_table()
+    assert tab.shape == (300, 18 + 18 + 3)
+    np.random.seed(0)
+    e = LocoEnv.make("UnitreeA1.simple", debug=True)
+    obs = e.reset()
+    row = tab[0 * 100 + 47]
+    assert np.abs(np.concatenate([row[2:18], row[18:36], row[36:]]) - obs).max() < 1e-12
+
+
+def test_compiled_model_facts():
+    m = mjcf.CompiledModel.load(mjcf.__file__.replace("mjcf.py", "assets/UnitreeA1.torque.model.npz"))
+    assert (m.nbody, m.nv, m.nu, m.ngeom) == (15, 18, 12, 38)
+    assert m.cone == mjcf.CONE_ELLIPTIC and m.impratio == 100 and m.integrator == mjcf.INT_EULER
+    assert np.isclose(m.body_mass.sum(), 4.713 + 4 * (0.696 + 1.013 + 0.226))
+    assert np.all(m.dof_frictionloss == 0.2)            # root dofs inherit it too (SURVEY.md §0.6 ii)
+    assert list(m.dof_damping[:9]) == [0, 0, 0, 0, 0, 0, 1, 2, 2]
+    foot = m.geom_names.index("FR_foot")
+    assert m.geom_condim[foot] == 6 and m.geom_priority[foot] == 1 and np.isclose(m.geom_margin[foot], 0.001)
+    assert np.allclose(m.geom_solimp[foot], [0.015, 1, 0.031, 0.5, 2])
+    assert np.allclose(m.act_gear, 34) and np.allclose(m.act_ctrlrange, [[-1, 1]] * 12)
+    # M^-1 diagonal / body inverse weights are consistent with an independent solve
+    mm = mjcf.mass_matrix(m, m.qpos0)[0]
+    assert np.allclose(np.diag(np.linalg.inv(mm)), m.dof_invweight0)
+
+
+def test_step_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    np.random.seed(0)
+    e = LocoEnv.make("UnitreeA1.simple", debug=True)
+    e.reset()
+    from loco_mujoco_amd.backend import BackendError
+    with pytest.raises(BackendError):
+        e.step(np.zeros(12))

@@ -1,0 +1,99 @@
+"""
+Pins the fp64 CPU oracle (oracle/oracle.c) to the reference's golden rollouts
+(/root/reference/tests/test_datasets/UnitreeA1.simple.real.npy, committed re-encoded in
+tests/golden/reference_rollouts.npz by tools/build_assets.py; generator: the reference's
+tests/test_environments.py:15-38,67-94).
+
+Strengths: (2) every row k -> k+1 is a one-control-step known-answer test from a fully
+observed state under the k-th seeded action; (3) the full rollout from row 0 through the host logic;
+(4) the last row is the first terminal one.
+"""
+
+import numpy as np
+import pytest
+
+from loco_mujoco_amd import LocoEnv, mjcf
+from loco_mujoco_amd.model_blob import pack_model
+from oracle.pyoracle import Oracle
+from oracle_backend import attach
+
+GOLD = np.load(__file__.replace("test_oracle_golden.py", "golden/reference_rollouts.npz"))
+
+
+def a1_actions(n):
+    """Action stream of the reference test: seed(0), three reset randints, then randn(12)*0.1 per step."""
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 3), np.random.randint(0, 100)
+    return [np.random.randn(12) * 0.1 for _ in range(n)]
+
+
+@pytest.fixture(scope="module")
+def a1():
+    m = mjcf.CompiledModel.load(mjcf.__file__.replace("mjcf.py", "assets/UnitreeA1.torque.model.npz"))
+    return m, Oracle(pack_model(m))
+
+
+def test_a1_one_control_step_kats(a1):
+    m, o = a1
+    g = GOLD["UnitreeA1.simple.real"]
+    acts = a1_actions(len(g) - 1)
+    for k in range(len(g) - 1):
+        qpos = np.concatenate([[0, 0], g[k, :16]])
+        q, v, w, st = o.step(qpos, g[k, 16:34], acts[k], nsub=10)
+        assert np.abs(q[2:] - g[k + 1, :16]).max() < 1e-9, k       # stated bar: 1e-6
+        assert np.abs(v - g[k + 1, 16:34]).max() < 1e-7, k         # stated bar: 1e-4
+
+
+def test_a1_full_rollout_matches_reference_test():
+    """The reference's own test_all_environments for this task: np.allclose with default tolerances."""
+    g = GOLD["UnitreeA1.simple.real"]
+    np.random.seed(0)
+    env = attach(LocoEnv.make("UnitreeA1.simple", debug=True))
+    obs = env.reset()
+    rows, absorbing = [obs], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, _, absorbing, _ = env.step(np.random.randn(12) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape                  # terminates exactly where the reference did
+    assert np.allclose(rows, g)
+    assert absorbing and env._has_fallen(g[-1]) and not any(env._has_fallen(r) for r in g[:-1])
+
+
+def test_oracle_mass_matrix_and_bias_against_lagrangian(a1):
+    """M from the oracle == M from the independent numpy implementation; bias == d/dt dL/dv - dL/dq."""
+    m, o = a1
+    g = GOLD["UnitreeA1.simple.real"]
+    qpos, qvel = np.concatenate([[0, 0], g[3, :16]]), g[3, 16:34]
+    f = o.forward(qpos, qvel, np.zeros(12))
+    M0 = mjcf.mass_matrix(m, qpos)[0]
+    assert np.abs(M0 - f["M"]).max() < 1e-12
+
+    def energy(q):
+        kin = mjcf.forward_kinematics(m, q)
+        return -sum(m.body_mass[b] * m.gravity @ kin["xipos"][b] for b in range(m.nbody))
+
+    eps, nv = 1e-6, m.nv
+    mdot, dT, dV = np.zeros((nv, nv)), np.zeros(nv), np.zeros(nv)
+    for k in range(nv):
+        e = np.zeros(nv)
+        e[k] = eps
+        mp, mm = mjcf.mass_matrix(m, qpos + e)[0], mjcf.mass_matrix(m, qpos - e)[0]
+        mdot += (mp - mm) / (2 * eps) * qvel[k]
+        dT[k] = 0.5 * qvel @ (mp - mm) @ qvel / (2 * eps)
+        dV[k] = (energy(qpos + e) - energy(qpos - e)) / (2 * eps)
+    assert np.abs(mdot @ qvel - dT + dV - f["bias"]).max() < 1e-6
+
+
+def test_oracle_solution_is_kkt_point(a1):
+    """The returned qacc satisfies M qacc = qfrc_smooth + J^T f with f the constraint forces."""
+    m, o = a1
+    g = GOLD["UnitreeA1.simple.real"]
+    for k in (2, 9, 15):
+        qpos, qvel = np.concatenate([[0, 0], g[k, :16]]), g[k, 16:34]
+        f = o.forward(qpos, qvel, np.zeros(12))
+        res = f["M"] @ f["qacc"] - f["M"] @ f["qacc_smooth"] - f["efc_J"].T @ f["efc_force"]
+        assert np.abs(res).max() < 1e-6          # solver tolerance 1e-8 * meaninertia * nv
+        assert f["ncon"] >= 1 and f["nefc"] >= 18

@@ -1,0 +1,63 @@
+"""
+Regenerates the bundled assets from a loco-mujoco checkout (default /root/reference). Run in the build
+container only; nothing at run time reads the checkout.
+
+  python tools/build_assets.py [--ref /path/to/loco-mujoco]
+
+Writes
+  loco_mujoco_amd/assets/UnitreeA1.torque.model.npz      compiled model (after the env's XML surgery)
+  loco_mujoco_amd/datasets/quadrupeds/real/mini_datasets/walk_straight.npz   re-encoded mini dataset
+  tests/golden/reference_rollouts.npz                     the reference's golden rollouts for our tasks
+"""
+
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from loco_mujoco_amd import mjcf                      # noqa: E402
+from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
+
+GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
+                "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ref = Path(ap.parse_args().ref)
+    pkg = ref / "loco_mujoco"
+
+    # --- models
+    (ROOT / "loco_mujoco_amd" / "assets").mkdir(exist_ok=True)
+    h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "quadrupeds" / "unitree_a1_torque.xml")
+    m = mjcf.compile_mjcf(UnitreeA1._add_dir_vector_to_xml_handle(h), timestep=0.001)
+    m.save(ROOT / "loco_mujoco_amd" / "assets" / "UnitreeA1.torque.model.npz")
+    print("UnitreeA1: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
+
+    # --- mini datasets (same keys/values, re-encoded)
+    for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz"]:
+        src = np.load(pkg / rel, allow_pickle=True)
+        dst = ROOT / "loco_mujoco_amd" / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        np.savez_compressed(dst, **{k: np.asarray(src[k]) for k in src.files})
+        print("dataset", rel, len(src.files), "keys")
+
+    # --- golden rollouts of the reference's own test (tests/test_environments.py:67-94)
+    gold = {}
+    for t in GOLDEN_TASKS:
+        p = ref / "tests" / "test_datasets" / (t + ".npy")
+        if p.exists():
+            gold[t] = np.load(p)
+    (ROOT / "tests" / "golden").mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(ROOT / "tests" / "golden" / "reference_rollouts.npz", **gold)
+    print("golden:", {k: v.shape for k, v in gold.items()})
+
+
+if __name__ == "__main__":
+    main()
