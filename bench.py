@@ -1,0 +1,163 @@
+"""
+bench.py — env-steps/s of the batched LocoEnv.step() hot path (BASELINE.json metric) on N GPUs of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 4096]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): UnitreeA1.simple, 4096 environments per GPU,
+zero action, initial states = the 300 samples of the bundled mini dataset drawn with RandomState(0),
+device-side auto-reset on _has_fallen or after 1000 control steps. A "step" = one control step of every
+environment (= 10 physics substeps + observation + reward + termination + resets), one kernel launch.
+Environments are independent: ranks shard them (weak scaling), the only collective is the metric
+all-reduce (RCCL) at report time.
+
+The timed region holds inputs resident in HBM (state lives on the device); it is bracketed by a barrier +
+device synchronisation on both sides, the maximum over ranks is taken.
+roofline: this path is not HBM-bound; `achieved` = algorithmic bytes per launch
+(636 B per env-step incl. warm start x envs) / mean kernel duration measured with HIP events on the
+library's own stream (lm_rollout returns it), against the 8 TB/s HBM peak — expect ~1e-4..1e-3.
+cpu_baseline: the fp64 C oracle restatement ("port"), single thread, on a bounded sample of the same
+workload (rank 0, N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes_per_env_step(nq, nv, nu, nobs):
+    # state in + state out + action + obs + reward + done, plus the solver warm start in/out
+    return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv
+
+
+def cpu_baseline(env, table, budget_s=12.0):
+    """fp64 oracle restatement, one thread, zero action, same initial-state distribution; bounded sample."""
+    from loco_mujoco_amd.model_blob import pack_model
+    from oracle.pyoracle import Oracle
+    oracle = Oracle(pack_model(env._model))
+    rs = np.random.RandomState(0)
+    ctrl = np.zeros(env._model.nu)
+    steps, t0, n_env = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        row = table[rs.randint(0, 3) * 100 + rs.randint(0, 100)]
+        q, v, w = row[:18].copy(), row[18:36].copy(), np.zeros(18)
+        n_env += 1
+        for _ in range(25):
+            q, v, w, _ = oracle.step(q, v, ctrl, 10, w)
+            steps += 1
+            if env._has_fallen(np.concatenate([q[2:], v, row[36:39]])):
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample="%d control steps over %d episodes of UnitreeA1.simple (zero action, until fallen or 25 steps), "
+                       "fp64 C oracle restatement, 1 thread, %.1f s" % (steps, n_env, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from loco_mujoco_amd import LocoEnv
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+
+    n = args.envs_per_gpu
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    table = env._reset_table()
+    hm = HipModel(env._chain_model(), device=local_rank)
+    b = HipBatch(hm, n)
+    offset = rank * n
+    rs = np.random.RandomState(0)
+    traj, step = rs.randint(0, 3, n * world), rs.randint(0, 100, n * world)
+    rows = table[(traj * 100 + step)[offset:offset + n]]
+    b.set_reset_table(table, seed=0, global_env_offset=offset)
+    b.set_auto_reset(True, horizon=env.info.horizon)
+    b.set_state(rows[:, :18], rows[:, 18:36])
+    b.set_goal(rows[:, 36:39])
+
+    def barrier():
+        b.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    b.rollout(args.warmup, action_mode=0)
+    b.stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    st = b.rollout(args.steps, action_mode=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
+                     st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"]], dtype=np.float64)
+    if dist is not None:
+        import torch
+        t = torch.tensor(vals, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        kernel_ms = float(tmax[8])
+        vals = t.cpu().numpy()
+    else:
+        kernel_ms = vals[8]
+    if rank != 0:
+        return
+    env_steps = vals[1]
+    value = env_steps / elapsed
+    nq = nv = env._model.nv
+    bytes_per_launch = algorithmic_bytes_per_env_step(nq, nv, env._model.nu, 37) * n
+    launch_s = kernel_ms * 1e-3 / args.steps
+    achieved = bytes_per_launch / launch_s / 1e9
+    out = {
+        "metric": "env-steps/sec at 4096 envs/GPU; qpos Linf vs CPU MuJoCo",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "UnitreeA1.simple, %d envs/GPU, zero-action rollout, device-side auto-reset "
+                               "(horizon 1000), 10 physics substeps per env-step" % n,
+                   "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "step_kernel<3,4,false>", "kernel_ms_per_launch": 1e3 * launch_s,
+                     "note": "path is VALU/latency-bound by design (SURVEY.md 8d): 636 algorithmic B per env-step"},
+        "stats": {"episodes": vals[2], "mean_reward": vals[3] / max(env_steps, 1), "nan_resets": vals[4],
+                  "overflow_contacts": vals[5], "unhandled_geom_substeps": vals[6],
+                  "newton_iters_per_substep": vals[7] / max(env_steps * 10, 1),
+                  "physics_substeps_per_s": 10 * value},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(env, table)
+        out["cpu_baseline"]["gpu_over_cpu_core"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

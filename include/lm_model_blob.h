@@ -1,5 +1,7 @@
 /*
- * lm_model_blob.h — flat model/task description handed across the C-ABI.
+ * lm_model_blob.h — flat GENERAL model description (body tree, joints, geoms, actuators) consumed by the
+ * fp64 test oracle (oracle/oracle.c). The product library takes the lowered "chain model" instead
+ * (lm_layout.h, lm_model_create in locohip.h).
  *
  * The reference hands MuJoCo an XML string (mushroom-rl MultiMuJoCo.__init__, invoked from
  * /root/reference/loco_mujoco/environments/base.py:109-111 -> mujoco.MjModel.from_xml_string) and
@@ -7,7 +9,6 @@
  * (/root/reference/loco_mujoco/environments/quadrupeds/unitreeA1.py:778-854, :503-536).
  * Here the host-side mini-compiler (loco_mujoco_amd/mjcf.py) produces ONE array of float64 ("blob");
  * integers are stored as doubles. This header only fixes the layout; it contains no algorithm.
- * It is shared by the product library (loco_mujoco_amd/csrc) and by the test oracle (oracle/).
  */
 #ifndef LM_MODEL_BLOB_H
 #define LM_MODEL_BLOB_H
@@ -42,26 +43,5 @@ enum { LM_INT_EULER = 0, LM_INT_RK4 = 1 };
  *  geom_solref[2ng] geom_solimp[5ng] geom_margin[ng] geom_gap[ng]
  *  act_dof[nu] act_gear[nu] act_ctrlrange[2nu] act_ctrllimited[nu]
  */
-
-/*
- * Task blob (float64 array): what LocoEnv.step() does around the physics
- * (reference: base.py:584-621 obs/action, unitreeA1.py:454-476,503-536, reward.py:66-117).
- *
- *  [0] magic 'LMT1'  [1] nobs  [2] n_qpos_obs  [3] n_qvel_obs  [4] n_goal (per-env constants appended
- *  to the observation)  [5] reward_type  [6] n_term  [7] n_substeps  [8..15] reward params
- *  then: qpos_obs_idx[n_qpos_obs]  qvel_obs_idx[n_qvel_obs]  act_ctrl_idx[nu]  act_mean[nu]
- *        act_delta[nu]  term_obs_idx[n_term] term_lo[n_term] term_hi[n_term]
- *
- *  observation = [ qpos[qpos_obs_idx], qvel[qvel_obs_idx], goal[0..n_goal) ]
- *  ctrl[act_ctrl_idx[k]] = action[k]*act_delta[k] + act_mean[k]
- *  done = any_k ( obs[term_obs_idx[k]] < term_lo[k]  ||  obs[term_obs_idx[k]] > term_hi[k] )
- *  reward_type: 0 none; 1 target-velocity exp(-(obs[p0]-p1)^2);
- *               2 velocity-vector exp(-5*|| (obs[p0],obs[p1]) - obs[p4]*(obs[p2],obs[p3]) ||),
- *  evaluated on the PREVIOUS observation (reward.py:73,110-115).
- */
-#define LM_TASK_MAGIC 0x4C4D5431 /* "LMT1" */
-enum { LMT_MAGIC = 0, LMT_NOBS, LMT_NQPOS_OBS, LMT_NQVEL_OBS, LMT_NGOAL, LMT_REWARD_TYPE, LMT_NTERM,
-       LMT_NSUBSTEPS, LMT_REWARD_P0 = 8, LMT_HEADER_SIZE = 16 };
-enum { LM_REWARD_NONE = 0, LM_REWARD_TARGET_VELOCITY = 1, LM_REWARD_VELOCITY_VECTOR = 2 };
 
 #endif

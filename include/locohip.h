@@ -6,7 +6,7 @@
  * below are what a loco-mujoco maintainer would bind with ctypes to replace, for
  * a whole batch of environments at once:
  *
- *   lm_model_create     <- MjModel.from_xml_string + MultiMuJoCo.__init__ bookkeeping
+ *   lm_model_create     <- MjModel.from_xml_string + MultiMuJoCo.__init__ bookkeeping (model upload)
  *                          (/root/reference/loco_mujoco/environments/base.py:109-126;
  *                           obs/action spec unitreeA1.py:778-854)
  *   lm_batch_create     <- mujoco.MjData(model), one per environment (base.py:185)
@@ -74,9 +74,10 @@ typedef struct {
 int lm_device_count(void);
 const char* lm_last_error(void);
 
-/* model_blob / task_blob: float64 arrays laid out as in lm_model_blob.h */
-int lm_model_create(const double* model_blob, size_t n_model, const double* task_blob, size_t n_task,
-                    int device, lm_model** out);
+/* chain_model: float64 array laid out as in lm_layout.h (header H_* + constant table), produced by the
+   host-side mini-compiler + lowering (loco_mujoco_amd/mjcf.py, lowering.py) from the MJCF model and the
+   task description (observation/action spec, termination bounds, reward). */
+int lm_model_create(const double* chain_model, size_t n, int device, lm_model** out);
 void lm_model_destroy(lm_model* m);
 int lm_model_dims(const lm_model* m, lm_dims* out);
 

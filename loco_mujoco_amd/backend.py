@@ -55,7 +55,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.lm_device_count.restype = C.c_int
     lib.lm_last_error.restype = C.c_char_p
-    lib.lm_model_create.argtypes = [_D, C.c_size_t, _D, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    lib.lm_model_create.argtypes = [_D, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     lib.lm_model_destroy.argtypes = [C.c_void_p]
     lib.lm_model_destroy.restype = None
     lib.lm_model_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
@@ -100,14 +100,13 @@ def _mask(mask, n):
 
 
 class HipModel:
-    def __init__(self, model_blob, task_blob, device=0):
+    def __init__(self, chain_model, device=0):
         lib = load_library()
         if lib.lm_device_count() <= 0:
             raise BackendError("no HIP device visible: the batched simulator needs an MI355X (no CPU fallback)")
-        mb = np.ascontiguousarray(model_blob, dtype=np.float64)
-        tb = np.ascontiguousarray(task_blob, dtype=np.float64)
+        cm = np.ascontiguousarray(chain_model, dtype=np.float64)
         h = C.c_void_p()
-        _check(lib.lm_model_create(mb.ctypes.data_as(_D), len(mb), tb.ctypes.data_as(_D), len(tb), device, C.byref(h)))
+        _check(lib.lm_model_create(cm.ctypes.data_as(_D), len(cm), device, C.byref(h)))
         self._h = h
         d = Dims()
         _check(lib.lm_model_dims(h, C.byref(d)))

@@ -1,0 +1,985 @@
+// lm_core.h — one physics substep of the "root + chains" model, written for ONE LANE = ONE CHAIN.
+//
+// The 4 lanes of a quad simulate one environment: lane c owns chain c (A1: one leg), every lane carries a
+// replica of the 6 root dofs. Cross-lane traffic is nothing but 4-lane sums (Q::sum), which on gfx950 are two
+// DPP quad_perm adds — no LDS, no barriers. All link quantities are spatial vectors about the root-frame
+// origin O in world axes, so neither Jacobians nor per-link transforms are ever stored:
+//   * joint-space inertia  M_ij = S_i . (Ic_k S_j)           (composite rigid body, Ic about O)
+//   * bias forces          spatial Newton-Euler about O       (gravity as base acceleration)
+//   * contact Jacobians    column j of a floor contact at r = p - O is (v_j + w_j x r, w_j) re-labelled by the
+//                          axis-aligned contact frame; rebuilt from the 9 twists whenever needed
+//   * M and the Newton Hessian H = M + J^T W J share the arrow sparsity {chain block, chain-root coupling,
+//     root block}: every lane eliminates its own chain block, the 6x6 root Schur complement is a 21-float
+//     quad sum, its Cholesky is replicated.
+// Semantics restated: MuJoCo 2.3.7 mj_step (third party; the reference reaches it through mushroom-rl's
+// MuJoCo.step): soft constraints with solref/solimp impedance, friction-loss,
+// joint-limit and elliptic-cone contact rows, Newton on the convex primal problem with exact line search,
+// semi-implicit Euler with implicit joint damping.
+//
+// This header has no HIP dependency: the includer defines LM_DEV (function qualifier) and supplies the quad
+// policy Q {sum(float), any(bool)}. csrc/lm_kernels.hip instantiates it with DPP intrinsics.
+#pragma once
+#include <math.h>
+#include "../../include/lm_layout.h"
+
+namespace lm {
+
+struct V3 { float x, y, z; };
+LM_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+LM_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LM_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LM_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+LM_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+LM_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+struct Sp { V3 w, v; };   // spatial motion (angular, linear at O)  |  spatial force (moment about O, force)
+LM_DEV Sp sp0() { Sp s; s.w = v3(0, 0, 0); s.v = v3(0, 0, 0); return s; }
+LM_DEV Sp operator+(Sp a, Sp b) { Sp s; s.w = a.w + b.w; s.v = a.v + b.v; return s; }
+LM_DEV Sp operator*(float k, Sp a) { Sp s; s.w = k * a.w; s.v = k * a.v; return s; }
+LM_DEV float spdot(Sp m, Sp f) { return dot(m.w, f.w) + dot(m.v, f.v); }   // motion . force
+
+struct M3 { float a[9]; };     // row-major
+LM_DEV V3 mul(const M3& m, V3 v) {
+  return v3(m.a[0] * v.x + m.a[1] * v.y + m.a[2] * v.z, m.a[3] * v.x + m.a[4] * v.y + m.a[5] * v.z,
+            m.a[6] * v.x + m.a[7] * v.y + m.a[8] * v.z);
+}
+LM_DEV M3 mul(const M3& p, const M3& q) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.a[3 * i + j] = p.a[3 * i] * q.a[j] + p.a[3 * i + 1] * q.a[3 + j] + p.a[3 * i + 2] * q.a[6 + j];
+  return r;
+}
+// R <- Rot(unit axis u, angle) * R
+LM_DEV void rotate_world(M3& R, V3 u, float angle) {
+  float s = sinf(angle), c1 = 1.0f - cosf(angle);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    V3 col = v3(R.a[j], R.a[3 + j], R.a[6 + j]);
+    V3 uc = cross(u, col);
+    V3 uuc = cross(u, uc);
+    col = col + s * uc + c1 * uuc;
+    R.a[j] = col.x; R.a[3 + j] = col.y; R.a[6 + j] = col.z;
+  }
+}
+
+// spatial inertia about O: mass, first moment h = m (c - O), rotational inertia about O (symmetric 6)
+struct SpI { float m; V3 h; float xx, yy, zz, xy, xz, yz; };
+LM_DEV SpI spi0() { SpI I; I.m = 0; I.h = v3(0, 0, 0); I.xx = I.yy = I.zz = I.xy = I.xz = I.yz = 0; return I; }
+LM_DEV SpI operator+(const SpI& a, const SpI& b) {
+  SpI I; I.m = a.m + b.m; I.h = a.h + b.h; I.xx = a.xx + b.xx; I.yy = a.yy + b.yy; I.zz = a.zz + b.zz;
+  I.xy = a.xy + b.xy; I.xz = a.xz + b.xz; I.yz = a.yz + b.yz; return I;
+}
+LM_DEV V3 imul(const SpI& I, V3 w) {
+  return v3(I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z);
+}
+// momentum of inertia I under motion S: (angular about O, linear)
+LM_DEV Sp apply(const SpI& I, Sp S) {
+  Sp f; f.v = I.m * S.v + cross(S.w, I.h); f.w = imul(I, S.w) + cross(I.h, S.v); return f;
+}
+// body inertia (m, com offset r from O, world inertia about com as symmetric 6) -> spatial inertia about O
+LM_DEV SpI make_spi(float m, V3 r, const float* Iw) {
+  SpI I; I.m = m; I.h = m * r;
+  float rr = dot(r, r);
+  I.xx = Iw[0] + m * (rr - r.x * r.x); I.yy = Iw[1] + m * (rr - r.y * r.y); I.zz = Iw[2] + m * (rr - r.z * r.z);
+  I.xy = Iw[3] - m * r.x * r.y; I.xz = Iw[4] - m * r.x * r.z; I.yz = Iw[5] - m * r.y * r.z;
+  return I;
+}
+// R diag/sym(I_local) R^T as symmetric 6 (xx,yy,zz,xy,xz,yz)
+LM_DEV void rotate_inertia(const M3& R, const float* Il, float* Iw) {
+  float L[9] = {Il[0], Il[3], Il[4], Il[3], Il[1], Il[5], Il[4], Il[5], Il[2]};
+  float T[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) T[3 * i + j] = R.a[3 * i] * L[j] + R.a[3 * i + 1] * L[3 + j] + R.a[3 * i + 2] * L[6 + j];
+  auto e = [&](int i, int j) { return T[3 * i] * R.a[3 * j] + T[3 * i + 1] * R.a[3 * j + 1] + T[3 * i + 2] * R.a[3 * j + 2]; };
+  Iw[0] = e(0, 0); Iw[1] = e(1, 1); Iw[2] = e(2, 2); Iw[3] = e(0, 1); Iw[4] = e(0, 2); Iw[5] = e(1, 2);
+}
+
+struct Params {
+  float h;            // timestep
+  V3 g;               // gravity
+  int iterations;     // Newton iteration cap
+  float tolerance;    // stop when scale*|grad| < tolerance (float32-appropriate)
+  float scale;        // 1 / (meaninertia * nv)
+  int nv;
+};
+
+struct Counters { int solver_iters; int overflow; int unhandled; int ncon; };
+
+// optional stage dump for parity tests (one environment): written by the owning lanes
+struct Debug {
+  float* M;        // [nv*nv]
+  float* bias; float* smooth; float* qacc_smooth; float* qacc; float* qfrc_constraint;   // [nv]
+};
+
+constexpr float kMinVal = 1e-15f;
+LM_DEV int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // lower-triangular index, j <= i
+
+LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float pos, float margin) {
+  float s0 = s[0], s1 = s[stride], s2 = s[2 * stride], s3 = s[3 * stride], s4 = s[4 * stride];
+  if (s0 == s1 || s2 <= kMinVal) return 0.5f * (s0 + s1);
+  float x = fabsf((pos - margin) / s2);
+  if (x >= 1.0f) return s1;
+  if (x <= 0.0f) return s0;
+  float y;
+  if (s4 == 1.0f) y = x;
+  else if (s4 == 2.0f) y = (x <= s3) ? x * x / s3 : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - s3);
+  else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1.0f);
+  else y = 1.0f - powf(1.0f - x, s4) / powf(1.0f - s3, s4 - 1.0f);
+  return s0 + y * (s1 - s0);
+}
+
+// ---- contact slot (one floor contact of this lane's chain) -------------------------------------------------
+struct Slot {
+  int on;        // 0 = empty
+  int link;      // link of this chain the geom sits on
+  int g;         // geom block index (for constants)
+  V3 r;          // contact point - O
+  float dist;
+  float D0;      // 1/R of the normal row
+  float aref[6];
+};
+
+// Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
+// because their D is 0). Dj = D of row j, fr = friction coefficients of rows 1..5, mu = regularised cone mu.
+// zone: 0 satisfied, 1 quadratic, 2 cone
+struct ConeEval { int zone; float cost; float f[6]; };
+
+template <bool WANT_FORCE>
+LM_DEV ConeEval cone_eval(const float* jar, const float* Dj, const float* fr, float mu, int dim) {
+  ConeEval e; e.cost = 0; e.zone = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) e.f[j] = 0;
+  float N = jar[0] * mu, T2 = 0, U[6];
+  U[0] = N;
+#pragma unroll
+  for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? jar[j] * fr[j - 1] : 0.0f; T2 = fmaf(U[j], U[j], T2); }
+  float T = sqrtf(T2);
+  if (N >= mu * T || (T <= 0 && N >= 0)) return e;
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    e.zone = 1;
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) { e.cost = fmaf(0.5f * Dj[j] * jar[j], jar[j], e.cost); if (WANT_FORCE) e.f[j] = -Dj[j] * jar[j]; }
+    return e;
+  }
+  e.zone = 2;
+  float Dm = Dj[0] / fmaxf(kMinVal, mu * mu * (1.0f + mu * mu));
+  float NmT = N - mu * T;
+  e.cost = 0.5f * Dm * NmT * NmT;
+  if (WANT_FORCE) {
+    e.f[0] = -Dm * NmT * mu;
+    float k = -e.f[0] / T;
+#pragma unroll
+    for (int j = 1; j < 6; j++) if (j < dim) e.f[j] = k * U[j] * fr[j - 1];
+  }
+  return e;
+}
+
+// 6x6 symmetric Hessian (lower tri, 21) of the cone cost w.r.t. jar
+LM_DEV void cone_hessian(const float* jar, const float* Dj, const float* fr, float mu, int dim, int zone, float* Hc) {
+#pragma unroll
+  for (int i = 0; i < 21; i++) Hc[i] = 0;
+  if (zone == 1) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) Hc[tri(j, j)] = Dj[j];
+    return;
+  }
+  if (zone != 2) return;
+  float Sc[6], U[6], T2 = 0;
+  Sc[0] = mu; U[0] = jar[0] * mu;
+#pragma unroll
+  for (int j = 1; j < 6; j++) { Sc[j] = (j < dim) ? fr[j - 1] : 0.0f; U[j] = jar[j] * Sc[j]; T2 = fmaf(U[j], U[j], T2); }
+  float T = sqrtf(T2), iT = 1.0f / T;
+  float Dm = Dj[0] / fmaxf(kMinVal, mu * mu * (1.0f + mu * mu)), g = U[0] - mu * T;
+  Hc[0] = Dm * Sc[0] * Sc[0];
+#pragma unroll
+  for (int j = 1; j < 6; j++) Hc[tri(j, 0)] = -Dm * mu * U[j] * iT * Sc[j] * Sc[0];
+#pragma unroll
+  for (int j = 1; j < 6; j++)
+#pragma unroll
+    for (int k = 1; k <= j; k++) {
+      float tt = U[j] * U[k] * iT * iT;
+      Hc[tri(j, k)] = (Dm * mu * mu * tt - Dm * g * mu * ((j == k ? 1.0f : 0.0f) - tt) * iT) * Sc[j] * Sc[k];
+    }
+}
+
+// first and second derivative of the cone cost along jar + alpha*jv
+LM_DEV void cone_line(const float* jar, const float* jv, float alpha, const float* Dj, const float* fr, float mu, int dim,
+                      float& d1, float& d2) {
+  float x0 = fmaf(alpha, jv[0], jar[0]);
+  float N = x0 * mu, Np = jv[0] * mu, UU = 0, UV = 0, VV = 0;
+#pragma unroll
+  for (int j = 1; j < 6; j++) if (j < dim) {
+    float u = fmaf(alpha, jv[j], jar[j]) * fr[j - 1], v = jv[j] * fr[j - 1];
+    UU = fmaf(u, u, UU); UV = fmaf(u, v, UV); VV = fmaf(v, v, VV);
+  }
+  float T = sqrtf(UU);
+  if (N >= mu * T || (T <= 0 && N >= 0)) return;
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) { float xj = fmaf(alpha, jv[j], jar[j]); d1 = fmaf(Dj[j] * xj, jv[j], d1); d2 = fmaf(Dj[j] * jv[j], jv[j], d2); }
+    return;
+  }
+  float Dm = Dj[0] / fmaxf(kMinVal, mu * mu * (1.0f + mu * mu));
+  float Tp = UV / T, Tpp = VV / T - UV * UV / (T * T * T);
+  float NmT = N - mu * T, NmTp = Np - mu * Tp;
+  d1 = fmaf(Dm * NmT, NmTp, d1);
+  d2 += Dm * (NmTp * NmTp - NmT * mu * Tpp);
+}
+
+// ---- arrow-structured factorisation -------------------------------------------------------------------------
+// H = [Hcc (MC x MC, per lane), Hcr (MC x 6, per lane); Hrr (6x6): `Hrr_rep` replicated part + quad-sum of
+// `Hrr_part`]. Overwrites: Hcc -> Lcc (lower Cholesky), Hcr -> W = Lcc^-1 Hcr, Lrr <- chol(Hrr - sum W^T W).
+template <class Q, int MC>
+LM_DEV void arrow_factor(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, const float* Hrr_part, float* Lrr) {
+#pragma unroll
+  for (int j = 0; j < MC; j++) {
+    float s = Hcc[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s = fmaf(-Hcc[tri(j, k)], Hcc[tri(j, k)], s);
+    float d = sqrtf(fmaxf(s, 1e-30f)), id = 1.0f / d;
+    Hcc[tri(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < MC; i++) {
+      float t = Hcc[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fmaf(-Hcc[tri(i, k)], Hcc[tri(j, k)], t);
+      Hcc[tri(i, j)] = t * id;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int i = 0; i < MC; i++) {
+      float t = Hcr[i][r];
+#pragma unroll
+      for (int k = 0; k < i; k++) t = fmaf(-Hcc[tri(i, k)], Hcr[k][r], t);
+      Hcr[i][r] = t / Hcc[tri(i, i)];
+    }
+  float S[21];
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      float t = Hrr_part[tri(a, b)];
+#pragma unroll
+      for (int k = 0; k < MC; k++) t = fmaf(-Hcr[k][a], Hcr[k][b], t);
+      S[tri(a, b)] = Q::sum(t) + Hrr_rep[tri(a, b)];
+    }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float s = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s = fmaf(-Lrr[tri(j, k)], Lrr[tri(j, k)], s);
+    float d = sqrtf(fmaxf(s, 1e-30f)), id = 1.0f / d;
+    Lrr[tri(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float t = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fmaf(-Lrr[tri(i, k)], Lrr[tri(j, k)], t);
+      Lrr[tri(i, j)] = t * id;
+    }
+  }
+}
+
+// solve H x = g in place (xc chain part, xr root part) with the factors from arrow_factor
+template <class Q, int MC>
+LM_DEV void arrow_solve(const float* Lcc, const float (*W)[6], const float* Lrr, float* xc, float* xr) {
+#pragma unroll
+  for (int i = 0; i < MC; i++) {
+    float t = xc[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t = fmaf(-Lcc[tri(i, k)], xc[k], t);
+    xc[i] = t / Lcc[tri(i, i)];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float t = 0;
+#pragma unroll
+    for (int k = 0; k < MC; k++) t = fmaf(W[k][r], xc[k], t);
+    xr[r] -= Q::sum(t);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t = fmaf(-Lrr[tri(i, k)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t = fmaf(-Lrr[tri(k, i)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 0; i < MC; i++) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) xc[i] = fmaf(-W[i][r], xr[r], xc[i]);
+  }
+#pragma unroll
+  for (int i = MC - 1; i >= 0; i--) {
+    float t = xc[i];
+#pragma unroll
+    for (int k = i + 1; k < MC; k++) t = fmaf(-Lcc[tri(k, i)], xc[k], t);
+    xc[i] = t / Lcc[tri(i, i)];
+  }
+}
+
+// contact-frame components (n=+z, t1=+y, t2=-x; then the same for rotation) of motion S at r
+LM_DEV void contact_rows(Sp S, V3 r, float* out) {
+  V3 u = S.v + cross(S.w, r);
+  out[0] = u.z; out[1] = u.y; out[2] = -u.x; out[3] = S.w.z; out[4] = S.w.y; out[5] = -S.w.x;
+}
+// spatial force about O of contact-frame force f[6] applied at r
+LM_DEV Sp contact_wrench(const float* f, V3 r) {
+  V3 lin = v3(-f[2], f[1], f[0]), tor = v3(-f[5], f[4], f[3]);
+  Sp F; F.v = lin; F.w = tor + cross(r, lin); return F;
+}
+
+// ---- the substep ---------------------------------------------------------------------------------------------
+// cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
+// actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
+template <class Q, int MC, int NS>
+LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
+                    float* war, float* wac, const float* actr, const float* actc, Counters& cnt, const Debug* dbg) {
+  const float* rb = cm + LM_CM_ROOT;
+#define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
+#define CH(f) cm[LM_CM_CHAINS + (f) * LM_NCHAIN + c]
+#define LK(k, f) CH(LM_C_LINKS + (k) * LM_LINK_SIZE + (f))
+#define LX(k, f) LK(k, LM_D_SIZE + (f))
+#define GE(g, f) CH(LM_C_GEOMS + (g) * LM_G_SIZE + (f))
+  const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
+  const int nl = (int)CH(LM_C_NLINKS);
+
+  // ================= position stage: kinematics, twists, inertias, contacts =================
+  M3 R; V3 p;
+#pragma unroll
+  for (int i = 0; i < 9; i++) R.a[i] = rb[LM_R_R0 + i];
+  p = v3(rb[LM_R_TX], rb[LM_R_TY], rb[LM_R_TZ]);
+  V3 ru[6], ra[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float t = RD(k, LM_D_TYPE);
+    V3 al = v3(RD(k, LM_D_PX), RD(k, LM_D_PY), RD(k, LM_D_PZ));
+    ra[k] = p + mul(R, al);
+    ru[k] = mul(R, v3(RD(k, LM_D_AX), RD(k, LM_D_AY), RD(k, LM_D_AZ)));
+    if (t != 0.0f) { rotate_world(R, ru[k], qr[k]); p = ra[k] - mul(R, al); }
+    else p = p + qr[k] * ru[k];
+  }
+  const V3 O = p;
+  Sp Sr[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (RD(k, LM_D_TYPE) != 0.0f) { Sr[k].w = ru[k]; Sr[k].v = cross(ru[k], O - ra[k]); }
+    else { Sr[k].w = v3(0, 0, 0); Sr[k].v = ru[k]; }
+  }
+  // root body inertia about O
+  SpI Iroot;
+  {
+    float Iw[6], Il[6] = {rb[LM_R_IXX], rb[LM_R_IXX + 1], rb[LM_R_IXX + 2], rb[LM_R_IXX + 3], rb[LM_R_IXX + 4], rb[LM_R_IXX + 5]};
+    rotate_inertia(R, Il, Iw);
+    Iroot = make_spi(rb[LM_R_MASS], mul(R, v3(rb[LM_R_CX], rb[LM_R_CY], rb[LM_R_CZ])), Iw);
+  }
+  // root velocity / acceleration recursion (replicated), base acceleration = -gravity
+  Sp Vroot = sp0(), Aroot; Aroot.w = v3(0, 0, 0); Aroot.v = v3(-P.g.x, -P.g.y, -P.g.z);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    Sp Sd; Sd.w = cross(Vroot.w, Sr[k].w); Sd.v = cross(Vroot.w, Sr[k].v) + cross(Vroot.v, Sr[k].w);
+    Vroot = Vroot + vr[k] * Sr[k];
+    Aroot = Aroot + vr[k] * Sd;
+  }
+  // collider-less root geoms that reach the floor are counted, not simulated
+  {
+    int nu = (int)rb[LM_R_NUNSUP];
+    for (int i = 0; i < nu; i++) {
+      const float* u = rb + LM_R_UNSUP + i * LM_U_SIZE;
+      V3 s = O + mul(R, v3(u[1], u[2], u[3]));
+      if (s.z - u[4] < u[5] && c == 0) cnt.unhandled++;
+    }
+  }
+
+  // chain
+  Sp Sc[MC], Vc[MC], Ac[MC];
+  SpI Ic[MC];
+  Slot slot[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) slot[s].on = 0;
+  int nslot = 0;
+  {
+    M3 Rk = R; V3 pk = O;
+    Sp V = Vroot, A = Aroot;
+    const int ng = (int)CH(LM_C_NGEOMS), nun = (int)CH(LM_C_NUNSUP);
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      if (k < nl) {
+        M3 T;
+#pragma unroll
+        for (int i = 0; i < 9; i++) T.a[i] = LX(k, LM_L_R0 + i);
+        pk = pk + mul(Rk, v3(LX(k, LM_L_TX), LX(k, LM_L_TY), LX(k, LM_L_TZ)));
+        Rk = mul(Rk, T);
+        float t = LK(k, LM_D_TYPE);
+        V3 al = v3(LK(k, LM_D_PX), LK(k, LM_D_PY), LK(k, LM_D_PZ));
+        V3 aw = pk + mul(Rk, al);
+        V3 uw = mul(Rk, v3(LK(k, LM_D_AX), LK(k, LM_D_AY), LK(k, LM_D_AZ)));
+        if (t != 0.0f) { rotate_world(Rk, uw, qc[k]); pk = aw - mul(Rk, al); Sc[k].w = uw; Sc[k].v = cross(uw, O - aw); }
+        else { pk = pk + qc[k] * uw; Sc[k].w = v3(0, 0, 0); Sc[k].v = uw; }
+        Sp Sd; Sd.w = cross(V.w, Sc[k].w); Sd.v = cross(V.w, Sc[k].v) + cross(V.v, Sc[k].w);
+        V = V + vc[k] * Sc[k];
+        A = A + vc[k] * Sd;
+        Vc[k] = V; Ac[k] = A;
+        float Il[6], Iw[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Il[i] = LX(k, LM_L_IXX + i);
+        rotate_inertia(Rk, Il, Iw);
+        Ic[k] = make_spi(LX(k, LM_L_MASS), pk + mul(Rk, v3(LX(k, LM_L_CX), LX(k, LM_L_CY), LX(k, LM_L_CZ))) - O, Iw);
+        // floor contacts of the geoms on this link (plane z = 0, normal +z)
+        for (int g = 0; g < ng; g++) {
+          if ((int)GE(g, LM_G_LINK) != k) continue;
+          V3 ctr = pk + mul(Rk, v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ)));
+          if (ctr.z - GE(g, LM_G_RBOUND) > 0.0f) continue;        // margin-less bounding-sphere prune
+          float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
+          V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
+          int npt = (GE(g, LM_G_TYPE) == 2.0f) ? 2 : 1;
+          for (int e = 0; e < npt; e++) {
+            V3 sc = (npt == 2) ? ctr + ((e == 0) ? half : -half) * ax : ctr;
+            float dist = sc.z - rad;
+            if (dist >= margin) continue;
+            if (nslot >= NS) { cnt.overflow++; continue; }
+            V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
+#pragma unroll
+            for (int s = 0; s < NS; s++) if (s == nslot) { slot[s].on = 1; slot[s].link = k; slot[s].g = g; slot[s].r = cp; slot[s].dist = dist; }
+            nslot++;
+          }
+        }
+        for (int i = 0; i < nun; i++) {
+          if ((int)CH(LM_C_UNSUP + i * LM_U_SIZE) != k) continue;
+          V3 s = pk + mul(Rk, v3(CH(LM_C_UNSUP + i * LM_U_SIZE + 1), CH(LM_C_UNSUP + i * LM_U_SIZE + 2), CH(LM_C_UNSUP + i * LM_U_SIZE + 3)));
+          if (s.z - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
+        }
+      } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
+    }
+  }
+  cnt.ncon += nslot;
+
+  // ================= inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) =================
+  float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
+  float bias_c[MC], bias_r[6];
+  {
+    SpI comp = spi0();
+    Sp Fsuf = sp0();
+#pragma unroll
+    for (int k = MC - 1; k >= 0; k--) {
+      // body force of link k:  I A + V x* (I V)
+      Sp mom = apply(Ic[k], Vc[k]);
+      Sp F = apply(Ic[k], Ac[k]);
+      F.w = F.w + cross(Vc[k].w, mom.w) + cross(Vc[k].v, mom.v);
+      F.v = F.v + cross(Vc[k].w, mom.v);
+      Fsuf = Fsuf + F;
+      bias_c[k] = spdot(Sc[k], Fsuf);
+      comp = comp + Ic[k];
+      Sp L = apply(comp, Sc[k]);
+#pragma unroll
+      for (int j = 0; j <= k; j++) Mcc[tri(k, j)] = spdot(Sc[j], L);
+#pragma unroll
+      for (int r = 0; r < 6; r++) Mcr[k][r] = spdot(Sr[r], L);
+      Mcc[tri(k, k)] += (k < nl) ? LK(k, LM_D_ARM) : 1.0f;
+    }
+    // whole-robot composite and force: root body + sum over the 4 chains
+    SpI tot = Iroot;
+    tot.m += Q::sum(comp.m);
+    tot.h = tot.h + v3(Q::sum(comp.h.x), Q::sum(comp.h.y), Q::sum(comp.h.z));
+    tot.xx += Q::sum(comp.xx); tot.yy += Q::sum(comp.yy); tot.zz += Q::sum(comp.zz);
+    tot.xy += Q::sum(comp.xy); tot.xz += Q::sum(comp.xz); tot.yz += Q::sum(comp.yz);
+    Sp mom = apply(Iroot, Vroot);
+    Sp F = apply(Iroot, Aroot);
+    F.w = F.w + cross(Vroot.w, mom.w) + cross(Vroot.v, mom.v);
+    F.v = F.v + cross(Vroot.w, mom.v);
+    F.w = F.w + v3(Q::sum(Fsuf.w.x), Q::sum(Fsuf.w.y), Q::sum(Fsuf.w.z));
+    F.v = F.v + v3(Q::sum(Fsuf.v.x), Q::sum(Fsuf.v.y), Q::sum(Fsuf.v.z));
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      Sp L = apply(tot, Sr[i]);
+#pragma unroll
+      for (int j = 0; j <= i; j++) Mrr[tri(i, j)] = spdot(Sr[j], L);
+      Mrr[tri(i, i)] += RD(i, LM_D_ARM);
+      bias_r[i] = spdot(Sr[i], F);
+    }
+  }
+
+  // ================= smooth forces =================
+  float sm_r[6], sm_c[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) sm_r[i] = -RD(i, LM_D_STIFF) * qr[i] - RD(i, LM_D_DAMP) * vr[i] - bias_r[i] + actr[i];
+#pragma unroll
+  for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k]) : 0.0f;
+
+  // ================= constraint rows =================
+  // friction loss (root rows replicated, chain rows own), joint limits (chain + root), contacts (slots)
+  float fl_aref_r[6], fl_aref_c[MC];     // friction-loss reference accelerations
+  float lim_s_c[MC], lim_D_c[MC], lim_aref_c[MC];   // active limit: sign (+1 lower, -1 upper, 0 none)
+#pragma unroll
+  for (int i = 0; i < 6; i++) fl_aref_r[i] = -RD(i, LM_D_FLOSS_B) * vr[i];
+#pragma unroll
+  for (int k = 0; k < MC; k++) {
+    fl_aref_c[k] = 0; lim_s_c[k] = 0; lim_D_c[k] = 0; lim_aref_c[k] = 0;
+    if (k < nl) {
+      fl_aref_c[k] = -LK(k, LM_D_FLOSS_B) * vc[k];
+      if (LK(k, LM_D_LIMITED) != 0.0f) {
+        float dlo = qc[k] - LK(k, LM_D_LO), dhi = LK(k, LM_D_HI) - qc[k];
+        float sgn = (dlo < 0.0f) ? 1.0f : ((dhi < 0.0f) ? -1.0f : 0.0f);
+        if (sgn != 0.0f) {
+          float dist = (sgn > 0) ? dlo : dhi;
+          float imp = impedance(&LK(k, LM_D_LIM_S0), LM_NCHAIN, dist, 0.0f);
+          float Rl = fmaxf(kMinVal, (1.0f - imp) * LK(k, LM_D_INVW) / imp);
+          lim_s_c[k] = sgn; lim_D_c[k] = 1.0f / Rl;
+          lim_aref_c[k] = -LK(k, LM_D_LIM_B) * (sgn * vc[k]) - LK(k, LM_D_LIM_K) * imp * dist;
+        }
+      }
+    }
+  }
+  // (root joint limits: none of the supported models limits a root dof; rejected at model creation)
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    if (slot[s].on) {
+      int g = slot[s].g;
+      float margin = GE(g, LM_G_MARGIN);
+      float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, slot[s].dist, margin);
+      float R0 = fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN) / imp);
+      slot[s].D0 = 1.0f / R0;
+      Sp Vl = Vroot;
+#pragma unroll
+      for (int k = 0; k < MC; k++) if (slot[s].link == k) Vl = Vc[k];
+      float vel[6];
+      contact_rows(Vl, slot[s].r, vel);
+      float B = GE(g, LM_G_B);
+#pragma unroll
+      for (int j = 0; j < 6; j++) slot[s].aref[j] = -B * vel[j];
+      slot[s].aref[0] -= GE(g, LM_G_K) * imp * (slot[s].dist - margin);
+    }
+  }
+
+  // ================= unconstrained acceleration =================
+  float Lcc[MC * (MC + 1) / 2], W[MC][6], Lrr[21], zero21[21];
+#pragma unroll
+  for (int i = 0; i < 21; i++) zero21[i] = 0;
+#pragma unroll
+  for (int i = 0; i < MC * (MC + 1) / 2; i++) Lcc[i] = Mcc[i];
+#pragma unroll
+  for (int k = 0; k < MC; k++)
+#pragma unroll
+    for (int r = 0; r < 6; r++) W[k][r] = Mcr[k][r];
+  arrow_factor<Q, MC>(Lcc, W, Mrr, zero21, Lrr);
+  float a0r[6], a0c[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) a0r[i] = sm_r[i];
+#pragma unroll
+  for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
+  arrow_solve<Q, MC>(Lcc, W, Lrr, a0c, a0r);
+
+  // ================= constraint solve: Newton on the primal problem =================
+  // helpers working on a candidate acceleration (xr, xc)
+  auto mulM = [&](const float* xr, const float* xc, float* yr, float* yc) {
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      float t = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) t = fmaf(Mcr[k][r], xr[r], t);
+#pragma unroll
+      for (int j = 0; j < MC; j++) t = fmaf(Mcc[(j <= k) ? tri(k, j) : tri(j, k)], xc[j], t);
+      yc[k] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      float t = 0;
+#pragma unroll
+      for (int k = 0; k < MC; k++) t = fmaf(Mcr[k][r], xc[k], t);
+      t = Q::sum(t);
+#pragma unroll
+      for (int j = 0; j < 6; j++) t = fmaf(Mrr[(j <= r) ? tri(r, j) : tri(j, r)], xr[j], t);
+      yr[r] = t;
+    }
+  };
+  // J x for contact slot s (no aref)
+  auto slotJx = [&](int s, const float* xr, const float* xc, float* out) {
+    Sp A = sp0();
+#pragma unroll
+    for (int r = 0; r < 6; r++) A = A + xr[r] * Sr[r];
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k <= slot[s].link) A = A + xc[k] * Sc[k];
+    contact_rows(A, slot[s].r, out);
+  };
+  auto slotD = [&](int s, float* Dj, float* fr, float& mu, int& dim) {
+    int g = slot[s].g;
+    dim = (int)GE(g, LM_G_DIM); mu = GE(g, LM_G_MU);
+    Dj[0] = slot[s].D0;
+#pragma unroll
+    for (int j = 1; j < 6; j++) { Dj[j] = (j < dim) ? slot[s].D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; fr[j - 1] = GE(g, LM_G_F0 + j - 1); }
+  };
+  // total cost at (xr, xc); Ma, jar are outputs for later reuse
+  struct Rows { float fr_r[6], fr_c[MC], lim_c[MC], con[NS][6]; };
+  auto rows_at = [&](const float* xr, const float* xc, Rows& jr, bool with_aref) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) jr.fr_r[i] = xr[i] - (with_aref ? fl_aref_r[i] : 0.0f);
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      jr.fr_c[k] = xc[k] - (with_aref ? fl_aref_c[k] : 0.0f);
+      jr.lim_c[k] = lim_s_c[k] * xc[k] - (with_aref ? lim_aref_c[k] : 0.0f);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      if (slot[s].on) {
+        slotJx(s, xr, xc, jr.con[s]);
+        if (with_aref) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) jr.con[s][j] -= slot[s].aref[j];
+        }
+      }
+    }
+  };
+  auto friction_cost = [&](float x, float f, float Rf_R, float& cost) {   // Rf_R = R
+    if (f <= 0.0f) return;
+    float Rf = Rf_R * f;
+    if (x <= -Rf) cost += -0.5f * Rf * f - f * x;
+    else if (x >= Rf) cost += -0.5f * Rf * f + f * x;
+    else cost += 0.5f * x * x / Rf_R;
+  };
+  auto cost_at = [&](const Rows& jr) -> float {   // lane-partial constraint cost
+    float cost = 0, cr = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) friction_cost(jr.fr_r[i], RD(i, LM_D_FLOSS), RD(i, LM_D_FLOSS_R), cr);
+    cost = w0 * cr;
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k < nl) {
+      friction_cost(jr.fr_c[k], LK(k, LM_D_FLOSS), LK(k, LM_D_FLOSS_R), cost);
+      if (lim_s_c[k] != 0.0f && jr.lim_c[k] < 0.0f) cost += 0.5f * lim_D_c[k] * jr.lim_c[k] * jr.lim_c[k];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) if (slot[s].on) {
+      float Dj[6], fr[5], mu; int dim;
+      slotD(s, Dj, fr, mu, dim);
+      cost += cone_eval<false>(jr.con[s], Dj, fr, mu, dim).cost;
+    }
+    return cost;
+  };
+
+  float ar[6], ac[MC];
+  {
+    // warm start: the better of (previous qacc, qacc_smooth)
+    Rows jr;
+    rows_at(a0r, a0c, jr, true);
+    float cost_smooth = Q::sum(cost_at(jr));
+    rows_at(war, wac, jr, true);
+    float yr[6], yc[MC], gauss = 0, gr = 0;
+    mulM(war, wac, yr, yc);
+#pragma unroll
+    for (int k = 0; k < MC; k++) gauss += 0.5f * (yc[k] - sm_c[k]) * (wac[k] - a0c[k]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) gr += 0.5f * (yr[i] - sm_r[i]) * (war[i] - a0r[i]);
+    float cost_warm = Q::sum(cost_at(jr) + gauss + w0 * gr);
+    bool use_warm = cost_warm < cost_smooth;
+#pragma unroll
+    for (int i = 0; i < 6; i++) ar[i] = use_warm ? war[i] : a0r[i];
+#pragma unroll
+    for (int k = 0; k < MC; k++) ac[k] = use_warm ? wac[k] : a0c[k];
+  }
+
+  float qf_r[6], qf_c[MC];      // constraint forces in joint space (qf_r: lane-partial until summed)
+#pragma unroll
+  for (int i = 0; i < 6; i++) qf_r[i] = 0;
+#pragma unroll
+  for (int k = 0; k < MC; k++) qf_c[k] = 0;
+  bool has_rows = false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) has_rows = has_rows || (RD(i, LM_D_FLOSS) > 0.0f);
+#pragma unroll
+  for (int k = 0; k < MC; k++) has_rows = has_rows || (k < nl && (LK(k, LM_D_FLOSS) > 0.0f || lim_s_c[k] != 0.0f));
+  has_rows = has_rows || nslot > 0;
+  bool done = !(Q::sum(has_rows ? 1.0f : 0.0f) > 0.0f);   // quad-uniform: nothing to solve in this environment
+  int iters = 0;
+  float prev_cost = 3.0e38f;
+
+  for (int it = 0; it <= P.iterations; it++) {
+    if (!Q::any(!done)) break;
+    if (!done) {
+      // ---- gradient at the current point
+      Rows jr;
+      rows_at(ar, ac, jr, true);
+      float Mar[6], Mac[MC];
+      mulM(ar, ac, Mar, Mac);
+      float cost = 0, cost_r = 0;
+      Sp Fsum = sp0();
+      float fcon[NS][6]; int zone[NS];
+      float fu_r[6], fu_c[MC];
+      unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R), x = jr.fr_r[i];
+        fu_r[i] = 0;
+        if (f > 0.0f) {
+          float Rf = Rr * f;
+          if (x <= -Rf) { fu_r[i] = f; cost_r += -0.5f * Rf * f - f * x; }
+          else if (x >= Rf) { fu_r[i] = -f; cost_r += -0.5f * Rf * f + f * x; }
+          else { fu_r[i] = -x / Rr; cost_r += 0.5f * x * x / Rr; act_fr_r |= 1u << i; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MC; k++) {
+        fu_c[k] = 0;
+        if (k < nl) {
+          float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R), x = jr.fr_c[k];
+          if (f > 0.0f) {
+            float Rf = Rr * f;
+            if (x <= -Rf) { fu_c[k] = f; cost += -0.5f * Rf * f - f * x; }
+            else if (x >= Rf) { fu_c[k] = -f; cost += -0.5f * Rf * f + f * x; }
+            else { fu_c[k] = -x / Rr; cost += 0.5f * x * x / Rr; act_fr_c |= 1u << k; }
+          }
+          if (lim_s_c[k] != 0.0f && jr.lim_c[k] < 0.0f) {
+            float fl = -lim_D_c[k] * jr.lim_c[k];
+            fu_c[k] += lim_s_c[k] * fl; cost += 0.5f * lim_D_c[k] * jr.lim_c[k] * jr.lim_c[k]; act_lim |= 1u << k;
+          }
+        }
+        qf_c[k] = fu_c[k];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        zone[s] = 0;
+        if (slot[s].on) {
+          float Dj[6], fr[5], mu; int dim;
+          slotD(s, Dj, fr, mu, dim);
+          ConeEval e = cone_eval<true>(jr.con[s], Dj, fr, mu, dim);
+          zone[s] = e.zone; cost += e.cost;
+#pragma unroll
+          for (int j = 0; j < 6; j++) fcon[s][j] = e.f[j];
+          if (e.zone) {
+            Sp Fw = contact_wrench(e.f, slot[s].r);
+            Fsum = Fsum + Fw;
+#pragma unroll
+            for (int k = 0; k < MC; k++) if (k <= slot[s].link) qf_c[k] += spdot(Sc[k], Fw);
+          }
+        }
+      }
+      float gc[MC], gr_[6], gauss = 0, gauss_r = 0, g2 = 0;
+#pragma unroll
+      for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; gauss += 0.5f * (Mac[k] - sm_c[k]) * (ac[k] - a0c[k]); g2 = fmaf(gc[k], gc[k], g2); }
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        qf_r[i] = fu_r[i] + Q::sum(spdot(Sr[i], Fsum));
+        gr_[i] = Mar[i] - sm_r[i] - qf_r[i];
+        gauss_r += 0.5f * (Mar[i] - sm_r[i]) * (ar[i] - a0r[i]);
+      }
+      float gnorm2 = Q::sum(g2);
+#pragma unroll
+      for (int i = 0; i < 6; i++) gnorm2 = fmaf(gr_[i], gr_[i], gnorm2);
+      float total = Q::sum(cost + gauss + w0 * (cost_r + gauss_r));
+      bool conv = (P.scale * sqrtf(gnorm2) < P.tolerance) || (it > 0 && P.scale * (prev_cost - total) < P.tolerance) || it == P.iterations;
+      prev_cost = total;
+      if (conv) done = true;
+      else {
+        iters++;
+        // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
+        float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21];
+#pragma unroll
+        for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Mcc[i];
+#pragma unroll
+        for (int k = 0; k < MC; k++) {
+#pragma unroll
+          for (int r = 0; r < 6; r++) Hcr[k][r] = Mcr[k][r];
+          if (act_fr_c & (1u << k)) Hcc[tri(k, k)] += 1.0f / LK(k, LM_D_FLOSS_R);
+          if (act_lim & (1u << k)) Hcc[tri(k, k)] += lim_D_c[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) Hpart[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hpart[tri(i, i)] = w0 / RD(i, LM_D_FLOSS_R);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          if (slot[s].on && zone[s]) {
+            float Dj[6], fr[5], mu, Hc[21]; int dim;
+            slotD(s, Dj, fr, mu, dim);
+            cone_hessian(jr.con[s], Dj, fr, mu, dim, zone[s], Hc);
+            float Jc[6 + MC][6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) contact_rows(Sr[r], slot[s].r, Jc[r]);
+#pragma unroll
+            for (int k = 0; k < MC; k++) {
+              if (k <= slot[s].link) contact_rows(Sc[k], slot[s].r, Jc[6 + k]);
+              else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 6 + MC; a++) {
+              float t[6];
+#pragma unroll
+              for (int i = 0; i < 6; i++) {
+                float acc = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc = fmaf(Hc[(j <= i) ? tri(i, j) : tri(j, i)], Jc[a][j], acc);
+                t[i] = acc;
+              }
+#pragma unroll
+              for (int b = 0; b <= a; b++) {
+                float d = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) d = fmaf(t[j], Jc[b][j], d);
+                if (a < 6) Hpart[tri(a, b)] += d;
+                else if (b < 6) Hcr[a - 6][b] += d;
+                else Hcc[tri(a - 6, b - 6)] += d;
+              }
+            }
+          }
+        }
+        float Lr[21];
+        arrow_factor<Q, MC>(Hcc, Hcr, Mrr, Hpart, Lr);
+        float sr[6], sc[MC];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sr[i] = -gr_[i];
+#pragma unroll
+        for (int k = 0; k < MC; k++) sc[k] = -gc[k];
+        arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+
+        // ---- exact line search along (sr, sc)
+        Rows jv;
+        rows_at(sr, sc, jv, false);
+        float Mvr[6], Mvc[MC];
+        mulM(sr, sc, Mvr, Mvc);
+        float q1 = 0, q2 = 0, q1r = 0, q2r = 0;
+#pragma unroll
+        for (int k = 0; k < MC; k++) { q1 = fmaf(sc[k], Mac[k] - sm_c[k], q1); q2 = fmaf(sc[k], Mvc[k], q2); }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { q1r = fmaf(sr[i], Mar[i] - sm_r[i], q1r); q2r = fmaf(sr[i], Mvr[i], q2r); }
+        q1 = Q::sum(q1 + w0 * q1r); q2 = Q::sum(q2 + w0 * q2r);
+        auto line = [&](float alpha, float& d1, float& d2) {
+          float a1 = 0, a2 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R);
+            if (f > 0.0f) {
+              float x = fmaf(alpha, jv.fr_r[i], jr.fr_r[i]), Rf = Rr * f;
+              if (x <= -Rf) r1 -= f * jv.fr_r[i];
+              else if (x >= Rf) r1 += f * jv.fr_r[i];
+              else { r1 += x * jv.fr_r[i] / Rr; r2 += jv.fr_r[i] * jv.fr_r[i] / Rr; }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < MC; k++) if (k < nl) {
+            float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R);
+            if (f > 0.0f) {
+              float x = fmaf(alpha, jv.fr_c[k], jr.fr_c[k]), Rf = Rr * f;
+              if (x <= -Rf) a1 -= f * jv.fr_c[k];
+              else if (x >= Rf) a1 += f * jv.fr_c[k];
+              else { a1 += x * jv.fr_c[k] / Rr; a2 += jv.fr_c[k] * jv.fr_c[k] / Rr; }
+            }
+            if (lim_s_c[k] != 0.0f) {
+              float x = fmaf(alpha, jv.lim_c[k], jr.lim_c[k]);
+              if (x < 0.0f) { a1 += lim_D_c[k] * x * jv.lim_c[k]; a2 += lim_D_c[k] * jv.lim_c[k] * jv.lim_c[k]; }
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < NS; s++) if (slot[s].on) {
+            float Dj[6], fr[5], mu; int dim;
+            slotD(s, Dj, fr, mu, dim);
+            cone_line(jr.con[s], jv.con[s], alpha, Dj, fr, mu, dim, a1, a2);
+          }
+          d1 = q1 + alpha * q2 + Q::sum(a1 + w0 * r1);
+          d2 = q2 + Q::sum(a2 + w0 * r2);
+        };
+        float d1, d2, alpha = 0, lo = 0, hi = -1.0f;
+        line(0.0f, d1, d2);
+        bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
+        float dref = fabsf(d1);
+        if (!ls_done) alpha = -d1 / d2;
+        for (int ls = 0; ls < 20; ls++) {
+          if (!Q::any(!ls_done)) break;
+          if (!ls_done) {
+            line(alpha, d1, d2);
+            if (fabsf(d1) < 1e-5f * dref) ls_done = true;
+            else {
+              if (d1 < 0.0f) lo = alpha; else hi = alpha;
+              float next = alpha - d1 / d2;
+              if (hi > 0.0f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);
+              if (hi < 0.0f && next <= lo) next = 2.0f * alpha;
+              if (fabsf(next - alpha) <= 1e-7f * fabsf(alpha)) ls_done = true;
+              alpha = next;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) ar[i] = fmaf(alpha, sr[i], ar[i]);
+#pragma unroll
+        for (int k = 0; k < MC; k++) ac[k] = fmaf(alpha, sc[k], ac[k]);
+        if (alpha == 0.0f) done = true;
+      }
+    }
+  }
+  cnt.solver_iters += (c == 0) ? iters : 0;
+
+  if (dbg) {
+    const int nv = P.nv;
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k < nl) {
+      int d = (int)LK(k, LM_D_DOF);
+      dbg->bias[d] = bias_c[k]; dbg->smooth[d] = sm_c[k]; dbg->qacc_smooth[d] = a0c[k]; dbg->qacc[d] = ac[k]; dbg->qfrc_constraint[d] = qf_c[k];
+#pragma unroll
+      for (int j = 0; j <= k; j++) { int e = (int)LK(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mcc[tri(k, j)]; }
+#pragma unroll
+      for (int r = 0; r < 6; r++) { int e = (int)RD(r, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mcr[k][r]; }
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        int d = (int)RD(i, LM_D_DOF);
+        dbg->bias[d] = bias_r[i]; dbg->smooth[d] = sm_r[i]; dbg->qacc_smooth[d] = a0r[i]; dbg->qacc[d] = ar[i]; dbg->qfrc_constraint[d] = qf_r[i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) { int e = (int)RD(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mrr[tri(i, j)]; }
+      }
+    }
+  }
+
+  // ================= integrate: semi-implicit Euler, joint damping implicit =================
+  // (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint ; qvel += h qacc' ; qpos += h qvel
+#pragma unroll
+  for (int i = 0; i < 6; i++) war[i] = ar[i];
+#pragma unroll
+  for (int k = 0; k < MC; k++) wac[k] = ac[k];
+  {
+    float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hrep[21], Lr[21];
+#pragma unroll
+    for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Mcc[i];
+#pragma unroll
+    for (int i = 0; i < 21; i++) Hrep[i] = Mrr[i];
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) Hcr[k][r] = Mcr[k][r];
+      if (k < nl) Hcc[tri(k, k)] += P.h * LK(k, LM_D_DAMP);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) Hrep[tri(i, i)] += P.h * RD(i, LM_D_DAMP);
+    arrow_factor<Q, MC>(Hcc, Hcr, Hrep, zero21, Lr);
+    float xr[6], xc[MC];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xr[i] = sm_r[i] + qf_r[i];
+#pragma unroll
+    for (int k = 0; k < MC; k++) xc[k] = sm_c[k] + qf_c[k];
+    arrow_solve<Q, MC>(Hcc, Hcr, Lr, xc, xr);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { vr[i] = fmaf(P.h, xr[i], vr[i]); qr[i] = fmaf(P.h, vr[i], qr[i]); }
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k < nl) { vc[k] = fmaf(P.h, xc[k], vc[k]); qc[k] = fmaf(P.h, vc[k], qc[k]); }
+  }
+#undef RD
+#undef CH
+#undef LK
+#undef LX
+#undef GE
+}
+
+}  // namespace lm

@@ -1,0 +1,534 @@
+// lm_kernels.hip — gfx950 kernels and the C-ABI (include/locohip.h) of the batched LocoEnv.step().
+//
+// Mapping: one 4-lane quad = one environment, lane c = chain c (lm_core.h). 64-thread workgroups = one
+// wave = 16 environments, so 4096 environments are 256 workgroups — one per CU, each wave alone on a SIMD
+// with the full 512-VGPR budget (the working set of the Newton solve lives in registers; the constant
+// model table sits in LDS and is read with quad-broadcast addresses). State is SoA [dof][env] in HBM:
+// a wave's 16 environments read 16 consecutive floats per dof. Per control step the kernel moves
+// 4*(2nq+2nv+nu+nobs+2) + 8nv bytes per environment — the path is VALU/latency bound, not
+// HBM bound, so everything between the state load and the state store happens in registers.
+//
+// One launch = one control step = n_substeps physics steps + observation + reward (on the previous
+// observation) + termination + optional device-side episode reset.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#define LM_DEV __device__ __forceinline__
+#include "lm_core.h"
+#include "../../include/locohip.h"
+
+namespace {
+
+// ---- quad policy on gfx950: DPP quad_perm butterflies, no LDS ------------------------------------------------
+struct QuadDpp {
+  static __device__ __forceinline__ float sum(float x) {
+    // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
+    float y = x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+    return y + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(y), 0x4E, 0xF, 0xF, true));
+  }
+  static __device__ __forceinline__ bool any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+};
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct Task {
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links;
+  float rp[8];
+};
+
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, pad; };
+
+struct KArgs {
+  const float* cm;          // constant table [LM_CM_SIZE]
+  float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
+  int* ep_step; unsigned* ep_count;
+  const float* action;      // [N][nu] or null
+  float* obs; float* reward; unsigned char* done;       // [N][nobs], [N], [N] (may be null)
+  const float* table; int table_rows;                   // reset rows [K][nq+nv+ngoal]
+  unsigned long long seed; long long env_offset;
+  int auto_reset, horizon, action_mode; unsigned step_index;
+  int N;
+  lm::Params P; Task T;
+  DevStats* stats;
+  // debug (forward only)
+  float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+template <int MC, int NS, bool FORWARD_ONLY>
+__global__ __launch_bounds__(64) void step_kernel(KArgs a) {
+  __shared__ float cm[LM_CM_SIZE];
+  for (int i = threadIdx.x; i < LM_CM_SIZE; i += 64) cm[i] = a.cm[i];
+  __syncthreads();
+  const int c = threadIdx.x & 3;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 2);
+  if (e >= a.N) return;                       // whole quads leave together
+  const int N = a.N, nv = a.T.nv;
+  const float* rb = cm + LM_CM_ROOT;
+#define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
+#define LK(k, f) cm[LM_CM_CHAINS + (LM_C_LINKS + (k) * LM_LINK_SIZE + (f)) * LM_NCHAIN + c]
+  const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
+
+  // ---- load state (root replicated in the 4 lanes: same address -> one transaction)
+  float qr[6], vr[6], war[6], qc[MC], vc[MC], wac[MC], goal[4];
+  int dr[6], dc[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { dr[i] = (int)RD(i, LM_D_DOF); qr[i] = a.qpos[dr[i] * N + e]; vr[i] = a.qvel[dr[i] * N + e]; war[i] = a.warm[dr[i] * N + e]; }
+#pragma unroll
+  for (int k = 0; k < MC; k++) {
+    dc[k] = (k < nl) ? (int)LK(k, LM_D_DOF) : 0;
+    qc[k] = (k < nl) ? a.qpos[dc[k] * N + e] : 0.0f; vc[k] = (k < nl) ? a.qvel[dc[k] * N + e] : 0.0f; wac[k] = (k < nl) ? a.warm[dc[k] * N + e] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) goal[i] = (i < a.T.ngoal) ? a.goal[i * N + e] : 0.0f;
+
+  // ---- reward on the PREVIOUS observation (reference utils/reward.py:73,110-115)
+  auto src = [&](float code) -> float {
+    int s = (int)code;
+    float v = 0;
+    if (s >= LM_SRC_ROOT_QPOS) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (s - LM_SRC_ROOT_QPOS == i) v = qr[i];
+    } else if (s >= LM_SRC_GOAL) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (s - LM_SRC_GOAL == i) v = goal[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (s == i) v = vr[i];
+    }
+    return v;
+  };
+  float reward = 0.0f;
+  if (a.T.reward_type == 1) { float d = src(a.T.rp[0]) - a.T.rp[1]; reward = expf(-d * d); }
+  else if (a.T.reward_type == 2) {
+    float gv = src(a.T.rp[4]);
+    float dx = src(a.T.rp[0]) - gv * src(a.T.rp[2]), dy = src(a.T.rp[1]) - gv * src(a.T.rp[3]);
+    reward = expf(-5.0f * sqrtf(dx * dx + dy * dy));
+  }
+
+  // ---- actuation: action in [-1,1] -> ctrl (reference base.py:606-621) -> clamp -> gear
+  const long long gid = a.env_offset + e;
+  auto actuate = [&](float kf, float delta, float mean, float lo, float hi, float gear) -> float {
+    int k = (int)kf;
+    if (k < 0) return 0.0f;
+    float act = 0.0f;
+    if (a.action_mode == 0 && a.action) act = a.action[(long long)e * a.T.nu + k];
+    else if (a.action_mode == 2) {
+      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + a.step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+      act = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
+    }
+    float ctrl = fminf(fmaxf(fmaf(act, delta, mean), lo), hi);
+    return gear * ctrl;
+  };
+  float actr[6], actc[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) actr[i] = actuate(RD(i, LM_D_ACT), RD(i, LM_D_ACT_DELTA), RD(i, LM_D_ACT_MEAN), RD(i, LM_D_CTRL_LO), RD(i, LM_D_CTRL_HI), RD(i, LM_D_GEAR));
+#pragma unroll
+  for (int k = 0; k < MC; k++) actc[k] = (k < nl) ? actuate(LK(k, LM_D_ACT), LK(k, LM_D_ACT_DELTA), LK(k, LM_D_ACT_MEAN), LK(k, LM_D_CTRL_LO), LK(k, LM_D_CTRL_HI), LK(k, LM_D_GEAR)) : 0.0f;
+
+  // ---- physics
+  lm::Counters cnt = {0, 0, 0, 0};
+  if (FORWARD_ONLY) {
+    lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
+    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, cnt, &dbg);
+    int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
+    if (c == 0) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
+    return;
+  }
+  for (int s = 0; s < a.T.nsub; s++)
+    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, cnt, nullptr);
+
+  // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
+  float bad = 0.0f, viol = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (!(fabsf(qr[i]) < 1e30f) || !(fabsf(vr[i]) < 1e30f)) bad = 1.0f;
+    if (qr[i] < RD(i, LM_D_TERM_QLO) || qr[i] > RD(i, LM_D_TERM_QHI) || vr[i] < RD(i, LM_D_TERM_VLO) || vr[i] > RD(i, LM_D_TERM_VHI)) viol = 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < MC; k++) if (k < nl) {
+    if (!(fabsf(qc[k]) < 1e30f) || !(fabsf(vc[k]) < 1e30f)) bad = 1.0f;
+    if (qc[k] < LK(k, LM_D_TERM_QLO) || qc[k] > LK(k, LM_D_TERM_QHI) || vc[k] < LK(k, LM_D_TERM_VLO) || vc[k] > LK(k, LM_D_TERM_VHI)) viol = 1.0f;
+  }
+  const bool nonfinite = QuadDpp::sum(bad) > 0.0f;
+  const bool absorbing = QuadDpp::sum(viol) > 0.0f || nonfinite;
+  int step_no = a.ep_step[e] + 1;
+  const bool trunc = a.horizon > 0 && step_no >= a.horizon;
+  float episodes = 0.0f;
+  if (absorbing || trunc) {
+    episodes = 1.0f;
+    if (a.auto_reset && a.table_rows > 0) {
+      // restart from a trajectory sample (reference trajectory.py:236-273 + base.py:478-497), counter-based RNG
+      unsigned ec = a.ep_count[e] + 1;
+      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32));
+      const float* row = a.table + (long long)(r % (unsigned long long)a.table_rows) * (2 * nv + a.T.ngoal);
+#pragma unroll
+      for (int i = 0; i < 6; i++) { qr[i] = row[dr[i]]; vr[i] = row[nv + dr[i]]; war[i] = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < MC; k++) if (k < nl) { qc[k] = row[dc[k]]; vc[k] = row[nv + dc[k]]; wac[k] = 0.0f; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i < a.T.ngoal) goal[i] = row[2 * nv + i];
+      if (c == 0) {
+        a.ep_count[e] = ec;
+        for (int i = 0; i < a.T.ngoal; i++) a.goal[i * N + e] = goal[i];
+      }
+      step_no = 0;
+    } else if (nonfinite) {
+      // no reset table: park the environment at rest in its last finite configuration is impossible; zero it
+#pragma unroll
+      for (int i = 0; i < 6; i++) { qr[i] = 0.0f; vr[i] = 0.0f; war[i] = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < MC; k++) { qc[k] = 0.0f; vc[k] = 0.0f; wac[k] = 0.0f; }
+    }
+  }
+
+  // ---- store state, observation [qpos[idx], qvel[idx], goal], reward, done
+  if (c == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a.qpos[dr[i] * N + e] = qr[i]; a.qvel[dr[i] * N + e] = vr[i]; a.warm[dr[i] * N + e] = war[i]; }
+    a.ep_step[e] = step_no;
+    if (a.reward) a.reward[e] = reward;
+    if (a.done) a.done[e] = absorbing ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < MC; k++) if (k < nl) { a.qpos[dc[k] * N + e] = qc[k]; a.qvel[dc[k] * N + e] = vc[k]; a.warm[dc[k] * N + e] = wac[k]; }
+  if (a.obs) {
+    float* o = a.obs + (long long)e * a.T.nobs;
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) { int iq = (int)RD(i, LM_D_QOBS), iv = (int)RD(i, LM_D_VOBS); if (iq >= 0) o[iq] = qr[i]; if (iv >= 0) o[iv] = vr[i]; }
+      for (int i = 0; i < a.T.ngoal; i++) o[a.T.nobs - a.T.ngoal + i] = goal[i];
+    }
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k < nl) { int iq = (int)LK(k, LM_D_QOBS), iv = (int)LK(k, LM_D_VOBS); if (iq >= 0) o[iq] = qc[k]; if (iv >= 0) o[iv] = vc[k]; }
+  }
+
+  // ---- statistics: one atomic per wave and counter
+  if (a.stats) {
+    float l0 = (c == 0) ? 1.0f : 0.0f;
+    float s_steps = wave_sum(l0), s_ep = wave_sum(l0 * episodes), s_rew = wave_sum(l0 * reward), s_nan = wave_sum(l0 * (nonfinite ? 1.0f : 0.0f));
+    float s_it = wave_sum((float)cnt.solver_iters), s_ov = wave_sum((float)cnt.overflow), s_un = wave_sum((float)cnt.unhandled);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&a.stats->env_steps, s_steps); atomicAdd(&a.stats->episodes, s_ep); atomicAdd(&a.stats->reward_sum, s_rew);
+      atomicAdd(&a.stats->nan_resets, s_nan); atomicAdd(&a.stats->solver_iters, s_it); atomicAdd(&a.stats->overflow, s_ov);
+      atomicAdd(&a.stats->unhandled, s_un);
+    }
+  }
+#undef RD
+#undef LK
+}
+
+}  // namespace
+
+// ================================================================================================================
+// C-ABI
+// ================================================================================================================
+struct lm_model {
+  int device;
+  float* d_cm;
+  lm::Params P; Task T;
+  int nroot;
+  std::vector<int> root_dofs;
+};
+
+struct lm_batch {
+  lm_model* m;
+  int N;
+  float *qpos, *qvel, *warm, *goal, *action, *obs, *reward, *table;
+  unsigned char* done;
+  int* ep_step; unsigned* ep_count;
+  DevStats* stats;
+  int table_rows; unsigned long long seed; long long env_offset; int auto_reset, horizon; unsigned step_index;
+  hipStream_t stream;
+  lm_stats acc;            // host-side accumulation (double)
+  hipEvent_t ev0, ev1;
+};
+
+extern "C" {
+
+const char* lm_last_error(void) { return g_err.c_str(); }
+
+int lm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
+  if (!cmod || n < LM_HEADER_SIZE + LM_CM_SIZE) return fail("chain model too short");
+  if ((unsigned)cmod[LM_H_MAGIC] != (unsigned)LM_LMC_MAGIC) return fail("bad chain-model magic");
+  if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
+  if ((int)cmod[LM_H_MAXLINKS] > 3) return fail("chains longer than 3 links need the MC=5 instantiation (not built yet)");
+  if ((int)cmod[LM_HEADER_SIZE + LM_R_NDOF] != 6) return fail("root body must have 6 dofs");
+  HIPCHK(hipSetDevice(device));
+  lm_model* m = new lm_model();
+  m->device = device;
+  std::vector<float> cm(LM_CM_SIZE);
+  for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)cmod[LM_HEADER_SIZE + i];
+  for (int i = 0; i < 6; i++) {
+    const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
+    if (blk[LM_D_LIMITED] != 0.0f) { delete m; return fail("limited root joints are not supported"); }
+  }
+  HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
+  HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));
+  Task& T = m->T;
+  T.nv = (int)cmod[LM_H_NV]; T.nu = (int)cmod[LM_H_NU]; T.nobs = (int)cmod[LM_H_NOBS]; T.ngoal = (int)cmod[LM_H_NGOAL];
+  T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
+  T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS];
+  if (T.ngoal > 4) { delete m; return fail("more than 4 goal entries"); }
+  for (int i = 0; i < 8; i++) T.rp[i] = (float)cmod[LM_H_REWARD_P0 + i];
+  lm::Params& P = m->P;
+  P.h = (float)cmod[LM_H_TIMESTEP];
+  P.g = lm::V3{(float)cmod[LM_H_GX], (float)cmod[LM_H_GY], (float)cmod[LM_H_GZ]};
+  P.iterations = (int)cmod[LM_H_ITERATIONS];
+  P.tolerance = 1e-6f;      // float32 stand-in for MuJoCo's 1e-8 (the gradient itself carries ~1e-6 relative noise)
+  P.nv = T.nv;
+  P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
+  *out = m;
+  return 0;
+}
+
+void lm_model_destroy(lm_model* m) {
+  if (!m) return;
+  (void)hipFree(m->d_cm);
+  delete m;
+}
+
+int lm_model_dims(const lm_model* m, lm_dims* out) {
+  out->nq = m->T.nv; out->nv = m->T.nv; out->nu = m->T.nu; out->nobs = m->T.nobs; out->ngoal = m->T.ngoal;
+  out->n_substeps = m->T.nsub; out->n_chains = m->T.n_chains; out->max_chain_dofs = m->T.max_links;
+  return 0;
+}
+
+int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
+  if (n_envs <= 0) return fail("n_envs must be positive");
+  HIPCHK(hipSetDevice(m->device));
+  lm_batch* b = new lm_batch();
+  memset(b, 0, sizeof(*b));
+  b->m = m; b->N = n_envs;
+  const int N = n_envs, nv = m->T.nv;
+  HIPCHK(hipMalloc(&b->qpos, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->qvel, sizeof(float) * nv * N));
+  HIPCHK(hipMalloc(&b->warm, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->goal, sizeof(float) * 4 * N));
+  HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
+  HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
+  HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
+  HIPCHK(hipMalloc(&b->stats, sizeof(DevStats)));
+  HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
+  HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
+  HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
+  HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats)));
+  HIPCHK(hipStreamCreate(&b->stream));
+  HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
+  *out = b;
+  return 0;
+}
+
+void lm_batch_destroy(lm_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->m->device);
+  hipStreamSynchronize(b->stream);
+  (void)hipFree(b->qpos); (void)hipFree(b->qvel); (void)hipFree(b->warm); (void)hipFree(b->goal); (void)hipFree(b->action); (void)hipFree(b->obs);
+  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table);
+  (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+static int upload_soa(lm_batch* b, float* dev, const float* host_aos, int dim, const uint8_t* mask) {
+  const int N = b->N;
+  std::vector<float> soa((size_t)dim * N);
+  if (mask) HIPCHK(hipMemcpyAsync(soa.data(), dev, sizeof(float) * dim * N, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int e = 0; e < N; e++) {
+    if (mask && !mask[e]) continue;
+    for (int d = 0; d < dim; d++) soa[(size_t)d * N + e] = host_aos[(size_t)e * dim + d];
+  }
+  HIPCHK(hipMemcpyAsync(dev, soa.data(), sizeof(float) * dim * N, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N, nv = b->m->T.nv;
+  if (upload_soa(b, b->qpos, qpos, nv, mask)) return 1;
+  if (upload_soa(b, b->qvel, qvel, nv, mask)) return 1;
+  std::vector<float> z((size_t)nv * N, 0.0f);
+  std::vector<int> zs(N, 0);
+  if (mask) {
+    // clear warm start / step counter only for the masked environments
+    std::vector<float> w((size_t)nv * N);
+    std::vector<int> st(N);
+    HIPCHK(hipMemcpy(w.data(), b->warm, sizeof(float) * nv * N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st.data(), b->ep_step, sizeof(int) * N, hipMemcpyDeviceToHost));
+    for (int e = 0; e < N; e++) if (mask[e]) { st[e] = 0; for (int d = 0; d < nv; d++) w[(size_t)d * N + e] = 0.0f; }
+    HIPCHK(hipMemcpy(b->warm, w.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->ep_step, st.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMemcpy(b->warm, z.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->ep_step, zs.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int lm_get_state(lm_batch* b, float* qpos, float* qvel) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N, nv = b->m->T.nv;
+  std::vector<float> soa((size_t)nv * N);
+  for (int pass = 0; pass < 2; pass++) {
+    float* dst = pass == 0 ? qpos : qvel;
+    if (!dst) continue;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(soa.data(), pass == 0 ? b->qpos : b->qvel, sizeof(float) * nv * N, hipMemcpyDeviceToHost));
+    for (int e = 0; e < N; e++) for (int d = 0; d < nv; d++) dst[(size_t)e * nv + d] = soa[(size_t)d * N + e];
+  }
+  return 0;
+}
+
+int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (b->m->T.ngoal == 0) return 0;
+  return upload_soa(b, b->goal, goal, b->m->T.ngoal, mask);
+}
+
+static KArgs make_args(lm_batch* b) {
+  KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cm = b->m->d_cm; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.ep_step = b->ep_step; a.ep_count = b->ep_count;
+  a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
+  a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
+  a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
+  return a;
+}
+
+static void launch_step(lm_batch* b, const KArgs& a) {
+  dim3 grid((b->N + 15) / 16), block(64);
+  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, 0, b->stream, a);
+}
+
+static int drain_stats(lm_batch* b) {
+  DevStats s;
+  HIPCHK(hipMemcpyAsync(&s, b->stats, sizeof(s), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemsetAsync(b->stats, 0, sizeof(DevStats), b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->acc.env_steps += s.env_steps; b->acc.episodes += s.episodes; b->acc.reward_sum += s.reward_sum;
+  b->acc.nan_resets += s.nan_resets; b->acc.solver_iters += s.solver_iters; b->acc.overflow_contacts += s.overflow;
+  b->acc.unhandled_geoms += s.unhandled;
+  return 0;
+}
+
+int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t* done) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N; const Task& T = b->m->T;
+  KArgs a = make_args(b);
+  if (action) { HIPCHK(hipMemcpyAsync(b->action, action, sizeof(float) * T.nu * N, hipMemcpyHostToDevice, b->stream)); a.action = b->action; a.action_mode = 0; }
+  else a.action_mode = 1;
+  a.obs = b->obs; a.reward = b->reward; a.done = b->done;
+  launch_step(b, a);
+  HIPCHK(hipGetLastError());
+  b->step_index++;
+  if (obs) HIPCHK(hipMemcpyAsync(obs, b->obs, sizeof(float) * T.nobs * N, hipMemcpyDeviceToHost, b->stream));
+  if (reward) HIPCHK(hipMemcpyAsync(reward, b->reward, sizeof(float) * N, hipMemcpyDeviceToHost, b->stream));
+  if (done) HIPCHK(hipMemcpyAsync(done, b->done, N, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int lm_set_reset_table(lm_batch* b, const float* rows, int n_rows, uint64_t seed, int64_t global_env_offset) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const Task& T = b->m->T;
+  const size_t w = 2 * T.nv + T.ngoal;
+  if (n_rows <= 0) return fail("empty reset table");
+  if (b->table) { HIPCHK(hipFree(b->table)); b->table = nullptr; }
+  HIPCHK(hipMalloc(&b->table, sizeof(float) * w * n_rows));
+  HIPCHK(hipMemcpy(b->table, rows, sizeof(float) * w * n_rows, hipMemcpyHostToDevice));
+  b->table_rows = n_rows; b->seed = seed; b->env_offset = global_env_offset;
+  return 0;
+}
+
+int lm_set_auto_reset(lm_batch* b, int enabled, int horizon) {
+  if (enabled && b->table_rows <= 0) return fail("auto reset needs a reset table (lm_set_reset_table)");
+  b->auto_reset = enabled; b->horizon = horizon;
+  return 0;
+}
+
+int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stats* stats) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (action_mode != 0 && action_mode != 1) return fail("action_mode must be 0 (zero) or 1 (uniform random)");
+  KArgs a = make_args(b);
+  a.action = nullptr; a.action_mode = action_mode == 0 ? 1 : 2;   // kernel: 1 = zero action, 2 = random
+  a.seed = b->seed ^ (seed * 0x9E3779B97F4A7C15ull);
+  a.obs = b->obs; a.reward = b->reward; a.done = b->done;
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  for (int s = 0; s < n_steps; s++) {
+    a.step_index = b->step_index++;
+    launch_step(b, a);
+  }
+  HIPCHK(hipEventRecord(b->ev1, b->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventSynchronize(b->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+  if (drain_stats(b)) return 1;
+  b->acc.kernel_ms += ms;
+  if (stats) { *stats = b->acc; stats->kernel_ms = ms; }
+  return 0;
+}
+
+int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N; const Task& T = b->m->T; const int nv = T.nv;
+  KArgs a = make_args(b);
+  a.stats = nullptr;
+  if (action) { HIPCHK(hipMemcpy(b->action, action, sizeof(float) * T.nu * N, hipMemcpyHostToDevice)); a.action = b->action; a.action_mode = 0; }
+  else a.action_mode = 1;
+  float* buf; int* ibuf;
+  const size_t per = (size_t)nv * nv + 5 * nv;
+  HIPCHK(hipMalloc(&buf, sizeof(float) * per * N)); HIPCHK(hipMalloc(&ibuf, sizeof(int) * 2 * N));
+  HIPCHK(hipMemset(buf, 0, sizeof(float) * per * N));
+  a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
+  a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
+  dim3 grid((N + 15) / 16), block(64);
+  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, 0, b->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->stream));
+  auto get = [&](float* dst, const float* src, size_t n) -> int { if (dst) HIPCHK(hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost)); return 0; };
+  if (get(out->M, a.dM, (size_t)nv * nv * N) || get(out->qfrc_bias, a.dbias, (size_t)nv * N) || get(out->qfrc_smooth, a.dsmooth, (size_t)nv * N) ||
+      get(out->qacc_smooth, a.dqacc_smooth, (size_t)nv * N) || get(out->qacc, a.dqacc, (size_t)nv * N) || get(out->qfrc_constraint, a.dqfrc, (size_t)nv * N)) return 1;
+  if (out->ncon) HIPCHK(hipMemcpy(out->ncon, a.dncon, sizeof(int) * N, hipMemcpyDeviceToHost));
+  if (out->solver_iter) HIPCHK(hipMemcpy(out->solver_iter, a.diter, sizeof(int) * N, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(buf)); HIPCHK(hipFree(ibuf));
+  return 0;
+}
+
+int lm_get_stats(lm_batch* b, lm_stats* out, int reset) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (drain_stats(b)) return 1;
+  if (out) *out = b->acc;
+  if (reset) memset(&b->acc, 0, sizeof(b->acc));
+  return 0;
+}
+
+int lm_sync(lm_batch* b) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+}  // extern "C"

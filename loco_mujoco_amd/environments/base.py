@@ -21,7 +21,6 @@ from itertools import product
 
 import numpy as np
 
-from ..model_blob import pack_model, pack_task
 from ..utils.reward import (CustomReward, NoReward, PosReward, TargetVelocityReward)
 from ..utils.trajectory import Trajectory
 from .observation import Box, MDPInfo, ObservationHelper, ObservationType
@@ -138,7 +137,7 @@ class LocoEnv:
         """The device batch (``HipBatch``). Created lazily; raises if the HIP library/GPU is missing."""
         if self._backend is None:
             from ..backend import HipBatch, HipModel
-            self._hip_model = HipModel(pack_model(self._model), self._make_task_blob(), self._device)
+            self._hip_model = HipModel(self._chain_model(), self._device)
             self._backend = HipBatch(self._hip_model, self.n_envs)
         return self._backend
 
@@ -393,7 +392,8 @@ class LocoEnv:
     def _n_goal(self):
         return 0
 
-    def _make_task_blob(self):
+    def _device_task(self):
+        """Everything around the physics that the step kernel evaluates itself (see ``lowering.lower``)."""
         qpos_idx, qvel_idx = [], []
         for key, name, ot in self.obs_helper.observation_spec[2:]:
             if ot == ObservationType.JOINT_POS:
@@ -406,9 +406,13 @@ class LocoEnv:
         spec = self._reward_function.device_spec()
         rtype, rparams = spec if spec is not None else (0, [])
         term = self._termination_spec() if self._use_absorbing_states else []
-        return pack_task(nobs, qpos_idx, qvel_idx, n_goal, self._action_indices, self.norm_act_mean,
-                         self.norm_act_delta, [t[0] for t in term], [t[1] for t in term], [t[2] for t in term],
-                         rtype, rparams, self._n_substeps)
+        return dict(nobs=nobs, qpos_obs_idx=qpos_idx, qvel_obs_idx=qvel_idx, n_goal=n_goal,
+                    act_ctrl_idx=self._action_indices, act_mean=self.norm_act_mean, act_delta=self.norm_act_delta,
+                    term=term, reward_type=rtype, reward_params=rparams, n_substeps=self._n_substeps)
+
+    def _chain_model(self):
+        from ..lowering import lower
+        return lower(self._model, self._device_task())[0]
 
     # ------------------------------------------------------------------ misc surface
     def _out(self, obs):

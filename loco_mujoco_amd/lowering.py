@@ -1,0 +1,390 @@
+"""
+Lowering of a :class:`~loco_mujoco_amd.mjcf.CompiledModel` to the "root + chains" device model the HIP
+step kernel is written for (csrc/lm_core.h).
+
+Topology the kernel supports (all four BASELINE robots have it): one root body
+hanging off the world with up to 6 scalar joints, and up to 4 serial chains of 1-dof links below it
+(A1: four 3-link legs; humanoids: two 5-dof legs + a 3-dof lumbar chain). One GPU lane simulates one
+chain of one environment; the 4 lanes of a quad share the root.
+
+Lowering steps:
+* bodies without joints are welded into their parent (mass, centre of mass, inertia tensor and geoms are
+  re-expressed in the parent's frame) — e.g. the A1 goal-arrow body;
+* every scalar joint becomes one "link"; a body with several joints becomes consecutive links of which only
+  the last carries the mass and the geoms;
+* constraint constants that do not depend on the state are folded on the host: friction-loss regulariser
+  R = (1-d0)/d0 * dof_invweight0 and its damping gain, joint-limit stiffness/damping from solref/solimp,
+  per-geom floor-contact parameters after MuJoCo's priority/max mixing with the floor plane (condim,
+  friction, solref -> (K, B), solimp, margin, the R_j/R_0 ratios of the elliptic friction rows and the cone mu).
+
+The result is ONE float64 array, the "chain model" that crosses the C-ABI (``lm_model_create``): a 32-slot
+header (``H_*``) followed by the constant table (``D_*``/``L_*``/``G_*``/``C_*``/``R_*`` offsets below).
+``include/lm_layout.h`` is generated from these enums by ``tools/gen_layout_header.py``.
+"""
+
+import numpy as np
+
+from . import mjcf
+
+MAXC = 5          # links per chain the table has room for
+NCHAIN = 4
+NROOT = 6
+MAXG = 8          # floor-collidable geoms per chain
+
+# ---- per-dof parameter block (used for root dofs and chain links)
+(D_TYPE, D_AX, D_AY, D_AZ, D_PX, D_PY, D_PZ, D_DAMP, D_ARM, D_STIFF, D_FLOSS, D_FLOSS_R, D_FLOSS_B, D_LIMITED,
+ D_LO, D_HI, D_LIM_K, D_LIM_B, D_LIM_S0, D_LIM_S1, D_LIM_S2, D_LIM_S3, D_LIM_S4, D_INVW, D_GEAR, D_CTRL_LO,
+ D_CTRL_HI, D_ACT, D_ACT_MEAN, D_ACT_DELTA, D_QOBS, D_VOBS, D_TERM_QLO, D_TERM_QHI, D_TERM_VLO, D_TERM_VHI, D_DOF,
+ D_SIZE) = range(38)
+# ---- per-link extras (chain links only), after the dof block
+(L_HAS_T, L_TX, L_TY, L_TZ, L_R0, L_R1, L_R2, L_R3, L_R4, L_R5, L_R6, L_R7, L_R8, L_MASS, L_CX, L_CY, L_CZ,
+ L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_SIZE) = range(24)
+LINK_SIZE = D_SIZE + L_SIZE
+# ---- per-geom block
+(G_LINK, G_TYPE, G_PX, G_PY, G_PZ, G_AX, G_AY, G_AZ, G_RADIUS, G_HALF, G_RBOUND, G_MARGIN, G_K, G_B, G_S0, G_S1,
+ G_S2, G_S3, G_S4, G_TRAN, G_DIM, G_MU, G_F0, G_F1, G_F2, G_F3, G_F4, G_RR1, G_RR2, G_RR3, G_RR4, G_RR5,
+ G_SIZE) = range(33)
+# ---- chain block = [nlinks, ngeoms, unsupported geoms (count), links..., geoms...]
+C_NLINKS, C_NGEOMS, C_NUNSUP, C_LINKS = 0, 1, 2, 4
+C_GEOMS = C_LINKS + MAXC * LINK_SIZE
+C_UNSUP = C_GEOMS + MAXG * G_SIZE                  # unsupported geoms: (link, px,py,pz, rbound, margin) x MAXG
+U_SIZE = 6
+CHAIN_SIZE = C_UNSUP + MAXG * U_SIZE
+# ---- root block (replicated for all lanes)
+(R_NDOF, R_TX, R_TY, R_TZ, R_R0, R_R1, R_R2, R_R3, R_R4, R_R5, R_R6, R_R7, R_R8, R_MASS, R_CX, R_CY, R_CZ, R_IXX,
+ R_IYY, R_IZZ, R_IXY, R_IXZ, R_IYZ, R_NUNSUP, R_DOFS) = range(25)
+R_UNSUP = R_DOFS + NROOT * D_SIZE
+ROOT_SIZE = R_UNSUP + 2 * MAXG * U_SIZE
+# ---- whole table: root block, then the chain blocks interleaved [field][chain]
+CM_ROOT = 0
+CM_CHAINS = ROOT_SIZE
+CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN
+
+GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE)
+MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
+
+
+class UnsupportedModel(ValueError):
+    pass
+
+
+def _kb(solref, solimp, timestep):
+    dmax = min(MAXIMP, max(MINIMP, solimp[1]))
+    if solref[0] > 0:
+        tc = max(solref[0], 2 * timestep)
+        return 1.0 / max(MINVAL, dmax * dmax * tc * tc * solref[1] * solref[1]), 2.0 / max(MINVAL, dmax * tc)
+    return -solref[0] / max(MINVAL, dmax * dmax), -solref[1] / max(MINVAL, dmax)
+
+
+def _clip_solimp(s):
+    return [min(MAXIMP, max(MINIMP, s[0])), min(MAXIMP, max(MINIMP, s[1])), max(0.0, s[2]),
+            min(MAXIMP, max(MINIMP, s[3])), max(1.0, s[4])]
+
+
+def _mix_with_floor(m, g, gf):
+    """MuJoCo's contact-parameter combination of geom ``g`` with the floor plane ``gf`` (priority wins,
+    else max condim / max friction / solmix-weighted solref+solimp); margin = max, gap = max."""
+    p, pf = m.geom_priority[g], m.geom_priority[gf]
+    if p != pf:
+        w = g if p > pf else gf
+        dim, solref, solimp, fr = m.geom_condim[w], m.geom_solref[w], m.geom_solimp[w], m.geom_friction[w]
+    else:
+        dim = max(m.geom_condim[g], m.geom_condim[gf])
+        s1, s2 = m.geom_solmix[g], m.geom_solmix[gf]
+        mix = s1 / (s1 + s2) if (s1 >= MINVAL and s2 >= MINVAL) else (0.5 if (s1 < MINVAL and s2 < MINVAL) else
+                                                                        (0.0 if s1 < MINVAL else 1.0))
+        r1, r2 = m.geom_solref[g], m.geom_solref[gf]
+        solref = mix * r1 + (1 - mix) * r2 if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
+        solimp = mix * m.geom_solimp[g] + (1 - mix) * m.geom_solimp[gf]
+        fr = np.maximum(m.geom_friction[g], m.geom_friction[gf])
+    friction = [fr[0], fr[0], fr[1], fr[2], fr[2]]
+    margin = max(m.geom_margin[g], m.geom_margin[gf])
+    gap = max(m.geom_gap[g], m.geom_gap[gf])
+    return int(dim), np.asarray(solref, float), np.asarray(solimp, float), friction, margin, gap
+
+
+HEADER_SIZE = 32
+LMC_MAGIC = 0x4C4D4331  # "LMC1"
+(H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
+ H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
+H_MEANINERTIA, H_CM_SIZE = 26, 27
+SRC_ROOT_QVEL, SRC_GOAL, SRC_ROOT_QPOS = 0, 100, 200
+
+
+def lower(m, task):
+    """
+    ``task``: dict(nobs, qpos_obs_idx, qvel_obs_idx, n_goal, act_ctrl_idx, act_mean, act_delta,
+    term=[(obs idx, lo, hi)], reward_type, reward_params, n_substeps) — see ``LocoEnv._device_task``.
+    Returns ``(chain_model float64[HEADER_SIZE + CM_SIZE], info dict)``; raises :class:`UnsupportedModel`.
+    """
+    qobs = {int(d): i for i, d in enumerate(task["qpos_obs_idx"])}
+    nq_obs = len(task["qpos_obs_idx"])
+    vobs = {int(d): nq_obs + i for i, d in enumerate(task["qvel_obs_idx"])}
+    action_of_act = {int(a): k for k, a in enumerate(task["act_ctrl_idx"])}
+    obs_src = {}
+    for d, i in qobs.items():
+        obs_src[i] = ("q", d)
+    for d, i in vobs.items():
+        obs_src[i] = ("v", d)
+    for i in range(task["n_goal"]):
+        obs_src[task["nobs"] - task["n_goal"] + i] = ("g", i)
+    term_q, term_v = {}, {}
+    for idx, lo, hi in task["term"]:
+        kind, d = obs_src[int(idx)]
+        if kind == "g":
+            raise UnsupportedModel("termination on a goal entry")
+        (term_q if kind == "q" else term_v)[d] = (max(lo, -3e38), min(hi, 3e38))
+    if m.integrator != mjcf.INT_EULER:
+        raise UnsupportedModel("RK4 models are not built on the device yet")
+    if m.cone != mjcf.CONE_ELLIPTIC:
+        raise UnsupportedModel("pyramidal friction cones are not built on the device yet")
+    nb = m.nbody
+    jointed = [b for b in range(1, nb) if m.body_jntnum[b] > 0]
+    roots = [b for b in jointed if m.body_weldid[m.body_parent[b]] == 0]
+    if len(roots) != 1:
+        raise UnsupportedModel("exactly one jointed root body expected")
+    root = roots[0]
+    if m.body_parent[root] != 0:
+        raise UnsupportedModel("root body must be a child of the world")
+    if m.body_jntnum[root] > NROOT:
+        raise UnsupportedModel("root body has more than %d dofs" % NROOT)
+
+    # jointed children of each jointed body (through welded bodies)
+    def jointed_parent(b):
+        return m.body_weldid[m.body_parent[b]]
+    children = {b: [c for c in jointed if c != b and jointed_parent(c) == b] for b in jointed}
+    chains = []
+    for start in children[root]:
+        chain, b = [], start
+        while True:
+            chain.append(b)
+            if len(children[b]) == 0:
+                break
+            if len(children[b]) > 1:
+                raise UnsupportedModel("branching below the root is not supported")
+            b = children[b][0]
+        chains.append(chain)
+    if len(chains) > NCHAIN:
+        raise UnsupportedModel("more than %d chains" % NCHAIN)
+
+    kin = mjcf.forward_kinematics(m, m.qpos0)
+
+    # ---- weld jointless bodies into their jointed ancestor: pose of every body relative to its weld body at qpos0
+    def rel_pose(b):
+        w = m.body_weldid[b]
+        rw = kin["xmat"][w]
+        return rw.T @ (kin["xpos"][b] - kin["xpos"][w]), rw.T @ kin["xmat"][b]
+
+    def merged_inertial(w):
+        """mass, com, inertia (about com) of weld group ``w`` in w's frame."""
+        members = [b for b in range(1, nb) if m.body_weldid[b] == w]
+        mass = sum(m.body_mass[b] for b in members)
+        if mass <= 0:
+            return 0.0, np.zeros(3), np.zeros((3, 3))
+        coms, rots = {}, {}
+        for b in members:
+            p, r = rel_pose(b)
+            coms[b], rots[b] = p + r @ m.body_ipos[b], r
+        com = sum(m.body_mass[b] * coms[b] for b in members) / mass
+        inertia = np.zeros((3, 3))
+        for b in members:
+            d = coms[b] - com
+            inertia += rots[b] @ m.body_inertia[b] @ rots[b].T + m.body_mass[b] * (d @ d * np.eye(3) - np.outer(d, d))
+        return mass, com, inertia
+
+    floor = [g for g in range(m.ngeom) if m.geom_type[g] == mjcf.GEOM_PLANE]
+    if len(floor) != 1 or m.geom_body[floor[0]] != 0:
+        raise UnsupportedModel("exactly one floor plane on the world body expected")
+    gf = floor[0]
+    if np.abs(m.geom_pos[gf]).max() > 0 or np.abs(m.geom_quat[gf] - [1, 0, 0, 0]).max() > 1e-12:
+        raise UnsupportedModel("floor plane must be z=0")
+
+    cm = np.zeros(CM_SIZE, dtype=np.float64)
+    act_of_dof = {int(d): a for a, d in enumerate(m.act_dof)}
+    dof_to_lane = -np.ones(m.nv, dtype=np.int64)
+
+    def fill_dof(block, d, qobs, vobs):
+        block[D_TYPE] = m.jnt_type[d]
+        block[D_AX:D_AX + 3] = m.jnt_axis[d]
+        block[D_PX:D_PX + 3] = m.jnt_pos[d]
+        block[D_DAMP], block[D_ARM], block[D_STIFF] = m.dof_damping[d], m.dof_armature[d], m.jnt_stiffness[d]
+        fl = m.dof_frictionloss[d]
+        block[D_FLOSS] = fl
+        if fl > 0:
+            si = _clip_solimp(m.dof_solimp[d])
+            d0 = si[0] if not (si[0] == si[1] or si[2] <= MINVAL) else 0.5 * (si[0] + si[1])
+            block[D_FLOSS_R] = max(MINVAL, (1 - d0) * m.dof_invweight0[d] / d0)
+            block[D_FLOSS_B] = _kb(m.dof_solref[d], m.dof_solimp[d], m.timestep)[1]
+        block[D_LIMITED] = m.jnt_limited[d]
+        block[D_LO], block[D_HI] = m.jnt_range[d]
+        if m.jnt_limited[d]:
+            assert m.jnt_margin[d] == 0, "joint margin != 0 not supported on the device"
+            block[D_LIM_K], block[D_LIM_B] = _kb(m.jnt_solref[d], m.jnt_solimp[d], m.timestep)
+            block[D_LIM_S0:D_LIM_S0 + 5] = _clip_solimp(m.jnt_solimp[d])
+        block[D_INVW] = m.dof_invweight0[d]
+        a = act_of_dof.get(int(d), -1)
+        block[D_ACT] = -1
+        if a >= 0:
+            block[D_GEAR] = m.act_gear[a]
+            lo, hi = (m.act_ctrlrange[a] if m.act_ctrllimited[a] else (-np.inf, np.inf))
+            block[D_CTRL_LO], block[D_CTRL_HI] = max(lo, -3e38), min(hi, 3e38)
+            k = action_of_act.get(a, -1)
+            block[D_ACT] = k
+            if k >= 0:
+                block[D_ACT_MEAN], block[D_ACT_DELTA] = task["act_mean"][k], task["act_delta"][k]
+        block[D_QOBS], block[D_VOBS] = qobs.get(int(d), -1), vobs.get(int(d), -1)
+        block[D_TERM_QLO], block[D_TERM_QHI] = term_q.get(int(d), (-3e38, 3e38))
+        block[D_TERM_VLO], block[D_TERM_VHI] = term_v.get(int(d), (-3e38, 3e38))
+        block[D_DOF] = d
+
+    def geom_blocks(w, link_index):
+        """floor-collidable geoms of weld group w: (supported blocks, unsupported blocks)."""
+        sup, unsup = [], []
+        for g in range(m.ngeom):
+            b = m.geom_body[g]
+            if b == 0 or m.body_weldid[b] != w:
+                continue
+            if not ((m.geom_contype[g] & m.geom_conaffinity[gf]) or (m.geom_contype[gf] & m.geom_conaffinity[g])):
+                continue
+            p, r = rel_pose(b)
+            gpos = p + r @ m.geom_pos[g]
+            grot = r @ mjcf.quat_to_mat(m.geom_quat[g])
+            dim, solref, solimp, fr, margin, gap = _mix_with_floor(m, g, gf)
+            assert gap == 0, "contact gap != 0 not supported on the device"
+            t, size = m.geom_type[g], m.geom_size[g]
+            rbound = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1],
+                      mjcf.GEOM_CYLINDER: np.hypot(size[0], size[1]), mjcf.GEOM_BOX: np.linalg.norm(size)}[t]
+            if t not in GEOM_SUPPORTED:
+                unsup.append([link_index, gpos[0], gpos[1], gpos[2], rbound, margin])
+                continue
+            blk = np.zeros(G_SIZE)
+            blk[G_LINK], blk[G_TYPE] = link_index, t
+            blk[G_PX:G_PX + 3] = gpos
+            blk[G_AX:G_AX + 3] = grot[:, 2]
+            blk[G_RADIUS], blk[G_HALF], blk[G_RBOUND], blk[G_MARGIN] = size[0], (size[1] if t == mjcf.GEOM_CAPSULE else 0), rbound, margin
+            blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
+            blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
+            blk[G_TRAN] = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
+            blk[G_DIM] = dim
+            if dim not in (1, 3, 4, 6):
+                raise UnsupportedModel("condim %d" % dim)
+            blk[G_F0:G_F0 + 5] = fr
+            blk[G_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
+            rr1 = 1.0 / max(MINVAL, m.impratio)
+            blk[G_RR1], blk[G_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
+            blk[G_RR3:G_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+            sup.append(blk)
+        return sup, unsup
+
+    info = dict(root=root, chains=chains)
+
+    # ---- root block
+    rb = cm[CM_ROOT:CM_ROOT + ROOT_SIZE]
+    rb[R_NDOF] = m.body_jntnum[root]
+    rb[R_TX:R_TX + 3] = m.body_pos[root]
+    rb[R_R0:R_R0 + 9] = mjcf.quat_to_mat(m.body_quat[root]).reshape(9)
+    mass, com, inertia = merged_inertial(root)
+    rb[R_MASS], rb[R_CX:R_CX + 3] = mass, com
+    rb[R_IXX:R_IXX + 6] = [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1], inertia[0, 2], inertia[1, 2]]
+    for k in range(m.body_jntnum[root]):
+        d = m.body_jntadr[root] + k
+        fill_dof(rb[R_DOFS + k * D_SIZE:R_DOFS + (k + 1) * D_SIZE], d, qobs, vobs)
+        dof_to_lane[d] = -2
+    sup, unsup = geom_blocks(root, 0)
+    unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
+    if len(unsup) > 2 * MAXG:
+        raise UnsupportedModel("too many root geoms")
+    rb[R_NUNSUP] = len(unsup)
+    for i, u in enumerate(unsup):
+        rb[R_UNSUP + i * U_SIZE:R_UNSUP + (i + 1) * U_SIZE] = u
+
+    # ---- chains, interleaved [field][chain]
+    max_links = 0
+    for c, chain in enumerate(chains):
+        blk = np.zeros(CHAIN_SIZE)
+        links = []
+        for b in chain:
+            for k in range(m.body_jntnum[b]):
+                links.append((b, m.body_jntadr[b] + k, k == 0, k == m.body_jntnum[b] - 1))
+        if len(links) > MAXC:
+            raise UnsupportedModel("chain with more than %d dofs" % MAXC)
+        max_links = max(max_links, len(links))
+        blk[C_NLINKS] = len(links)
+        geoms, unsup = [], []
+        for li, (b, d, first, last) in enumerate(links):
+            lb = blk[C_LINKS + li * LINK_SIZE:C_LINKS + (li + 1) * LINK_SIZE]
+            fill_dof(lb[:D_SIZE], d, qobs, vobs)
+            dof_to_lane[d] = c
+            ex = lb[D_SIZE:]
+            if first:
+                # pose of body b relative to its jointed parent's frame (through welded ancestors), at qpos0
+                pw = jointed_parent(b)
+                rp = kin["xmat"][pw]
+                ex[L_HAS_T] = 1
+                ex[L_TX:L_TX + 3] = rp.T @ (kin["xpos"][b] - kin["xpos"][pw])
+                ex[L_R0:L_R0 + 9] = (rp.T @ kin["xmat"][b]).reshape(9)
+            else:
+                ex[L_R0:L_R0 + 9] = np.eye(3).reshape(9)
+            if last:
+                mass, com, inertia = merged_inertial(b)
+                ex[L_MASS], ex[L_CX:L_CX + 3] = mass, com
+                ex[L_IXX:L_IXX + 6] = [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1], inertia[0, 2],
+                                       inertia[1, 2]]
+                s, u = geom_blocks(b, li)
+                geoms += s
+                unsup += u
+        if len(geoms) > MAXG or len(unsup) > MAXG:
+            raise UnsupportedModel("too many geoms on one chain")
+        blk[C_NGEOMS], blk[C_NUNSUP] = len(geoms), len(unsup)
+        for i, gblk in enumerate(geoms):
+            blk[C_GEOMS + i * G_SIZE:C_GEOMS + (i + 1) * G_SIZE] = gblk
+        for i, u in enumerate(unsup):
+            blk[C_UNSUP + i * U_SIZE:C_UNSUP + (i + 1) * U_SIZE] = u
+        cm[CM_CHAINS + np.arange(CHAIN_SIZE) * NCHAIN + c] = blk
+
+    if (dof_to_lane == -1).any():
+        raise UnsupportedModel("some dofs are outside the root+chains structure")
+
+    def src_code(obs_idx):
+        kind, i = obs_src[int(obs_idx) % task["nobs"]]
+        if kind == "g":
+            return SRC_GOAL + i
+        k = i - m.body_jntadr[root]
+        if not (0 <= k < m.body_jntnum[root]):
+            raise UnsupportedModel("device reward reads a non-root dof")
+        return (SRC_ROOT_QVEL if kind == "v" else SRC_ROOT_QPOS) + k
+
+    h = np.zeros(HEADER_SIZE)
+    h[H_MAGIC], h[H_VERSION] = LMC_MAGIC, 1
+    h[H_NV], h[H_NU], h[H_NCHAINS], h[H_MAXLINKS] = m.nv, len(task["act_ctrl_idx"]), len(chains), max_links
+    h[H_TIMESTEP] = m.timestep
+    h[H_GX:H_GX + 3] = m.gravity
+    h[H_IMPRATIO], h[H_ITERATIONS], h[H_TOLERANCE] = m.impratio, m.iterations, m.tolerance
+    h[H_NSUBSTEPS], h[H_NOBS], h[H_NGOAL] = task["n_substeps"], task["nobs"], task["n_goal"]
+    rt, rp = task["reward_type"], list(task["reward_params"])
+    h[H_REWARD_TYPE] = rt
+    if rt == 1:
+        h[H_REWARD_P0:H_REWARD_P0 + 2] = [src_code(rp[0]), rp[1]]
+    elif rt == 2:
+        h[H_REWARD_P0:H_REWARD_P0 + 5] = [src_code(p) for p in rp[:5]]
+    h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
+    info.update(n_chains=len(chains), max_links=max_links, dof_to_lane=dof_to_lane,
+                self_collision_pairs=_count_self_pairs(m))
+    return np.concatenate([h, cm]), info
+
+
+def _count_self_pairs(m):
+    """Number of non-floor geom pairs MuJoCo's filters would let collide (ignored by the device path)."""
+    n = 0
+    for g1 in range(m.ngeom):
+        for g2 in range(g1 + 1, m.ngeom):
+            b1, b2 = m.geom_body[g1], m.geom_body[g2]
+            w1, w2 = m.body_weldid[b1], m.body_weldid[b2]
+            if w1 == 0 or w2 == 0 or w1 == w2:
+                continue
+            p1, p2 = m.body_weldid[m.body_parent[w1]], m.body_weldid[m.body_parent[w2]]
+            if w1 == p2 or w2 == p1:
+                continue
+            if (m.geom_contype[g1] & m.geom_conaffinity[g2]) or (m.geom_contype[g2] & m.geom_conaffinity[g1]):
+                n += 1
+    return n

@@ -1,16 +1,13 @@
 """
-Pack a :class:`loco_mujoco_amd.mjcf.CompiledModel` (and the task description) into the flat float64
-arrays that cross the C-ABI. Layout: ``include/lm_model_blob.h``.
+Pack a :class:`loco_mujoco_amd.mjcf.CompiledModel` into the flat float64 "general model" array
+(``include/lm_model_blob.h``) that the fp64 test oracle consumes. The product path uses
+``loco_mujoco_amd.lowering.lower`` instead.
 """
 
 import numpy as np
 
 LM_BLOB_MAGIC = 0x4C4D4231
-LM_TASK_MAGIC = 0x4C4D5431
 HEADER_SIZE = 32
-TASK_HEADER_SIZE = 16
-
-REWARD_NONE, REWARD_TARGET_VELOCITY, REWARD_VELOCITY_VECTOR = 0, 1, 2
 
 
 def pack_model(m):
@@ -32,17 +29,4 @@ def pack_model(m):
              m.geom_condim, m.geom_priority, m.geom_friction, m.geom_solmix, m.geom_solref, m.geom_solimp,
              m.geom_margin, m.geom_gap,
              m.act_dof, m.act_gear, m.act_ctrlrange, m.act_ctrllimited]
-    return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))
-
-
-def pack_task(nobs, qpos_obs_idx, qvel_obs_idx, n_goal, act_ctrl_idx, act_mean, act_delta,
-              term_obs_idx, term_lo, term_hi, reward_type, reward_params, n_substeps):
-    h = np.zeros(TASK_HEADER_SIZE)
-    h[0] = LM_TASK_MAGIC
-    h[1:8] = [nobs, len(qpos_obs_idx), len(qvel_obs_idx), n_goal, reward_type, len(term_obs_idx), n_substeps]
-    rp = np.asarray(reward_params, dtype=np.float64).ravel()
-    assert len(rp) <= 8
-    h[8:8 + len(rp)] = rp
-    assert nobs == len(qpos_obs_idx) + len(qvel_obs_idx) + n_goal
-    parts = [h, qpos_obs_idx, qvel_obs_idx, act_ctrl_idx, act_mean, act_delta, term_obs_idx, term_lo, term_hi]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

@@ -1,0 +1,94 @@
+// TEST TOOLING ONLY — CPU emulation of one quad of GPU lanes, so that the device code in
+// loco_mujoco_amd/csrc/lm_core.h can be debugged against the fp64 oracle in a container without a GPU.
+// Four OS threads play the four lanes; the quad sum (two DPP adds on gfx950) becomes a barrier + the same
+// (x0+x1)+(x2+x3) association. Nothing in the product loads this file; it is built by tests/test_emu_core.py.
+#include <barrier>
+#include <cstring>
+#include <thread>
+#include <vector>
+#define LM_DEV inline
+#include "../../loco_mujoco_amd/csrc/lm_core.h"
+
+namespace {
+std::barrier<> g_bar(4);
+float g_buf[4];
+int g_ibuf[4];
+thread_local int t_lane = 0;
+struct QuadThreads {
+  static float sum(float x) {
+    g_buf[t_lane] = x; g_bar.arrive_and_wait();
+    float s = (g_buf[0] + g_buf[1]) + (g_buf[2] + g_buf[3]);
+    g_bar.arrive_and_wait(); return s;
+  }
+  static bool any(bool b) {
+    g_ibuf[t_lane] = b; g_bar.arrive_and_wait();
+    bool r = g_ibuf[0] | g_ibuf[1] | g_ibuf[2] | g_ibuf[3];
+    g_bar.arrive_and_wait(); return r;
+  }
+};
+constexpr int MC = 3, NS = 4;
+}  // namespace
+
+// chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
+extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                       int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
+                       int* counters /*4*/) {
+  const double* H = chain_model;
+  const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
+  std::vector<float> cm(LM_CM_SIZE);
+  for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)H[LM_HEADER_SIZE + i];
+  lm::Params P;
+  P.h = (float)H[LM_H_TIMESTEP]; P.g = lm::v3((float)H[LM_H_GX], (float)H[LM_H_GY], (float)H[LM_H_GZ]);
+  P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
+  P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
+  int cnt_tot[4] = {0, 0, 0, 0};
+  auto lane_main = [&](int c) {
+    t_lane = c;
+    const float* rb = cm.data();
+    for (int e = 0; e < n; e++) {
+      float qr[6], vr[6], war[6], actr[6], qc[MC], vc[MC], wac[MC], actc[MC];
+      int dr[6], dc[MC];
+      const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
+      auto actuate = [&](const float* blk, int stride) -> float {
+        int k = (int)blk[LM_D_ACT * stride];
+        if (k < 0) return 0.0f;
+        float ctrl = (float)action[e * nu + k] * blk[LM_D_ACT_DELTA * stride] + blk[LM_D_ACT_MEAN * stride];
+        ctrl = fminf(fmaxf(ctrl, blk[LM_D_CTRL_LO * stride]), blk[LM_D_CTRL_HI * stride]);
+        return blk[LM_D_GEAR * stride] * ctrl;
+      };
+      for (int i = 0; i < 6; i++) {
+        const float* blk = rb + LM_R_DOFS + i * LM_D_SIZE;
+        dr[i] = (int)blk[LM_D_DOF];
+        qr[i] = (float)qpos[e * nv + dr[i]]; vr[i] = (float)qvel[e * nv + dr[i]]; war[i] = (float)warm[e * nv + dr[i]];
+        actr[i] = actuate(blk, 1);
+      }
+      for (int k = 0; k < MC; k++) {
+        qc[k] = vc[k] = wac[k] = actc[k] = 0; dc[k] = -1;
+        if (k < nl) {
+          const float* blk = cm.data() + LM_CM_CHAINS + (LM_C_LINKS + k * LM_LINK_SIZE) * LM_NCHAIN + c;
+          dc[k] = (int)blk[LM_D_DOF * LM_NCHAIN];
+          qc[k] = (float)qpos[e * nv + dc[k]]; vc[k] = (float)qvel[e * nv + dc[k]]; wac[k] = (float)warm[e * nv + dc[k]];
+          actc[k] = actuate(blk, LM_NCHAIN);
+        }
+      }
+      lm::Counters cnt = {0, 0, 0, 0};
+      lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
+      for (int s = 0; s < nsub; s++)
+        lm::substep<QuadThreads, MC, NS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, cnt,
+                                         (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr);
+      g_bar.arrive_and_wait();
+      if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
+      for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
+      static int acc[4][4];
+      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon;
+      g_bar.arrive_and_wait();
+      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 4; j++) cnt_tot[j] += acc[l][j];
+      g_bar.arrive_and_wait();
+    }
+  };
+  std::thread t1(lane_main, 1), t2(lane_main, 2), t3(lane_main, 3);
+  lane_main(0);
+  t1.join(); t2.join(); t3.join();
+  if (counters) memcpy(counters, cnt_tot, sizeof(cnt_tot));
+  return 0;
+}

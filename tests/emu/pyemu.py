@@ -1,0 +1,37 @@
+"""ctypes wrapper of the CPU lane emulator (tests/emu/emu.cpp) — test tooling only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libemu.so")
+
+
+def build():
+    srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
+            os.path.join(_HERE, "../../include/lm_layout.h")]
+    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-o", _LIB, srcs[0]])
+    return _LIB
+
+
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1):
+    lib = C.CDLL(build())
+    cmod = np.ascontiguousarray(chain_model, dtype=np.float64)
+    nv = int(cmod[2])
+    q = np.array(qpos, dtype=np.float64).reshape(-1, nv)
+    v = np.array(qvel, dtype=np.float64).reshape(-1, nv)
+    n = q.shape[0]
+    w = np.zeros_like(q) if warm is None else np.array(warm, dtype=np.float64).reshape(n, nv)
+    a = np.ascontiguousarray(action, dtype=np.float64).reshape(n, -1)
+    M = np.zeros((nv, nv), dtype=np.float32)
+    d5 = np.zeros((5, nv), dtype=np.float32)
+    cnt = np.zeros(4, dtype=np.int32)
+    dp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
+                dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt))
+    dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
+    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3])), dbg

@@ -1,0 +1,191 @@
+"""
+GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path behind the C-ABI against the fp64 CPU
+oracle on the same inputs, against the reference's golden rollout, and — at the full 4096-environment
+size — through size-independent properties (KKT residual of the constraint solve, symmetry/definiteness of
+M, sharding invariance, determinism).
+
+Stated fp32 tolerance: after one control step qpos Linf <= 1e-4, qvel Linf <= 1e-2.
+"""
+
+import numpy as np
+import pytest
+
+from loco_mujoco_amd import LocoEnv, lowering
+from loco_mujoco_amd.model_blob import pack_model
+from oracle.pyoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(__file__.replace("test_gpu_parity.py", "golden/reference_rollouts.npz"))
+QTOL, VTOL = 1e-4, 1e-2
+
+
+def a1_actions(n):
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 3), np.random.randint(0, 100)
+    return np.array([np.random.randn(12) * 0.1 for _ in range(n)])
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    hm = HipModel(env._chain_model())
+    oracle = Oracle(pack_model(env._model))
+    oracle.set_option("disable_self_collision", 1)      # the device path has floor contacts only
+    return env, hm, oracle, HipBatch
+
+
+def golden_states():
+    g = GOLD["UnitreeA1.simple.real"]
+    qpos = np.concatenate([np.zeros((len(g), 2)), g[:, :16]], axis=1)
+    return g, qpos, g[:, 16:34]
+
+
+def test_native_library_is_loaded(setup):
+    from loco_mujoco_amd import backend
+    assert backend.load_library().lm_device_count() >= 1
+    assert any("liblocohip.so" in line for line in open("/proc/self/maps"))
+
+
+def test_forward_stages_match_oracle(setup):
+    env, hm, oracle, HipBatch = setup
+    g, qpos, qvel = golden_states()
+    acts = a1_actions(len(g) - 1)
+    n = len(g) - 1
+    b = HipBatch(hm, n)
+    b.set_state(qpos[:n], qvel[:n])
+    d = b.forward_debug(acts)
+    for k in range(n):
+        f = oracle.forward(qpos[k].astype(np.float32), qvel[k].astype(np.float32), acts[k].astype(np.float32))
+        assert d["ncon"][k] == f["ncon"], k
+        assert np.abs(d["M"][k] - f["M"]).max() < 2e-5
+        assert np.abs(d["qfrc_bias"][k] - f["bias"]).max() < 2e-4
+        scale = max(1.0, np.abs(f["qacc_smooth"]).max())
+        assert np.abs(d["qacc_smooth"][k] - f["qacc_smooth"]).max() < 2e-5 * scale + 1e-3
+        scale = max(1.0, np.abs(f["qacc"]).max())
+        assert np.abs(d["qacc"][k] - f["qacc"]).max() < 1e-4 * scale, (k, np.abs(d["qacc"][k] - f["qacc"]).max())
+
+
+def test_one_control_step_kats_vs_golden_and_oracle(setup):
+    """Rows k -> k+1 of the reference's golden rollout, all 17 in one batch."""
+    env, hm, oracle, HipBatch = setup
+    g, qpos, qvel = golden_states()
+    n = len(g) - 1
+    acts = a1_actions(n)
+    b = HipBatch(hm, n)
+    b.set_state(qpos[:n], qvel[:n])
+    b.set_goal(np.tile(g[0, 34:37], (n, 1)))
+    obs, rew, done = b.step(acts)
+    assert np.abs(obs[:, :16] - g[1:, :16]).max() < QTOL
+    assert np.abs(obs[:, 16:34] - g[1:, 16:34]).max() < VTOL
+    assert np.allclose(obs[:, 34:37], g[0, 34:37], atol=1e-6)
+    assert list(done) == [False] * 16 + [True]               # last golden row is the first terminal one
+    # reward is evaluated on the previous observation (reward.py:108-117)
+    want = [env.reward(g[k], None, None, False) for k in range(n)]
+    assert np.abs(rew - want).max() < 1e-5
+    errs_q, errs_v = [], []
+    for k in range(n):
+        q, v, _, _ = oracle.step(qpos[k].astype(np.float32), qvel[k].astype(np.float32), acts[k].astype(np.float32), 10)
+        errs_q.append(np.abs(obs[k, :16] - q[2:]).max())
+        errs_v.append(np.abs(obs[k, 16:34] - v).max())
+    print("KAT errors vs oracle: qpos max %.2e median %.2e | qvel max %.2e median %.2e"
+          % (max(errs_q), np.median(errs_q), max(errs_v), np.median(errs_v)))
+    assert max(errs_q) < QTOL and max(errs_v) < VTOL
+
+
+def test_env_rollout_follows_reference_test():
+    """The reference's test loop (tests/test_environments.py:15-38) through LocoEnv on the GPU, n_envs=1."""
+    g = GOLD["UnitreeA1.simple.real"]
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-12
+    rows, absorbing = [obs], False
+    for _ in range(100):
+        if absorbing:
+            break
+        obs, r, absorbing, info = env.step(np.random.randn(12) * 0.1)
+        assert obs.dtype == np.float64 and obs.shape == (37,) and isinstance(r, float) and info == {}
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    # fp32 physics drifts over a 17-step chaotic contact rollout; the fp64 oracle passes np.allclose on this
+    assert np.abs(rows[:, :16] - g[:, :16]).max() < 2e-3
+    assert np.abs(rows[:, 16:34] - g[:, 16:34]).max() < 0.2
+
+
+def test_random_states_one_step_vs_oracle(setup):
+    """256 perturbed trajectory states, random actions in [-1,1]: error distribution vs the fp64 oracle."""
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    n = 256
+    rows = tab[rs.randint(0, len(tab), n)]
+    qpos = rows[:, :18] + rs.uniform(-0.03, 0.03, (n, 18))
+    qpos[:, 2] -= rs.uniform(0, 0.03, n)                     # push some feet into the ground
+    qvel = rows[:, 18:36] * rs.uniform(0.5, 1.0, (n, 1))
+    acts = rs.uniform(-1, 1, (n, 12))
+    b = HipBatch(hm, n)
+    b.set_state(qpos, qvel)
+    obs, _, _ = b.step(acts)
+    q1, v1 = b.get_state()
+    eq, ev = [], []
+    for k in range(n):
+        q, v, _, st = oracle.step(qpos[k].astype(np.float32), qvel[k].astype(np.float32), acts[k].astype(np.float32), 10)
+        eq.append(np.abs(q1[k] - q).max())
+        ev.append(np.abs(v1[k] - v).max())
+    eq, ev = np.array(eq), np.array(ev)
+    print("random states: qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e"
+          % (eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev)))
+    assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
+    assert eq.max() < 10 * QTOL and ev.max() < 10 * VTOL
+    st = b.stats()
+    assert st["overflow_contacts"] == 0
+
+
+def test_full_size_properties_4096(setup):
+    """BASELINE size: KKT residual of the solve, M symmetric positive definite, no dropped contacts."""
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+    n = 4096
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, 3, n) * 100 + rs.randint(0, 100, n)]
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :18], rows[:, 18:36])
+    b.set_goal(rows[:, 36:39])
+    b.rollout(5, action_mode=0)                              # settle onto the feet
+    d = b.forward_debug(np.zeros((n, 12)))
+    M = d["M"].astype(np.float64)
+    assert np.abs(M - M.transpose(0, 2, 1)).max() == 0
+    assert np.linalg.eigvalsh(M).min() > 0
+    res = np.einsum("nij,nj->ni", M, d["qacc"].astype(np.float64)) - d["qfrc_smooth"] - d["qfrc_constraint"]
+    scale = np.abs(d["qfrc_smooth"]).max(axis=1) + 1.0
+    print("KKT residual max %.2e (relative %.2e); contacts per env mean %.2f" % (np.abs(res).max(), (np.abs(res).max(axis=1) / scale).max(), d["ncon"].mean()))
+    assert (np.abs(res).max(axis=1) / scale).max() < 2e-3
+    assert d["ncon"].max() >= 2
+
+
+def test_auto_reset_and_sharding_invariance(setup):
+    """Episodes restart on the device; results depend on (seed, global env id) only, not on the batch split."""
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+
+    def run(n, offset):
+        b = HipBatch(hm, n)
+        b.set_reset_table(tab, seed=7, global_env_offset=offset)
+        b.set_auto_reset(True, horizon=50)
+        rows = tab[(np.arange(offset, offset + n) * 37) % len(tab)]
+        b.set_state(rows[:, :18], rows[:, 18:36])
+        b.set_goal(rows[:, 36:39])
+        st = b.rollout(60, action_mode=1, seed=3)
+        return b.get_state(), st
+
+    (qa, va), sa = run(64, 0)
+    (qb0, vb0), sb0 = run(32, 0)
+    (qb1, vb1), sb1 = run(32, 32)
+    assert np.array_equal(qa, np.concatenate([qb0, qb1])) and np.array_equal(va, np.concatenate([vb0, vb1]))
+    assert sa["episodes"] >= 64 and sa["nan_resets"] == 0 and sa["env_steps"] == 64 * 60
+    assert sa["episodes"] == sb0["episodes"] + sb1["episodes"]
+    assert np.isfinite(qa).all()
