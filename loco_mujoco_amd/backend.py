@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblocohip.so")
+LIB_PATH = os.environ.get("LOCOHIP_LIB", os.path.join(_HERE, "csrc", "liblocohip.so"))   # override: kernel A/B builds
 
 _F = C.POINTER(C.c_float)
 _U8 = C.POINTER(C.c_uint8)

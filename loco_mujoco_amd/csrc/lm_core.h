@@ -132,16 +132,11 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
   return s0 + y * (s1 - s0);
 }
 
-// ---- contact slot (one floor contact of this lane's chain) -------------------------------------------------
-struct Slot {
-  int on;        // 0 = empty
-  int link;      // link of this chain the geom sits on
-  int g;         // geom block index (for constants)
-  V3 r;          // contact point - O
-  float dist;
-  float D0;      // 1/R of the normal row
-  float aref[6];
-};
+// ---- contact slot record (one floor contact of this lane's chain), kept in lane-local memory --------------
+// On the GPU this is an LDS array indexed [field][lane] (stride = lanes per workgroup, conflict-free); slots are
+// walked with ordinary loops so that only one contact's working set is in registers at a time.
+enum { SL_LINK = 0, SL_GEOM, SL_RX, SL_RY, SL_RZ, SL_DIST, SL_D0, SL_AREF, SL_JAR = SL_AREF + 6, SL_JV = SL_JAR + 6,
+       SL_ZONE = SL_JV + 6, SL_SIZE };
 
 // Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
 // because their D is 0). Dj = D of row j, fr = friction coefficients of rows 1..5, mu = regularised cone mu.
@@ -345,15 +340,22 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // ---- the substep ---------------------------------------------------------------------------------------------
 // cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
 // actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
+// lmem/ls: lane-local scratch of NS*SL_SIZE floats, element i at lmem[i*ls].
 template <class Q, int MC, int NS>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
-                    float* war, float* wac, const float* actr, const float* actc, Counters& cnt, const Debug* dbg) {
+                    float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
+                    Counters& cnt, const Debug* dbg) {
+  // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
+  // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
+  // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
+  int oz = LM_OPAQUE_ZERO();
   const float* rb = cm + LM_CM_ROOT;
-#define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
-#define CH(f) cm[LM_CM_CHAINS + (f) * LM_NCHAIN + c]
+#define RD(k, f) rb[oz + LM_R_DOFS + (k) * LM_D_SIZE + (f)]
+#define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
 #define LK(k, f) CH(LM_C_LINKS + (k) * LM_LINK_SIZE + (f))
 #define LX(k, f) LK(k, LM_D_SIZE + (f))
 #define GE(g, f) CH(LM_C_GEOMS + (g) * LM_G_SIZE + (f))
+#define SL(s, f) lmem[((s) * SL_SIZE + (f)) * ls]
   const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
   const int nl = (int)CH(LM_C_NLINKS);
 
@@ -404,73 +406,80 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
 
-  // chain
-  Sp Sc[MC], Vc[MC], Ac[MC];
-  SpI Ic[MC];
-  Slot slot[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) slot[s].on = 0;
-  int nslot = 0;
-  {
-    M3 Rk = R; V3 pk = O;
-    Sp V = Vroot, A = Aroot;
-    const int ng = (int)CH(LM_C_NGEOMS), nun = (int)CH(LM_C_NUNSUP);
-#pragma unroll
-    for (int k = 0; k < MC; k++) {
-      if (k < nl) {
-        M3 T;
-#pragma unroll
-        for (int i = 0; i < 9; i++) T.a[i] = LX(k, LM_L_R0 + i);
-        pk = pk + mul(Rk, v3(LX(k, LM_L_TX), LX(k, LM_L_TY), LX(k, LM_L_TZ)));
-        Rk = mul(Rk, T);
-        float t = LK(k, LM_D_TYPE);
-        V3 al = v3(LK(k, LM_D_PX), LK(k, LM_D_PY), LK(k, LM_D_PZ));
-        V3 aw = pk + mul(Rk, al);
-        V3 uw = mul(Rk, v3(LK(k, LM_D_AX), LK(k, LM_D_AY), LK(k, LM_D_AZ)));
-        if (t != 0.0f) { rotate_world(Rk, uw, qc[k]); pk = aw - mul(Rk, al); Sc[k].w = uw; Sc[k].v = cross(uw, O - aw); }
-        else { pk = pk + qc[k] * uw; Sc[k].w = v3(0, 0, 0); Sc[k].v = uw; }
-        Sp Sd; Sd.w = cross(V.w, Sc[k].w); Sd.v = cross(V.w, Sc[k].v) + cross(V.v, Sc[k].w);
-        V = V + vc[k] * Sc[k];
-        A = A + vc[k] * Sd;
-        Vc[k] = V; Ac[k] = A;
-        float Il[6], Iw[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) Il[i] = LX(k, LM_L_IXX + i);
-        rotate_inertia(Rk, Il, Iw);
-        Ic[k] = make_spi(LX(k, LM_L_MASS), pk + mul(Rk, v3(LX(k, LM_L_CX), LX(k, LM_L_CY), LX(k, LM_L_CZ))) - O, Iw);
-        // floor contacts of the geoms on this link (plane z = 0, normal +z)
-        for (int g = 0; g < ng; g++) {
-          if ((int)GE(g, LM_G_LINK) != k) continue;
-          V3 ctr = pk + mul(Rk, v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ)));
-          if (ctr.z - GE(g, LM_G_RBOUND) > 0.0f) continue;        // margin-less bounding-sphere prune
-          float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
-          V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
-          int npt = (GE(g, LM_G_TYPE) == 2.0f) ? 2 : 1;
-          for (int e = 0; e < npt; e++) {
-            V3 sc = (npt == 2) ? ctr + ((e == 0) ? half : -half) * ax : ctr;
-            float dist = sc.z - rad;
-            if (dist >= margin) continue;
-            if (nslot >= NS) { cnt.overflow++; continue; }
-            V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
-#pragma unroll
-            for (int s = 0; s < NS; s++) if (s == nslot) { slot[s].on = 1; slot[s].link = k; slot[s].g = g; slot[s].r = cp; slot[s].dist = dist; }
-            nslot++;
-          }
-        }
-        for (int i = 0; i < nun; i++) {
-          if ((int)CH(LM_C_UNSUP + i * LM_U_SIZE) != k) continue;
-          V3 s = pk + mul(Rk, v3(CH(LM_C_UNSUP + i * LM_U_SIZE + 1), CH(LM_C_UNSUP + i * LM_U_SIZE + 2), CH(LM_C_UNSUP + i * LM_U_SIZE + 3)));
-          if (s.z - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
-        }
-      } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
-    }
-  }
-  cnt.ncon += nslot;
-
-  // ================= inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) =================
+  // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots
+  Sp Sc[MC];
   float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
   float bias_c[MC], bias_r[6];
+  int nslot = 0;
   {
+    Sp Vc[MC], Ac[MC];
+    SpI Ic[MC];
+    {
+      M3 Rk = R; V3 pk = O;
+      Sp V = Vroot, A = Aroot;
+      const int ng = (int)CH(LM_C_NGEOMS), nun = (int)CH(LM_C_NUNSUP);
+#pragma unroll
+      for (int k = 0; k < MC; k++) {
+        if (k < nl) {
+          M3 T;
+#pragma unroll
+          for (int i = 0; i < 9; i++) T.a[i] = LX(k, LM_L_R0 + i);
+          pk = pk + mul(Rk, v3(LX(k, LM_L_TX), LX(k, LM_L_TY), LX(k, LM_L_TZ)));
+          Rk = mul(Rk, T);
+          float t = LK(k, LM_D_TYPE);
+          V3 al = v3(LK(k, LM_D_PX), LK(k, LM_D_PY), LK(k, LM_D_PZ));
+          V3 aw = pk + mul(Rk, al);
+          V3 uw = mul(Rk, v3(LK(k, LM_D_AX), LK(k, LM_D_AY), LK(k, LM_D_AZ)));
+          if (t != 0.0f) { rotate_world(Rk, uw, qc[k]); pk = aw - mul(Rk, al); Sc[k].w = uw; Sc[k].v = cross(uw, O - aw); }
+          else { pk = pk + qc[k] * uw; Sc[k].w = v3(0, 0, 0); Sc[k].v = uw; }
+          Sp Sd; Sd.w = cross(V.w, Sc[k].w); Sd.v = cross(V.w, Sc[k].v) + cross(V.v, Sc[k].w);
+          V = V + vc[k] * Sc[k];
+          A = A + vc[k] * Sd;
+          Vc[k] = V; Ac[k] = A;
+          float Il[6], Iw[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) Il[i] = LX(k, LM_L_IXX + i);
+          rotate_inertia(Rk, Il, Iw);
+          Ic[k] = make_spi(LX(k, LM_L_MASS), pk + mul(Rk, v3(LX(k, LM_L_CX), LX(k, LM_L_CY), LX(k, LM_L_CZ))) - O, Iw);
+          // floor contacts of the geoms on this link (plane z = 0, normal +z)
+          for (int g = 0; g < ng; g++) {
+            if ((int)GE(g, LM_G_LINK) != k) continue;
+            V3 ctr = pk + mul(Rk, v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ)));
+            if (ctr.z - GE(g, LM_G_RBOUND) > 0.0f) continue;        // margin-less bounding-sphere prune
+            float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
+            V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
+            int npt = (GE(g, LM_G_TYPE) == 2.0f) ? 2 : 1;
+            for (int e = 0; e < npt; e++) {
+              V3 sc = (npt == 2) ? ctr + ((e == 0) ? half : -half) * ax : ctr;
+              float dist = sc.z - rad;
+              if (dist >= margin) continue;
+              if (nslot >= NS) { cnt.overflow++; continue; }
+              // contact point (midway between the surfaces) relative to O; row parameters
+              V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
+              float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
+              float R0 = fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN) / imp);
+              float vel[6];
+              contact_rows(V, cp, vel);
+              float B = GE(g, LM_G_B);
+              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_GEOM) = (float)g;
+              SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
+              SL(nslot, SL_DIST) = dist; SL(nslot, SL_D0) = 1.0f / R0;
+#pragma unroll
+              for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? GE(g, LM_G_K) * imp * (dist - margin) : 0.0f);
+              nslot++;
+            }
+          }
+          for (int i = 0; i < nun; i++) {
+            if ((int)CH(LM_C_UNSUP + i * LM_U_SIZE) != k) continue;
+            V3 s = pk + mul(Rk, v3(CH(LM_C_UNSUP + i * LM_U_SIZE + 1), CH(LM_C_UNSUP + i * LM_U_SIZE + 2), CH(LM_C_UNSUP + i * LM_U_SIZE + 3)));
+            if (s.z - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
+          }
+        } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
+      }
+    }
+    cnt.ncon += nslot;
+
+    // ======== inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) ========
     SpI comp = spi0();
     Sp Fsuf = sp0();
 #pragma unroll
@@ -519,8 +528,8 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
   for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k]) : 0.0f;
 
-  // ================= constraint rows =================
-  // friction loss (root rows replicated, chain rows own), joint limits (chain + root), contacts (slots)
+  oz = LM_OPAQUE_ZERO();
+  // ================= unit constraint rows: friction loss, joint limits =================
   float fl_aref_r[6], fl_aref_c[MC];     // friction-loss reference accelerations
   float lim_s_c[MC], lim_D_c[MC], lim_aref_c[MC];   // active limit: sign (+1 lower, -1 upper, 0 none)
 #pragma unroll
@@ -543,47 +552,30 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       }
     }
   }
-  // (root joint limits: none of the supported models limits a root dof; rejected at model creation)
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    if (slot[s].on) {
-      int g = slot[s].g;
-      float margin = GE(g, LM_G_MARGIN);
-      float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, slot[s].dist, margin);
-      float R0 = fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN) / imp);
-      slot[s].D0 = 1.0f / R0;
-      Sp Vl = Vroot;
-#pragma unroll
-      for (int k = 0; k < MC; k++) if (slot[s].link == k) Vl = Vc[k];
-      float vel[6];
-      contact_rows(Vl, slot[s].r, vel);
-      float B = GE(g, LM_G_B);
-#pragma unroll
-      for (int j = 0; j < 6; j++) slot[s].aref[j] = -B * vel[j];
-      slot[s].aref[0] -= GE(g, LM_G_K) * imp * (slot[s].dist - margin);
-    }
-  }
 
   // ================= unconstrained acceleration =================
-  float Lcc[MC * (MC + 1) / 2], W[MC][6], Lrr[21], zero21[21];
+  float zero21[21];
 #pragma unroll
   for (int i = 0; i < 21; i++) zero21[i] = 0;
-#pragma unroll
-  for (int i = 0; i < MC * (MC + 1) / 2; i++) Lcc[i] = Mcc[i];
-#pragma unroll
-  for (int k = 0; k < MC; k++)
-#pragma unroll
-    for (int r = 0; r < 6; r++) W[k][r] = Mcr[k][r];
-  arrow_factor<Q, MC>(Lcc, W, Mrr, zero21, Lrr);
   float a0r[6], a0c[MC];
+  {
+    float Lcc[MC * (MC + 1) / 2], W[MC][6], Lrr[21];
 #pragma unroll
-  for (int i = 0; i < 6; i++) a0r[i] = sm_r[i];
+    for (int i = 0; i < MC * (MC + 1) / 2; i++) Lcc[i] = Mcc[i];
 #pragma unroll
-  for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
-  arrow_solve<Q, MC>(Lcc, W, Lrr, a0c, a0r);
+    for (int k = 0; k < MC; k++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) W[k][r] = Mcr[k][r];
+    arrow_factor<Q, MC>(Lcc, W, Mrr, zero21, Lrr);
+#pragma unroll
+    for (int i = 0; i < 6; i++) a0r[i] = sm_r[i];
+#pragma unroll
+    for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
+    arrow_solve<Q, MC>(Lcc, W, Lrr, a0c, a0r);
+  }
 
   // ================= constraint solve: Newton on the primal problem =================
-  // helpers working on a candidate acceleration (xr, xc)
+  // y = M x ; returns nothing, yr is fully summed (replicated)
   auto mulM = [&](const float* xr, const float* xc, float* yr, float* yc) {
 #pragma unroll
     for (int k = 0; k < MC; k++) {
@@ -605,65 +597,50 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       yr[r] = t;
     }
   };
-  // J x for contact slot s (no aref)
+  // contact-frame image J x of joint-space vector x for the contact in slot s
   auto slotJx = [&](int s, const float* xr, const float* xc, float* out) {
     Sp A = sp0();
 #pragma unroll
     for (int r = 0; r < 6; r++) A = A + xr[r] * Sr[r];
+    const int link = (int)SL(s, SL_LINK);
 #pragma unroll
-    for (int k = 0; k < MC; k++) if (k <= slot[s].link) A = A + xc[k] * Sc[k];
-    contact_rows(A, slot[s].r, out);
+    for (int k = 0; k < MC; k++) if (k <= link) A = A + xc[k] * Sc[k];
+    contact_rows(A, v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), out);
   };
   auto slotD = [&](int s, float* Dj, float* fr, float& mu, int& dim) {
-    int g = slot[s].g;
+    int g = (int)SL(s, SL_GEOM);
+    float D0 = SL(s, SL_D0);
     dim = (int)GE(g, LM_G_DIM); mu = GE(g, LM_G_MU);
-    Dj[0] = slot[s].D0;
+    Dj[0] = D0;
 #pragma unroll
-    for (int j = 1; j < 6; j++) { Dj[j] = (j < dim) ? slot[s].D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; fr[j - 1] = GE(g, LM_G_F0 + j - 1); }
+    for (int j = 1; j < 6; j++) { Dj[j] = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; fr[j - 1] = GE(g, LM_G_F0 + j - 1); }
   };
-  // total cost at (xr, xc); Ma, jar are outputs for later reuse
-  struct Rows { float fr_r[6], fr_c[MC], lim_c[MC], con[NS][6]; };
-  auto rows_at = [&](const float* xr, const float* xc, Rows& jr, bool with_aref) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) jr.fr_r[i] = xr[i] - (with_aref ? fl_aref_r[i] : 0.0f);
-#pragma unroll
-    for (int k = 0; k < MC; k++) {
-      jr.fr_c[k] = xc[k] - (with_aref ? fl_aref_c[k] : 0.0f);
-      jr.lim_c[k] = lim_s_c[k] * xc[k] - (with_aref ? lim_aref_c[k] : 0.0f);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      if (slot[s].on) {
-        slotJx(s, xr, xc, jr.con[s]);
-        if (with_aref) {
-#pragma unroll
-          for (int j = 0; j < 6; j++) jr.con[s][j] -= slot[s].aref[j];
-        }
-      }
-    }
+  auto friction_cost = [&](float x, float f, float Rr) -> float {
+    if (f <= 0.0f) return 0.0f;
+    float Rf = Rr * f;
+    if (x <= -Rf) return -0.5f * Rf * f - f * x;
+    if (x >= Rf) return -0.5f * Rf * f + f * x;
+    return 0.5f * x * x / Rr;
   };
-  auto friction_cost = [&](float x, float f, float Rf_R, float& cost) {   // Rf_R = R
-    if (f <= 0.0f) return;
-    float Rf = Rf_R * f;
-    if (x <= -Rf) cost += -0.5f * Rf * f - f * x;
-    else if (x >= Rf) cost += -0.5f * Rf * f + f * x;
-    else cost += 0.5f * x * x / Rf_R;
-  };
-  auto cost_at = [&](const Rows& jr) -> float {   // lane-partial constraint cost
+  // lane-partial constraint cost at acceleration (xr, xc) (root rows weighted so that the quad sum counts them once)
+  auto cost_at = [&](const float* xr, const float* xc) -> float {
     float cost = 0, cr = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) friction_cost(jr.fr_r[i], RD(i, LM_D_FLOSS), RD(i, LM_D_FLOSS_R), cr);
+    for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], RD(i, LM_D_FLOSS), RD(i, LM_D_FLOSS_R));
     cost = w0 * cr;
 #pragma unroll
     for (int k = 0; k < MC; k++) if (k < nl) {
-      friction_cost(jr.fr_c[k], LK(k, LM_D_FLOSS), LK(k, LM_D_FLOSS_R), cost);
-      if (lim_s_c[k] != 0.0f && jr.lim_c[k] < 0.0f) cost += 0.5f * lim_D_c[k] * jr.lim_c[k] * jr.lim_c[k];
+      cost += friction_cost(xc[k] - fl_aref_c[k], LK(k, LM_D_FLOSS), LK(k, LM_D_FLOSS_R));
+      float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
+      if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
     }
-#pragma unroll
-    for (int s = 0; s < NS; s++) if (slot[s].on) {
-      float Dj[6], fr[5], mu; int dim;
+    for (int s = 0; s < nslot; s++) {
+      float Dj[6], fr[5], mu, jar[6]; int dim;
       slotD(s, Dj, fr, mu, dim);
-      cost += cone_eval<false>(jr.con[s], Dj, fr, mu, dim).cost;
+      slotJx(s, xr, xc, jar);
+#pragma unroll
+      for (int j = 0; j < 6; j++) jar[j] -= SL(s, SL_AREF + j);
+      cost += cone_eval<false>(jar, Dj, fr, mu, dim).cost;
     }
     return cost;
   };
@@ -671,17 +648,14 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   float ar[6], ac[MC];
   {
     // warm start: the better of (previous qacc, qacc_smooth)
-    Rows jr;
-    rows_at(a0r, a0c, jr, true);
-    float cost_smooth = Q::sum(cost_at(jr));
-    rows_at(war, wac, jr, true);
+    float cost_smooth = Q::sum(cost_at(a0r, a0c));
     float yr[6], yc[MC], gauss = 0, gr = 0;
     mulM(war, wac, yr, yc);
 #pragma unroll
     for (int k = 0; k < MC; k++) gauss += 0.5f * (yc[k] - sm_c[k]) * (wac[k] - a0c[k]);
 #pragma unroll
     for (int i = 0; i < 6; i++) gr += 0.5f * (yr[i] - sm_r[i]) * (war[i] - a0r[i]);
-    float cost_warm = Q::sum(cost_at(jr) + gauss + w0 * gr);
+    float cost_warm = Q::sum(cost_at(war, wac) + gauss + w0 * gr);
     bool use_warm = cost_warm < cost_smooth;
 #pragma unroll
     for (int i = 0; i < 6; i++) ar[i] = use_warm ? war[i] : a0r[i];
@@ -689,7 +663,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     for (int k = 0; k < MC; k++) ac[k] = use_warm ? wac[k] : a0c[k];
   }
 
-  float qf_r[6], qf_c[MC];      // constraint forces in joint space (qf_r: lane-partial until summed)
+  float qf_r[6], qf_c[MC];      // constraint forces in joint space
 #pragma unroll
   for (int i = 0; i < 6; i++) qf_r[i] = 0;
 #pragma unroll
@@ -702,86 +676,75 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   has_rows = has_rows || nslot > 0;
   bool done = !(Q::sum(has_rows ? 1.0f : 0.0f) > 0.0f);   // quad-uniform: nothing to solve in this environment
   int iters = 0;
-  float prev_cost = 3.0e38f;
 
   for (int it = 0; it <= P.iterations; it++) {
     if (!Q::any(!done)) break;
+    oz = LM_OPAQUE_ZERO();
     if (!done) {
       // ---- gradient at the current point
-      Rows jr;
-      rows_at(ar, ac, jr, true);
+      float jfr_r[6], jfr_c[MC], jlim_c[MC];     // jar of the unit rows
       float Mar[6], Mac[MC];
       mulM(ar, ac, Mar, Mac);
-      float cost = 0, cost_r = 0;
       Sp Fsum = sp0();
-      float fcon[NS][6]; int zone[NS];
-      float fu_r[6], fu_c[MC];
+      float fu_r[6];
       unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R), x = jr.fr_r[i];
-        fu_r[i] = 0;
+        float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R), x = ar[i] - fl_aref_r[i];
+        jfr_r[i] = x; fu_r[i] = 0;
         if (f > 0.0f) {
           float Rf = Rr * f;
-          if (x <= -Rf) { fu_r[i] = f; cost_r += -0.5f * Rf * f - f * x; }
-          else if (x >= Rf) { fu_r[i] = -f; cost_r += -0.5f * Rf * f + f * x; }
-          else { fu_r[i] = -x / Rr; cost_r += 0.5f * x * x / Rr; act_fr_r |= 1u << i; }
+          if (x <= -Rf) fu_r[i] = f;
+          else if (x >= Rf) fu_r[i] = -f;
+          else { fu_r[i] = -x / Rr; act_fr_r |= 1u << i; }
         }
       }
 #pragma unroll
       for (int k = 0; k < MC; k++) {
-        fu_c[k] = 0;
+        float fu = 0;
+        jfr_c[k] = ac[k] - fl_aref_c[k];
+        jlim_c[k] = lim_s_c[k] * ac[k] - lim_aref_c[k];
         if (k < nl) {
-          float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R), x = jr.fr_c[k];
+          float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R), x = jfr_c[k];
           if (f > 0.0f) {
             float Rf = Rr * f;
-            if (x <= -Rf) { fu_c[k] = f; cost += -0.5f * Rf * f - f * x; }
-            else if (x >= Rf) { fu_c[k] = -f; cost += -0.5f * Rf * f + f * x; }
-            else { fu_c[k] = -x / Rr; cost += 0.5f * x * x / Rr; act_fr_c |= 1u << k; }
+            if (x <= -Rf) fu = f;
+            else if (x >= Rf) fu = -f;
+            else { fu = -x / Rr; act_fr_c |= 1u << k; }
           }
-          if (lim_s_c[k] != 0.0f && jr.lim_c[k] < 0.0f) {
-            float fl = -lim_D_c[k] * jr.lim_c[k];
-            fu_c[k] += lim_s_c[k] * fl; cost += 0.5f * lim_D_c[k] * jr.lim_c[k] * jr.lim_c[k]; act_lim |= 1u << k;
-          }
+          if (lim_s_c[k] != 0.0f && jlim_c[k] < 0.0f) { fu -= lim_s_c[k] * lim_D_c[k] * jlim_c[k]; act_lim |= 1u << k; }
         }
-        qf_c[k] = fu_c[k];
+        qf_c[k] = fu;
       }
+      for (int s = 0; s < nslot; s++) {
+        float Dj[6], fr[5], mu, jar[6]; int dim;
+        slotD(s, Dj, fr, mu, dim);
+        slotJx(s, ar, ac, jar);
 #pragma unroll
-      for (int s = 0; s < NS; s++) {
-        zone[s] = 0;
-        if (slot[s].on) {
-          float Dj[6], fr[5], mu; int dim;
-          slotD(s, Dj, fr, mu, dim);
-          ConeEval e = cone_eval<true>(jr.con[s], Dj, fr, mu, dim);
-          zone[s] = e.zone; cost += e.cost;
+        for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; }
+        ConeEval e = cone_eval<true>(jar, Dj, fr, mu, dim);
+        SL(s, SL_ZONE) = (float)e.zone;
+        if (e.zone) {
+          Sp Fw = contact_wrench(e.f, v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)));
+          Fsum = Fsum + Fw;
+          const int link = (int)SL(s, SL_LINK);
 #pragma unroll
-          for (int j = 0; j < 6; j++) fcon[s][j] = e.f[j];
-          if (e.zone) {
-            Sp Fw = contact_wrench(e.f, slot[s].r);
-            Fsum = Fsum + Fw;
-#pragma unroll
-            for (int k = 0; k < MC; k++) if (k <= slot[s].link) qf_c[k] += spdot(Sc[k], Fw);
-          }
+          for (int k = 0; k < MC; k++) if (k <= link) qf_c[k] += spdot(Sc[k], Fw);
         }
       }
-      float gc[MC], gr_[6], gauss = 0, gauss_r = 0, g2 = 0;
+      float gc[MC], gr_[6], g2 = 0;
 #pragma unroll
-      for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; gauss += 0.5f * (Mac[k] - sm_c[k]) * (ac[k] - a0c[k]); g2 = fmaf(gc[k], gc[k], g2); }
+      for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; g2 = fmaf(gc[k], gc[k], g2); }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         qf_r[i] = fu_r[i] + Q::sum(spdot(Sr[i], Fsum));
         gr_[i] = Mar[i] - sm_r[i] - qf_r[i];
-        gauss_r += 0.5f * (Mar[i] - sm_r[i]) * (ar[i] - a0r[i]);
       }
       float gnorm2 = Q::sum(g2);
 #pragma unroll
       for (int i = 0; i < 6; i++) gnorm2 = fmaf(gr_[i], gr_[i], gnorm2);
-      float total = Q::sum(cost + gauss + w0 * (cost_r + gauss_r));
-      bool conv = (P.scale * sqrtf(gnorm2) < P.tolerance) || (it > 0 && P.scale * (prev_cost - total) < P.tolerance) || it == P.iterations;
-      prev_cost = total;
-      if (conv) done = true;
+      if (P.scale * sqrtf(gnorm2) < P.tolerance || it == P.iterations) done = true;
       else {
-        iters++;
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
         float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21];
 #pragma unroll
@@ -797,23 +760,29 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hpart[tri(i, i)] = w0 / RD(i, LM_D_FLOSS_R);
+        for (int s = 0; s < nslot; s++) {
+          oz = LM_OPAQUE_ZERO();
+          const int zone = (int)SL(s, SL_ZONE);
+          if (zone == 0) continue;
+          float Dj[6], fr[5], mu, Hc[21], jar[6]; int dim;
+          slotD(s, Dj, fr, mu, dim);
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-          if (slot[s].on && zone[s]) {
-            float Dj[6], fr[5], mu, Hc[21]; int dim;
-            slotD(s, Dj, fr, mu, dim);
-            cone_hessian(jr.con[s], Dj, fr, mu, dim, zone[s], Hc);
-            float Jc[6 + MC][6];
+          for (int j = 0; j < 6; j++) jar[j] = SL(s, SL_JAR + j);
+          cone_hessian(jar, Dj, fr, mu, dim, zone, Hc);
+          const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
+          const int link = (int)SL(s, SL_LINK);
+          float Jc[6 + MC][6];
 #pragma unroll
-            for (int r = 0; r < 6; r++) contact_rows(Sr[r], slot[s].r, Jc[r]);
+          for (int r = 0; r < 6; r++) contact_rows(Sr[r], rc, Jc[r]);
 #pragma unroll
-            for (int k = 0; k < MC; k++) {
-              if (k <= slot[s].link) contact_rows(Sc[k], slot[s].r, Jc[6 + k]);
-              else {
+          for (int k = 0; k < MC; k++) {
+            if (k <= link) contact_rows(Sc[k], rc, Jc[6 + k]);
+            else {
 #pragma unroll
-                for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
-              }
+              for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
             }
+          }
+          if (dim > 3) {
 #pragma unroll
             for (int a = 0; a < 6 + MC; a++) {
               float t[6];
@@ -834,6 +803,27 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
                 else Hcc[tri(a - 6, b - 6)] += d;
               }
             }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 6 + MC; a++) {
+              float t[3];
+#pragma unroll
+              for (int i = 0; i < 3; i++) {
+                float acc = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc = fmaf(Hc[(j <= i) ? tri(i, j) : tri(j, i)], Jc[a][j], acc);
+                t[i] = acc;
+              }
+#pragma unroll
+              for (int b = 0; b <= a; b++) {
+                float d = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) d = fmaf(t[j], Jc[b][j], d);
+                if (a < 6) Hpart[tri(a, b)] += d;
+                else if (b < 6) Hcr[a - 6][b] += d;
+                else Hcc[tri(a - 6, b - 6)] += d;
+              }
+            }
           }
         }
         float Lr[21];
@@ -845,77 +835,99 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
         arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
 
-        // ---- exact line search along (sr, sc)
-        Rows jv;
-        rows_at(sr, sc, jv, false);
-        float Mvr[6], Mvc[MC];
-        mulM(sr, sc, Mvr, Mvc);
-        float q1 = 0, q2 = 0, q1r = 0, q2r = 0;
+        // ---- Newton decrement: lambda^2 = -g.s estimates twice the remaining cost gap
+        float q1 = 0, q1r = 0;
 #pragma unroll
-        for (int k = 0; k < MC; k++) { q1 = fmaf(sc[k], Mac[k] - sm_c[k], q1); q2 = fmaf(sc[k], Mvc[k], q2); }
+        for (int k = 0; k < MC; k++) q1 = fmaf(sc[k], gc[k], q1);
 #pragma unroll
-        for (int i = 0; i < 6; i++) { q1r = fmaf(sr[i], Mar[i] - sm_r[i], q1r); q2r = fmaf(sr[i], Mvr[i], q2r); }
-        q1 = Q::sum(q1 + w0 * q1r); q2 = Q::sum(q2 + w0 * q2r);
-        auto line = [&](float alpha, float& d1, float& d2) {
-          float a1 = 0, a2 = 0, r1 = 0, r2 = 0;
+        for (int i = 0; i < 6; i++) q1r = fmaf(sr[i], gr_[i], q1r);
+        const float dec = -Q::sum(q1 + w0 * q1r);
+        if (!(P.scale * dec >= P.tolerance)) done = true;        // converged (also catches NaN)
+        else {
+          iters++;
+          // ---- exact line search along (sr, sc): Newton iterations on phi'(alpha) with a safeguarding bracket
+          float jv_r[6], jv_c[MC], jvlim_c[MC];
 #pragma unroll
-          for (int i = 0; i < 6; i++) {
-            float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R);
-            if (f > 0.0f) {
-              float x = fmaf(alpha, jv.fr_r[i], jr.fr_r[i]), Rf = Rr * f;
-              if (x <= -Rf) r1 -= f * jv.fr_r[i];
-              else if (x >= Rf) r1 += f * jv.fr_r[i];
-              else { r1 += x * jv.fr_r[i] / Rr; r2 += jv.fr_r[i] * jv.fr_r[i] / Rr; }
+          for (int i = 0; i < 6; i++) jv_r[i] = sr[i];
+#pragma unroll
+          for (int k = 0; k < MC; k++) { jv_c[k] = sc[k]; jvlim_c[k] = lim_s_c[k] * sc[k]; }
+          for (int s = 0; s < nslot; s++) {
+            float jv[6];
+            slotJx(s, sr, sc, jv);
+#pragma unroll
+            for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
+          }
+          float Mvr[6], Mvc[MC];
+          mulM(sr, sc, Mvr, Mvc);
+          float q2 = 0, q2r = 0, g1 = 0, g1r = 0;    // Gauss part: phi'(a) = g1 + a*q2 with g1 = s.(Ma - f_smooth)
+#pragma unroll
+          for (int k = 0; k < MC; k++) { g1 = fmaf(sc[k], Mac[k] - sm_c[k], g1); q2 = fmaf(sc[k], Mvc[k], q2); }
+#pragma unroll
+          for (int i = 0; i < 6; i++) { g1r = fmaf(sr[i], Mar[i] - sm_r[i], g1r); q2r = fmaf(sr[i], Mvr[i], q2r); }
+          g1 = Q::sum(g1 + w0 * g1r); q2 = Q::sum(q2 + w0 * q2r);
+          auto line = [&](float alpha, float& d1, float& d2) {
+            oz = LM_OPAQUE_ZERO();
+            float a1 = 0, a2 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R);
+              if (f > 0.0f) {
+                float x = fmaf(alpha, jv_r[i], jfr_r[i]), Rf = Rr * f;
+                if (x <= -Rf) r1 -= f * jv_r[i];
+                else if (x >= Rf) r1 += f * jv_r[i];
+                else { r1 += x * jv_r[i] / Rr; r2 += jv_r[i] * jv_r[i] / Rr; }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < MC; k++) if (k < nl) {
+              float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R);
+              if (f > 0.0f) {
+                float x = fmaf(alpha, jv_c[k], jfr_c[k]), Rf = Rr * f;
+                if (x <= -Rf) a1 -= f * jv_c[k];
+                else if (x >= Rf) a1 += f * jv_c[k];
+                else { a1 += x * jv_c[k] / Rr; a2 += jv_c[k] * jv_c[k] / Rr; }
+              }
+              if (lim_s_c[k] != 0.0f) {
+                float x = fmaf(alpha, jvlim_c[k], jlim_c[k]);
+                if (x < 0.0f) { a1 += lim_D_c[k] * x * jvlim_c[k]; a2 += lim_D_c[k] * jvlim_c[k] * jvlim_c[k]; }
+              }
+            }
+            for (int s = 0; s < nslot; s++) {
+              float Dj[6], fr[5], mu, jar[6], jv[6]; int dim;
+              slotD(s, Dj, fr, mu, dim);
+#pragma unroll
+              for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); }
+              cone_line(jar, jv, alpha, Dj, fr, mu, dim, a1, a2);
+            }
+            d1 = g1 + alpha * q2 + Q::sum(a1 + w0 * r1);
+            d2 = q2 + Q::sum(a2 + w0 * r2);
+          };
+          float d1, d2, alpha = 0, lo = 0, hi = -1.0f;
+          line(0.0f, d1, d2);
+          bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
+          float dref = fabsf(d1);
+          if (!ls_done) alpha = -d1 / d2;
+          for (int lsi = 0; lsi < 20; lsi++) {
+            if (!Q::any(!ls_done)) break;
+            if (!ls_done) {
+              line(alpha, d1, d2);
+              if (fabsf(d1) < 1e-4f * dref) ls_done = true;
+              else {
+                if (d1 < 0.0f) lo = alpha; else hi = alpha;
+                float next = alpha - d1 / d2;
+                if (hi > 0.0f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);
+                if (hi < 0.0f && next <= lo) next = 2.0f * alpha;
+                if (fabsf(next - alpha) <= 1e-6f * fabsf(alpha)) ls_done = true;
+                alpha = next;
+              }
             }
           }
 #pragma unroll
-          for (int k = 0; k < MC; k++) if (k < nl) {
-            float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R);
-            if (f > 0.0f) {
-              float x = fmaf(alpha, jv.fr_c[k], jr.fr_c[k]), Rf = Rr * f;
-              if (x <= -Rf) a1 -= f * jv.fr_c[k];
-              else if (x >= Rf) a1 += f * jv.fr_c[k];
-              else { a1 += x * jv.fr_c[k] / Rr; a2 += jv.fr_c[k] * jv.fr_c[k] / Rr; }
-            }
-            if (lim_s_c[k] != 0.0f) {
-              float x = fmaf(alpha, jv.lim_c[k], jr.lim_c[k]);
-              if (x < 0.0f) { a1 += lim_D_c[k] * x * jv.lim_c[k]; a2 += lim_D_c[k] * jv.lim_c[k] * jv.lim_c[k]; }
-            }
-          }
+          for (int i = 0; i < 6; i++) ar[i] = fmaf(alpha, sr[i], ar[i]);
 #pragma unroll
-          for (int s = 0; s < NS; s++) if (slot[s].on) {
-            float Dj[6], fr[5], mu; int dim;
-            slotD(s, Dj, fr, mu, dim);
-            cone_line(jr.con[s], jv.con[s], alpha, Dj, fr, mu, dim, a1, a2);
-          }
-          d1 = q1 + alpha * q2 + Q::sum(a1 + w0 * r1);
-          d2 = q2 + Q::sum(a2 + w0 * r2);
-        };
-        float d1, d2, alpha = 0, lo = 0, hi = -1.0f;
-        line(0.0f, d1, d2);
-        bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
-        float dref = fabsf(d1);
-        if (!ls_done) alpha = -d1 / d2;
-        for (int ls = 0; ls < 20; ls++) {
-          if (!Q::any(!ls_done)) break;
-          if (!ls_done) {
-            line(alpha, d1, d2);
-            if (fabsf(d1) < 1e-5f * dref) ls_done = true;
-            else {
-              if (d1 < 0.0f) lo = alpha; else hi = alpha;
-              float next = alpha - d1 / d2;
-              if (hi > 0.0f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);
-              if (hi < 0.0f && next <= lo) next = 2.0f * alpha;
-              if (fabsf(next - alpha) <= 1e-7f * fabsf(alpha)) ls_done = true;
-              alpha = next;
-            }
-          }
+          for (int k = 0; k < MC; k++) ac[k] = fmaf(alpha, sc[k], ac[k]);
+          if (alpha == 0.0f) done = true;
         }
-#pragma unroll
-        for (int i = 0; i < 6; i++) ar[i] = fmaf(alpha, sr[i], ar[i]);
-#pragma unroll
-        for (int k = 0; k < MC; k++) ac[k] = fmaf(alpha, sc[k], ac[k]);
-        if (alpha == 0.0f) done = true;
       }
     }
   }
@@ -943,6 +955,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
 
+  oz = LM_OPAQUE_ZERO();
   // ================= integrate: semi-implicit Euler, joint damping implicit =================
   // (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint ; qvel += h qacc' ; qpos += h qvel
 #pragma unroll
@@ -980,6 +993,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #undef LK
 #undef LX
 #undef GE
+#undef SL
 }
 
 }  // namespace lm

@@ -14,11 +14,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string>
 #include <vector>
 
 #define LM_DEV __device__ __forceinline__
+// an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
+#define LM_OPAQUE_ZERO() ([]() __device__ { int z = 0; asm volatile("" : "+v"(z)); return z; }())
 #include "lm_core.h"
 #include "../../include/locohip.h"
 
@@ -55,6 +58,7 @@ struct KArgs {
   unsigned long long seed; long long env_offset;
   int auto_reset, horizon, action_mode; unsigned step_index;
   int N;
+  int epb;                  // environments per workgroup (workgroup = 4*epb threads)
   lm::Params P; Task T;
   DevStats* stats;
   // debug (forward only)
@@ -74,11 +78,15 @@ __device__ __forceinline__ float wave_sum(float x) {
 template <int MC, int NS, bool FORWARD_ONLY>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
-  for (int i = threadIdx.x; i < LM_CM_SIZE; i += 64) cm[i] = a.cm[i];
+  __shared__ float blk_stats[8];
+  extern __shared__ float lane_mem[];                      // contact slot records, [field][lane], NS*SL_SIZE*blockDim floats
+  for (int i = threadIdx.x; i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
+  for (int i = threadIdx.x; i < 8; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 3;
-  const int e = blockIdx.x * 16 + (threadIdx.x >> 2);
-  if (e >= a.N) return;                       // whole quads leave together
+  const int e_raw = blockIdx.x * a.epb + (threadIdx.x >> 2);
+  const bool valid = e_raw < a.N;             // padding quads of the last workgroup recompute env N-1, store nothing
+  const int e = valid ? e_raw : a.N - 1;
   const int N = a.N, nv = a.T.nv;
   const float* rb = cm + LM_CM_ROOT;
 #define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
@@ -144,15 +152,18 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {0, 0, 0, 0};
+  float* lmem = lane_mem + threadIdx.x;
+  const int ls = blockDim.x;
   if (FORWARD_ONLY) {
+    if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
-    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, cnt, &dbg);
+    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg);
     int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
-    if (c == 0) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
+    if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, cnt, nullptr);
+    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       for (int k = 0; k < MC; k++) if (k < nl) { qc[k] = row[dc[k]]; vc[k] = row[nv + dc[k]]; wac[k] = 0.0f; }
 #pragma unroll
       for (int i = 0; i < 4; i++) if (i < a.T.ngoal) goal[i] = row[2 * nv + i];
-      if (c == 0) {
+      if (c == 0 && valid) {
         a.ep_count[e] = ec;
         for (int i = 0; i < a.T.ngoal; i++) a.goal[i * N + e] = goal[i];
       }
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 
   // ---- store state, observation [qpos[idx], qvel[idx], goal], reward, done
+  if (valid) {
   if (c == 0) {
 #pragma unroll
     for (int i = 0; i < 6; i++) { a.qpos[dr[i] * N + e] = qr[i]; a.qvel[dr[i] * N + e] = vr[i]; a.warm[dr[i] * N + e] = war[i]; }
@@ -218,16 +230,22 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #pragma unroll
     for (int k = 0; k < MC; k++) if (k < nl) { int iq = (int)LK(k, LM_D_QOBS), iv = (int)LK(k, LM_D_VOBS); if (iq >= 0) o[iq] = qc[k]; if (iv >= 0) o[iv] = vc[k]; }
   }
+  }
 
-  // ---- statistics: one atomic per wave and counter
+  // ---- statistics: LDS adds inside the workgroup, one plain read-modify-write per workgroup slot (no global atomics)
   if (a.stats) {
-    float l0 = (c == 0) ? 1.0f : 0.0f;
-    float s_steps = wave_sum(l0), s_ep = wave_sum(l0 * episodes), s_rew = wave_sum(l0 * reward), s_nan = wave_sum(l0 * (nonfinite ? 1.0f : 0.0f));
-    float s_it = wave_sum((float)cnt.solver_iters), s_ov = wave_sum((float)cnt.overflow), s_un = wave_sum((float)cnt.unhandled);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&a.stats->env_steps, s_steps); atomicAdd(&a.stats->episodes, s_ep); atomicAdd(&a.stats->reward_sum, s_rew);
-      atomicAdd(&a.stats->nan_resets, s_nan); atomicAdd(&a.stats->solver_iters, s_it); atomicAdd(&a.stats->overflow, s_ov);
-      atomicAdd(&a.stats->unhandled, s_un);
+    if (valid) {
+      if (c == 0) {
+        atomicAdd(&blk_stats[0], 1.0f); atomicAdd(&blk_stats[1], episodes); atomicAdd(&blk_stats[2], reward);
+        atomicAdd(&blk_stats[3], nonfinite ? 1.0f : 0.0f); atomicAdd(&blk_stats[4], (float)cnt.solver_iters);
+      }
+      if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
+      if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 7; i += blockDim.x) {
+      float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
+      *dst += blk_stats[i];
     }
   }
 #undef RD
@@ -255,6 +273,7 @@ struct lm_batch {
   int* ep_step; unsigned* ep_count;
   DevStats* stats;
   int table_rows; unsigned long long seed; long long env_offset; int auto_reset, horizon; unsigned step_index;
+  int epb, nblocks;
   hipStream_t stream;
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
@@ -322,17 +341,31 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   lm_batch* b = new lm_batch();
   memset(b, 0, sizeof(*b));
   b->m = m; b->N = n_envs;
+  // The step is latency-bound with one wave per SIMD (512-register budget), so small batches are spread
+  // over as many SIMDs as possible: fewer environments per wave until every one of the 256 CUs x 4 SIMDs
+  // has a wave (4096 envs -> 4 envs = 16 lanes per wave, 1024 waves). LM_ENVS_PER_BLOCK overrides.
+  {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int epb = 16;
+    while (epb > 1 && (n_envs + epb - 1) / epb < 4 * cus) epb >>= 1;
+    const char* ov = getenv("LM_ENVS_PER_BLOCK");
+    if (ov && atoi(ov) >= 1 && atoi(ov) <= 16) epb = atoi(ov);
+    b->epb = epb;
+  }
   const int N = n_envs, nv = m->T.nv;
   HIPCHK(hipMalloc(&b->qpos, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->qvel, sizeof(float) * nv * N));
   HIPCHK(hipMalloc(&b->warm, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->goal, sizeof(float) * 4 * N));
   HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
   HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
-  HIPCHK(hipMalloc(&b->stats, sizeof(DevStats)));
+  b->nblocks = (n_envs + b->epb - 1) / b->epb;
+  HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
-  HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats)));
+  HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
   HIPCHK(hipStreamCreate(&b->stream));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
   *out = b;
@@ -414,22 +447,25 @@ static KArgs make_args(lm_batch* b) {
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
+  a.epb = b->epb;
   return a;
 }
 
 static void launch_step(lm_batch* b, const KArgs& a) {
-  dim3 grid((b->N + 15) / 16), block(64);
-  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, 0, b->stream, a);
+  dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
+  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, sizeof(float) * 4 * lm::SL_SIZE * block.x, b->stream, a);
 }
 
 static int drain_stats(lm_batch* b) {
-  DevStats s;
-  HIPCHK(hipMemcpyAsync(&s, b->stats, sizeof(s), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipMemsetAsync(b->stats, 0, sizeof(DevStats), b->stream));
+  std::vector<DevStats> s(b->nblocks);
+  HIPCHK(hipMemcpyAsync(s.data(), b->stats, sizeof(DevStats) * b->nblocks, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemsetAsync(b->stats, 0, sizeof(DevStats) * b->nblocks, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  b->acc.env_steps += s.env_steps; b->acc.episodes += s.episodes; b->acc.reward_sum += s.reward_sum;
-  b->acc.nan_resets += s.nan_resets; b->acc.solver_iters += s.solver_iters; b->acc.overflow_contacts += s.overflow;
-  b->acc.unhandled_geoms += s.unhandled;
+  for (const DevStats& x : s) {
+    b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
+    b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
+    b->acc.unhandled_geoms += x.unhandled;
+  }
   return 0;
 }
 
@@ -504,8 +540,8 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   HIPCHK(hipMemset(buf, 0, sizeof(float) * per * N));
   a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
   a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
-  dim3 grid((N + 15) / 16), block(64);
-  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, 0, b->stream, a);
+  dim3 grid((N + b->epb - 1) / b->epb), block(4 * b->epb);
+  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, sizeof(float) * 4 * lm::SL_SIZE * block.x, b->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->stream));
   auto get = [&](float* dst, const float* src, size_t n) -> int { if (dst) HIPCHK(hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost)); return 0; };

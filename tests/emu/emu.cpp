@@ -7,6 +7,7 @@
 #include <thread>
 #include <vector>
 #define LM_DEV inline
+#define LM_OPAQUE_ZERO() 0
 #include "../../loco_mujoco_amd/csrc/lm_core.h"
 
 namespace {
@@ -72,9 +73,10 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
         }
       }
       lm::Counters cnt = {0, 0, 0, 0};
+      float lmem[NS * lm::SL_SIZE];
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, cnt,
+        lm::substep<QuadThreads, MC, NS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                          (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr);
       g_bar.arrive_and_wait();
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
