@@ -56,6 +56,7 @@ typedef struct {
   double solver_iters;     /* Newton iterations, summed over environments and substeps */
   double overflow_contacts;/* contacts dropped because a per-chain contact slot budget was exceeded */
   double unhandled_geoms;  /* substeps in which a geom without a device collider came within margin */
+  double linesearch_evals; /* line-search function evaluations after the first, summed like solver_iters */
   double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
 } lm_stats;
 

@@ -104,10 +104,13 @@ struct Params {
   int iterations;     // Newton iteration cap
   float tolerance;    // stop when scale*|grad| < tolerance (float32-appropriate)
   float scale;        // 1 / (meaninertia * nv)
+  float ls_tol;       // line search: stop when |phi'| < ls_tol * |phi'(0)|
+  int ls_iters;       // line search iteration cap
+  int ablate;         // profiling only: bitmask of solver regions to skip (0 in production)
   int nv;
 };
 
-struct Counters { int solver_iters; int overflow; int unhandled; int ncon; };
+struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; };
 
 // optional stage dump for parity tests (one environment): written by the owning lanes
 struct Debug {
@@ -760,7 +763,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hpart[tri(i, i)] = w0 / RD(i, LM_D_FLOSS_R);
-        for (int s = 0; s < nslot; s++) {
+        for (int s = 0; s < ((P.ablate & 2) ? 0 : nslot); s++) {
           oz = LM_OPAQUE_ZERO();
           const int zone = (int)SL(s, SL_ZONE);
           if (zone == 0) continue;
@@ -827,13 +830,15 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
           }
         }
         float Lr[21];
-        arrow_factor<Q, MC>(Hcc, Hcr, Mrr, Hpart, Lr);
         float sr[6], sc[MC];
 #pragma unroll
         for (int i = 0; i < 6; i++) sr[i] = -gr_[i];
 #pragma unroll
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
-        arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+        if (!(P.ablate & 4)) {
+          arrow_factor<Q, MC>(Hcc, Hcr, Mrr, Hpart, Lr);
+          arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+        }
 
         // ---- Newton decrement: lambda^2 = -g.s estimates twice the remaining cost gap
         float q1 = 0, q1r = 0;
@@ -865,31 +870,34 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
           for (int i = 0; i < 6; i++) { g1r = fmaf(sr[i], Mar[i] - sm_r[i], g1r); q2r = fmaf(sr[i], Mvr[i], q2r); }
           g1 = Q::sum(g1 + w0 * g1r); q2 = Q::sum(q2 + w0 * q2r);
-          auto line = [&](float alpha, float& d1, float& d2) {
+          // phi'(alpha), phi''(alpha) and `mag` = sum of |terms| of phi' (its float32 noise floor is ~1e-6*mag)
+          auto line = [&](float alpha, float& d1, float& d2, float& mag) {
             oz = LM_OPAQUE_ZERO();
-            float a1 = 0, a2 = 0, r1 = 0, r2 = 0;
+            float a1 = 0, a2 = 0, r1 = 0, r2 = 0, am = 0, rm = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
               float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R);
               if (f > 0.0f) {
-                float x = fmaf(alpha, jv_r[i], jfr_r[i]), Rf = Rr * f;
-                if (x <= -Rf) r1 -= f * jv_r[i];
-                else if (x >= Rf) r1 += f * jv_r[i];
-                else { r1 += x * jv_r[i] / Rr; r2 += jv_r[i] * jv_r[i] / Rr; }
+                float x = fmaf(alpha, jv_r[i], jfr_r[i]), Rf = Rr * f, t;
+                if (x <= -Rf) t = -f * jv_r[i];
+                else if (x >= Rf) t = f * jv_r[i];
+                else { float iR = 1.0f / Rr; t = x * jv_r[i] * iR; r2 = fmaf(jv_r[i] * jv_r[i], iR, r2); }
+                r1 += t; rm += fabsf(t);
               }
             }
 #pragma unroll
             for (int k = 0; k < MC; k++) if (k < nl) {
               float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R);
               if (f > 0.0f) {
-                float x = fmaf(alpha, jv_c[k], jfr_c[k]), Rf = Rr * f;
-                if (x <= -Rf) a1 -= f * jv_c[k];
-                else if (x >= Rf) a1 += f * jv_c[k];
-                else { a1 += x * jv_c[k] / Rr; a2 += jv_c[k] * jv_c[k] / Rr; }
+                float x = fmaf(alpha, jv_c[k], jfr_c[k]), Rf = Rr * f, t;
+                if (x <= -Rf) t = -f * jv_c[k];
+                else if (x >= Rf) t = f * jv_c[k];
+                else { float iR = 1.0f / Rr; t = x * jv_c[k] * iR; a2 = fmaf(jv_c[k] * jv_c[k], iR, a2); }
+                a1 += t; am += fabsf(t);
               }
               if (lim_s_c[k] != 0.0f) {
                 float x = fmaf(alpha, jvlim_c[k], jlim_c[k]);
-                if (x < 0.0f) { a1 += lim_D_c[k] * x * jvlim_c[k]; a2 += lim_D_c[k] * jvlim_c[k] * jvlim_c[k]; }
+                if (x < 0.0f) { float t = lim_D_c[k] * x * jvlim_c[k]; a1 += t; am += fabsf(t); a2 = fmaf(lim_D_c[k] * jvlim_c[k], jvlim_c[k], a2); }
               }
             }
             for (int s = 0; s < nslot; s++) {
@@ -897,27 +905,39 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
               slotD(s, Dj, fr, mu, dim);
 #pragma unroll
               for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); }
-              cone_line(jar, jv, alpha, Dj, fr, mu, dim, a1, a2);
+              float c1 = 0, c2 = 0;
+              cone_line(jar, jv, alpha, Dj, fr, mu, dim, c1, c2);
+              a1 += c1; a2 += c2; am += fabsf(c1);
             }
             d1 = g1 + alpha * q2 + Q::sum(a1 + w0 * r1);
             d2 = q2 + Q::sum(a2 + w0 * r2);
+            mag = fabsf(g1) + fabsf(alpha * q2) + Q::sum(am + w0 * rm);
           };
-          float d1, d2, alpha = 0, lo = 0, hi = -1.0f;
-          line(0.0f, d1, d2);
+          // root of the increasing, piecewise-smooth phi': Newton steps from the current point; once the root is
+          // bracketed a step that leaves the bracket is replaced by false position with Illinois down-weighting
+          // (superlinear on the piecewise-linear phi' of friction/limit rows, never worse than bisection)
+          float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f;
+          int last_side = 0;
+          line(0.0f, d1, d2, mag);
           bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
-          float dref = fabsf(d1);
+          const float dref = fabsf(d1);
+          dlo = d1;
           if (!ls_done) alpha = -d1 / d2;
-          for (int lsi = 0; lsi < 20; lsi++) {
+          for (int lsi = 0; lsi < ((P.ablate & 8) ? 0 : P.ls_iters); lsi++) {
             if (!Q::any(!ls_done)) break;
             if (!ls_done) {
-              line(alpha, d1, d2);
-              if (fabsf(d1) < 1e-4f * dref) ls_done = true;
+              line(alpha, d1, d2, mag);
+              if (c == 0) cnt.ls_evals++;
+              if (fabsf(d1) < fmaxf(P.ls_tol * dref, 2e-6f * mag)) ls_done = true;
               else {
-                if (d1 < 0.0f) lo = alpha; else hi = alpha;
+                if (d1 < 0.0f) { if (last_side < 0) dhi *= 0.5f; lo = alpha; dlo = d1; last_side = -1; }
+                else { if (last_side > 0) dlo *= 0.5f; hi = alpha; dhi = d1; last_side = 1; }
                 float next = alpha - d1 / d2;
-                if (hi > 0.0f && !(next > lo && next < hi)) next = 0.5f * (lo + hi);
-                if (hi < 0.0f && next <= lo) next = 2.0f * alpha;
-                if (fabsf(next - alpha) <= 1e-6f * fabsf(alpha)) ls_done = true;
+                if (hi > 0.0f) {
+                  if (!(next > lo && next < hi)) next = (lo * dhi - hi * dlo) / (dhi - dlo);
+                  if (!(next > lo && next < hi)) next = 0.5f * (lo + hi);
+                  if (hi - lo <= 1e-4f * hi) ls_done = true;
+                } else if (next <= lo) next = 2.0f * alpha;
                 alpha = next;
               }
             }

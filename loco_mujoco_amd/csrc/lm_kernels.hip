@@ -21,7 +21,8 @@
 
 #define LM_DEV __device__ __forceinline__
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
-#define LM_OPAQUE_ZERO() ([]() __device__ { int z = 0; asm volatile("" : "+v"(z)); return z; }())
+__device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+#define LM_OPAQUE_ZERO() lm_opaque_zero()
 #include "lm_core.h"
 #include "../../include/locohip.h"
 
@@ -46,7 +47,7 @@ struct Task {
   float rp[8];
 };
 
-struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, pad; };
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals; };
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   for (int k = 0; k < MC; k++) actc[k] = (k < nl) ? actuate(LK(k, LM_D_ACT), LK(k, LM_D_ACT_DELTA), LK(k, LM_D_ACT_MEAN), LK(k, LM_D_CTRL_LO), LK(k, LM_D_CTRL_HI), LK(k, LM_D_GEAR)) : 0.0f;
 
   // ---- physics
-  lm::Counters cnt = {0, 0, 0, 0};
+  lm::Counters cnt = {0, 0, 0, 0, 0};
   float* lmem = lane_mem + threadIdx.x;
   const int ls = blockDim.x;
   if (FORWARD_ONLY) {
@@ -238,12 +239,13 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (c == 0) {
         atomicAdd(&blk_stats[0], 1.0f); atomicAdd(&blk_stats[1], episodes); atomicAdd(&blk_stats[2], reward);
         atomicAdd(&blk_stats[3], nonfinite ? 1.0f : 0.0f); atomicAdd(&blk_stats[4], (float)cnt.solver_iters);
+        atomicAdd(&blk_stats[7], (float)cnt.ls_evals);
       }
       if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 7; i += blockDim.x) {
+    for (int i = threadIdx.x; i < 8; i += blockDim.x) {
       float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
       *dst += blk_stats[i];
     }
@@ -319,6 +321,11 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.tolerance = 1e-6f;      // float32 stand-in for MuJoCo's 1e-8 (the gradient itself carries ~1e-6 relative noise)
   P.nv = T.nv;
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
+  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ablate = 0;
+  if (const char* v = getenv("LM_ABLATE")) P.ablate = atoi(v);
+  if (const char* v = getenv("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes
+  if (const char* v = getenv("LM_LS_TOL")) P.ls_tol = (float)atof(v);
+  if (const char* v = getenv("LM_LS_ITERS")) P.ls_iters = atoi(v);
   *out = m;
   return 0;
 }
@@ -464,7 +471,7 @@ static int drain_stats(lm_batch* b) {
   for (const DevStats& x : s) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
     b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
-    b->acc.unhandled_geoms += x.unhandled;
+    b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals;
   }
   return 0;
 }

@@ -42,6 +42,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   P.h = (float)H[LM_H_TIMESTEP]; P.g = lm::v3((float)H[LM_H_GX], (float)H[LM_H_GY], (float)H[LM_H_GZ]);
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
+  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ablate = 0;
   int cnt_tot[4] = {0, 0, 0, 0};
   auto lane_main = [&](int c) {
     t_lane = c;
@@ -72,7 +73,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
           actc[k] = actuate(blk, LM_NCHAIN);
         }
       }
-      lm::Counters cnt = {0, 0, 0, 0};
+      lm::Counters cnt = {0, 0, 0, 0, 0};
       float lmem[NS * lm::SL_SIZE];
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
