@@ -57,6 +57,8 @@ typedef struct {
   double overflow_contacts;/* contacts dropped because a per-chain contact slot budget was exceeded */
   double unhandled_geoms;  /* substeps in which a geom without a device collider came within margin */
   double linesearch_evals; /* line-search function evaluations after the first, summed like solver_iters */
+  double linesearch_capped;/* line searches that ran into the iteration cap */
+  double steps_with_8plus_iters; /* env-steps in which some substep needed >= 8 Newton iterations */
   double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
 } lm_stats;
 

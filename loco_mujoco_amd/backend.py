@@ -22,7 +22,7 @@ class Dims(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("env_steps", "episodes", "reward_sum", "nan_resets", "solver_iters",
-                                          "overflow_contacts", "unhandled_geoms", "linesearch_evals", "kernel_ms")]
+                                          "overflow_contacts", "unhandled_geoms", "linesearch_evals", "linesearch_capped", "steps_with_8plus_iters", "kernel_ms")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

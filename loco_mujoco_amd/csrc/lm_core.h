@@ -106,11 +106,23 @@ struct Params {
   float scale;        // 1 / (meaninertia * nv)
   float ls_tol;       // line search: stop when |phi'| < ls_tol * |phi'(0)|
   int ls_iters;       // line search iteration cap
+  float ls_noise;     // float32 noise floor of phi' relative to the sum of |terms|
   int ablate;         // profiling only: bitmask of solver regions to skip (0 in production)
   int nv;
 };
 
-struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; };
+struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
+#ifdef LM_TIMERS
+  long long t[10];
+#endif
+};
+#ifdef LM_TIMERS
+#define LM_TICK(i) do { long long now_ = LM_CLOCK(); cnt.t[i] += now_ - tick_; tick_ = now_; } while (0)
+#define LM_TICK_INIT() long long tick_ = LM_CLOCK()
+#else
+#define LM_TICK(i) do {} while (0)
+#define LM_TICK_INIT() do {} while (0)
+#endif
 
 // optional stage dump for parity tests (one environment): written by the owning lanes
 struct Debug {
@@ -138,8 +150,18 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // ---- contact slot record (one floor contact of this lane's chain), kept in lane-local memory --------------
 // On the GPU this is an LDS array indexed [field][lane] (stride = lanes per workgroup, conflict-free); slots are
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
-enum { SL_LINK = 0, SL_GEOM, SL_RX, SL_RY, SL_RZ, SL_DIST, SL_D0, SL_AREF, SL_JAR = SL_AREF + 6, SL_JV = SL_JAR + 6,
-       SL_ZONE = SL_JV + 6, SL_SIZE };
+enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
+       SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
+// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6]
+template <int MC, int NS> struct LaneMem {
+  static constexpr int kSlots = 0;
+  static constexpr int kMcc = NS * SL_SIZE;
+  static constexpr int kMcr = kMcc + MC * (MC + 1) / 2;
+  static constexpr int kMrr = kMcr + MC * 6;
+  static constexpr int kSr = kMrr + 21;
+  static constexpr int kSc = kSr + 36;
+  static constexpr int kSize = kSc + MC * 6;
+};
 
 // Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
 // because their D is 0). Dj = D of row j, fr = friction coefficients of rows 1..5, mu = regularised cone mu.
@@ -343,7 +365,7 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // ---- the substep ---------------------------------------------------------------------------------------------
 // cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
 // actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
-// lmem/ls: lane-local scratch of NS*SL_SIZE floats, element i at lmem[i*ls].
+// lmem/ls: lane-local scratch of LaneMem<MC,NS>::kSize floats, element i at lmem[i*ls].
 template <class Q, int MC, int NS>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
@@ -361,6 +383,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #define SL(s, f) lmem[((s) * SL_SIZE + (f)) * ls]
   const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
   const int nl = (int)CH(LM_C_NLINKS);
+  LM_TICK_INIT();
 
   // ================= position stage: kinematics, twists, inertias, contacts =================
   M3 R; V3 p;
@@ -409,12 +432,18 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
 
-  // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots
-  Sp Sc[MC];
-  float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
+  // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots.
+  // Everything that must survive into the solver (M, twists) is parked in lane memory so that the Newton loop
+  // keeps only small vectors in registers.
+  using LMm = LaneMem<MC, NS>;
+#define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
+  float a0r[6], a0c[MC];
+  float sm_r[6], sm_c[MC];
   int nslot = 0;
   {
+    Sp Sc[MC];
+    float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
     Sp Vc[MC], Ac[MC];
     SpI Ic[MC];
     {
@@ -460,13 +489,16 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
               // contact point (midway between the surfaces) relative to O; row parameters
               V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
               float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
-              float R0 = fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN) / imp);
+              float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
               float vel[6];
               contact_rows(V, cp, vel);
-              float B = GE(g, LM_G_B);
-              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_GEOM) = (float)g;
+              const float B = GE(g, LM_G_B);
+              const int dim = (int)GE(g, LM_G_DIM);
+              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = GE(g, LM_G_MU);
               SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
-              SL(nslot, SL_DIST) = dist; SL(nslot, SL_D0) = 1.0f / R0;
+              SL(nslot, SL_D) = D0;
+#pragma unroll
+              for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
 #pragma unroll
               for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? GE(g, LM_G_K) * imp * (dist - margin) : 0.0f);
               nslot++;
@@ -481,6 +513,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       }
     }
     cnt.ncon += nslot;
+    LM_TICK(0);
 
     // ======== inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) ========
     SpI comp = spi0();
@@ -522,14 +555,47 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       Mrr[tri(i, i)] += RD(i, LM_D_ARM);
       bias_r[i] = spdot(Sr[i], F);
     }
-  }
+    LM_TICK(1);
 
-  // ================= smooth forces =================
-  float sm_r[6], sm_c[MC];
+    // ======== smooth forces, unconstrained acceleration ========
 #pragma unroll
-  for (int i = 0; i < 6; i++) sm_r[i] = -RD(i, LM_D_STIFF) * qr[i] - RD(i, LM_D_DAMP) * vr[i] - bias_r[i] + actr[i];
+    for (int i = 0; i < 6; i++) sm_r[i] = -RD(i, LM_D_STIFF) * qr[i] - RD(i, LM_D_DAMP) * vr[i] - bias_r[i] + actr[i];
 #pragma unroll
-  for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k]) : 0.0f;
+    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k]) : 0.0f;
+    // park M and the twists in lane memory
+#pragma unroll
+    for (int i = 0; i < MC * (MC + 1) / 2; i++) LMEM(LMm::kMcc + i) = Mcc[i];
+#pragma unroll
+    for (int k = 0; k < MC; k++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) LMEM(LMm::kMcr + k * 6 + r) = Mcr[k][r];
+#pragma unroll
+    for (int i = 0; i < 21; i++) LMEM(LMm::kMrr + i) = Mrr[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      LMEM(LMm::kSr + i * 6 + 0) = Sr[i].w.x; LMEM(LMm::kSr + i * 6 + 1) = Sr[i].w.y; LMEM(LMm::kSr + i * 6 + 2) = Sr[i].w.z;
+      LMEM(LMm::kSr + i * 6 + 3) = Sr[i].v.x; LMEM(LMm::kSr + i * 6 + 4) = Sr[i].v.y; LMEM(LMm::kSr + i * 6 + 5) = Sr[i].v.z;
+    }
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      LMEM(LMm::kSc + k * 6 + 0) = Sc[k].w.x; LMEM(LMm::kSc + k * 6 + 1) = Sc[k].w.y; LMEM(LMm::kSc + k * 6 + 2) = Sc[k].w.z;
+      LMEM(LMm::kSc + k * 6 + 3) = Sc[k].v.x; LMEM(LMm::kSc + k * 6 + 4) = Sc[k].v.y; LMEM(LMm::kSc + k * 6 + 5) = Sc[k].v.z;
+    }
+    {
+      float Lrr[21], zero21[21];
+#pragma unroll
+      for (int i = 0; i < 21; i++) zero21[i] = 0;
+      arrow_factor<Q, MC>(Mcc, Mcr, Mrr, zero21, Lrr);       // M's register copy is consumed here
+#pragma unroll
+      for (int i = 0; i < 6; i++) a0r[i] = sm_r[i];
+#pragma unroll
+      for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
+      arrow_solve<Q, MC>(Mcc, Mcr, Lrr, a0c, a0r);
+    }
+  }
+  auto ldS = [&](int base) -> Sp {       // twist from lane memory
+    Sp S; S.w = v3(LMEM(base), LMEM(base + 1), LMEM(base + 2)); S.v = v3(LMEM(base + 3), LMEM(base + 4), LMEM(base + 5)); return S;
+  };
 
   oz = LM_OPAQUE_ZERO();
   // ================= unit constraint rows: friction loss, joint limits =================
@@ -555,68 +621,43 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       }
     }
   }
-
-  // ================= unconstrained acceleration =================
-  float zero21[21];
-#pragma unroll
-  for (int i = 0; i < 21; i++) zero21[i] = 0;
-  float a0r[6], a0c[MC];
-  {
-    float Lcc[MC * (MC + 1) / 2], W[MC][6], Lrr[21];
-#pragma unroll
-    for (int i = 0; i < MC * (MC + 1) / 2; i++) Lcc[i] = Mcc[i];
-#pragma unroll
-    for (int k = 0; k < MC; k++)
-#pragma unroll
-      for (int r = 0; r < 6; r++) W[k][r] = Mcr[k][r];
-    arrow_factor<Q, MC>(Lcc, W, Mrr, zero21, Lrr);
-#pragma unroll
-    for (int i = 0; i < 6; i++) a0r[i] = sm_r[i];
-#pragma unroll
-    for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
-    arrow_solve<Q, MC>(Lcc, W, Lrr, a0c, a0r);
-  }
+  LM_TICK(2);
 
   // ================= constraint solve: Newton on the primal problem =================
-  // y = M x ; returns nothing, yr is fully summed (replicated)
+  // y = M x (M from lane memory); yr is fully summed (replicated)
   auto mulM = [&](const float* xr, const float* xc, float* yr, float* yc) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) yr[r] = 0;
 #pragma unroll
     for (int k = 0; k < MC; k++) {
       float t = 0;
 #pragma unroll
-      for (int r = 0; r < 6; r++) t = fmaf(Mcr[k][r], xr[r], t);
+      for (int r = 0; r < 6; r++) { float m = LMEM(LMm::kMcr + k * 6 + r); t = fmaf(m, xr[r], t); yr[r] = fmaf(m, xc[k], yr[r]); }
 #pragma unroll
-      for (int j = 0; j < MC; j++) t = fmaf(Mcc[(j <= k) ? tri(k, j) : tri(j, k)], xc[j], t);
+      for (int j = 0; j < MC; j++) t = fmaf(LMEM(LMm::kMcc + ((j <= k) ? tri(k, j) : tri(j, k))), xc[j], t);
       yc[k] = t;
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      float t = 0;
+      float t = Q::sum(yr[r]);
 #pragma unroll
-      for (int k = 0; k < MC; k++) t = fmaf(Mcr[k][r], xc[k], t);
-      t = Q::sum(t);
-#pragma unroll
-      for (int j = 0; j < 6; j++) t = fmaf(Mrr[(j <= r) ? tri(r, j) : tri(j, r)], xr[j], t);
+      for (int j = 0; j < 6; j++) t = fmaf(LMEM(LMm::kMrr + ((j <= r) ? tri(r, j) : tri(j, r))), xr[j], t);
       yr[r] = t;
     }
   };
-  // contact-frame image J x of joint-space vector x for the contact in slot s
-  auto slotJx = [&](int s, const float* xr, const float* xc, float* out) {
+  // spatial image of joint-space vector x on every link of this chain: Al[k] = sum_root x_r S_r + sum_{j<=k} x_j S_j
+  auto link_images = [&](const float* xr, const float* xc, Sp* Al) {
     Sp A = sp0();
 #pragma unroll
-    for (int r = 0; r < 6; r++) A = A + xr[r] * Sr[r];
-    const int link = (int)SL(s, SL_LINK);
+    for (int r = 0; r < 6; r++) A = A + xr[r] * ldS(LMm::kSr + r * 6);
 #pragma unroll
-    for (int k = 0; k < MC; k++) if (k <= link) A = A + xc[k] * Sc[k];
-    contact_rows(A, v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), out);
+    for (int k = 0; k < MC; k++) { A = A + xc[k] * ldS(LMm::kSc + k * 6); Al[k] = A; }
   };
-  auto slotD = [&](int s, float* Dj, float* fr, float& mu, int& dim) {
-    int g = (int)SL(s, SL_GEOM);
-    float D0 = SL(s, SL_D0);
-    dim = (int)GE(g, LM_G_DIM); mu = GE(g, LM_G_MU);
-    Dj[0] = D0;
+  auto pick = [&](const Sp* Al, int link) -> Sp {
+    Sp A = Al[0];
 #pragma unroll
-    for (int j = 1; j < 6; j++) { Dj[j] = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; fr[j - 1] = GE(g, LM_G_F0 + j - 1); }
+    for (int k = 1; k < MC; k++) if (link == k) A = Al[k];
+    return A;
   };
   auto friction_cost = [&](float x, float f, float Rr) -> float {
     if (f <= 0.0f) return 0.0f;
@@ -637,13 +678,18 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
       if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
     }
-    for (int s = 0; s < nslot; s++) {
-      float Dj[6], fr[5], mu, jar[6]; int dim;
-      slotD(s, Dj, fr, mu, dim);
-      slotJx(s, xr, xc, jar);
+    if (nslot > 0) {
+      Sp Al[MC];
+      link_images(xr, xc, Al);
+      for (int s = 0; s < nslot; s++) {
+        float Dj[6], fr[5], jar[6];
+        contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
 #pragma unroll
-      for (int j = 0; j < 6; j++) jar[j] -= SL(s, SL_AREF + j);
-      cost += cone_eval<false>(jar, Dj, fr, mu, dim).cost;
+        for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+        for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+        cost += cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM)).cost;
+      }
     }
     return cost;
   };
@@ -666,6 +712,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     for (int k = 0; k < MC; k++) ac[k] = use_warm ? wac[k] : a0c[k];
   }
 
+  LM_TICK(3);
   float qf_r[6], qf_c[MC];      // constraint forces in joint space
 #pragma unroll
   for (int i = 0; i < 6; i++) qf_r[i] = 0;
@@ -687,99 +734,114 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       // ---- gradient at the current point
       float jfr_r[6], jfr_c[MC], jlim_c[MC];     // jar of the unit rows
       float Mar[6], Mac[MC];
-      mulM(ar, ac, Mar, Mac);
-      Sp Fsum = sp0();
+      if (!(P.ablate & 16)) mulM(ar, ac, Mar, Mac);
+      else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) Mar[i] = ar[i];
+#pragma unroll
+        for (int k = 0; k < MC; k++) Mac[k] = ac[k];
+      }
       float fu_r[6];
+      // friction-loss rows: force = -clamp(x/R, -f, f); quadratic zone (Hessian 1/R) iff |x| < R f
+      float ff_r[6], iR_r[6], ff_c[MC], iR_c[MC];
       unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R), x = ar[i] - fl_aref_r[i];
-        jfr_r[i] = x; fu_r[i] = 0;
-        if (f > 0.0f) {
-          float Rf = Rr * f;
-          if (x <= -Rf) fu_r[i] = f;
-          else if (x >= Rf) fu_r[i] = -f;
-          else { fu_r[i] = -x / Rr; act_fr_r |= 1u << i; }
-        }
+        ff_r[i] = RD(i, LM_D_FLOSS); const float Rr = RD(i, LM_D_FLOSS_R);
+        iR_r[i] = (ff_r[i] > 0.0f) ? 1.0f / Rr : 0.0f;
+        const float x = ar[i] - fl_aref_r[i];
+        jfr_r[i] = x;
+        fu_r[i] = -fminf(fmaxf(x * iR_r[i], -ff_r[i]), ff_r[i]);
+        if (fabsf(x) < Rr * ff_r[i]) act_fr_r |= 1u << i;
       }
 #pragma unroll
       for (int k = 0; k < MC; k++) {
-        float fu = 0;
+        ff_c[k] = (k < nl) ? LK(k, LM_D_FLOSS) : 0.0f; const float Rr = (k < nl) ? LK(k, LM_D_FLOSS_R) : 1.0f;
+        iR_c[k] = (ff_c[k] > 0.0f) ? 1.0f / Rr : 0.0f;
         jfr_c[k] = ac[k] - fl_aref_c[k];
         jlim_c[k] = lim_s_c[k] * ac[k] - lim_aref_c[k];
-        if (k < nl) {
-          float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R), x = jfr_c[k];
-          if (f > 0.0f) {
-            float Rf = Rr * f;
-            if (x <= -Rf) fu = f;
-            else if (x >= Rf) fu = -f;
-            else { fu = -x / Rr; act_fr_c |= 1u << k; }
-          }
-          if (lim_s_c[k] != 0.0f && jlim_c[k] < 0.0f) { fu -= lim_s_c[k] * lim_D_c[k] * jlim_c[k]; act_lim |= 1u << k; }
-        }
+        float fu = -fminf(fmaxf(jfr_c[k] * iR_c[k], -ff_c[k]), ff_c[k]);
+        if (fabsf(jfr_c[k]) < Rr * ff_c[k]) act_fr_c |= 1u << k;
+        if (jlim_c[k] < 0.0f && lim_s_c[k] != 0.0f) { fu -= lim_s_c[k] * lim_D_c[k] * jlim_c[k]; act_lim |= 1u << k; }
         qf_c[k] = fu;
       }
-      for (int s = 0; s < nslot; s++) {
-        float Dj[6], fr[5], mu, jar[6]; int dim;
-        slotD(s, Dj, fr, mu, dim);
-        slotJx(s, ar, ac, jar);
+      Sp Fl[MC];                 // contact wrench sums per link
 #pragma unroll
-        for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; }
-        ConeEval e = cone_eval<true>(jar, Dj, fr, mu, dim);
-        SL(s, SL_ZONE) = (float)e.zone;
-        if (e.zone) {
-          Sp Fw = contact_wrench(e.f, v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)));
-          Fsum = Fsum + Fw;
+      for (int k = 0; k < MC; k++) Fl[k] = sp0();
+      if (nslot > 0 && !(P.ablate & 32)) {
+        Sp Al[MC];
+        link_images(ar, ac, Al);
+        for (int s = 0; s < nslot; s++) {
+          float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
+          const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
+          contact_rows(pick(Al, link), rc, jar);
 #pragma unroll
-          for (int k = 0; k < MC; k++) if (k <= link) qf_c[k] += spdot(Sc[k], Fw);
+          for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+          for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+          ConeEval e = cone_eval<true>(jar, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM));
+          SL(s, SL_ZONE) = (float)e.zone;
+          if (e.zone) {
+            Sp Fw = contact_wrench(e.f, rc);
+#pragma unroll
+            for (int k = 0; k < MC; k++) if (link == k) Fl[k] = Fl[k] + Fw;
+          }
         }
       }
+      Sp Fsum = sp0();
+#pragma unroll
+      for (int k = MC - 1; k >= 0; k--) { Fsum = Fsum + Fl[k]; qf_c[k] += spdot(ldS(LMm::kSc + k * 6), Fsum); }
       float gc[MC], gr_[6], g2 = 0;
 #pragma unroll
       for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; g2 = fmaf(gc[k], gc[k], g2); }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        qf_r[i] = fu_r[i] + Q::sum(spdot(Sr[i], Fsum));
+        qf_r[i] = fu_r[i] + ((P.ablate & 64) ? 0.0f : Q::sum(spdot(ldS(LMm::kSr + i * 6), Fsum)));
         gr_[i] = Mar[i] - sm_r[i] - qf_r[i];
       }
       float gnorm2 = Q::sum(g2);
 #pragma unroll
       for (int i = 0; i < 6; i++) gnorm2 = fmaf(gr_[i], gr_[i], gnorm2);
+      LM_TICK(4);
       if (P.scale * sqrtf(gnorm2) < P.tolerance || it == P.iterations) done = true;
       else {
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
-        float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21];
+        float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21], Hrep[21];
 #pragma unroll
-        for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Mcc[i];
+        for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = LMEM(LMm::kMcc + i);
+#pragma unroll
+        for (int i = 0; i < 21; i++) Hrep[i] = LMEM(LMm::kMrr + i);
 #pragma unroll
         for (int k = 0; k < MC; k++) {
 #pragma unroll
-          for (int r = 0; r < 6; r++) Hcr[k][r] = Mcr[k][r];
-          if (act_fr_c & (1u << k)) Hcc[tri(k, k)] += 1.0f / LK(k, LM_D_FLOSS_R);
+          for (int r = 0; r < 6; r++) Hcr[k][r] = LMEM(LMm::kMcr + k * 6 + r);
+          if (act_fr_c & (1u << k)) Hcc[tri(k, k)] += iR_c[k];
           if (act_lim & (1u << k)) Hcc[tri(k, k)] += lim_D_c[k];
         }
 #pragma unroll
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hpart[tri(i, i)] = w0 / RD(i, LM_D_FLOSS_R);
+        for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hrep[tri(i, i)] += iR_r[i];
         for (int s = 0; s < ((P.ablate & 2) ? 0 : nslot); s++) {
           oz = LM_OPAQUE_ZERO();
           const int zone = (int)SL(s, SL_ZONE);
           if (zone == 0) continue;
-          float Dj[6], fr[5], mu, Hc[21], jar[6]; int dim;
-          slotD(s, Dj, fr, mu, dim);
+          float Dj[6], fr[5], Hc[21], jar[6];
+          const int dim = (int)SL(s, SL_DIM);
 #pragma unroll
-          for (int j = 0; j < 6; j++) jar[j] = SL(s, SL_JAR + j);
-          cone_hessian(jar, Dj, fr, mu, dim, zone, Hc);
+          for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+          for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+          cone_hessian(jar, Dj, fr, SL(s, SL_MU), dim, zone, Hc);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
           const int link = (int)SL(s, SL_LINK);
           float Jc[6 + MC][6];
 #pragma unroll
-          for (int r = 0; r < 6; r++) contact_rows(Sr[r], rc, Jc[r]);
+          for (int r = 0; r < 6; r++) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
 #pragma unroll
           for (int k = 0; k < MC; k++) {
-            if (k <= link) contact_rows(Sc[k], rc, Jc[6 + k]);
+            if (k <= link) contact_rows(ldS(LMm::kSc + k * 6), rc, Jc[6 + k]);
             else {
 #pragma unroll
               for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
@@ -829,6 +891,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
             }
           }
         }
+        LM_TICK(5);
         float Lr[21];
         float sr[6], sc[MC];
 #pragma unroll
@@ -836,10 +899,11 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
         if (!(P.ablate & 4)) {
-          arrow_factor<Q, MC>(Hcc, Hcr, Mrr, Hpart, Lr);
+          arrow_factor<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr);
           arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
         }
 
+        LM_TICK(6);
         // ---- Newton decrement: lambda^2 = -g.s estimates twice the remaining cost gap
         float q1 = 0, q1r = 0;
 #pragma unroll
@@ -850,17 +914,21 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
         if (!(P.scale * dec >= P.tolerance)) done = true;        // converged (also catches NaN)
         else {
           iters++;
-          // ---- exact line search along (sr, sc): Newton iterations on phi'(alpha) with a safeguarding bracket
+          // ---- exact line search along (sr, sc)
           float jv_r[6], jv_c[MC], jvlim_c[MC];
 #pragma unroll
           for (int i = 0; i < 6; i++) jv_r[i] = sr[i];
 #pragma unroll
           for (int k = 0; k < MC; k++) { jv_c[k] = sc[k]; jvlim_c[k] = lim_s_c[k] * sc[k]; }
-          for (int s = 0; s < nslot; s++) {
-            float jv[6];
-            slotJx(s, sr, sc, jv);
+          if (nslot > 0) {
+            Sp Al[MC];
+            link_images(sr, sc, Al);
+            for (int s = 0; s < nslot; s++) {
+              float jv[6];
+              contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
 #pragma unroll
-            for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
+              for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
+            }
           }
           float Mvr[6], Mvc[MC];
           mulM(sr, sc, Mvr, Mvc);
@@ -870,55 +938,57 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
           for (int i = 0; i < 6; i++) { g1r = fmaf(sr[i], Mar[i] - sm_r[i], g1r); q2r = fmaf(sr[i], Mvr[i], q2r); }
           g1 = Q::sum(g1 + w0 * g1r); q2 = Q::sum(q2 + w0 * q2r);
+          LM_TICK(7);
           // phi'(alpha), phi''(alpha) and `mag` = sum of |terms| of phi' (its float32 noise floor is ~1e-6*mag)
           auto line = [&](float alpha, float& d1, float& d2, float& mag) {
-            oz = LM_OPAQUE_ZERO();
             float a1 = 0, a2 = 0, r1 = 0, r2 = 0, am = 0, rm = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-              float f = RD(i, LM_D_FLOSS), Rr = RD(i, LM_D_FLOSS_R);
-              if (f > 0.0f) {
-                float x = fmaf(alpha, jv_r[i], jfr_r[i]), Rf = Rr * f, t;
-                if (x <= -Rf) t = -f * jv_r[i];
-                else if (x >= Rf) t = f * jv_r[i];
-                else { float iR = 1.0f / Rr; t = x * jv_r[i] * iR; r2 = fmaf(jv_r[i] * jv_r[i], iR, r2); }
-                r1 += t; rm += fabsf(t);
-              }
+              const float x = fmaf(alpha, jv_r[i], jfr_r[i]);
+              const float t = jv_r[i] * fminf(fmaxf(x * iR_r[i], -ff_r[i]), ff_r[i]);
+              r1 += t; rm += fabsf(t);
+              r2 = fmaf((fabsf(x) * iR_r[i] < ff_r[i]) ? iR_r[i] : 0.0f, jv_r[i] * jv_r[i], r2);
             }
 #pragma unroll
-            for (int k = 0; k < MC; k++) if (k < nl) {
-              float f = LK(k, LM_D_FLOSS), Rr = LK(k, LM_D_FLOSS_R);
-              if (f > 0.0f) {
-                float x = fmaf(alpha, jv_c[k], jfr_c[k]), Rf = Rr * f, t;
-                if (x <= -Rf) t = -f * jv_c[k];
-                else if (x >= Rf) t = f * jv_c[k];
-                else { float iR = 1.0f / Rr; t = x * jv_c[k] * iR; a2 = fmaf(jv_c[k] * jv_c[k], iR, a2); }
-                a1 += t; am += fabsf(t);
-              }
-              if (lim_s_c[k] != 0.0f) {
-                float x = fmaf(alpha, jvlim_c[k], jlim_c[k]);
-                if (x < 0.0f) { float t = lim_D_c[k] * x * jvlim_c[k]; a1 += t; am += fabsf(t); a2 = fmaf(lim_D_c[k] * jvlim_c[k], jvlim_c[k], a2); }
-              }
+            for (int k = 0; k < MC; k++) {
+              const float x = fmaf(alpha, jv_c[k], jfr_c[k]);
+              float t = jv_c[k] * fminf(fmaxf(x * iR_c[k], -ff_c[k]), ff_c[k]);
+              a2 = fmaf((fabsf(x) * iR_c[k] < ff_c[k]) ? iR_c[k] : 0.0f, jv_c[k] * jv_c[k], a2);
+              const float xl = fminf(fmaf(alpha, jvlim_c[k], jlim_c[k]), 0.0f);       // lim_D_c = 0 when no limit is active
+              t = fmaf(lim_D_c[k] * xl, jvlim_c[k], t);
+              a2 = fmaf((xl < 0.0f) ? lim_D_c[k] : 0.0f, jvlim_c[k] * jvlim_c[k], a2);
+              a1 += t; am += fabsf(t);
+#ifdef LM_LS_TRACE
+              if (getenv("LM_ROWS")) printf("      lane %d row %d alpha %.6g t %.6g x %.5g iR %.4g f %.3g limD %.4g xl %.5g\n", c, k, alpha, t, x, iR_c[k], ff_c[k], lim_D_c[k], xl);
+#endif
             }
             for (int s = 0; s < nslot; s++) {
-              float Dj[6], fr[5], mu, jar[6], jv[6]; int dim;
-              slotD(s, Dj, fr, mu, dim);
+              float Dj[6], fr[5], jar[6], jv[6];
 #pragma unroll
-              for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); }
+              for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+              for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
               float c1 = 0, c2 = 0;
-              cone_line(jar, jv, alpha, Dj, fr, mu, dim, c1, c2);
+              cone_line(jar, jv, alpha, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM), c1, c2);
+#ifdef LM_LS_TRACE
+              if (getenv("LM_ROWS")) printf("      lane %d slot %d alpha %.6g c1 %.6g c2 %.6g jar %.5g %.5g %.5g jv %.5g %.5g %.5g D %.4g %.4g %.4g mu %.4g fr %.3g %.3g dim %d\n", c, s, alpha, c1, c2, jar[0], jar[1], jar[2], jv[0], jv[1], jv[2], Dj[0], Dj[1], Dj[2], SL(s, SL_MU), fr[0], fr[1], (int)SL(s, SL_DIM));
+#endif
               a1 += c1; a2 += c2; am += fabsf(c1);
             }
             d1 = g1 + alpha * q2 + Q::sum(a1 + w0 * r1);
             d2 = q2 + Q::sum(a2 + w0 * r2);
             mag = fabsf(g1) + fabsf(alpha * q2) + Q::sum(am + w0 * rm);
           };
-          // root of the increasing, piecewise-smooth phi': Newton steps from the current point; once the root is
-          // bracketed a step that leaves the bracket is replaced by false position with Illinois down-weighting
-          // (superlinear on the piecewise-linear phi' of friction/limit rows, never worse than bisection)
-          float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f;
-          int last_side = 0;
+          // Root of the increasing phi'. It is piecewise smooth with very different slopes: saturating friction
+          // rows give S-shapes, a stiff contact crossing its sticking sliver gives a near-jump. Newton from the
+          // current point; once the root is bracketed: Newton if it lands inside the bracket, else the secant
+          // through the bracket ends, and a bisection whenever the previous step failed to halve the bracket
+          // (that is what finds the slivers).
+          float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f, w_prev = 3.0e38f;
           line(0.0f, d1, d2, mag);
+#ifdef LM_LS_TRACE
+          if (getenv("LM_SCAN")) { for (float aa = 1e-7f; aa < 2.0f; aa *= 3.0f) { float x1, x2, xm; line(aa, x1, x2, xm); if (c == 0) printf("    scan alpha %.3g d1 %.6g d2 %.6g\n", aa, x1, x2); } line(0.0f, d1, d2, mag); }
+#endif
           bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
           const float dref = fabsf(d1);
           dlo = d1;
@@ -928,20 +998,26 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
             if (!ls_done) {
               line(alpha, d1, d2, mag);
               if (c == 0) cnt.ls_evals++;
-              if (fabsf(d1) < fmaxf(P.ls_tol * dref, 2e-6f * mag)) ls_done = true;
+#ifdef LM_LS_TRACE
+              if (c == 0) printf("  ls %d alpha %.9g d1 %.6g d2 %.6g mag %.4g lo %.9g hi %.9g dref %.4g\n", lsi, alpha, d1, d2, mag, lo, hi, dref);
+#endif
+              if (fabsf(d1) < fmaxf(P.ls_tol * dref, P.ls_noise * mag)) ls_done = true;
               else {
-                if (d1 < 0.0f) { if (last_side < 0) dhi *= 0.5f; lo = alpha; dlo = d1; last_side = -1; }
-                else { if (last_side > 0) dlo *= 0.5f; hi = alpha; dhi = d1; last_side = 1; }
+                if (d1 < 0.0f) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; }
                 float next = alpha - d1 / d2;
                 if (hi > 0.0f) {
-                  if (!(next > lo && next < hi)) next = (lo * dhi - hi * dlo) / (dhi - dlo);
-                  if (!(next > lo && next < hi)) next = 0.5f * (lo + hi);
-                  if (hi - lo <= 1e-4f * hi) ls_done = true;
+                  const float w = hi - lo, in_lo = lo + 0.01f * w, in_hi = hi - 0.01f * w;
+                  if (!(next > in_lo && next < in_hi)) next = (lo * dhi - hi * dlo) / (dhi - dlo);
+                  if (!(next > in_lo && next < in_hi) || w > 0.5f * w_prev) next = 0.5f * (lo + hi);
+                  if (w <= 1e-4f * hi) ls_done = true;
+                  w_prev = w;
                 } else if (next <= lo) next = 2.0f * alpha;
                 alpha = next;
               }
             }
           }
+          if (c == 0 && !ls_done) cnt.ls_capped++;
+          LM_TICK(8);
 #pragma unroll
           for (int i = 0; i < 6; i++) ar[i] = fmaf(alpha, sr[i], ar[i]);
 #pragma unroll
@@ -952,6 +1028,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
   cnt.solver_iters += (c == 0) ? iters : 0;
+  if (c == 0 && iters > cnt.it_max) cnt.it_max = iters;
 
   if (dbg) {
     const int nv = P.nv;
@@ -960,9 +1037,9 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       int d = (int)LK(k, LM_D_DOF);
       dbg->bias[d] = bias_c[k]; dbg->smooth[d] = sm_c[k]; dbg->qacc_smooth[d] = a0c[k]; dbg->qacc[d] = ac[k]; dbg->qfrc_constraint[d] = qf_c[k];
 #pragma unroll
-      for (int j = 0; j <= k; j++) { int e = (int)LK(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mcc[tri(k, j)]; }
+      for (int j = 0; j <= k; j++) { int e = (int)LK(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = LMEM(LMm::kMcc + tri(k, j)); }
 #pragma unroll
-      for (int r = 0; r < 6; r++) { int e = (int)RD(r, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mcr[k][r]; }
+      for (int r = 0; r < 6; r++) { int e = (int)RD(r, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = LMEM(LMm::kMcr + k * 6 + r); }
     }
     if (c == 0) {
 #pragma unroll
@@ -970,11 +1047,12 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
         int d = (int)RD(i, LM_D_DOF);
         dbg->bias[d] = bias_r[i]; dbg->smooth[d] = sm_r[i]; dbg->qacc_smooth[d] = a0r[i]; dbg->qacc[d] = ar[i]; dbg->qfrc_constraint[d] = qf_r[i];
 #pragma unroll
-        for (int j = 0; j <= i; j++) { int e = (int)RD(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = Mrr[tri(i, j)]; }
+        for (int j = 0; j <= i; j++) { int e = (int)RD(j, LM_D_DOF); dbg->M[d * nv + e] = dbg->M[e * nv + d] = LMEM(LMm::kMrr + tri(i, j)); }
       }
     }
   }
 
+  LM_TICK(4);
   oz = LM_OPAQUE_ZERO();
   // ================= integrate: semi-implicit Euler, joint damping implicit =================
   // (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint ; qvel += h qacc' ; qpos += h qvel
@@ -983,15 +1061,15 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
   for (int k = 0; k < MC; k++) wac[k] = ac[k];
   {
-    float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hrep[21], Lr[21];
+    float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hrep[21], Lr[21], zero21[21];
 #pragma unroll
-    for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Mcc[i];
+    for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = LMEM(LMm::kMcc + i);
 #pragma unroll
-    for (int i = 0; i < 21; i++) Hrep[i] = Mrr[i];
+    for (int i = 0; i < 21; i++) { Hrep[i] = LMEM(LMm::kMrr + i); zero21[i] = 0; }
 #pragma unroll
     for (int k = 0; k < MC; k++) {
 #pragma unroll
-      for (int r = 0; r < 6; r++) Hcr[k][r] = Mcr[k][r];
+      for (int r = 0; r < 6; r++) Hcr[k][r] = LMEM(LMm::kMcr + k * 6 + r);
       if (k < nl) Hcc[tri(k, k)] += P.h * LK(k, LM_D_DAMP);
     }
 #pragma unroll
@@ -1008,12 +1086,14 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
     for (int k = 0; k < MC; k++) if (k < nl) { vc[k] = fmaf(P.h, xc[k], vc[k]); qc[k] = fmaf(P.h, vc[k], qc[k]); }
   }
+  LM_TICK(9);
 #undef RD
 #undef CH
 #undef LK
 #undef LX
 #undef GE
 #undef SL
+#undef LMEM
 }
 
 }  // namespace lm

@@ -23,6 +23,7 @@
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
 __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 #define LM_OPAQUE_ZERO() lm_opaque_zero()
+#define LM_CLOCK() ((long long)__builtin_readcyclecounter())
 #include "lm_core.h"
 #include "../../include/locohip.h"
 
@@ -47,7 +48,7 @@ struct Task {
   float rp[8];
 };
 
-struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals; };
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, pad0, pad1; };
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
@@ -62,6 +63,7 @@ struct KArgs {
   int epb;                  // environments per workgroup (workgroup = 4*epb threads)
   lm::Params P; Task T;
   DevStats* stats;
+  unsigned long long* timers;   // LM_TIMERS builds: cycle counters per solver region (lane 0 of each workgroup)
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
 };
@@ -79,10 +81,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 template <int MC, int NS, bool FORWARD_ONLY>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
-  __shared__ float blk_stats[8];
-  extern __shared__ float lane_mem[];                      // contact slot records, [field][lane], NS*SL_SIZE*blockDim floats
+  __shared__ float blk_stats[12];
+  extern __shared__ float lane_mem[];                      // contact slot records, [field][lane], LaneMem<MC,NS>::kSize * blockDim floats
   for (int i = threadIdx.x; i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
-  for (int i = threadIdx.x; i < 8; i += blockDim.x) blk_stats[i] = 0.0f;
+  for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 3;
   const int e_raw = blockIdx.x * a.epb + (threadIdx.x >> 2);
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   for (int k = 0; k < MC; k++) actc[k] = (k < nl) ? actuate(LK(k, LM_D_ACT), LK(k, LM_D_ACT_DELTA), LK(k, LM_D_ACT_MEAN), LK(k, LM_D_CTRL_LO), LK(k, LM_D_CTRL_HI), LK(k, LM_D_GEAR)) : 0.0f;
 
   // ---- physics
-  lm::Counters cnt = {0, 0, 0, 0, 0};
+  lm::Counters cnt = {};
   float* lmem = lane_mem + threadIdx.x;
   const int ls = blockDim.x;
   if (FORWARD_ONLY) {
@@ -239,13 +241,17 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (c == 0) {
         atomicAdd(&blk_stats[0], 1.0f); atomicAdd(&blk_stats[1], episodes); atomicAdd(&blk_stats[2], reward);
         atomicAdd(&blk_stats[3], nonfinite ? 1.0f : 0.0f); atomicAdd(&blk_stats[4], (float)cnt.solver_iters);
-        atomicAdd(&blk_stats[7], (float)cnt.ls_evals);
+        atomicAdd(&blk_stats[7], (float)cnt.ls_evals); atomicAdd(&blk_stats[8], (float)cnt.ls_capped);
+        atomicAdd(&blk_stats[9], cnt.it_max >= 8 ? 1.0f : 0.0f);
       }
       if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
     }
+#ifdef LM_TIMERS
+    if (threadIdx.x == 0) for (int i = 0; i < 10; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+#endif
     __syncthreads();
-    for (int i = threadIdx.x; i < 8; i += blockDim.x) {
+    for (int i = threadIdx.x; i < 12; i += blockDim.x) {
       float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
       *dst += blk_stats[i];
     }
@@ -276,6 +282,7 @@ struct lm_batch {
   DevStats* stats;
   int table_rows; unsigned long long seed; long long env_offset; int auto_reset, horizon; unsigned step_index;
   int epb, nblocks;
+  unsigned long long* timers;
   hipStream_t stream;
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
@@ -321,7 +328,8 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.tolerance = 1e-6f;      // float32 stand-in for MuJoCo's 1e-8 (the gradient itself carries ~1e-6 relative noise)
   P.nv = T.nv;
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
-  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ablate = 0;
+  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  if (const char* v = getenv("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
   if (const char* v = getenv("LM_ABLATE")) P.ablate = atoi(v);
   if (const char* v = getenv("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes
   if (const char* v = getenv("LM_LS_TOL")) P.ls_tol = (float)atof(v);
@@ -373,6 +381,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
   HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
+  HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * 16)); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * 16));
   HIPCHK(hipStreamCreate(&b->stream));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
   *out = b;
@@ -454,13 +463,14 @@ static KArgs make_args(lm_batch* b) {
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
-  a.epb = b->epb;
+  a.epb = b->epb; a.timers = b->timers;
   return a;
 }
 
 static void launch_step(lm_batch* b, const KArgs& a) {
   dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
-  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, sizeof(float) * 4 * lm::SL_SIZE * block.x, b->stream, a);
+  const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
+  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, lane_bytes, b->stream, a);
 }
 
 static int drain_stats(lm_batch* b) {
@@ -471,7 +481,7 @@ static int drain_stats(lm_batch* b) {
   for (const DevStats& x : s) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
     b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
-    b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals;
+    b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals; b->acc.linesearch_capped += x.ls_capped; b->acc.steps_with_8plus_iters += x.it_ge8;
   }
   return 0;
 }
@@ -548,7 +558,8 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
   a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
   dim3 grid((N + b->epb - 1) / b->epb), block(4 * b->epb);
-  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, sizeof(float) * 4 * lm::SL_SIZE * block.x, b->stream, a);
+  const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
+  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, lane_bytes, b->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->stream));
   auto get = [&](float* dst, const float* src, size_t n) -> int { if (dst) HIPCHK(hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost)); return 0; };
@@ -565,6 +576,15 @@ int lm_get_stats(lm_batch* b, lm_stats* out, int reset) {
   if (drain_stats(b)) return 1;
   if (out) *out = b->acc;
   if (reset) memset(&b->acc, 0, sizeof(b->acc));
+  return 0;
+}
+
+/* profiling builds (-DLM_TIMERS): cycles spent per solver region, summed over workgroups (not part of the ABI header) */
+int lm_debug_timers(lm_batch* b, unsigned long long* out16) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out16, b->timers, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * 16));
   return 0;
 }
 

@@ -3,6 +3,7 @@
 // Four OS threads play the four lanes; the quad sum (two DPP adds on gfx950) becomes a barrier + the same
 // (x0+x1)+(x2+x3) association. Nothing in the product loads this file; it is built by tests/test_emu_core.py.
 #include <barrier>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -73,8 +74,8 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
           actc[k] = actuate(blk, LM_NCHAIN);
         }
       }
-      lm::Counters cnt = {0, 0, 0, 0, 0};
-      float lmem[NS * lm::SL_SIZE];
+      lm::Counters cnt = {};
+      float lmem[lm::LaneMem<MC, NS>::kSize];
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
         lm::substep<QuadThreads, MC, NS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
@@ -83,7 +84,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
       static int acc[4][4];
-      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon;
+      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow + 1000 * cnt.ls_capped; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon;
       g_bar.arrive_and_wait();
       if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 4; j++) cnt_tot[j] += acc[l][j];
       g_bar.arrive_and_wait();

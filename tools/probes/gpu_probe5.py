@@ -19,7 +19,7 @@ b.set_reset_table(tab, seed=0); b.set_auto_reset(True, horizon=1000)
 b.set_state(rows[:, :18], rows[:, 18:36]); b.set_goal(rows[:, 36:39])
 b.rollout(20)
 st = b.rollout(100)
-out = dict(ms_per_step=round(st["kernel_ms"] / 100, 4), iters=round(st["solver_iters"] / st["env_steps"] / 10, 3), ls_per_iter=round(st["linesearch_evals"] / max(st["solver_iters"], 1), 3))
+out = dict(ms_per_step=round(st["kernel_ms"] / 100, 4), iters=round(st["solver_iters"] / st["env_steps"] / 10, 3), ls_per_iter=round(st["linesearch_evals"] / max(st["solver_iters"], 1), 3), ls_capped_frac=st["linesearch_capped"] / max(st["solver_iters"], 1), steps8=st["steps_with_8plus_iters"] / st["env_steps"])
 rs = np.random.RandomState(1)
 n = 256
 r2 = tab[rs.randint(0, len(tab), n)]

@@ -21,7 +21,7 @@ st = b.rollout(10)
 print(round(st["kernel_ms"] / 10, 4))
 ''' % ROOT
 res = {}
-for cap, abl in [(0, 0), (1, 0), (1, 2), (1, 4), (1, 8), (1, 14), (2, 0), (2, 14)]:
+for cap, abl in [(0, 0), (1, 0), (1, 8), (1, 14), (1, 14 + 16), (1, 14 + 32), (1, 14 + 64), (1, 14 + 112), (3, 14), (3, 14 + 112)]:
     env = dict(os.environ, CAP=str(cap), LM_ABLATE=str(abl))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     res["cap%d_abl%d" % (cap, abl)] = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
