@@ -136,6 +136,15 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_env_step(nq, nv, env._model.nu, 37) * n
     launch_s = kernel_ms * 1e-3 / args.steps
     achieved = bytes_per_launch / launch_s / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r1_pmc.json")
+    if os.path.exists(prof) and n == 4096:
+        try:
+            pmc = json.load(open(prof))["pmc"]
+            # separate --pmc passes (tools/probes/prof_run.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)
+            traffic = pmc["FETCH_SIZE"]["bytes_per_dispatch_corrected_x2"] + pmc["WRITE_SIZE"]["bytes_per_dispatch"]
+        except Exception:
+            traffic = None
     out = {
         "metric": "env-steps/sec at 4096 envs/GPU; qpos Linf vs CPU MuJoCo",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,9 +154,10 @@ def main():
                                "(horizon 1000), 10 physics substeps per env-step" % n,
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
                      "kernel": "step_kernel<3,4,false>", "kernel_ms_per_launch": 1e3 * launch_s,
-                     "note": "path is VALU/latency-bound by design (SURVEY.md 8d): 636 algorithmic B per env-step"},
+                     "note": "path is VALU/latency-bound by design (SURVEY.md 8d): 636 algorithmic B per env-step; traffic = PMC bytes per launch from profiles/r1_pmc.json (same command, separate rocprofv3 --pmc passes)"},
         "stats": {"episodes": vals[2], "mean_reward": vals[3] / max(env_steps, 1), "nan_resets": vals[4],
                   "overflow_contacts": vals[5], "unhandled_geom_substeps": vals[6],
                   "newton_iters_per_substep": vals[7] / max(env_steps * 10, 1),

@@ -34,7 +34,7 @@ constexpr int MC = 3, NS = 4;
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
-                       int* counters /*4*/) {
+                       int* counters /*6*/) {
   const double* H = chain_model;
   const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
   std::vector<float> cm(LM_CM_SIZE);
@@ -44,7 +44,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ablate = 0;
-  int cnt_tot[4] = {0, 0, 0, 0};
+  int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int c) {
     t_lane = c;
     const float* rb = cm.data();
@@ -83,10 +83,10 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
       g_bar.arrive_and_wait();
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
-      static int acc[4][4];
-      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow + 1000 * cnt.ls_capped; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon;
+      static int acc[4][6];
+      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped;
       g_bar.arrive_and_wait();
-      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 4; j++) cnt_tot[j] += acc[l][j];
+      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 6; j++) cnt_tot[j] += acc[l][j];
       g_bar.arrive_and_wait();
     }
   };

@@ -29,9 +29,9 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1):
     a = np.ascontiguousarray(action, dtype=np.float64).reshape(n, -1)
     M = np.zeros((nv, nv), dtype=np.float32)
     d5 = np.zeros((5, nv), dtype=np.float32)
-    cnt = np.zeros(4, dtype=np.int32)
+    cnt = np.zeros(6, dtype=np.int32)
     dp = lambda x: x.ctypes.data_as(C.c_void_p)
     lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
                 dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt))
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
-    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3])), dbg
+    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5])), dbg

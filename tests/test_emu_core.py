@@ -49,7 +49,7 @@ def test_core_stages_and_golden_steps(setup):
         assert cnt["ncon"] == f["ncon"] and cnt["overflow"] == 0
         assert np.abs(d["M"] - f["M"]).max() < 1e-5
         assert np.abs(d["bias"] - f["bias"]).max() < 1e-4
-        assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-5 * max(1.0, np.abs(f["qacc"]).max())
+        assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())   # float32 Newton-decrement stop
         q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10)
         assert np.abs(q10[0, 2:] - g[k + 1, :16]).max() < 1e-5
         assert np.abs(v10[0] - g[k + 1, 16:34]).max() < 1e-3
