@@ -1,5 +1,7 @@
 from .base import LocoEnv, ValidTaskConf
 from .unitree_a1 import UnitreeA1
+from .atlas import Atlas
 from .gymnasium import GymnasiumWrapper
 
 UnitreeA1.register()
+Atlas.register()

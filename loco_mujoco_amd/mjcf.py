@@ -292,9 +292,8 @@ def compile_mjcf(handle, timestep=None):
         else:
             cc = el.get("childclass", childclass)
             childclass = cc
-            q = _floats(el.get("quat", "1 0 0 0"), 4)
             b = dict(name=el.get("name", "body%d" % len(bodies)), parent=parent_id,
-                     pos=_floats(el.get("pos", "0 0 0"), 3), quat=q / np.linalg.norm(q),
+                     pos=_floats(el.get("pos", "0 0 0"), 3), quat=_orientation(el.attrib),
                      mass=0.0, ipos=np.zeros(3), inertia=np.zeros((3, 3)), jntadr=-1, jntnum=0)
             bodies.append(b)
             bid = len(bodies) - 1
@@ -334,8 +333,7 @@ def compile_mjcf(handle, timestep=None):
             sz = _floats(a["size"]) if "size" in a else np.zeros(0)
             size[:len(sz)] = sz
             pos = _floats(a.get("pos", "0 0 0"), 3)
-            q = _floats(a.get("quat", "1 0 0 0"), 4)
-            q = q / np.linalg.norm(q)
+            q = _orientation(a)
             if "fromto" in a and gt in (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX):
                 ft = _floats(a["fromto"], 6)
                 vec = ft[0:3] - ft[3:6]
@@ -361,7 +359,7 @@ def compile_mjcf(handle, timestep=None):
         for s in el.findall("site"):
             a = defaults.resolve("site", s, childclass)
             pos = _floats(a.get("pos", "0 0 0"), 3)
-            q = _floats(a.get("quat", "1 0 0 0"), 4)
+            q = _orientation(a)
             if "fromto" in a:
                 ft = _floats(a["fromto"], 6)
                 pos = 0.5 * (ft[0:3] + ft[3:6])
@@ -473,6 +471,25 @@ def compile_mjcf(handle, timestep=None):
 
     _set_const(m)
     return m
+
+
+def _orientation(attrs):
+    """Body/geom/site orientation from ``quat`` | ``axisangle`` | ``euler`` (radians, default xyz sequence)."""
+    if "quat" in attrs:
+        q = _floats(attrs["quat"], 4)
+    elif "axisangle" in attrs:
+        a = _floats(attrs["axisangle"], 4)
+        q = axis_angle_quat(a[:3], a[3])
+    elif "euler" in attrs:
+        e = _floats(attrs["euler"], 3)
+        q = np.array([1.0, 0, 0, 0])
+        for ax, ang in zip(np.eye(3), e):          # intrinsic x-y-z
+            q = quat_mul(q, axis_angle_quat(ax, ang))
+    else:
+        q = np.array([1.0, 0, 0, 0])
+    for bad in ("xyaxes", "zaxis"):
+        assert bad not in attrs, "orientation attribute %s not supported" % bad
+    return q / np.linalg.norm(q)
 
 
 def _pad_solimp(s):

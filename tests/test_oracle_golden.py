@@ -97,3 +97,48 @@ def test_oracle_solution_is_kkt_point(a1):
         res = f["M"] @ f["qacc"] - f["M"] @ f["qacc_smooth"] - f["efc_J"].T @ f["efc_force"]
         assert np.abs(res).max() < 1e-6          # solver tolerance 1e-8 * meaninertia * nv
         assert f["ncon"] >= 1 and f["nefc"] >= 18
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Atlas.walk: pins RK4, joint-limit rows, pyramidal cones (shared regulariser Rpy = 2 mu^2 R) and the plane-box
+# collider of the oracle. 26 one-control-step KATs + the reference's full-rollout test.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_atlas_one_control_step_kats():
+    np.random.seed(0)
+    env = LocoEnv.make("Atlas.walk", debug=True)
+    m = env._model
+    o = Oracle(pack_model(m))
+    g = GOLD["Atlas.walk.real"]
+    spec = env.obs_helper.observation_spec
+    qidx = [m.jnt_id(n) for k, n, t in spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    for k in range(len(g) - 1):
+        a = np.random.randn(10) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :14]
+        qvel[qidx] = g[k, 14:30]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+        assert np.abs(q[qidx[2:]] - g[k + 1, :14]).max() < 1e-12, k
+        assert np.abs(v[qidx] - g[k + 1, 14:30]).max() < 1e-10, k
+
+
+def test_atlas_full_rollout_matches_reference_test():
+    g = GOLD["Atlas.walk.real"]
+    np.random.seed(0)
+    env = attach(LocoEnv.make("Atlas.walk", debug=True))
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, r, absorbing, _ = env.step(np.random.randn(10) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape and np.allclose(rows, g)
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
+    assert np.isclose(r, np.exp(-(g[-2][14] - 1.25) ** 2))         # TargetVelocityReward on the previous observation

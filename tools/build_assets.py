@@ -5,7 +5,7 @@ container only; nothing at run time reads the checkout.
   python tools/build_assets.py [--ref /path/to/loco-mujoco]
 
 Writes
-  loco_mujoco_amd/assets/UnitreeA1.torque.model.npz      compiled model (after the env's XML surgery)
+  loco_mujoco_amd/assets/{UnitreeA1.torque,Atlas.default}.model.npz   compiled models (after the env's XML surgery)
   loco_mujoco_amd/datasets/quadrupeds/real/mini_datasets/walk_straight.npz   re-encoded mini dataset
   tests/golden/reference_rollouts.npz                     the reference's golden rollouts for our tasks
 """
@@ -22,6 +22,7 @@ sys.path.insert(0, str(ROOT))
 
 from loco_mujoco_amd import mjcf                      # noqa: E402
 from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
+from loco_mujoco_amd.environments.atlas import Atlas, _ARM, _BACK   # noqa: E402
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
                 "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"]
@@ -40,8 +41,15 @@ def main():
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "UnitreeA1.torque.model.npz")
     print("UnitreeA1: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
 
+    h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "atlas" / "atlas.xml")
+    Atlas._delete_from_xml_handle(h, _ARM + _BACK, [j + "_actuator" for j in _ARM + _BACK], [])
+    m = mjcf.compile_mjcf(h, timestep=0.001)
+    m.save(ROOT / "loco_mujoco_amd" / "assets" / "Atlas.default.model.npz")
+    print("Atlas: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
+
     # --- mini datasets (same keys/values, re-encoded)
-    for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz"]:
+    for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
+                "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz"]:
         src = np.load(pkg / rel, allow_pickle=True)
         dst = ROOT / "loco_mujoco_amd" / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
