@@ -109,6 +109,8 @@ struct Params {
   float ls_noise;     // float32 noise floor of phi' relative to the sum of |terms|
   int ablate;         // profiling only: bitmask of solver regions to skip (0 in production)
   int nv;
+  int integrator;     // LM_INT_EULER (0) | LM_INT_RK4 (1)
+  int cone;           // 0 pyramidal | 1 elliptic
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
@@ -250,6 +252,29 @@ LM_DEV void cone_line(const float* jar, const float* jv, float alpha, const floa
   d2 += Dm * (NmTp * NmTp - NmT * mu * Tpp);
 }
 
+// ---- pyramidal friction cone (condim 3): 4 edge rows x_r = j_n +- mu j_t1 | j_n +- mu j_t2, all with the same D.
+// A row is active (quadratic) iff x_r < 0; cost 0.5 D x_r^2, edge force -D x_r >= 0.
+LM_DEV void pyr_rows(const float* j3, float mu, float* x) {
+  x[0] = fmaf(mu, j3[1], j3[0]); x[1] = fmaf(-mu, j3[1], j3[0]); x[2] = fmaf(mu, j3[2], j3[0]); x[3] = fmaf(-mu, j3[2], j3[0]);
+}
+// contact-frame force (n, t1, t2) and active mask from the 4 row residuals
+LM_DEV unsigned pyr_force(const float* x, float D, float mu, float* f3, float& cost) {
+  float e[4]; unsigned act = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { float xm = fminf(x[r], 0.0f); e[r] = -D * xm; cost = fmaf(0.5f * D * xm, xm, cost); if (x[r] < 0.0f) act |= 1u << r; }
+  f3[0] = (e[0] + e[1]) + (e[2] + e[3]); f3[1] = mu * (e[0] - e[1]); f3[2] = mu * (e[2] - e[3]);
+  return act;
+}
+// 3x3 contact-frame Hessian as the leading block of a 6x6 lower triangle
+LM_DEV void pyr_hessian(unsigned act, float D, float mu, float* Hc) {
+#pragma unroll
+  for (int i = 0; i < 21; i++) Hc[i] = 0;
+  float a0 = (act & 1u) ? 1.0f : 0.0f, a1 = (act & 2u) ? 1.0f : 0.0f, a2 = (act & 4u) ? 1.0f : 0.0f, a3 = (act & 8u) ? 1.0f : 0.0f;
+  Hc[tri(0, 0)] = D * ((a0 + a1) + (a2 + a3));
+  Hc[tri(1, 0)] = D * mu * (a0 - a1); Hc[tri(2, 0)] = D * mu * (a2 - a3);
+  Hc[tri(1, 1)] = D * mu * mu * (a0 + a1); Hc[tri(2, 2)] = D * mu * mu * (a2 + a3);
+}
+
 // ---- arrow-structured factorisation -------------------------------------------------------------------------
 // H = [Hcc (MC x MC, per lane), Hcr (MC x 6, per lane); Hrr (6x6): `Hrr_rep` replicated part + quad-sum of
 // `Hrr_part`]. Overwrites: Hcc -> Lcc (lower Cholesky), Hcr -> W = Lcc^-1 Hcr, Lrr <- chol(Hrr - sum W^T W).
@@ -366,8 +391,10 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
 // actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
 // lmem/ls: lane-local scratch of LaneMem<MC,NS>::kSize floats, element i at lmem[i*ls].
-template <class Q, int MC, int NS>
-LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
+// forward dynamics at (q, v): constrained acceleration in war/wac (in: warm start, out: qacc). With EULER the state
+// is also advanced by one semi-implicit Euler step (implicit joint damping), otherwise q, v are left untouched.
+template <class Q, int MC, int NS, bool EULER>
+LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
                     Counters& cnt, const Debug* dbg) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
@@ -479,12 +506,31 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
             V3 ctr = pk + mul(Rk, v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ)));
             if (ctr.z - GE(g, LM_G_RBOUND) > 0.0f) continue;        // margin-less bounding-sphere prune
             float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
+            const int gtype = (int)GE(g, LM_G_TYPE);
             V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
-            int npt = (GE(g, LM_G_TYPE) == 2.0f) ? 2 : 1;
+            M3 Rg;
+            if (gtype == LM_GEOM_BOX) {
+              M3 Gr;
+#pragma unroll
+              for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
+              Rg = mul(Rk, Gr);
+            }
+            // candidate points: sphere centre | the two capsule end centres | the box corners below the box centre
+            // in bit order, at most 4 contacts per box
+            const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
+            int made = 0;
             for (int e = 0; e < npt; e++) {
-              V3 sc = (npt == 2) ? ctr + ((e == 0) ? half : -half) * ax : ctr;
-              float dist = sc.z - rad;
+              V3 sc = ctr; float rad_e = rad;
+              if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
+              else if (gtype == LM_GEOM_BOX) {
+                V3 off = mul(Rg, v3((e & 1) ? GE(g, LM_G_SX) : -GE(g, LM_G_SX), (e & 2) ? GE(g, LM_G_SY) : -GE(g, LM_G_SY),
+                                    (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
+                if (off.z > 0.0f || made >= 4) continue;
+                sc = ctr + off; rad_e = 0.0f;
+              }
+              float dist = sc.z - rad_e;
               if (dist >= margin) continue;
+              made++;
               if (nslot >= NS) { cnt.overflow++; continue; }
               // contact point (midway between the surfaces) relative to O; row parameters
               V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
@@ -492,15 +538,22 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
               float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
               float vel[6];
               contact_rows(V, cp, vel);
-              const float B = GE(g, LM_G_B);
+              const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
               const int dim = (int)GE(g, LM_G_DIM);
-              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = GE(g, LM_G_MU);
+              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
               SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
               SL(nslot, SL_D) = D0;
+              if (P.cone == 0 && dim == 3) {
+                float xv[4];
+                pyr_rows(vel, mu, xv);
 #pragma unroll
-              for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
+                for (int r = 0; r < 4; r++) SL(nslot, SL_AREF + r) = -B * xv[r] - Kr;
+              } else {
 #pragma unroll
-              for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? GE(g, LM_G_K) * imp * (dist - margin) : 0.0f);
+                for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
+#pragma unroll
+                for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? Kr : 0.0f);
+              }
               nslot++;
             }
           }
@@ -684,11 +737,20 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
       for (int s = 0; s < nslot; s++) {
         float Dj[6], fr[5], jar[6];
         contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
+        const int dim = (int)SL(s, SL_DIM);
+        if (P.cone == 0 && dim == 3) {
+          float x[4], f3[3];
+          pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
-        for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
+          for (int r = 0; r < 4; r++) x[r] -= SL(s, SL_AREF + r);
+          pyr_force(x, SL(s, SL_D), SL(s, SL_MU), f3, cost);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
-        cost += cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM)).cost;
+          for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+          for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+          cost += cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
+        }
       }
     }
     return cost;
@@ -776,14 +838,29 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
           contact_rows(pick(Al, link), rc, jar);
+          const int dim = (int)SL(s, SL_DIM);
+          float fc[6];
+          int zone;
+          if (P.cone == 0 && dim == 3) {
+            float x[4], dummy = 0;
+            pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
-          for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; Dj[j] = SL(s, SL_D + j); }
+            for (int r = 0; r < 4; r++) { x[r] -= SL(s, SL_AREF + r); SL(s, SL_JAR + r) = x[r]; }
+            zone = (int)pyr_force(x, SL(s, SL_D), SL(s, SL_MU), fc, dummy);
+            fc[3] = fc[4] = fc[5] = 0.0f;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
-          ConeEval e = cone_eval<true>(jar, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM));
-          SL(s, SL_ZONE) = (float)e.zone;
-          if (e.zone) {
-            Sp Fw = contact_wrench(e.f, rc);
+            for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+            for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+            ConeEval e = cone_eval<true>(jar, Dj, fr, SL(s, SL_MU), dim);
+            zone = e.zone;
+#pragma unroll
+            for (int j = 0; j < 6; j++) fc[j] = e.f[j];
+          }
+          SL(s, SL_ZONE) = (float)zone;
+          if (zone) {
+            Sp Fw = contact_wrench(fc, rc);
 #pragma unroll
             for (int k = 0; k < MC; k++) if (link == k) Fl[k] = Fl[k] + Fw;
           }
@@ -829,11 +906,14 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
           if (zone == 0) continue;
           float Dj[6], fr[5], Hc[21], jar[6];
           const int dim = (int)SL(s, SL_DIM);
+          if (P.cone == 0 && dim == 3) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
+          else {
 #pragma unroll
-          for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
+            for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
 #pragma unroll
-          for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
-          cone_hessian(jar, Dj, fr, SL(s, SL_MU), dim, zone, Hc);
+            for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+            cone_hessian(jar, Dj, fr, SL(s, SL_MU), dim, zone, Hc);
+          }
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
           const int link = (int)SL(s, SL_LINK);
           float Jc[6 + MC][6];
@@ -926,8 +1006,15 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
             for (int s = 0; s < nslot; s++) {
               float jv[6];
               contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
+              if (P.cone == 0 && (int)SL(s, SL_DIM) == 3) {
+                float xv[4];
+                pyr_rows(jv, SL(s, SL_MU), xv);
 #pragma unroll
-              for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
+                for (int r = 0; r < 4; r++) SL(s, SL_JV + r) = xv[r];
+              } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
+              }
             }
           }
           float Mvr[6], Mvc[MC];
@@ -964,14 +1051,24 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
             }
             for (int s = 0; s < nslot; s++) {
               float Dj[6], fr[5], jar[6], jv[6];
-#pragma unroll
-              for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); Dj[j] = SL(s, SL_D + j); }
-#pragma unroll
-              for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+              const int dim = (int)SL(s, SL_DIM);
               float c1 = 0, c2 = 0;
-              cone_line(jar, jv, alpha, Dj, fr, SL(s, SL_MU), (int)SL(s, SL_DIM), c1, c2);
+              if (P.cone == 0 && dim == 3) {
+                const float D = SL(s, SL_D);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                  const float xv = SL(s, SL_JV + r), x = fminf(fmaf(alpha, xv, SL(s, SL_JAR + r)), 0.0f);
+                  c1 = fmaf(D * x, xv, c1); c2 = fmaf((x < 0.0f) ? D : 0.0f, xv * xv, c2);
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+                for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+                cone_line(jar, jv, alpha, Dj, fr, SL(s, SL_MU), dim, c1, c2);
+              }
 #ifdef LM_LS_TRACE
-              if (getenv("LM_ROWS")) printf("      lane %d slot %d alpha %.6g c1 %.6g c2 %.6g jar %.5g %.5g %.5g jv %.5g %.5g %.5g D %.4g %.4g %.4g mu %.4g fr %.3g %.3g dim %d\n", c, s, alpha, c1, c2, jar[0], jar[1], jar[2], jv[0], jv[1], jv[2], Dj[0], Dj[1], Dj[2], SL(s, SL_MU), fr[0], fr[1], (int)SL(s, SL_DIM));
+              if (getenv("LM_ROWS")) printf("      lane %d slot %d alpha %.6g c1 %.6g c2 %.6g\n", c, s, alpha, c1, c2);
 #endif
               a1 += c1; a2 += c2; am += fabsf(c1);
             }
@@ -1060,7 +1157,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int i = 0; i < 6; i++) war[i] = ar[i];
 #pragma unroll
   for (int k = 0; k < MC; k++) wac[k] = ac[k];
-  {
+  if (EULER) {
     float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hrep[21], Lr[21], zero21[21];
 #pragma unroll
     for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = LMEM(LMm::kMcc + i);
@@ -1094,6 +1191,40 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #undef GE
 #undef SL
 #undef LMEM
+}
+
+// one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
+// forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
+template <class Q, int MC, int NS, bool RK4>
+LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
+                    float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
+                    Counters& cnt, const Debug* dbg) {
+  if (!RK4) { forward<Q, MC, NS, true>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg); return; }
+  float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
+#pragma unroll
+  for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
+#pragma nounroll
+  for (int st = 0; st < 4; st++) {
+    forward<Q, MC, NS, false>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr);
+    const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+    const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      dqr[i] = fmaf(b, vr[i], dqr[i]); dvr[i] = fmaf(b, war[i], dvr[i]);
+      if (st < 3) { qr[i] = fmaf(P.h * a, vr[i], q0r[i]); vr[i] = fmaf(P.h * a, war[i], v0r[i]); }
+    }
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      dqc[k] = fmaf(b, vc[k], dqc[k]); dvc[k] = fmaf(b, wac[k], dvc[k]);
+      if (st < 3) { qc[k] = fmaf(P.h * a, vc[k], q0c[k]); vc[k] = fmaf(P.h * a, wac[k], v0c[k]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { qr[i] = fmaf(P.h, dqr[i], q0r[i]); vr[i] = fmaf(P.h, dvr[i], v0r[i]); }
+#pragma unroll
+  for (int k = 0; k < MC; k++) { qc[k] = fmaf(P.h, dqc[k], q0c[k]); vc[k] = fmaf(P.h, dvc[k], v0c[k]); }
 }
 
 }  // namespace lm

@@ -78,7 +78,7 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool FORWARD_ONLY>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
   __shared__ float blk_stats[12];
@@ -160,13 +160,13 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   if (FORWARD_ONLY) {
     if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
-    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg);
+    lm::forward<QuadDpp, MC, NS, false>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg);
     int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
+    lm::substep<QuadDpp, MC, NS, RK4>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -288,6 +288,22 @@ struct lm_batch {
   hipEvent_t ev0, ev1;
 };
 
+// kernel variants: MC = links per chain the code is unrolled for, NS = contact slots per chain, RK4 = integrator
+template <bool FWD>
+static void launch_variant(lm_batch* b, const KArgs& a) {
+  dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
+  const bool big = b->m->T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4;
+  if (!big) {
+    const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
+    if (!rk4) hipLaunchKernelGGL((step_kernel<3, 4, false, FWD>), grid, block, lane_bytes, b->stream, a);
+    else hipLaunchKernelGGL((step_kernel<3, 4, true, FWD>), grid, block, lane_bytes, b->stream, a);
+  } else {
+    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kSize * block.x;
+    if (!rk4) hipLaunchKernelGGL((step_kernel<5, 8, false, FWD>), grid, block, lane_bytes, b->stream, a);
+    else hipLaunchKernelGGL((step_kernel<5, 8, true, FWD>), grid, block, lane_bytes, b->stream, a);
+  }
+}
+
 extern "C" {
 
 const char* lm_last_error(void) { return g_err.c_str(); }
@@ -302,7 +318,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   if (!cmod || n < LM_HEADER_SIZE + LM_CM_SIZE) return fail("chain model too short");
   if ((unsigned)cmod[LM_H_MAGIC] != (unsigned)LM_LMC_MAGIC) return fail("bad chain-model magic");
   if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
-  if ((int)cmod[LM_H_MAXLINKS] > 3) return fail("chains longer than 3 links need the MC=5 instantiation (not built yet)");
+  if ((int)cmod[LM_H_MAXLINKS] > 5) return fail("chains longer than 5 links are not supported");
   if ((int)cmod[LM_HEADER_SIZE + LM_R_NDOF] != 6) return fail("root body must have 6 dofs");
   HIPCHK(hipSetDevice(device));
   lm_model* m = new lm_model();
@@ -327,6 +343,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.iterations = (int)cmod[LM_H_ITERATIONS];
   P.tolerance = 1e-6f;      // float32 stand-in for MuJoCo's 1e-8 (the gradient itself carries ~1e-6 relative noise)
   P.nv = T.nv;
+  P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE];
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   if (const char* v = getenv("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
@@ -467,11 +484,7 @@ static KArgs make_args(lm_batch* b) {
   return a;
 }
 
-static void launch_step(lm_batch* b, const KArgs& a) {
-  dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
-  const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
-  hipLaunchKernelGGL((step_kernel<3, 4, false>), grid, block, lane_bytes, b->stream, a);
-}
+static void launch_step(lm_batch* b, const KArgs& a) { launch_variant<false>(b, a); }
 
 static int drain_stats(lm_batch* b) {
   std::vector<DevStats> s(b->nblocks);
@@ -557,9 +570,7 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   HIPCHK(hipMemset(buf, 0, sizeof(float) * per * N));
   a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
   a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
-  dim3 grid((N + b->epb - 1) / b->epb), block(4 * b->epb);
-  const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
-  hipLaunchKernelGGL((step_kernel<3, 4, true>), grid, block, lane_bytes, b->stream, a);
+  launch_variant<true>(b, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->stream));
   auto get = [&](float* dst, const float* src, size_t n) -> int { if (dst) HIPCHK(hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost)); return 0; };

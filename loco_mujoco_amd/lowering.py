@@ -29,7 +29,8 @@ from . import mjcf
 MAXC = 5          # links per chain the table has room for
 NCHAIN = 4
 NROOT = 6
-MAXG = 8          # floor-collidable geoms per chain
+MAXG = 12         # floor-collidable geoms per chain (with / without a device collider, each)
+MAXRG = 80        # geoms welded to the root (no device collider: proximity is counted)
 
 # ---- per-dof parameter block (used for root dofs and chain links)
 (D_TYPE, D_AX, D_AY, D_AZ, D_PX, D_PY, D_PZ, D_DAMP, D_ARM, D_STIFF, D_FLOSS, D_FLOSS_R, D_FLOSS_B, D_LIMITED,
@@ -43,7 +44,8 @@ LINK_SIZE = D_SIZE + L_SIZE
 # ---- per-geom block
 (G_LINK, G_TYPE, G_PX, G_PY, G_PZ, G_AX, G_AY, G_AZ, G_RADIUS, G_HALF, G_RBOUND, G_MARGIN, G_K, G_B, G_S0, G_S1,
  G_S2, G_S3, G_S4, G_TRAN, G_DIM, G_MU, G_F0, G_F1, G_F2, G_F3, G_F4, G_RR1, G_RR2, G_RR3, G_RR4, G_RR5,
- G_SIZE) = range(33)
+ G_SX, G_SY, G_SZ, G_R0, G_R1, G_R2, G_R3, G_R4, G_R5, G_R6, G_R7, G_R8, G_SIZE) = range(45)
+# G_TRAN: elliptic: tran (R_normal = (1-imp)/imp * tran); pyramidal: 2 mu^2 (1+mu^2) tran (shared R of all edges)
 # ---- chain block = [nlinks, ngeoms, unsupported geoms (count), links..., geoms...]
 C_NLINKS, C_NGEOMS, C_NUNSUP, C_LINKS = 0, 1, 2, 4
 C_GEOMS = C_LINKS + MAXC * LINK_SIZE
@@ -54,13 +56,13 @@ CHAIN_SIZE = C_UNSUP + MAXG * U_SIZE
 (R_NDOF, R_TX, R_TY, R_TZ, R_R0, R_R1, R_R2, R_R3, R_R4, R_R5, R_R6, R_R7, R_R8, R_MASS, R_CX, R_CY, R_CZ, R_IXX,
  R_IYY, R_IZZ, R_IXY, R_IXZ, R_IYZ, R_NUNSUP, R_DOFS) = range(25)
 R_UNSUP = R_DOFS + NROOT * D_SIZE
-ROOT_SIZE = R_UNSUP + 2 * MAXG * U_SIZE
+ROOT_SIZE = R_UNSUP + MAXRG * U_SIZE
 # ---- whole table: root block, then the chain blocks interleaved [field][chain]
 CM_ROOT = 0
 CM_CHAINS = ROOT_SIZE
 CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN
 
-GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE)
+GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX)
 MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
 
 
@@ -107,7 +109,7 @@ HEADER_SIZE = 32
 LMC_MAGIC = 0x4C4D4331  # "LMC1"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
-H_MEANINERTIA, H_CM_SIZE = 26, 27
+H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS = 26, 27, 28, 29, 30
 SRC_ROOT_QVEL, SRC_GOAL, SRC_ROOT_QPOS = 0, 100, 200
 
 
@@ -134,10 +136,6 @@ def lower(m, task):
         if kind == "g":
             raise UnsupportedModel("termination on a goal entry")
         (term_q if kind == "q" else term_v)[d] = (max(lo, -3e38), min(hi, 3e38))
-    if m.integrator != mjcf.INT_EULER:
-        raise UnsupportedModel("RK4 models are not built on the device yet")
-    if m.cone != mjcf.CONE_ELLIPTIC:
-        raise UnsupportedModel("pyramidal friction cones are not built on the device yet")
     nb = m.nbody
     jointed = [b for b in range(1, nb) if m.body_jntnum[b] > 0]
     roots = [b for b in jointed if m.body_weldid[m.body_parent[b]] == 0]
@@ -261,18 +259,32 @@ def lower(m, task):
             blk[G_LINK], blk[G_TYPE] = link_index, t
             blk[G_PX:G_PX + 3] = gpos
             blk[G_AX:G_AX + 3] = grot[:, 2]
+            blk[G_SX:G_SX + 3] = size
+            blk[G_R0:G_R0 + 9] = grot.reshape(9)
             blk[G_RADIUS], blk[G_HALF], blk[G_RBOUND], blk[G_MARGIN] = size[0], (size[1] if t == mjcf.GEOM_CAPSULE else 0), rbound, margin
             blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
             blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
-            blk[G_TRAN] = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
+            tran = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
             blk[G_DIM] = dim
-            if dim not in (1, 3, 4, 6):
-                raise UnsupportedModel("condim %d" % dim)
             blk[G_F0:G_F0 + 5] = fr
-            blk[G_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
-            rr1 = 1.0 / max(MINVAL, m.impratio)
-            blk[G_RR1], blk[G_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
-            blk[G_RR3:G_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+            if m.cone == mjcf.CONE_ELLIPTIC:
+                if dim not in (1, 3, 4, 6):
+                    raise UnsupportedModel("condim %d" % dim)
+                blk[G_TRAN] = tran
+                blk[G_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
+                rr1 = 1.0 / max(MINVAL, m.impratio)
+                blk[G_RR1], blk[G_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
+                blk[G_RR3:G_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+            else:
+                if dim not in (1, 3):
+                    raise UnsupportedModel("pyramidal condim %d is not built on the device" % dim)
+                if fr[0] != fr[1]:
+                    raise UnsupportedModel("anisotropic sliding friction")
+                mu = fr[0]
+                blk[G_MU] = mu
+                # every edge of the pyramid: diagApprox = (1+mu^2) tran, shared regulariser Rpy = 2 mu^2 R
+                blk[G_TRAN] = 2 * mu * mu * (1 + mu * mu) * tran if dim == 3 else tran
+                blk[G_RR1:G_RR1 + 5] = 1.0
             sup.append(blk)
         return sup, unsup
 
@@ -292,7 +304,7 @@ def lower(m, task):
         dof_to_lane[d] = -2
     sup, unsup = geom_blocks(root, 0)
     unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
-    if len(unsup) > 2 * MAXG:
+    if len(unsup) > MAXRG:
         raise UnsupportedModel("too many root geoms")
     rb[R_NUNSUP] = len(unsup)
     for i, u in enumerate(unsup):
@@ -300,6 +312,7 @@ def lower(m, task):
 
     # ---- chains, interleaved [field][chain]
     max_links = 0
+    max_contacts = 0
     for c, chain in enumerate(chains):
         blk = np.zeros(CHAIN_SIZE)
         links = []
@@ -336,6 +349,7 @@ def lower(m, task):
         if len(geoms) > MAXG or len(unsup) > MAXG:
             raise UnsupportedModel("too many geoms on one chain")
         blk[C_NGEOMS], blk[C_NUNSUP] = len(geoms), len(unsup)
+        max_contacts = max(max_contacts, sum({mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4}[int(gb[G_TYPE])] for gb in geoms))
         for i, gblk in enumerate(geoms):
             blk[C_GEOMS + i * G_SIZE:C_GEOMS + (i + 1) * G_SIZE] = gblk
         for i, u in enumerate(unsup):
@@ -368,7 +382,8 @@ def lower(m, task):
     elif rt == 2:
         h[H_REWARD_P0:H_REWARD_P0 + 5] = [src_code(p) for p in rp[:5]]
     h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
-    info.update(n_chains=len(chains), max_links=max_links, dof_to_lane=dof_to_lane,
+    h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
+    info.update(n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
                 self_collision_pairs=_count_self_pairs(m))
     return np.concatenate([h, cm]), info
 

@@ -28,13 +28,12 @@ struct QuadThreads {
     g_bar.arrive_and_wait(); return r;
   }
 };
-constexpr int MC = 3, NS = 4;
 }  // namespace
 
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
-extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
-                       int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
-                       int* counters /*6*/) {
+template <int MC, int NS, bool RK4>
+static int emu_run_t(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                     int nsub, int debug_env, float* dbgM, float* dbg5, int* counters) {
   const double* H = chain_model;
   const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
   std::vector<float> cm(LM_CM_SIZE);
@@ -43,7 +42,8 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   P.h = (float)H[LM_H_TIMESTEP]; P.g = lm::v3((float)H[LM_H_GX], (float)H[LM_H_GY], (float)H[LM_H_GZ]);
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
-  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ablate = 0;
+  P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE];
   int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int c) {
     t_lane = c;
@@ -78,8 +78,8 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
       float lmem[lm::LaneMem<MC, NS>::kSize];
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                         (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr);
+        lm::substep<QuadThreads, MC, NS, RK4>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+                                              (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr);
       g_bar.arrive_and_wait();
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
@@ -95,4 +95,15 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   t1.join(); t2.join(); t3.join();
   if (counters) memcpy(counters, cnt_tot, sizeof(cnt_tot));
   return 0;
+}
+
+extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                       int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
+                       int* counters /*6*/) {
+  const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
+  const bool big = (int)chain_model[LM_H_MAXLINKS] > 3 || (int)chain_model[LM_H_MAXCONTACTS] > 11;
+  if (!big && !rk4) return emu_run_t<3, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  if (!rk4) return emu_run_t<5, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  return emu_run_t<5, 8, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
 }

@@ -189,3 +189,77 @@ def test_auto_reset_and_sharding_invariance(setup):
     assert sa["episodes"] >= 64 and sa["nan_resets"] == 0 and sa["env_steps"] == 64 * 60
     assert sa["episodes"] == sb0["episodes"] + sb1["episodes"]
     assert np.isfinite(qa).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Atlas.walk (BASELINE config 4's robot): RK4, pyramidal cones, box feet, 2 chains of 5 links (kernel variant <5,8,RK4>)
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def atlas():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("Atlas.walk", debug=True)
+    hm = HipModel(env._chain_model())
+    return env, hm, Oracle(pack_model(env._model)), HipBatch
+
+
+def test_atlas_one_control_step_kats(atlas):
+    env, hm, oracle, HipBatch = atlas
+    m = env._model
+    g = GOLD["Atlas.walk.real"]
+    n = len(g) - 1
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(10) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :14]
+    qvel[:, qidx] = g[:n, 14:30]
+    b = HipBatch(hm, n)
+    b.set_state(qpos, qvel)
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :14] - g[1:, :14]).max(axis=1), np.abs(obs[:, 14:30] - g[1:, 14:30]).max(axis=1)
+    print("Atlas KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e" % (eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL
+    assert list(done) == [False] * (n - 1) + [True]
+    want = [np.exp(-(g[k][14] - 1.25) ** 2) for k in range(n)]          # TargetVelocityReward(1.25) on the previous obs
+    assert np.abs(rew - want).max() < 1e-5
+    st = b.stats()
+    assert st["overflow_contacts"] == 0
+
+
+def test_atlas_env_rollout_follows_reference_test():
+    g = GOLD["Atlas.walk.real"]
+    np.random.seed(0)
+    env = LocoEnv.make("Atlas.walk", debug=True)
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(100):
+        if absorbing:
+            break
+        obs, r, absorbing, info = env.step(np.random.randn(10) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    assert np.abs(rows[:, :14] - g[:, :14]).max() < 5e-3
+
+
+def test_atlas_batch_rollout_properties(atlas):
+    """2048 environments (BASELINE config 4's per-GPU share), random policy, device auto-reset."""
+    env, hm, oracle, HipBatch = atlas
+    tab = env._reset_table()
+    n = 2048
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, len(tab), n)]
+    b = HipBatch(hm, n)
+    b.set_reset_table(tab, seed=1)
+    b.set_auto_reset(True, horizon=1000)
+    b.set_state(rows[:, :16], rows[:, 16:32])
+    st = b.rollout(30, action_mode=1, seed=5)
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
+    print("Atlas 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
+          % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))
