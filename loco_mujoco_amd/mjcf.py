@@ -171,7 +171,7 @@ class CompiledModel:
     # arrays are attached dynamically (see compile_mjcf)
 
     _SCALARS = ("timestep", "cone", "impratio", "integrator", "iterations", "tolerance", "nbody", "njnt", "nv",
-                "ngeom", "nu", "nsite", "meaninertia")
+                "ngeom", "nu", "nsite", "meaninertia", "n_dropped_mesh_geoms")
     _NAMES = ("body_names", "jnt_names", "geom_names", "act_names", "site_names")
 
     def save(self, path):
@@ -254,11 +254,13 @@ def _inertia_from_inertial(attrs):
     return mass, ipos, inertia
 
 
-def compile_mjcf(handle, timestep=None):
+def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     """
     Compile an :class:`MjcfHandle` into a :class:`CompiledModel`.
 
     ``timestep`` overrides ``<option timestep>`` like the reference does (``base.py:33,109-111``).
+    ``drop_mesh_geoms``: collidable mesh geoms need a convex-hull collider that is not built yet; when True they
+    are removed from collision (and counted in ``m.n_dropped_mesh_geoms``) instead of raising.
     """
     root = handle.root
     comp = root.find("compiler")
@@ -266,6 +268,9 @@ def compile_mjcf(handle, timestep=None):
     assert comp.get("angle", "degree") == "radian", "only angle=radian models are supported"
     assert comp.get("coordinate", "local") == "local"
     autolimits = comp.get("autolimits", "false") == "true"
+    balanceinertia = comp.get("balanceinertia", "false") == "true"
+    boundmass = float(comp.get("boundmass", 0))
+    boundinertia = float(comp.get("boundinertia", 0))
 
     m = CompiledModel()
     opt = root.find("option")
@@ -300,6 +305,15 @@ def compile_mjcf(handle, timestep=None):
             inertial = el.find("inertial")
             if inertial is not None:
                 b["mass"], b["ipos"], b["inertia"] = _inertia_from_inertial(inertial.attrib)
+                # compiler bounds act on the principal moments (MuJoCo: boundmass / boundinertia / balanceinertia)
+                ev, evec = np.linalg.eigh(b["inertia"])
+                if boundinertia > 0:
+                    ev = np.maximum(ev, boundinertia)          # lower bound first ...
+                if balanceinertia and (ev[0] + ev[1] < ev[2]):
+                    ev[:] = ev.mean()                          # ... then the triangle-inequality repair
+                b["inertia"] = evec @ np.diag(ev) @ evec.T
+                if boundmass > 0:
+                    b["mass"] = max(b["mass"], boundmass)
             for j in el.findall("joint"):
                 a = defaults.resolve("joint", j, childclass)
                 jt = a.get("type", "hinge")
@@ -420,6 +434,9 @@ def compile_mjcf(handle, timestep=None):
 
     # ---------------- geoms (drop purely visual ones: contype == conaffinity == 0)
     geoms = [g for g in geoms if (g["contype"] != 0 or g["conaffinity"] != 0)]
+    m.n_dropped_mesh_geoms = sum(1 for g in geoms if g["type"] == GEOM_MESH)
+    if drop_mesh_geoms:
+        geoms = [g for g in geoms if g["type"] != GEOM_MESH]
     for g in geoms:
         assert g["type"] != GEOM_MESH, "collidable mesh geoms need the convex-hull path (not built yet)"
     m.ngeom = len(geoms)
