@@ -1,0 +1,212 @@
+"""
+Torque-actuated musculoskeletal-skeleton humanoid — host-side mirror of the reference's
+``loco_mujoco/environments/humanoids/base_humanoid.py`` + ``humanoids.py`` (``HumanoidTorque``) for the default
+configuration of BASELINE config 3: box feet (``base_humanoid.py:435-470``), arms disabled and re-oriented
+(``:101-127, :472-496``), torque motors (13 of them, ctrl range +-1).
+19 dofs (6 pelvis + 2 x 5 leg + 3 lumbar), 36-dim observation, RK4 integrator, pyramidal friction cones
+(``data/humanoid/humanoid_torque.xml:8-19``).
+
+The skeleton's bones are collidable MESH geoms in the reference model. No convex-hull collider is built here
+(SURVEY.md §8f): they are kept as proximity-only bounding spheres, and every substep in which one of them comes
+within reach of the floor is counted in the ``unhandled_geoms`` statistic instead of producing a contact. The box
+feet — the only geoms that touch the floor while the model is upright — are simulated. The reference's golden
+rollouts of this environment (tests/test_datasets/HumanoidTorque.*.npy) are reproduced to 1e-13 this way.
+"""
+
+import os
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from .. import mjcf
+from ..utils.checks import check_validity_task_mode_dataset
+from .base import LocoEnv, ValidTaskConf
+from .observation import ObservationType
+
+_PKG = Path(__file__).resolve().parent.parent
+
+_PELVIS = ["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", "pelvis_rotation"]
+_LEG = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle", "subtalar_angle", "mtp_angle"]
+_LUMBAR = ["lumbar_extension", "lumbar_bending", "lumbar_rotation"]
+_ARM_JOINTS = ["arm_flex", "arm_add", "arm_rot", "elbow_flex", "pro_sup", "wrist_flex", "wrist_dev"]
+_ARM_MOTORS = ["shoulder_flex", "shoulder_add", "shoulder_rot", "elbow_flex", "pro_sup", "wrist_flex", "wrist_dev"]
+
+
+class BaseHumanoid(LocoEnv):
+    """Common part of the humanoid family (reference ``base_humanoid.py:14``)."""
+
+    def __init__(self, use_muscles=False, use_box_feet=True, disable_arms=True, alpha_box_feet=0.5, xml_path=None,
+                 timestep=0.001, **kwargs):
+        if use_muscles:
+            raise NotImplementedError("muscle actuation (tendons, muscle dynamics) is not built yet (SURVEY.md §8f rank 2)")
+        if not use_box_feet or not disable_arms:
+            raise NotImplementedError("only the default humanoid configuration (box feet, arms disabled) is built: "
+                                      "mesh feet need a convex-hull collider (SURVEY.md §8f)")
+        self._use_muscles, self._use_box_feet, self._disable_arms = use_muscles, use_box_feet, disable_arms
+        joints_to_remove, motors_to_remove, equ_constr_to_remove, collision_groups = self._get_xml_modifications()
+        drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
+        observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
+        action_spec = [a for a in self._get_action_specification(use_muscles) if a not in motors_to_remove]
+        if xml_path is not None:
+            handle = mjcf.MjcfHandle.from_path(xml_path)
+            model = self._compile(handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet)
+        else:
+            model = mjcf.CompiledModel.load(_PKG / "assets" / "HumanoidTorque.default.model.npz")
+            assert abs(model.timestep - timestep) < 1e-12
+        super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+
+    @classmethod
+    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet=0.5):
+        """The reference's constructor-time XML surgery (``base_humanoid.py:49-64``), then the mini-compiler."""
+        cls._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, equ_constr_to_remove)
+        cls._add_box_feet_to_xml_handle(handle, alpha_box_feet)
+        cls._reorient_arms(handle)
+        return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)
+
+    @staticmethod
+    def _delete_from_xml_handle(xml_handle, joints_to_remove, motors_to_remove, equ_constraints):
+        """Remove joints / motors / equality constraints by name (reference ``base.py:865-890``)."""
+        for j in joints_to_remove:
+            assert xml_handle.remove(xml_handle.find("joint", j)), j
+        for mname in motors_to_remove:
+            assert xml_handle.remove(xml_handle.find("motor", mname)), mname
+        eq = xml_handle.root.find("equality")
+        if eq is not None:
+            for el in list(eq):
+                if el.get("name") in equ_constraints:
+                    eq.remove(el)
+            remaining = [el.get("name") for el in eq if el.get("active", "true") != "false"]
+            assert not remaining, "equality constraints are not simulated: %s" % remaining
+        return xml_handle
+
+    @staticmethod
+    def _add_box_feet_to_xml_handle(xml_handle, alpha_box_feet, scaling=1.0):
+        """A box under each toe body; the foot meshes stop colliding (``base_humanoid.py:435-470``)."""
+        size = (np.array([0.112, 0.03, 0.05]) * scaling).tolist()
+        pos = (np.array([-0.09, 0.019, 0.0]) * scaling).tolist()
+        for side, pitch in (("l", 0.15), ("r", -0.15)):
+            xml_handle.add(xml_handle.find("body", "toes_" + side), "geom", name="foot_box_" + side, type="box",
+                           size=size, pos=pos, rgba=[0.5, 0.5, 0.5, alpha_box_feet], euler=[0.0, pitch, 0.0])
+        for g in ("r_foot", "r_bofoot", "l_foot", "l_bofoot"):
+            el = xml_handle.find("geom", g)
+            el.set("contype", "0")
+            el.set("conaffinity", "0")
+        return xml_handle
+
+    @staticmethod
+    def _reorient_arms(xml_handle):
+        """Fixed arm pose once the arm joints are gone (``base_humanoid.py:472-496``)."""
+        for body, quat in (("humerus_l", [1.0, -0.1, -1.0, -0.1]), ("ulna_l", [1.0, 0.6, 0.0, 0.0]),
+                           ("humerus_r", [1.0, 0.1, 1.0, -0.1]), ("ulna_r", [1.0, -0.6, 0.0, 0.0])):
+            xml_handle.find("body", body).set("quat", " ".join(repr(x) for x in quat))
+        return xml_handle
+
+    def _get_xml_modifications(self):
+        """Joints, motors, equality constraints to remove and the collision groups (``base_humanoid.py:86-127``)."""
+        joints, motors, equ = [], [], []
+        if self._use_box_feet:
+            joints += ["subtalar_angle_l", "mtp_angle_l", "subtalar_angle_r", "mtp_angle_r"]
+            if not self._use_muscles:
+                motors += ["mot_" + j for j in joints]
+            equ += [j + "_constraint" for j in joints]
+            groups = [("floor", ["floor"]), ("foot_r", ["foot_box_r"]), ("foot_l", ["foot_box_l"])]
+        else:
+            groups = [("floor", ["floor"]), ("foot_r", ["r_foot"]), ("front_foot_r", ["r_bofoot"]),
+                      ("foot_l", ["l_foot"]), ("front_foot_l", ["l_bofoot"])]
+        if self._disable_arms:
+            joints += [j + "_r" for j in _ARM_JOINTS] + [j + "_l" for j in _ARM_JOINTS]
+            motors += ["mot_" + j + "_r" for j in _ARM_MOTORS] + ["mot_" + j + "_l" for j in _ARM_MOTORS]
+            equ += ["wrist_flex_r_constraint", "wrist_dev_r_constraint", "wrist_flex_l_constraint", "wrist_dev_l_constraint"]
+        return joints, motors, equ, groups
+
+    def create_dataset(self, ignore_keys=None):
+        """``base_humanoid.py:66-84``: the two horizontal pelvis coordinates are not part of the dataset."""
+        return super().create_dataset(["q_pelvis_tx", "q_pelvis_tz"] if ignore_keys is None else ignore_keys)
+
+    # ------------------------------------------------------------------ termination
+    _BOUNDS = [("height", None, -0.46, 0.1, "pelvis_height_condition"),
+               ("tilt", "q_pelvis_tilt", -np.pi / 4.5, np.pi / 12, "pelvis_tilt_condition"),
+               ("list", "q_pelvis_list", -np.pi / 12, np.pi / 8, "pelvis_list_condition"),
+               ("rotation", "q_pelvis_rotation", -np.pi / 9, np.pi / 9, "pelvis_rotation_condition"),
+               ("lext", "q_lumbar_extension", -np.pi / 4, np.pi / 10, "lumbar_extension_condition"),
+               ("lbend", "q_lumbar_bending", -np.pi / 10, np.pi / 10, "lumbar_bending_condition"),
+               ("lrot", "q_lumbar_rotation", -np.pi / 4.5, np.pi / 4.5, "lumbar_rotation_condition")]
+
+    def _has_fallen(self, obs, return_err_msg=False):
+        """Pelvis height/orientation or lumbar angles outside their bands (``base_humanoid.py:129-180``)."""
+        msg, fallen = "", False
+        for _, key, lo, hi, name in self._BOUNDS:
+            v = obs[0] if key is None else self._get_from_obs(obs, [key])[0]
+            if v < lo or v > hi:
+                fallen = True
+                msg += name + " violated.\n"
+        return (fallen, msg) if return_err_msg else fallen
+
+    def _termination_spec(self):
+        return [(0 if key is None else self.get_obs_idx(key)[0], lo, hi) for _, key, lo, hi, _ in self._BOUNDS]
+
+    def _get_grf_size(self):
+        return 6 if self._use_box_feet else 12
+
+    # ------------------------------------------------------------------ task factory
+    @staticmethod
+    def generate(env, path, task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):
+        """``base_humanoid.py:211-291``: target speed 1.25 m/s (walk) or 2.5 m/s (run), 500 Hz mocap."""
+        if dataset_type == "perfect":
+            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
+        reward_type = kwargs.pop("reward_type", "target_velocity")
+        reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25 if task == "walk" else 2.5))
+        mdp = env(reward_type=reward_type, reward_params=reward_params, **kwargs)
+        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
+        use_mini = not (root / path).exists()
+        if debug or use_mini:
+            if use_mini and not debug:
+                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
+                              "the datasets to use this environment for imitation learning!")
+            parts = path.split("/")
+            parts.insert(3, "mini_datasets")
+            path = "/".join(parts)
+        traj_path = root / path
+        if not traj_path.exists():
+            traj_path = _PKG / path
+        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
+                                 clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+        return mdp
+
+    # ------------------------------------------------------------------ specs
+    @staticmethod
+    def _get_observation_specification():
+        """``base_humanoid.py:293-391``: pelvis, right leg, left leg, lumbar, right arm, left arm."""
+        joints = (_PELVIS + [j + "_r" for j in _LEG] + [j + "_l" for j in _LEG] + _LUMBAR
+                  + [j + "_r" for j in _ARM_JOINTS] + [j + "_l" for j in _ARM_JOINTS])
+        return ([("q_" + j, j, ObservationType.JOINT_POS) for j in joints]
+                + [("dq_" + j, j, ObservationType.JOINT_VEL) for j in joints])
+
+    @staticmethod
+    def _get_action_specification(use_muscles):
+        """``base_humanoid.py:393-433`` (torque variant): lumbar, right arm, left arm, right leg, left leg."""
+        assert not use_muscles
+        legs = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle", "subtalar_angle", "mtp_angle"]
+        return (["mot_lumbar_ext", "mot_lumbar_bend", "mot_lumbar_rot"]
+                + ["mot_" + j + "_r" for j in _ARM_MOTORS] + ["mot_" + j + "_l" for j in _ARM_MOTORS]
+                + ["mot_" + j + "_r" for j in legs] + ["mot_" + j + "_l" for j in legs])
+
+
+class HumanoidTorque(BaseHumanoid):
+    """One torque motor per joint (reference ``humanoids.py:260-317``)."""
+
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], data_types=["real", "perfect"])
+
+    def __init__(self, **kwargs):
+        if "use_muscles" in kwargs:
+            assert kwargs.pop("use_muscles") is False, "Activating muscles in this environment not allowed. "
+        super().__init__(use_muscles=False, **kwargs)
+
+    @staticmethod
+    def generate(task="walk", dataset_type="real", **kwargs):
+        check_validity_task_mode_dataset(HumanoidTorque.__name__, task, None, dataset_type,
+                                         *HumanoidTorque.valid_task_confs.get_all())
+        path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
+                "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
+        return BaseHumanoid.generate(HumanoidTorque, path, task, dataset_type, **kwargs)

@@ -113,6 +113,36 @@ H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS = 26, 27, 28, 29, 
 SRC_ROOT_QVEL, SRC_GOAL, SRC_ROOT_QPOS = 0, 100, 200
 
 
+def _merge_proximity_spheres(spheres, cap):
+    """Reduce [link, x, y, z, r, margin] proximity spheres to at most `cap` by repeatedly replacing the two
+    spheres of one link whose enclosing sphere is smallest by that enclosing sphere (conservative)."""
+    spheres = [list(map(float, u)) for u in spheres]
+    while len(spheres) > cap:
+        best = None
+        for i in range(len(spheres)):
+            for j in range(i + 1, len(spheres)):
+                a, b = spheres[i], spheres[j]
+                if a[0] != b[0]:
+                    continue
+                d = np.linalg.norm(np.subtract(b[1:4], a[1:4]))
+                r = max(a[4], b[4], 0.5 * (d + a[4] + b[4]))
+                if best is None or r < best[0]:
+                    best = (r, i, j, d)
+        if best is None:
+            raise UnsupportedModel("too many geoms without a device collider")
+        r, i, j, d = best
+        a, b = spheres[i], spheres[j]
+        if r == a[4]:
+            c = a[1:4]
+        elif r == b[4]:
+            c = b[1:4]
+        else:
+            c = np.add(a[1:4], np.subtract(b[1:4], a[1:4]) * ((r - a[4]) / d))
+        merged = [a[0], c[0], c[1], c[2], r, max(a[5], b[5])]
+        spheres = [u for k, u in enumerate(spheres) if k not in (i, j)] + [merged]
+    return spheres
+
+
 def lower(m, task):
     """
     ``task``: dict(nobs, qpos_obs_idx, qvel_obs_idx, n_goal, act_ctrl_idx, act_mean, act_delta,
@@ -250,8 +280,14 @@ def lower(m, task):
             dim, solref, solimp, fr, margin, gap = _mix_with_floor(m, g, gf)
             assert gap == 0, "contact gap != 0 not supported on the device"
             t, size = m.geom_type[g], m.geom_size[g]
-            rbound = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1],
+            rbound = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1], mjcf.GEOM_MESH: size[0] + size[1],
                       mjcf.GEOM_CYLINDER: np.hypot(size[0], size[1]), mjcf.GEOM_BOX: np.linalg.norm(size)}[t]
+            if t == mjcf.GEOM_MESH:
+                # proximity-only bounding capsule (mjcf.compile_mjcf): the floor is within reach of a capsule exactly
+                # when it is within reach of one of its two end spheres
+                ends = [gpos] if size[1] == 0 else [gpos - size[1] * grot[:, 2], gpos + size[1] * grot[:, 2]]
+                unsup += [[link_index, e[0], e[1], e[2], size[0], margin] for e in ends]
+                continue
             if t not in GEOM_SUPPORTED:
                 unsup.append([link_index, gpos[0], gpos[1], gpos[2], rbound, margin])
                 continue
@@ -304,8 +340,7 @@ def lower(m, task):
         dof_to_lane[d] = -2
     sup, unsup = geom_blocks(root, 0)
     unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
-    if len(unsup) > MAXRG:
-        raise UnsupportedModel("too many root geoms")
+    unsup = _merge_proximity_spheres(unsup, MAXRG)
     rb[R_NUNSUP] = len(unsup)
     for i, u in enumerate(unsup):
         rb[R_UNSUP + i * U_SIZE:R_UNSUP + (i + 1) * U_SIZE] = u
@@ -346,7 +381,8 @@ def lower(m, task):
                 s, u = geom_blocks(b, li)
                 geoms += s
                 unsup += u
-        if len(geoms) > MAXG or len(unsup) > MAXG:
+        unsup = _merge_proximity_spheres(unsup, MAXG)
+        if len(geoms) > MAXG:
             raise UnsupportedModel("too many geoms on one chain")
         blk[C_NGEOMS], blk[C_NUNSUP] = len(geoms), len(unsup)
         max_contacts = max(max_contacts, sum({mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4}[int(gb[G_TYPE])] for gb in geoms))

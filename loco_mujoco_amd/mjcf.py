@@ -21,6 +21,7 @@ Everything here is fp64 numpy; nothing here is on the hot path.
 """
 
 import copy
+import os
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 
@@ -101,19 +102,20 @@ class MjcfHandle:
     ``unitreeA1.py:768-774``, ``base_humanoid.py:86-127``, ``atlas.py:338-364``.
     """
 
-    def __init__(self, root):
+    def __init__(self, root, base_dir=None):
         self.root = root
+        self.base_dir = base_dir      # where relative mesh files are resolved (None: meshes are not read)
 
     @classmethod
     def from_path(cls, path):
-        return cls(ET.parse(str(path)).getroot())
+        return cls(ET.parse(str(path)).getroot(), os.path.dirname(os.path.abspath(str(path))))
 
     @classmethod
     def from_string(cls, s):
         return cls(ET.fromstring(s))
 
     def copy(self):
-        return MjcfHandle(copy.deepcopy(self.root))
+        return MjcfHandle(copy.deepcopy(self.root), self.base_dir)
 
     def find(self, tag, name):
         for el in self.root.iter(tag):
@@ -254,13 +256,58 @@ def _inertia_from_inertial(attrs):
     return mass, ipos, inertia
 
 
+def _bounding_capsule(v):
+    """Bounding capsule of a point cloud: (centre, unit axis, radius, half length); half = 0 for stubby clouds."""
+    c0 = 0.5 * (v.min(0) + v.max(0))
+    r_sphere = float(np.linalg.norm(v - c0, axis=1).max())
+    ev, evec = np.linalg.eigh(np.cov((v - v.mean(0)).T))
+    axis = evec[:, 2]
+    t = (v - c0) @ axis
+    perp = (v - c0) - np.outer(t, axis)
+    c = c0 + 0.5 * (perp.min(0) + perp.max(0))          # recentre the axis across the section
+    t = (v - c) @ axis
+    d = np.linalg.norm((v - c) - np.outer(t, axis), axis=1)
+    r = float(d.max()) * (1 + 1e-9)
+    reach = np.sqrt(np.maximum(r * r - d * d, 0.0))     # how far each point may lie beyond a segment end
+    lo, hi = float(np.min(t + reach)), float(np.max(t - reach))
+    if hi <= lo or r > 0.75 * r_sphere:
+        return c0, np.array([0.0, 0.0, 1.0]), r_sphere, 0.0
+    return c + 0.5 * (lo + hi) * axis, axis, r, 0.5 * (hi - lo)
+
+
+def _mesh_bounds(root, comp, base_dir):
+    """{mesh name: bounding capsule (centre, axis, radius, half length)} in the mesh's own frame, from binary STL files."""
+    out = {}
+    if base_dir is None:
+        return out
+    meshdir = comp.get("meshdir", "")
+    for el in root.iter("mesh"):
+        f = el.get("file")
+        if f is None or not f.lower().endswith(".stl"):
+            continue
+        path = os.path.join(base_dir, meshdir, f)
+        if not os.path.exists(path):
+            continue
+        raw = open(path, "rb").read()
+        ntri = int(np.frombuffer(raw[80:84], "<u4")[0])
+        if len(raw) != 84 + 50 * ntri:
+            continue                      # ASCII STL: not read
+        tri = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", 9), ("a", "<u2")]), count=ntri)
+        v = tri["v"].reshape(-1, 3).astype(np.float64) * _floats(el.get("scale", "1 1 1"), 3)
+        out[el.get("name", os.path.splitext(os.path.basename(f))[0])] = _bounding_capsule(v)
+    return out
+
+
 def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     """
     Compile an :class:`MjcfHandle` into a :class:`CompiledModel`.
 
     ``timestep`` overrides ``<option timestep>`` like the reference does (``base.py:33,109-111``).
     ``drop_mesh_geoms``: collidable mesh geoms need a convex-hull collider that is not built yet; when True they
-    are removed from collision (and counted in ``m.n_dropped_mesh_geoms``) instead of raising.
+    take no part in collision (counted in ``m.n_dropped_mesh_geoms``) instead of raising. When the mesh files can be
+    read (``handle.base_dir``), each such geom is kept as a ``GEOM_MESH`` PROXIMITY geom — a bounding capsule
+    (``geom_pos``/``geom_quat`` = capsule frame in the body frame, z along the capsule; ``geom_size`` = radius, half length) that the step only uses to count
+    how often a mesh came within reach of the floor (``unhandled_geoms`` statistic); without files they are removed.
     """
     root = handle.root
     comp = root.find("compiler")
@@ -435,10 +482,19 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     # ---------------- geoms (drop purely visual ones: contype == conaffinity == 0)
     geoms = [g for g in geoms if (g["contype"] != 0 or g["conaffinity"] != 0)]
     m.n_dropped_mesh_geoms = sum(1 for g in geoms if g["type"] == GEOM_MESH)
-    if drop_mesh_geoms:
-        geoms = [g for g in geoms if g["type"] != GEOM_MESH]
+    if m.n_dropped_mesh_geoms and not drop_mesh_geoms:
+        raise NotImplementedError("collidable mesh geoms need the convex-hull path (not built yet)")
+    bounds = _mesh_bounds(root, comp, handle.base_dir) if m.n_dropped_mesh_geoms else {}
+    kept = []
     for g in geoms:
-        assert g["type"] != GEOM_MESH, "collidable mesh geoms need the convex-hull path (not built yet)"
+        if g["type"] == GEOM_MESH:
+            if g["mesh"] not in bounds:
+                continue
+            centre, axis, radius, half = bounds[g["mesh"]]
+            g = dict(g, pos=g["pos"] + quat_to_mat(g["quat"]) @ centre, quat=quat_mul(g["quat"], z_to_quat(axis)),
+                     size=np.array([radius, half, 0.0]))
+        kept.append(g)
+    geoms = kept
     m.ngeom = len(geoms)
     m.geom_names = [g["name"] for g in geoms]
     m.geom_type = np.array([g["type"] for g in geoms], dtype=np.int32)

@@ -398,12 +398,38 @@ static void sphere_sphere(work* w, const lmo_contact* tm, const double* c1, doub
   add_contact(w, tm, dist, pos, n, NULL);
 }
 
+/* largest gap between two oriented boxes over the 15 candidate separating axes (<= true distance;
+   negative when the boxes overlap). R are row-major world rotations: column k = box axis k. */
+static double box_box_gap(const double* p1, const double* R1, const double* s1,
+                          const double* p2, const double* R2, const double* s2) {
+  double d[3], best = -1e30; sub3(d, p2, p1);
+  double ax[15][3]; int na = 0;
+  for (int k = 0; k < 3; k++) { ax[na][0] = R1[k]; ax[na][1] = R1[3+k]; ax[na][2] = R1[6+k]; na++; }
+  for (int k = 0; k < 3; k++) { ax[na][0] = R2[k]; ax[na][1] = R2[3+k]; ax[na][2] = R2[6+k]; na++; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double c[3]; cross3(c, ax[i], ax[3+j]);
+    double n = norm3(c); if (n < 1e-9) continue;
+    ax[na][0] = c[0]/n; ax[na][1] = c[1]/n; ax[na][2] = c[2]/n; na++;
+  }
+  for (int a = 0; a < na; a++) {
+    double r1 = 0, r2 = 0;
+    for (int k = 0; k < 3; k++) {
+      r1 += s1[k] * fabs(ax[a][0]*R1[k] + ax[a][1]*R1[3+k] + ax[a][2]*R1[6+k]);
+      r2 += s2[k] * fabs(ax[a][0]*R2[k] + ax[a][1]*R2[3+k] + ax[a][2]*R2[6+k]);
+    }
+    double gap = fabs(dot3(d, ax[a])) - r1 - r2;
+    if (gap > best) best = gap;
+  }
+  return best;
+}
+
 static double rbound(int type, const double* size) {
   switch (type) {
     case LM_GEOM_SPHERE: return size[0];
     case LM_GEOM_CAPSULE: return size[0] + size[1];
     case LM_GEOM_CYLINDER: return sqrt(size[0]*size[0] + size[1]*size[1]);
     case LM_GEOM_BOX: return norm3(size);
+    case LM_GEOM_MESH: return size[0] + size[1];   /* proximity-only geom: bounding capsule (loco_mujoco_amd/mjcf.py) */
     default: return 0;
   }
 }
@@ -496,6 +522,11 @@ static void collide(const lmo_model* m, work* w) {
             }
           }
         }
+      } else if (t2 == LM_GEOM_MESH) {
+        /* no convex-hull collider (not restated): count the bounding capsule coming within reach */
+        double ax[3] = { R2[2], R2[5], R2[8] };
+        sub3(rel, p2, p1);
+        if (dot3(rel, n) - s2[1] * fabs(dot3(ax, n)) - s2[0] < margin) w->unhandled_pairs++;
       } else w->unhandled_pairs++;
       continue;
     }
@@ -517,9 +548,20 @@ static void collide(const lmo_model* m, work* w) {
       segment_closest(p1, a1, s1[1], p2, a2, s2[1], &s, &t);
       double c1[3], c2[3]; copy3(c1, p1); addscl3(c1, a1, s); copy3(c2, p2); addscl3(c2, a2, t);
       sphere_sphere(w, &tm, c1, s1[0], c2, s2[0]);
+    } else if (t1 == LM_GEOM_MESH && t2 == LM_GEOM_MESH) {
+      /* mesh-mesh (libccd in the reference's engine): not restated; count bounding capsules within reach */
+      double a1[3] = { R1[2], R1[5], R1[8] }, a2[3] = { R2[2], R2[5], R2[8] }, sa, ta;
+      segment_closest(p1, a1, s1[1], p2, a2, s2[1], &sa, &ta);
+      double c1[3], c2[3], dd[3]; copy3(c1, p1); addscl3(c1, a1, sa); copy3(c2, p2); addscl3(c2, a2, ta);
+      sub3(dd, c2, c1);
+      if (norm3(dd) - s1[0] - s2[0] < margin) w->unhandled_pairs++;
+    } else if (t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX) {
+      /* box-box contacts are not restated; the pair is only COUNTED, and only when no separating axis
+         (3 + 3 face normals, 9 edge cross products) keeps the boxes more than `margin` apart */
+      if (box_box_gap(p1, R1, s1, p2, R2, s2) < margin) w->unhandled_pairs++;
     } else {
-      /* box / cylinder vs non-plane: not restated. Count the pair if bounding spheres overlap so that
-         a test can assert the situation never arises on the workloads it checks. */
+      /* box / cylinder vs other non-plane geoms: not restated. Count the pair if bounding spheres overlap
+         so that a test can assert the situation never arises on the workloads it checks. */
       double ra = rbound(t1, s1), rb = rb2;
       double rel[3]; sub3(rel, p2, p1);
       if (norm3(rel) - ra - rb < margin) w->unhandled_pairs++;

@@ -53,3 +53,33 @@ def test_core_stages_and_golden_steps(setup):
         q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10)
         assert np.abs(q10[0, 2:] - g[k + 1, :16]).max() < 1e-5
         assert np.abs(v10[0] - g[k + 1, 16:34]).max() < 1e-3
+
+
+@pytest.mark.parametrize("task,nu,rows", [("Atlas.walk", 10, (0, 7, 20)), ("HumanoidTorque.run", 13, (0, 9, 30))])
+def test_core_humanoids_rk4_pyramidal(task, nu, rows):
+    """kernel variant <5,8,RK4> (chains of 5 links, pyramidal cones, plane-box feet) against oracle and golden rows."""
+    np.random.seed(0)
+    env = LocoEnv.make(task, debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    o = Oracle(pack_model(m))
+    g = GOLD[task + ".real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    nq = len(qidx) - 2
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = [np.random.randn(nu) * 0.1 for _ in range(max(rows) + 1)]
+    for k in rows:
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :nq]
+        qvel[qidx] = g[k, nq:]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[k])
+        f = o.forward(qpos, qvel, ctrl)
+        q, v, w, cnt, d = pyemu.run(cmod, qpos, qvel, acts[k], nsub=1, debug_env=0)
+        assert cnt["ncon"] == 4 * f["ncon"] and cnt["overflow"] == 0          # 4 pyramid edges per frictional contact
+        assert np.abs(d["M"] - f["M"]).max() < 2e-5
+        assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())
+        q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10)
+        assert np.abs(q10[0][qidx[2:]] - g[k + 1, :nq]).max() < 1e-5
+        assert np.abs(v10[0][qidx] - g[k + 1, nq:]).max() < 1e-3

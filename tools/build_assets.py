@@ -5,7 +5,7 @@ container only; nothing at run time reads the checkout.
   python tools/build_assets.py [--ref /path/to/loco-mujoco]
 
 Writes
-  loco_mujoco_amd/assets/{UnitreeA1.torque,Atlas.default}.model.npz   compiled models (after the env's XML surgery)
+  loco_mujoco_amd/assets/{UnitreeA1.torque,Atlas.default,HumanoidTorque.default}.model.npz   compiled models (after the env's XML surgery)
   loco_mujoco_amd/datasets/quadrupeds/real/mini_datasets/walk_straight.npz   re-encoded mini dataset
   tests/golden/reference_rollouts.npz                     the reference's golden rollouts for our tasks
 """
@@ -23,6 +23,7 @@ sys.path.insert(0, str(ROOT))
 from loco_mujoco_amd import mjcf                      # noqa: E402
 from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
 from loco_mujoco_amd.environments.atlas import Atlas, _ARM, _BACK   # noqa: E402
+from loco_mujoco_amd.environments.humanoids import HumanoidTorque   # noqa: E402
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
                 "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"]
@@ -47,9 +48,19 @@ def main():
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "Atlas.default.model.npz")
     print("Atlas: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
 
+    h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_torque.xml")
+    ht = HumanoidTorque.__new__(HumanoidTorque)
+    ht._use_muscles, ht._use_box_feet, ht._disable_arms = False, True, True
+    m = HumanoidTorque._compile(h, 0.001, *ht._get_xml_modifications()[:3])
+    m.save(ROOT / "loco_mujoco_amd" / "assets" / "HumanoidTorque.default.model.npz")
+    print("HumanoidTorque: nbody %d nv %d ngeom %d nu %d (mesh geoms kept as proximity spheres: %d)"
+          % (m.nbody, m.nv, m.ngeom, m.nu, m.n_dropped_mesh_geoms))
+
     # --- mini datasets (same keys/values, re-encoded)
     for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
-                "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz"]:
+                "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz",
+                "datasets/humanoids/real/mini_datasets/02-constspeed_reduced_humanoid.npz",
+                "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"]:
         src = np.load(pkg / rel, allow_pickle=True)
         dst = ROOT / "loco_mujoco_amd" / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
