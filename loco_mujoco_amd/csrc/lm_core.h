@@ -163,6 +163,11 @@ template <int MC, int NS> struct LaneMem {
   static constexpr int kSr = kMrr + 21;
   static constexpr int kSc = kSr + 36;
   static constexpr int kSize = kSc + MC * 6;
+  // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
+  // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
+  // so that the four groups of a wave start 16 banks apart
+  static constexpr int kPadded = kSize + ((5 - kSize % 4) % 4);
+  static constexpr int kGroup = kPadded * 16;
 };
 
 // Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
@@ -393,7 +398,8 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // lmem/ls: lane-local scratch of LaneMem<MC,NS>::kSize floats, element i at lmem[i*ls].
 // forward dynamics at (q, v): constrained acceleration in war/wac (in: warm start, out: qacc). With EULER the state
 // is also advanced by one semi-implicit Euler step (implicit joint damping), otherwise q, v are left untouched.
-template <class Q, int MC, int NS, bool EULER>
+// CONE: LM_CONE_PYRAMIDAL / LM_CONE_ELLIPTIC compiles the other cone's code out; -1 reads it from P.cone
+template <class Q, int MC, int NS, bool EULER, int CONE = -1>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
                     Counters& cnt, const Debug* dbg) {
@@ -401,6 +407,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
   int oz = LM_OPAQUE_ZERO();
+  const bool pyramidal = (CONE < 0) ? (P.cone == 0) : (CONE == 0);
   const float* rb = cm + LM_CM_ROOT;
 #define RD(k, f) rb[oz + LM_R_DOFS + (k) * LM_D_SIZE + (f)]
 #define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
@@ -543,7 +550,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
               SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
               SL(nslot, SL_D) = D0;
-              if (P.cone == 0 && dim == 3) {
+              if (pyramidal && dim == 3) {
                 float xv[4];
                 pyr_rows(vel, mu, xv);
 #pragma unroll
@@ -738,7 +745,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         float Dj[6], fr[5], jar[6];
         contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
-        if (P.cone == 0 && dim == 3) {
+        if (pyramidal && dim == 3) {
           float x[4], f3[3];
           pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
@@ -841,7 +848,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
-          if (P.cone == 0 && dim == 3) {
+          if (pyramidal && dim == 3) {
             float x[4], dummy = 0;
             pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
@@ -906,7 +913,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           if (zone == 0) continue;
           float Dj[6], fr[5], Hc[21], jar[6];
           const int dim = (int)SL(s, SL_DIM);
-          if (P.cone == 0 && dim == 3) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
+          if (pyramidal && dim == 3) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
           else {
 #pragma unroll
             for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
@@ -991,6 +998,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
         for (int i = 0; i < 6; i++) q1r = fmaf(sr[i], gr_[i], q1r);
         const float dec = -Q::sum(q1 + w0 * q1r);
+#ifdef LM_LS_TRACE
+        if (c == 0) printf(" newton it %d scaled decrement %.4g (tol %.3g) nslot %d\n", iters, P.scale * dec, P.tolerance, nslot);
+#endif
         if (!(P.scale * dec >= P.tolerance)) done = true;        // converged (also catches NaN)
         else {
           iters++;
@@ -1006,7 +1016,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             for (int s = 0; s < nslot; s++) {
               float jv[6];
               contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
-              if (P.cone == 0 && (int)SL(s, SL_DIM) == 3) {
+              if (pyramidal && (int)SL(s, SL_DIM) == 3) {
                 float xv[4];
                 pyr_rows(jv, SL(s, SL_MU), xv);
 #pragma unroll
@@ -1053,7 +1063,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               float Dj[6], fr[5], jar[6], jv[6];
               const int dim = (int)SL(s, SL_DIM);
               float c1 = 0, c2 = 0;
-              if (P.cone == 0 && dim == 3) {
+              if (pyramidal && dim == 3) {
                 const float D = SL(s, SL_D);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1195,11 +1205,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
                     Counters& cnt, const Debug* dbg) {
-  if (!RK4) { forward<Q, MC, NS, true>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
@@ -1207,7 +1217,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
-    forward<Q, MC, NS, false>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr);
+    forward<Q, MC, NS, false, CONE>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr);
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]
 #pragma unroll

@@ -78,11 +78,11 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
   __shared__ float blk_stats[12];
-  extern __shared__ float lane_mem[];                      // contact slot records, [field][lane], LaneMem<MC,NS>::kSize * blockDim floats
+  extern __shared__ float lane_mem[];                      // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
   for (int i = threadIdx.x; i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
   for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {};
-  float* lmem = lane_mem + threadIdx.x;
-  const int ls = blockDim.x;
+  float* lmem = lane_mem + (threadIdx.x >> 4) * lm::LaneMem<MC, NS>::kGroup + (threadIdx.x & 15);
+  constexpr int ls = 16;
   if (FORWARD_ONLY) {
     if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -288,18 +288,24 @@ struct lm_batch {
   hipEvent_t ev0, ev1;
 };
 
-// kernel variants: MC = links per chain the code is unrolled for, NS = contact slots per chain, RK4 = integrator
+// kernel variants: MC = links per chain the code is unrolled for, NS = contact slots per chain, RK4 = integrator,
+// CONE = friction cone compiled in (the two shipped robot families get a specialised step kernel:
+// quadruped = <3,4,Euler,elliptic>, humanoids = <5,8,RK4,pyramidal>; everything else reads the cone at run time)
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
   const bool big = b->m->T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4;
+  const int cone = b->m->P.cone;
   if (!big) {
-    const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kSize * block.x;
-    if (!rk4) hipLaunchKernelGGL((step_kernel<3, 4, false, FWD>), grid, block, lane_bytes, b->stream, a);
-    else hipLaunchKernelGGL((step_kernel<3, 4, true, FWD>), grid, block, lane_bytes, b->stream, a);
+    const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kGroup * ((block.x + 15) / 16);
+    if (!rk4) {
+      if (!FWD && cone == LM_CONE_ELLIPTIC) hipLaunchKernelGGL((step_kernel<3, 4, false, FWD, LM_CONE_ELLIPTIC>), grid, block, lane_bytes, b->stream, a);
+      else hipLaunchKernelGGL((step_kernel<3, 4, false, FWD>), grid, block, lane_bytes, b->stream, a);
+    } else hipLaunchKernelGGL((step_kernel<3, 4, true, FWD>), grid, block, lane_bytes, b->stream, a);
   } else {
-    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kSize * block.x;
+    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kGroup * ((block.x + 15) / 16);
     if (!rk4) hipLaunchKernelGGL((step_kernel<5, 8, false, FWD>), grid, block, lane_bytes, b->stream, a);
+    else if (!FWD && cone == LM_CONE_PYRAMIDAL) hipLaunchKernelGGL((step_kernel<5, 8, true, FWD, LM_CONE_PYRAMIDAL>), grid, block, lane_bytes, b->stream, a);
     else hipLaunchKernelGGL((step_kernel<5, 8, true, FWD>), grid, block, lane_bytes, b->stream, a);
   }
 }
