@@ -115,7 +115,7 @@ struct Params {
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
 #ifdef LM_TIMERS
-  long long t[10];
+  long long t[12];
 #endif
 };
 #ifdef LM_TIMERS
@@ -154,7 +154,7 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
-// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6]
+// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6]
 template <int MC, int NS> struct LaneMem {
   static constexpr int kSlots = 0;
   static constexpr int kMcc = NS * SL_SIZE;
@@ -162,7 +162,8 @@ template <int MC, int NS> struct LaneMem {
   static constexpr int kMrr = kMcr + MC * 6;
   static constexpr int kSr = kMrr + 21;
   static constexpr int kSc = kSr + 36;
-  static constexpr int kSize = kSc + MC * 6;
+  static constexpr int kAl = kSc + MC * 6;       // link images of the current joint-space vector (MC x 6)
+  static constexpr int kSize = kAl + MC * 6;
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -706,19 +707,19 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
   };
   // spatial image of joint-space vector x on every link of this chain: Al[k] = sum_root x_r S_r + sum_{j<=k} x_j S_j
-  auto link_images = [&](const float* xr, const float* xc, Sp* Al) {
+  // (kept in lane memory: a register array indexed by the contact's link number ends up in scratch)
+  auto link_images = [&](const float* xr, const float* xc) {
     Sp A = sp0();
 #pragma unroll
     for (int r = 0; r < 6; r++) A = A + xr[r] * ldS(LMm::kSr + r * 6);
 #pragma unroll
-    for (int k = 0; k < MC; k++) { A = A + xc[k] * ldS(LMm::kSc + k * 6); Al[k] = A; }
+    for (int k = 0; k < MC; k++) {
+      A = A + xc[k] * ldS(LMm::kSc + k * 6);
+      LMEM(LMm::kAl + k * 6 + 0) = A.w.x; LMEM(LMm::kAl + k * 6 + 1) = A.w.y; LMEM(LMm::kAl + k * 6 + 2) = A.w.z;
+      LMEM(LMm::kAl + k * 6 + 3) = A.v.x; LMEM(LMm::kAl + k * 6 + 4) = A.v.y; LMEM(LMm::kAl + k * 6 + 5) = A.v.z;
+    }
   };
-  auto pick = [&](const Sp* Al, int link) -> Sp {
-    Sp A = Al[0];
-#pragma unroll
-    for (int k = 1; k < MC; k++) if (link == k) A = Al[k];
-    return A;
-  };
+  auto pick = [&](int link) -> Sp { return ldS(LMm::kAl + link * 6); };
   auto friction_cost = [&](float x, float f, float Rr) -> float {
     if (f <= 0.0f) return 0.0f;
     float Rf = Rr * f;
@@ -739,11 +740,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
     }
     if (nslot > 0) {
-      Sp Al[MC];
-      link_images(xr, xc, Al);
+      link_images(xr, xc);
       for (int s = 0; s < nslot; s++) {
         float Dj[6], fr[5], jar[6];
-        contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
+        contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
         if (pyramidal && dim == 3) {
           float x[4], f3[3];
@@ -838,13 +838,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
       for (int k = 0; k < MC; k++) Fl[k] = sp0();
       if (nslot > 0 && !(P.ablate & 32)) {
-        Sp Al[MC];
-        link_images(ar, ac, Al);
+        link_images(ar, ac);
         for (int s = 0; s < nslot; s++) {
           float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
-          contact_rows(pick(Al, link), rc, jar);
+          contact_rows(pick(link), rc, jar);
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
@@ -1011,11 +1010,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
           for (int k = 0; k < MC; k++) { jv_c[k] = sc[k]; jvlim_c[k] = lim_s_c[k] * sc[k]; }
           if (nslot > 0) {
-            Sp Al[MC];
-            link_images(sr, sc, Al);
+            link_images(sr, sc);
             for (int s = 0; s < nslot; s++) {
               float jv[6];
-              contact_rows(pick(Al, (int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
+              contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
               if (pyramidal && (int)SL(s, SL_DIM) == 3) {
                 float xv[4];
                 pyr_rows(jv, SL(s, SL_MU), xv);
@@ -1159,7 +1157,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
 
-  LM_TICK(4);
+  LM_TICK(10);      // lockstep wait: this environment converged, others of the wave still iterate
   oz = LM_OPAQUE_ZERO();
   // ================= integrate: semi-implicit Euler, joint damping implicit =================
   // (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint ; qvel += h qacc' ; qpos += h qvel

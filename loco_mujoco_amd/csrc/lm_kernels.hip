@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
     }
 #ifdef LM_TIMERS
-    if (threadIdx.x == 0) for (int i = 0; i < 10; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
 #endif
     __syncthreads();
     for (int i = threadIdx.x; i < 12; i += blockDim.x) {

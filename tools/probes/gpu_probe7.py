@@ -21,8 +21,8 @@ lib.lm_debug_timers.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.lm_debug_timers(b._h, buf)
 st = b.rollout(100)
 lib.lm_debug_timers(b._h, buf)
-t = np.array(list(buf)[:10], dtype=np.float64)
-names = ["kinematics+contacts", "M+bias", "rows+a0", "warmstart", "gradient", "hessian", "factor+solve", "jv/Mv", "linesearch", "integrate"]
+t = np.array(list(buf)[:11], dtype=np.float64)
+names = ["kinematics+contacts", "M+bias", "rows+a0", "warmstart", "gradient", "hessian", "factor+solve", "jv/Mv", "linesearch", "integrate", "lockstep wait"]
 nblocks = (N + b_epb - 1) // b_epb if (b_epb := int(os.environ.get("LM_ENVS_PER_BLOCK", 4))) else 0
 tot = t.sum()
 print(json.dumps(dict(ms_per_step=st["kernel_ms"] / 100, iters=st["solver_iters"] / st["env_steps"] / 10, ls_per_iter=st["linesearch_evals"] / st["solver_iters"],
