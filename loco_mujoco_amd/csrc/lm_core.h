@@ -51,9 +51,26 @@ LM_DEV M3 mul(const M3& p, const M3& q) {
     for (int j = 0; j < 3; j++) r.a[3 * i + j] = p.a[3 * i] * q.a[j] + p.a[3 * i + 1] * q.a[3 + j] + p.a[3 * i + 2] * q.a[6 + j];
   return r;
 }
+// sin and cos together: one Cody-Waite reduction by pi/2 (joint angles are a few turns at most), then the two
+// float32 minimax polynomials on [-pi/4, pi/4] (~1 ulp there). About 25 instructions for the pair, where the
+// library's separate sinf + cosf (full-range reduction each) inline to ~270.
+LM_DEV void sincos_small(float x, float& s, float& c) {
+  const float k = rintf(x * 0.636619772367581f);
+  float r = fmaf(-k, 1.5707962513e+0f, x);
+  r = fmaf(-k, 7.5497894159e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k;
+  const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
 // R <- Rot(unit axis u, angle) * R
 LM_DEV void rotate_world(M3& R, V3 u, float angle) {
-  float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  float s, c;
+  sincos_small(angle, s, c);
+  const float c1 = 1.0f - c;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     V3 col = v3(R.a[j], R.a[3 + j], R.a[6 + j]);
@@ -135,6 +152,7 @@ struct Debug {
 constexpr float kMinVal = 1e-15f;
 LM_DEV int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // lower-triangular index, j <= i
 
+// LM_POW01(x, p): x^p for 0 < x <= 1 (solimp power other than the special-cased 1 and 2)
 LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float pos, float margin) {
   float s0 = s[0], s1 = s[stride], s2 = s[2 * stride], s3 = s[3 * stride], s4 = s[4 * stride];
   if (s0 == s1 || s2 <= kMinVal) return 0.5f * (s0 + s1);
@@ -144,8 +162,8 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
   float y;
   if (s4 == 1.0f) y = x;
   else if (s4 == 2.0f) y = (x <= s3) ? x * x / s3 : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - s3);
-  else if (x <= s3) y = powf(x, s4) / powf(s3, s4 - 1.0f);
-  else y = 1.0f - powf(1.0f - x, s4) / powf(1.0f - s3, s4 - 1.0f);
+  else if (x <= s3) y = LM_POW01(x, s4) / LM_POW01(s3, s4 - 1.0f);
+  else y = 1.0f - LM_POW01(1.0f - x, s4) / LM_POW01(1.0f - s3, s4 - 1.0f);
   return s0 + y * (s1 - s0);
 }
 

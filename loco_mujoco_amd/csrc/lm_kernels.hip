@@ -23,6 +23,7 @@
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
 __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 #define LM_OPAQUE_ZERO() lm_opaque_zero()
+#define LM_POW01(x, p) __builtin_amdgcn_exp2f((p) * __builtin_amdgcn_logf(x))   // v_exp_f32(p * v_log_f32(x))
 #define LM_CLOCK() ((long long)__builtin_readcyclecounter())
 #include "lm_core.h"
 #include "../../include/locohip.h"

@@ -9,6 +9,7 @@
 #include <vector>
 #define LM_DEV inline
 #define LM_OPAQUE_ZERO() 0
+#define LM_POW01(x, p) exp2f((p) * log2f(x))
 #include "../../loco_mujoco_amd/csrc/lm_core.h"
 
 namespace {
