@@ -172,7 +172,7 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
-// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6]
+// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18]
 template <int MC, int NS> struct LaneMem {
   static constexpr int kSlots = 0;
   static constexpr int kMcc = NS * SL_SIZE;
@@ -181,7 +181,8 @@ template <int MC, int NS> struct LaneMem {
   static constexpr int kSr = kMrr + 21;
   static constexpr int kSc = kSr + 36;
   static constexpr int kAl = kSc + MC * 6;       // link images of the current joint-space vector (MC x 6)
-  static constexpr int kSize = kAl + MC * 6;
+  static constexpr int kFrame = kAl + MC * 6;    // link frames for the collision pass: position 3, rotation 9, velocity 6
+  static constexpr int kSize = kFrame + MC * 18;
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -478,10 +479,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // collider-less root geoms that reach the floor are counted, not simulated
   {
     int nu = (int)rb[LM_R_NUNSUP];
-    for (int i = 0; i < nu; i++) {
+    for (int i = c; i < nu; i += 4) {            // the quad's lanes share the list
       const float* u = rb + LM_R_UNSUP + i * LM_U_SIZE;
-      V3 s = O + mul(R, v3(u[1], u[2], u[3]));
-      if (s.z - u[4] < u[5] && c == 0) cnt.unhandled++;
+      const float sz = O.z + R.a[6] * u[1] + R.a[7] * u[2] + R.a[8] * u[3];
+      if (sz - u[4] < u[5]) cnt.unhandled++;
     }
   }
 
@@ -526,69 +527,83 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int i = 0; i < 6; i++) Il[i] = LX(k, LM_L_IXX + i);
           rotate_inertia(Rk, Il, Iw);
           Ic[k] = make_spi(LX(k, LM_L_MASS), pk + mul(Rk, v3(LX(k, LM_L_CX), LX(k, LM_L_CY), LX(k, LM_L_CZ))) - O, Iw);
-          // floor contacts of the geoms on this link (plane z = 0, normal +z)
-          for (int g = 0; g < ng; g++) {
-            if ((int)GE(g, LM_G_LINK) != k) continue;
-            V3 ctr = pk + mul(Rk, v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ)));
-            if (ctr.z - GE(g, LM_G_RBOUND) > 0.0f) continue;        // margin-less bounding-sphere prune
-            float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
-            const int gtype = (int)GE(g, LM_G_TYPE);
-            V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
-            M3 Rg;
-            if (gtype == LM_GEOM_BOX) {
-              M3 Gr;
+          LMEM(LMm::kFrame + k * 18 + 0) = pk.x; LMEM(LMm::kFrame + k * 18 + 1) = pk.y; LMEM(LMm::kFrame + k * 18 + 2) = pk.z;
 #pragma unroll
-              for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
-              Rg = mul(Rk, Gr);
-            }
-            // candidate points: sphere centre | the two capsule end centres | the box corners below the box centre
-            // in bit order, at most 4 contacts per box
-            const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
-            int made = 0;
-            for (int e = 0; e < npt; e++) {
-              V3 sc = ctr; float rad_e = rad;
-              if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
-              else if (gtype == LM_GEOM_BOX) {
-                V3 off = mul(Rg, v3((e & 1) ? GE(g, LM_G_SX) : -GE(g, LM_G_SX), (e & 2) ? GE(g, LM_G_SY) : -GE(g, LM_G_SY),
-                                    (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
-                if (off.z > 0.0f || made >= 4) continue;
-                sc = ctr + off; rad_e = 0.0f;
-              }
-              float dist = sc.z - rad_e;
-              if (dist >= margin) continue;
-              made++;
-              if (nslot >= NS) { cnt.overflow++; continue; }
-              // contact point (midway between the surfaces) relative to O; row parameters
-              V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
-              float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
-              float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
-              float vel[6];
-              contact_rows(V, cp, vel);
-              const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
-              const int dim = (int)GE(g, LM_G_DIM);
-              SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
-              SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
-              SL(nslot, SL_D) = D0;
-              if (pyramidal && dim == 3) {
-                float xv[4];
-                pyr_rows(vel, mu, xv);
-#pragma unroll
-                for (int r = 0; r < 4; r++) SL(nslot, SL_AREF + r) = -B * xv[r] - Kr;
-              } else {
-#pragma unroll
-                for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
-#pragma unroll
-                for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? Kr : 0.0f);
-              }
-              nslot++;
-            }
-          }
-          for (int i = 0; i < nun; i++) {
-            if ((int)CH(LM_C_UNSUP + i * LM_U_SIZE) != k) continue;
-            V3 s = pk + mul(Rk, v3(CH(LM_C_UNSUP + i * LM_U_SIZE + 1), CH(LM_C_UNSUP + i * LM_U_SIZE + 2), CH(LM_C_UNSUP + i * LM_U_SIZE + 3)));
-            if (s.z - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
-          }
+          for (int i = 0; i < 9; i++) LMEM(LMm::kFrame + k * 18 + 3 + i) = Rk.a[i];
+          LMEM(LMm::kFrame + k * 18 + 12) = V.w.x; LMEM(LMm::kFrame + k * 18 + 13) = V.w.y; LMEM(LMm::kFrame + k * 18 + 14) = V.w.z;
+          LMEM(LMm::kFrame + k * 18 + 15) = V.v.x; LMEM(LMm::kFrame + k * 18 + 16) = V.v.y; LMEM(LMm::kFrame + k * 18 + 17) = V.v.z;
         } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
+      }
+  // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link
+      for (int g = 0; g < ng; g++) {
+        const int k = (int)GE(g, LM_G_LINK);
+        const int fb = LMm::kFrame + k * 18;
+        const V3 gl = v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ));
+        // margin-less bounding-sphere prune on the height of the geom centre (third row of the link rotation)
+        if (LMEM(fb + 2) + LMEM(fb + 9) * gl.x + LMEM(fb + 10) * gl.y + LMEM(fb + 11) * gl.z - GE(g, LM_G_RBOUND) > 0.0f) continue;
+        const V3 pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+        M3 Rk;
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
+        Sp V; V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+        V3 ctr = pk + mul(Rk, gl);
+        float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
+        const int gtype = (int)GE(g, LM_G_TYPE);
+        V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
+        M3 Rg;
+        if (gtype == LM_GEOM_BOX) {
+          M3 Gr;
+#pragma unroll
+          for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
+          Rg = mul(Rk, Gr);
+        }
+        // candidate points: sphere centre | the two capsule end centres | the box corners below the box centre
+        // in bit order, at most 4 contacts per box
+        const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
+        int made = 0;
+        for (int e = 0; e < npt; e++) {
+          V3 sc = ctr; float rad_e = rad;
+          if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
+          else if (gtype == LM_GEOM_BOX) {
+            V3 off = mul(Rg, v3((e & 1) ? GE(g, LM_G_SX) : -GE(g, LM_G_SX), (e & 2) ? GE(g, LM_G_SY) : -GE(g, LM_G_SY),
+                                (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
+            if (off.z > 0.0f || made >= 4) continue;
+            sc = ctr + off; rad_e = 0.0f;
+          }
+          float dist = sc.z - rad_e;
+          if (dist >= margin) continue;
+          made++;
+          if (nslot >= NS) { cnt.overflow++; continue; }
+          // contact point (midway between the surfaces) relative to O; row parameters
+          V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
+          float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
+          float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
+          float vel[6];
+          contact_rows(V, cp, vel);
+          const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
+          const int dim = (int)GE(g, LM_G_DIM);
+          SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
+          SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
+          SL(nslot, SL_D) = D0;
+          if (pyramidal && dim == 3) {
+            float xv[4];
+            pyr_rows(vel, mu, xv);
+#pragma unroll
+            for (int r = 0; r < 4; r++) SL(nslot, SL_AREF + r) = -B * xv[r] - Kr;
+          } else {
+#pragma unroll
+            for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
+#pragma unroll
+            for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? Kr : 0.0f);
+          }
+          nslot++;
+        }
+      }
+      for (int i = 0; i < nun; i++) {
+        const int fb = LMm::kFrame + (int)CH(LM_C_UNSUP + i * LM_U_SIZE) * 18;
+        const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CH(LM_C_UNSUP + i * LM_U_SIZE + 1) + LMEM(fb + 10) * CH(LM_C_UNSUP + i * LM_U_SIZE + 2)
+                         + LMEM(fb + 11) * CH(LM_C_UNSUP + i * LM_U_SIZE + 3);
+        if (sz - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
       }
     }
     cnt.ncon += nslot;
