@@ -14,13 +14,13 @@
 #define LM_MODEL_BLOB_H
 
 #define LM_BLOB_MAGIC 0x4C4D4231 /* "LMB1" */
-#define LM_BLOB_VERSION 1
+#define LM_BLOB_VERSION 2
 
 /* header slots (doubles) */
 enum {
   LMH_MAGIC = 0, LMH_VERSION, LMH_NBODY, LMH_NV, LMH_NGEOM, LMH_NU, LMH_CONE, LMH_INTEGRATOR,
   LMH_ITERATIONS, LMH_TIMESTEP, LMH_IMPRATIO, LMH_TOLERANCE, LMH_GRAV_X, LMH_GRAV_Y, LMH_GRAV_Z,
-  LMH_MEANINERTIA, LMH_HEADER_SIZE = 32
+  LMH_MEANINERTIA, LMH_NSITE, LMH_NTENDON, LMH_NWRAP, LMH_NA, LMH_HEADER_SIZE = 32
 };
 
 /* geom types / joint types / cones / integrators (private numbering of this framework) */
@@ -28,6 +28,7 @@ enum { LM_GEOM_PLANE = 0, LM_GEOM_SPHERE, LM_GEOM_CAPSULE, LM_GEOM_CYLINDER, LM_
 enum { LM_JNT_SLIDE = 0, LM_JNT_HINGE = 1 };
 enum { LM_CONE_PYRAMIDAL = 0, LM_CONE_ELLIPTIC = 1 };
 enum { LM_INT_EULER = 0, LM_INT_RK4 = 1 };
+enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1 };
 
 /*
  * Array order after the header. "nb"=nbody, "nv"=number of dofs (= joints, all 1-dof), "ng"=ngeom.
@@ -42,6 +43,11 @@ enum { LM_INT_EULER = 0, LM_INT_RK4 = 1 };
  *  geom_conaffinity[ng] geom_condim[ng] geom_priority[ng] geom_friction[3ng] geom_solmix[ng]
  *  geom_solref[2ng] geom_solimp[5ng] geom_margin[ng] geom_gap[ng]
  *  act_dof[nu] act_gear[nu] act_ctrlrange[2nu] act_ctrllimited[nu]
+ *  -- spatial tendons through sites and muscle actuators (ns = sites on tendon paths, nt = tendons, nw = path entries)
+ *  site_body[ns] site_pos[3ns] tendon_adr[nt] tendon_num[nt] wrap_site[nw]
+ *  act_kind[nu] act_tendon[nu] act_dynprm[3nu] act_gainprm[9nu] act_lengthrange[2nu]
+ *  (act_kind: LM_ACT_MOTOR joint torque gear*ctrl | LM_ACT_MUSCLE: activation state + force-length-velocity
+ *   curves on a tendon; gainprm = range0 range1 force scale lmin lmax vmax fpmax fvmax, dynprm = tau_act tau_deact tausmooth)
  */
 
 #endif

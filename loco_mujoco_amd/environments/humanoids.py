@@ -31,6 +31,13 @@ _LEG = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_ang
 _LUMBAR = ["lumbar_extension", "lumbar_bending", "lumbar_rotation"]
 _ARM_JOINTS = ["arm_flex", "arm_add", "arm_rot", "elbow_flex", "pro_sup", "wrist_flex", "wrist_dev"]
 _ARM_MOTORS = ["shoulder_flex", "shoulder_add", "shoulder_rot", "elbow_flex", "pro_sup", "wrist_flex", "wrist_dev"]
+# the 43 muscles of one leg (reference base_humanoid.py:404-420), then 6 trunk muscles
+_LEG_MUSCLES = ["glut_med1", "glut_med2", "glut_med3", "glut_min1", "glut_min2", "glut_min3", "semimem", "semiten", "bifemlh",
+                "bifemsh", "sar", "add_long", "add_brev", "add_mag1", "add_mag2", "add_mag3", "tfl", "pect", "grac",
+                "glut_max1", "glut_max2", "glut_max3", "iliacus", "psoas", "quad_fem", "gem", "peri", "rect_fem", "vas_med",
+                "vas_int", "vas_lat", "med_gas", "lat_gas", "soleus", "tib_post", "flex_dig", "flex_hal", "tib_ant",
+                "per_brev", "per_long", "per_tert", "ext_dig", "ext_hal"]
+_TRUNK_MUSCLES = ["ercspn_r", "ercspn_l", "intobl_r", "intobl_l", "extobl_r", "extobl_l"]
 
 
 class BaseHumanoid(LocoEnv):
@@ -38,8 +45,6 @@ class BaseHumanoid(LocoEnv):
 
     def __init__(self, use_muscles=False, use_box_feet=True, disable_arms=True, alpha_box_feet=0.5, xml_path=None,
                  timestep=0.001, **kwargs):
-        if use_muscles:
-            raise NotImplementedError("muscle actuation (tendons, muscle dynamics) is not built yet (SURVEY.md §8f rank 2)")
         if not use_box_feet or not disable_arms:
             raise NotImplementedError("only the default humanoid configuration (box feet, arms disabled) is built: "
                                       "mesh feet need a convex-hull collider (SURVEY.md §8f)")
@@ -52,7 +57,8 @@ class BaseHumanoid(LocoEnv):
             handle = mjcf.MjcfHandle.from_path(xml_path)
             model = self._compile(handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet)
         else:
-            model = mjcf.CompiledModel.load(_PKG / "assets" / "HumanoidTorque.default.model.npz")
+            name = "HumanoidMuscle" if use_muscles else "HumanoidTorque"
+            model = mjcf.CompiledModel.load(_PKG / "assets" / (name + ".default.model.npz"))
             assert abs(model.timestep - timestep) < 1e-12
         super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
 
@@ -185,8 +191,11 @@ class BaseHumanoid(LocoEnv):
 
     @staticmethod
     def _get_action_specification(use_muscles):
-        """``base_humanoid.py:393-433`` (torque variant): lumbar, right arm, left arm, right leg, left leg."""
-        assert not use_muscles
+        """``base_humanoid.py:393-433``: torque variant = lumbar, right arm, left arm, right leg, left leg motors;
+        muscle variant = arm motors, 43 right-leg muscles, 43 left-leg muscles, 6 trunk muscles."""
+        if use_muscles:
+            return (["mot_" + j + "_r" for j in _ARM_MOTORS] + ["mot_" + j + "_l" for j in _ARM_MOTORS]
+                    + [n + "_r" for n in _LEG_MUSCLES] + [n + "_l" for n in _LEG_MUSCLES] + _TRUNK_MUSCLES)
         legs = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle", "subtalar_angle", "mtp_angle"]
         return (["mot_lumbar_ext", "mot_lumbar_bend", "mot_lumbar_rot"]
                 + ["mot_" + j + "_r" for j in _ARM_MOTORS] + ["mot_" + j + "_l" for j in _ARM_MOTORS]
@@ -210,3 +219,23 @@ class HumanoidTorque(BaseHumanoid):
         path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
                 "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
         return BaseHumanoid.generate(HumanoidTorque, path, task, dataset_type, **kwargs)
+
+
+class HumanoidMuscle(BaseHumanoid):
+    """92 Hill-type muscles on spatial tendons drive the legs and the trunk (reference ``humanoids.py:320-786``;
+    ``data/humanoid/humanoid_muscle.xml``): Euler integrator, 92 activation states per environment."""
+
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], data_types=["real", "perfect"])
+
+    def __init__(self, **kwargs):
+        if "use_muscles" in kwargs:
+            assert kwargs.pop("use_muscles") is True, "Activating torque actuators in this environment not allowed. "
+        super().__init__(use_muscles=True, **kwargs)
+
+    @staticmethod
+    def generate(task="walk", dataset_type="real", **kwargs):
+        check_validity_task_mode_dataset(HumanoidMuscle.__name__, task, None, dataset_type,
+                                         *HumanoidMuscle.valid_task_confs.get_all())
+        path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
+                "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
+        return BaseHumanoid.generate(HumanoidMuscle, path, task, dataset_type, **kwargs)

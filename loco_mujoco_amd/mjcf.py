@@ -33,6 +33,7 @@ GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSUL
               "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}
 JNT_SLIDE, JNT_HINGE = 0, 1
 CONE_PYRAMIDAL, CONE_ELLIPTIC = 0, 1
+ACT_MOTOR, ACT_MUSCLE = 0, 1
 INT_EULER, INT_RK4 = 0, 1
 
 _DEFAULT_SOLREF = (0.02, 1.0)
@@ -164,17 +165,20 @@ class CompiledModel:
     ngeom: int = 0
     nu: int = 0
     nsite: int = 0
+    na: int = 0
+    ntendon: int = 0
     # names
     body_names: list = field(default_factory=list)
     jnt_names: list = field(default_factory=list)
     geom_names: list = field(default_factory=list)
     act_names: list = field(default_factory=list)
     site_names: list = field(default_factory=list)
+    tendon_names: list = field(default_factory=list)
     # arrays are attached dynamically (see compile_mjcf)
 
     _SCALARS = ("timestep", "cone", "impratio", "integrator", "iterations", "tolerance", "nbody", "njnt", "nv",
-                "ngeom", "nu", "nsite", "meaninertia", "n_dropped_mesh_geoms")
-    _NAMES = ("body_names", "jnt_names", "geom_names", "act_names", "site_names")
+                "ngeom", "nu", "na", "nsite", "ntendon", "meaninertia", "n_dropped_mesh_geoms")
+    _NAMES = ("body_names", "jnt_names", "geom_names", "act_names", "site_names", "tendon_names")
 
     def save(self, path):
         """Serialise to an ``.npz`` (arrays + a JSON header); see :meth:`load`."""
@@ -520,27 +524,80 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.site_pos = np.array([s["pos"] for s in sites]).reshape(-1, 3)
     m.site_quat = np.array([s["quat"] for s in sites]).reshape(-1, 4)
 
-    # ---------------- actuators (motors on joints)
+    # ---------------- tendons: spatial paths through sites only (no wrapping geoms, no pulleys)
+    tendons, wrap = [], []
+    ten_root = root.find("tendon")
+    if ten_root is not None:
+        for t_el in ten_root:
+            if t_el.tag != "spatial":
+                raise NotImplementedError("tendon type <%s>" % t_el.tag)
+            path = []
+            for w_el in t_el:
+                if w_el.tag != "site":
+                    raise NotImplementedError("tendon path element <%s> (wrapping / pulleys)" % w_el.tag)
+                path.append(m.site_names.index(w_el.get("site")))
+            a = defaults.resolve("tendon", t_el, None)
+            if float(a.get("stiffness", 0)) != 0 or float(a.get("damping", 0)) != 0 or a.get("limited", "false") == "true" \
+                    or float(a.get("frictionloss", 0)) != 0:
+                raise NotImplementedError("tendon springs / dampers / limits / friction")
+            tendons.append(dict(name=t_el.get("name", ""), adr=len(wrap), num=len(path)))
+            wrap += path
+    m.ntendon = len(tendons)
+    m.tendon_names = [t["name"] for t in tendons]
+    m.tendon_adr = np.array([t["adr"] for t in tendons], dtype=np.int32)
+    m.tendon_num = np.array([t["num"] for t in tendons], dtype=np.int32)
+    m.wrap_site = np.array(wrap, dtype=np.int32)
+
+    # ---------------- actuators: motors on joints, muscles on tendons
     acts = []
     act_root = root.find("actuator")
     if act_root is not None:
         for a_el in act_root:
-            assert a_el.tag == "motor", "actuator type %s not supported" % a_el.tag
-            a = defaults.resolve("motor", a_el, None)
+            if a_el.tag not in ("motor", "muscle"):
+                raise NotImplementedError("actuator type <%s>" % a_el.tag)
+            a = defaults.resolve(a_el.tag, a_el, None)
             gear = _floats(a.get("gear", "1"))[0]
             cr = _floats(a.get("ctrlrange", "0 0"), 2)
             if "ctrllimited" in a and a["ctrllimited"] in ("true", "false"):
                 cl = a["ctrllimited"] == "true"
             else:
                 cl = ("ctrlrange" in a) and autolimits
-            acts.append(dict(name=a.get("name", ""), dof=m.jnt_names.index(a["joint"]), gear=gear,
-                             ctrlrange=cr, ctrllimited=cl))
+            act = dict(name=a.get("name", ""), kind=ACT_MOTOR, dof=-1, tendon=-1, gear=gear, ctrlrange=cr, ctrllimited=cl,
+                       dynprm=np.zeros(3), gainprm=np.zeros(9), lengthrange=np.zeros(2))
+            if a_el.tag == "motor":
+                act["dof"] = m.jnt_names.index(a["joint"])
+            else:
+                # <muscle> shortcut: activation dynamics (timeconst, tausmooth) and the force-length-velocity curve
+                # parameters (range, force, scale, lmin, lmax, vmax, fpmax, fvmax), shared by gain and bias
+                act["kind"] = ACT_MUSCLE
+                if "tendon" not in a:
+                    raise NotImplementedError("muscle %s: only tendon transmission is supported" % act["name"])
+                act["tendon"] = m.tendon_names.index(a["tendon"])
+                tc = _floats(a.get("timeconst", "0.01 0.04"), 2)
+                act["dynprm"] = np.array([tc[0], tc[1], float(a.get("tausmooth", 0))])
+                rng = _floats(a.get("range", "0.75 1.05"), 2)
+                force = float(a.get("force", -1))
+                if force < 0:
+                    raise NotImplementedError("muscle %s: force from scale/acc0 is not built" % act["name"])
+                if "lengthrange" not in a:
+                    raise NotImplementedError("muscle %s: automatic length-range computation is not built" % act["name"])
+                act["gainprm"] = np.array([rng[0], rng[1], force, float(a.get("scale", 200)), float(a.get("lmin", 0.5)),
+                                           float(a.get("lmax", 1.6)), float(a.get("vmax", 1.5)), float(a.get("fpmax", 1.3)),
+                                           float(a.get("fvmax", 1.2))])
+                act["lengthrange"] = _floats(a["lengthrange"], 2)
+            acts.append(act)
     m.nu = len(acts)
+    m.na = sum(1 for a in acts if a["kind"] == ACT_MUSCLE)
     m.act_names = [a["name"] for a in acts]
+    m.act_kind = np.array([a["kind"] for a in acts], dtype=np.int32)
     m.act_dof = np.array([a["dof"] for a in acts], dtype=np.int32)
+    m.act_tendon = np.array([a["tendon"] for a in acts], dtype=np.int32)
     m.act_gear = np.array([a["gear"] for a in acts])
     m.act_ctrlrange = np.array([a["ctrlrange"] for a in acts]).reshape(-1, 2)
     m.act_ctrllimited = np.array([a["ctrllimited"] for a in acts], dtype=np.int32)
+    m.act_dynprm = np.array([a["dynprm"] for a in acts]).reshape(-1, 3)
+    m.act_gainprm = np.array([a["gainprm"] for a in acts]).reshape(-1, 9)
+    m.act_lengthrange = np.array([a["lengthrange"] for a in acts]).reshape(-1, 2)
 
     _set_const(m)
     return m

@@ -13,11 +13,19 @@ HEADER_SIZE = 32
 def pack_model(m):
     h = np.zeros(HEADER_SIZE)
     h[0] = LM_BLOB_MAGIC
-    h[1] = 1
+    h[1] = 2
     h[2:9] = [m.nbody, m.nv, m.ngeom, m.nu, m.cone, m.integrator, m.iterations]
     h[9:12] = [m.timestep, m.impratio, m.tolerance]
     h[12:15] = m.gravity
     h[15] = m.meaninertia
+    # tendon paths only reference a subset of the sites: pack those (renumbered)
+    used = sorted(set(int(i) for i in getattr(m, "wrap_site", [])))
+    renum = {s: i for i, s in enumerate(used)}
+    wrap = np.array([renum[int(i)] for i in getattr(m, "wrap_site", [])], dtype=np.float64)
+    nt = int(getattr(m, "ntendon", 0))
+    h[16:20] = [len(used), nt, len(wrap), int(getattr(m, "na", 0))]
+    zeros = lambda *shape: np.zeros(shape)
+    nu = m.nu
     parts = [h,
              m.body_parent, m.body_pos, m.body_quat, m.body_mass, m.body_ipos, m.body_inertia, m.body_jntadr,
              m.body_jntnum, m.body_weldid, m.body_invweight0,
@@ -28,5 +36,9 @@ def pack_model(m):
              m.geom_type, m.geom_body, m.geom_pos, m.geom_quat, m.geom_size, m.geom_contype, m.geom_conaffinity,
              m.geom_condim, m.geom_priority, m.geom_friction, m.geom_solmix, m.geom_solref, m.geom_solimp,
              m.geom_margin, m.geom_gap,
-             m.act_dof, m.act_gear, m.act_ctrlrange, m.act_ctrllimited]
+             m.act_dof, m.act_gear, m.act_ctrlrange, m.act_ctrllimited,
+             m.site_body[used] if used else zeros(0), m.site_pos[used] if used else zeros(0),
+             getattr(m, "tendon_adr", zeros(0)), getattr(m, "tendon_num", zeros(0)), wrap,
+             getattr(m, "act_kind", zeros(nu)), getattr(m, "act_tendon", -np.ones(nu)), getattr(m, "act_dynprm", zeros(nu, 3)),
+             getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2))]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

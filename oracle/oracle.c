@@ -84,6 +84,9 @@ struct lmo_model {
       *geom_condim, *geom_priority, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin,
       *geom_gap;
   const double *act_dof, *act_gear, *act_ctrlrange, *act_ctrllimited;
+  int nsite, ntendon, nwrap, na;
+  const double *site_body, *site_pos, *tendon_adr, *tendon_num, *wrap_site;
+  const double *act_kind, *act_tendon, *act_dynprm, *act_gainprm, *act_lengthrange;
   unsigned char affects[LMO_MAXBODY][LMO_MAXV]; /* dof d moves body b */
   /* static candidate geom pairs after type/affinity/parent filtering */
   int npair;
@@ -106,6 +109,8 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   m->gravity[0] = p[LMH_GRAV_X]; m->gravity[1] = p[LMH_GRAV_Y]; m->gravity[2] = p[LMH_GRAV_Z];
   m->meaninertia = p[LMH_MEANINERTIA];
   if (m->nbody > LMO_MAXBODY || m->nv > LMO_MAXV || m->ngeom > LMO_MAXGEOM) { free(m->blob); free(m); return NULL; }
+  m->nsite = (int)p[LMH_NSITE]; m->ntendon = (int)p[LMH_NTENDON]; m->nwrap = (int)p[LMH_NWRAP]; m->na = (int)p[LMH_NA];
+  if (m->nu > LMO_MAXU) { free(m->blob); free(m); return NULL; }
   int nb = m->nbody, nv = m->nv, ng = m->ngeom, nu = m->nu;
   p += LMH_HEADER_SIZE;
 #define TAKE(field, count) m->field = p; p += (count)
@@ -121,6 +126,9 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   TAKE(geom_friction, 3*ng); TAKE(geom_solmix, ng); TAKE(geom_solref, 2*ng); TAKE(geom_solimp, 5*ng);
   TAKE(geom_margin, ng); TAKE(geom_gap, ng);
   TAKE(act_dof, nu); TAKE(act_gear, nu); TAKE(act_ctrlrange, 2*nu); TAKE(act_ctrllimited, nu);
+  TAKE(site_body, m->nsite); TAKE(site_pos, 3*m->nsite); TAKE(tendon_adr, m->ntendon); TAKE(tendon_num, m->ntendon);
+  TAKE(wrap_site, m->nwrap);
+  TAKE(act_kind, nu); TAKE(act_tendon, nu); TAKE(act_dynprm, 3*nu); TAKE(act_gainprm, 9*nu); TAKE(act_lengthrange, 2*nu);
 #undef TAKE
   if (p - m->blob != n) { free(m->blob); free(m); return NULL; }
 
@@ -161,6 +169,7 @@ void lmo_set_option(lmo_model* m, int what, double value) {
 }
 int lmo_nv(const lmo_model* m) { return m->nv; }
 int lmo_nu(const lmo_model* m) { return m->nu; }
+int lmo_na(const lmo_model* m) { return m->na; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* work data                                                                                   */
@@ -186,6 +195,7 @@ typedef struct {
   double vel[LMO_MAXEFC], aref[LMO_MAXEFC], force[LMO_MAXEFC];
   int state[LMO_MAXEFC];
   double qfrc_constraint[LMO_MAXV], qacc[LMO_MAXV];
+  double act_dot[LMO_MAXU], actuator_force[LMO_MAXU], actuator_length[LMO_MAXU], actuator_velocity[LMO_MAXU];
   int solver_iter;
   int unhandled_pairs;
 } work;
@@ -939,8 +949,89 @@ static void solve_constraints(const lmo_model* m, work* w, const double* warmsta
 /* ------------------------------------------------------------------------------------------ */
 /* forward dynamics, integrators                                                               */
 /* ------------------------------------------------------------------------------------------ */
+/* ---- muscle model (MuJoCo 2.3.7 mju_muscleGain / mju_muscleBias / mju_muscleDynamics, restated) ---- */
+/* Active force-length curve exactly as the reference's engine (MuJoCo 2.3.7) evaluates it. Its branch chain is
+   "lmin <= L <= a", else "L <= 1", else "L <= b", else "L <= lmax", else 0 — so a muscle SHORTER than lmin falls into
+   the second branch and gets 1 - 0.5((1-L)/(1-a))^2, which is negative there (about -1 just below lmin = 0.5).
+   Pinned by HumanoidMuscle.walk golden rows 15-18 and 22-27 (glut_max3_r / peri_r shorten below 0.5): with FL = 0
+   below lmin those rows miss by 0.4-0.8 rad/s, with the fall-through they match to 1e-15. L > lmax is unpinned. */
+static double muscle_gain_length(double L, double lmin, double lmax) {
+  double a = 0.5 * (lmin + 1), b = 0.5 * (1 + lmax), x;
+  if (L >= lmin && L <= a) { x = (L - lmin) / fmax(MINVAL, a - lmin); return 0.5 * x * x; }
+  if (L <= 1) { x = (1 - L) / fmax(MINVAL, 1 - a); return 1 - 0.5 * x * x; }
+  if (L <= b) { x = (L - 1) / fmax(MINVAL, b - 1); return 1 - 0.5 * x * x; }
+  if (L <= lmax) { x = (lmax - L) / fmax(MINVAL, lmax - b); return 0.5 * x * x; }
+  return 0;
+}
+static double muscle_gain(double len, double vel, const double* lengthrange, const double* prm) {
+  double range0 = prm[0], range1 = prm[1], force = prm[2], lmin = prm[4], lmax = prm[5], vmax = prm[6], fvmax = prm[8];
+  double L0 = (lengthrange[1] - lengthrange[0]) / fmax(MINVAL, range1 - range0);
+  double L = range0 + (len - lengthrange[0]) / fmax(MINVAL, L0);
+  double V = vel / fmax(MINVAL, L0 * vmax);
+  double FL = muscle_gain_length(L, lmin, lmax), FV, y = fvmax - 1;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V + 1) * (V + 1);
+  else if (V <= y) FV = fvmax - (y - V) * (y - V) / fmax(MINVAL, y);
+  else FV = fvmax;
+  return -force * FL * FV;
+}
+static double muscle_bias(double len, const double* lengthrange, const double* prm) {
+  double range0 = prm[0], range1 = prm[1], force = prm[2], lmax = prm[5], fpmax = prm[7];
+  double L0 = (lengthrange[1] - lengthrange[0]) / fmax(MINVAL, range1 - range0);
+  double L = range0 + (len - lengthrange[0]) / fmax(MINVAL, L0);
+  double b = 0.5 * (1 + lmax), x;
+  if (L <= 1) return 0;
+  if (L <= b) { x = (L - 1) / fmax(MINVAL, b - 1); return -force * fpmax * 0.5 * x * x; }
+  x = (L - b) / fmax(MINVAL, b - 1); return -force * fpmax * (0.5 + x);
+}
+static double muscle_dynamics(double ctrl, double act, const double* prm) {
+  double c = ctrl < 0 ? 0 : (ctrl > 1 ? 1 : ctrl), a = act < 0 ? 0 : (act > 1 ? 1 : act);
+  double tau_act = prm[0] * (0.5 + 1.5 * a), tau_deact = prm[1] / (0.5 + 1.5 * a);
+  double dctrl = c - act, tau;
+  if (prm[2] < MINVAL) tau = dctrl > 0 ? tau_act : tau_deact;
+  else {                                      /* quintic sigmoid blend over the width prm[2] */
+    double x = dctrl / prm[2] + 0.5, sg;
+    if (x <= 0) sg = 0; else if (x >= 1) sg = 1; else sg = x * x * x * (3 * x * (2 * x - 5) + 10);
+    tau = tau_deact + (tau_act - tau_deact) * sg;
+  }
+  return dctrl / fmax(MINVAL, tau);
+}
+
+/* spatial tendon through sites: length and moment arms (d length / d qpos) */
+static double tendon_length(const lmo_model* m, const work* w, int t, double* moment /* nv */) {
+  int nv = m->nv, adr = IDX(m->tendon_adr, t), num = IDX(m->tendon_num, t);
+  double len = 0;
+  memset(moment, 0, sizeof(double) * nv);
+  for (int i = 0; i + 1 < num; i++) {
+    int s0 = IDX(m->wrap_site, adr + i), s1 = IDX(m->wrap_site, adr + i + 1);
+    int b0 = IDX(m->site_body, s0), b1 = IDX(m->site_body, s1);
+    double p0[3], p1[3], d[3];
+    mulmat3(p0, w->xmat[b0], m->site_pos + 3*s0); for (int k = 0; k < 3; k++) p0[k] += w->xpos[b0][k];
+    mulmat3(p1, w->xmat[b1], m->site_pos + 3*s1); for (int k = 0; k < 3; k++) p1[k] += w->xpos[b1][k];
+    sub3(d, p1, p0);
+    double seg = norm3(d);
+    len += seg;
+    if (b0 == b1 || seg < MINVAL) continue;
+    for (int k = 0; k < 3; k++) d[k] /= seg;
+    for (int dof = 0; dof < nv; dof++) {
+      /* velocity of p1 minus velocity of p0 per unit qvel[dof], projected on the segment direction */
+      double j = 0;
+      for (int side = 0; side < 2; side++) {
+        int b = side ? b1 : b0; const double* p = side ? p1 : p0;
+        if (!m->affects[b][dof]) continue;
+        double jv[3];
+        if (IDX(m->jnt_type, dof) == LM_JNT_HINGE) { double r[3]; sub3(r, p, w->xanchor[dof]); cross3(jv, w->xaxis[dof], r); }
+        else copy3(jv, w->xaxis[dof]);
+        j += (side ? 1.0 : -1.0) * dot3(d, jv);
+      }
+      moment[dof] += j;
+    }
+  }
+  return len;
+}
+
 static void forward(const lmo_model* m, const double* qpos, const double* qvel, const double* ctrl,
-                    const double* warmstart, work* w) {
+                    const double* act, const double* warmstart, work* w) {
   int nv = m->nv;
   kinematics(m, qpos, w);
   mass_matrix(m, w);
@@ -957,10 +1048,21 @@ static void forward(const lmo_model* m, const double* qpos, const double* qvel, 
   rne_bias(m, qvel, w);
   /* actuation */
   memset(w->actuator, 0, sizeof(double) * nv);
-  for (int a = 0; a < m->nu; a++) {
+  for (int a = 0, ia = 0; a < m->nu; a++) {
     double c = ctrl[a];
     if (IDX(m->act_ctrllimited, a)) { if (c < m->act_ctrlrange[2*a]) c = m->act_ctrlrange[2*a]; if (c > m->act_ctrlrange[2*a + 1]) c = m->act_ctrlrange[2*a + 1]; }
-    w->actuator[IDX(m->act_dof, a)] += m->act_gear[a] * c;
+    if (IDX(m->act_kind, a) == LM_ACT_MOTOR) { w->actuator[IDX(m->act_dof, a)] += m->act_gear[a] * c; w->actuator_force[a] = c; continue; }
+    /* muscle on a tendon: length/velocity through the gear, force = gain(len, vel) * act + bias(len) */
+    double moment[LMO_MAXV], gear = m->act_gear[a];
+    double len = gear * tendon_length(m, w, IDX(m->act_tendon, a), moment), vel = 0;
+    for (int d = 0; d < nv; d++) { moment[d] *= gear; vel += moment[d] * qvel[d]; }
+    double av = act ? act[ia] : 0.0;
+    double f = muscle_gain(len, vel, m->act_lengthrange + 2*a, m->act_gainprm + 9*a) * av
+             + muscle_bias(len, m->act_lengthrange + 2*a, m->act_gainprm + 9*a);
+    w->act_dot[ia] = muscle_dynamics(c, av, m->act_dynprm + 3*a);
+    w->actuator_force[a] = f; w->actuator_length[a] = len; w->actuator_velocity[a] = vel;
+    for (int d = 0; d < nv; d++) w->actuator[d] += moment[d] * f;
+    ia++;
   }
   for (int d = 0; d < nv; d++) { w->smooth[d] = w->passive[d] - w->bias[d] + w->actuator[d]; w->qacc_smooth[d] = w->smooth[d]; }
   chol_solve(w->L, nv, w->qacc_smooth);
@@ -986,14 +1088,22 @@ static void euler(const lmo_model* m, double* qpos, double* qvel, work* w) {
 
 int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl, double* warmstart, int nsub,
              lmo_stats* stats) {
+  if (m->na > 0) return -1;          /* models with activation states go through lmo_step_act */
+  return lmo_step_act(m, qpos, qvel, NULL, ctrl, warmstart, nsub, stats);
+}
+
+int lmo_step_act(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
+                 int nsub, lmo_stats* stats) {
+  if (m->na > 0 && (!act || m->integrator != LM_INT_EULER)) return -1;
   work* w = (work*)malloc(sizeof(work));
   int nv = m->nv;
   if (stats) memset(stats, 0, sizeof(*stats));
   for (int s = 0; s < nsub; s++) {
     if (m->integrator == LM_INT_EULER) {
-      forward(m, qpos, qvel, ctrl, warmstart, w);
+      forward(m, qpos, qvel, ctrl, act, warmstart, w);
       if (warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
       euler(m, qpos, qvel, w);
+      for (int i = 0; i < m->na; i++) act[i] += m->timestep * w->act_dot[i];      /* explicit Euler on activations */
     } else {
       /* classical RK4 on (qpos,qvel); every stage is a full forward pass, no implicit damping */
       static const double A[3] = {0.5, 0.5, 1.0}, Bw[4] = {1.0/6, 1.0/3, 1.0/3, 1.0/6};
@@ -1002,7 +1112,7 @@ int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl,
       memset(dq, 0, sizeof(dq)); memset(dv, 0, sizeof(dv));
       memcpy(X, q0, sizeof(double) * nv); memcpy(V, v0, sizeof(double) * nv);
       for (int st = 0; st < 4; st++) {
-        forward(m, X, V, ctrl, warmstart, w);
+        forward(m, X, V, ctrl, NULL, warmstart, w);
         if (st == 0 && warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
         for (int d = 0; d < nv; d++) { dq[d] += Bw[st] * V[d]; dv[d] += Bw[st] * w->qacc[d]; }
         if (st < 3) for (int d = 0; d < nv; d++) { double vn = v0[d] + h * A[st] * w->qacc[d]; X[d] = q0[d] + h * A[st] * V[d]; V[d] = vn; }
@@ -1023,9 +1133,16 @@ int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl,
 /* stage-level dump for parity tests: one forward pass at (qpos,qvel,ctrl) */
 int lmo_forward(const lmo_model* m, const double* qpos, const double* qvel, const double* ctrl, const double* warmstart,
                 lmo_forward_out* out) {
+  return lmo_forward_act(m, qpos, qvel, NULL, ctrl, warmstart, out);
+}
+
+int lmo_forward_act(const lmo_model* m, const double* qpos, const double* qvel, const double* act, const double* ctrl,
+                    const double* warmstart, lmo_forward_out* out) {
   work* w = (work*)malloc(sizeof(work));
   int nv = m->nv;
-  forward(m, qpos, qvel, ctrl, warmstart, w);
+  forward(m, qpos, qvel, ctrl, act, warmstart, w);
+  if (out->actuator_force) memcpy(out->actuator_force, w->actuator_force, sizeof(double) * m->nu);
+  if (out->actuator_length) memcpy(out->actuator_length, w->actuator_length, sizeof(double) * m->nu);
   if (out->M) memcpy(out->M, w->M, sizeof(double) * nv * nv);
   if (out->bias) memcpy(out->bias, w->bias, sizeof(double) * nv);
   if (out->passive) memcpy(out->passive, w->passive, sizeof(double) * nv);

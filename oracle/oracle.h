@@ -8,6 +8,7 @@
 
 #define LMO_MAXBODY 40
 #define LMO_MAXV 32
+#define LMO_MAXU 128
 #define LMO_MAXGEOM 160
 #define LMO_MAXPAIR 8192
 #define LMO_MAXCON 96
@@ -33,6 +34,7 @@ typedef struct {
   double *M, *bias, *passive, *actuator, *qacc_smooth, *qacc, *qfrc_constraint, *xpos, *xmat, *geom_xpos;
   lmo_contact* contacts; int max_con;
   double *efc_J, *efc_aref, *efc_R, *efc_force; int* efc_type; int max_efc;
+  double *actuator_force, *actuator_length;   /* [nu] (length: muscles only) */
   /* outputs */
   int ncon, nefc, solver_iter, unhandled_pairs;
 } lmo_forward_out;
@@ -43,13 +45,19 @@ void lmo_model_destroy(lmo_model* m);
 void lmo_set_option(lmo_model* m, int what, double value);
 int lmo_nv(const lmo_model* m);
 int lmo_nu(const lmo_model* m);
+int lmo_na(const lmo_model* m);   /* activation states (muscles) */
 
 /* advance (qpos,qvel) by nsub physics substeps under constant ctrl; warmstart (nv) may be NULL */
 int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl, double* warmstart, int nsub,
              lmo_stats* stats);
+/* same with activation states act[na] (advanced in place; explicit Euler); required when lmo_na() > 0 */
+int lmo_step_act(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
+                 int nsub, lmo_stats* stats);
 /* one forward-dynamics pass with intermediate results */
 int lmo_forward(const lmo_model* m, const double* qpos, const double* qvel, const double* ctrl,
                 const double* warmstart, lmo_forward_out* out);
+int lmo_forward_act(const lmo_model* m, const double* qpos, const double* qvel, const double* act, const double* ctrl,
+                    const double* warmstart, lmo_forward_out* out);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ class ForwardOut(C.Structure):
                                    "xpos", "xmat", "geom_xpos")] + \
                [("contacts", C.POINTER(Contact)), ("max_con", C.c_int)] + \
                [(n, _DP) for n in ("efc_J", "efc_aref", "efc_R", "efc_force")] + \
-               [("efc_type", C.POINTER(C.c_int)), ("max_efc", C.c_int),
+               [("efc_type", C.POINTER(C.c_int)), ("max_efc", C.c_int), ("actuator_force", _DP), ("actuator_length", _DP),
                 ("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter", C.c_int), ("unhandled_pairs", C.c_int)]
 
 
@@ -57,6 +57,9 @@ def lib():
         _lib.lmo_set_option.argtypes = [C.c_void_p, C.c_int, C.c_double]
         _lib.lmo_step.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
         _lib.lmo_forward.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.POINTER(ForwardOut)]
+        _lib.lmo_step_act.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
+        _lib.lmo_forward_act.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, C.POINTER(ForwardOut)]
+        _lib.lmo_na.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -76,6 +79,7 @@ class Oracle:
         self.nu = int(blob[5])
         self.nbody = int(blob[2])
         self.ngeom = int(blob[4])
+        self.na = int(blob[19])
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -92,10 +96,26 @@ class Oracle:
         c = np.ascontiguousarray(ctrl, dtype=np.float64)
         w = np.zeros(self.nv) if warmstart is None else np.array(warmstart, dtype=np.float64)
         st = Stats()
-        lib().lmo_step(self._h, _p(q), _p(v), _p(c), _p(w), int(nsub), C.byref(st))
+        rc = lib().lmo_step(self._h, _p(q), _p(v), _p(c), _p(w), int(nsub), C.byref(st))
+        if rc != 0:
+            raise ValueError("model has activation states: use step_act")
         return q, v, w, {n: getattr(st, n) for n, _ in Stats._fields_}
 
-    def forward(self, qpos, qvel, ctrl, warmstart=None):
+    def step_act(self, qpos, qvel, act, ctrl, nsub=1, warmstart=None):
+        """Models with muscle activations: returns new (qpos, qvel, act, warmstart, stats-dict)."""
+        q = np.array(qpos, dtype=np.float64)
+        v = np.array(qvel, dtype=np.float64)
+        a = np.array(act, dtype=np.float64)
+        assert a.shape == (self.na,)
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        w = np.zeros(self.nv) if warmstart is None else np.array(warmstart, dtype=np.float64)
+        st = Stats()
+        rc = lib().lmo_step_act(self._h, _p(q), _p(v), _p(a), _p(c), _p(w), int(nsub), C.byref(st))
+        if rc != 0:
+            raise ValueError("oracle rejected the step (RK4 with activation states is not restated)")
+        return q, v, a, w, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def forward(self, qpos, qvel, ctrl, warmstart=None, act=None):
         nv = self.nv
         q = np.ascontiguousarray(qpos, dtype=np.float64)
         v = np.ascontiguousarray(qvel, dtype=np.float64)
@@ -105,7 +125,7 @@ class Oracle:
                    qacc_smooth=np.zeros(nv), qacc=np.zeros(nv), qfrc_constraint=np.zeros(nv),
                    xpos=np.zeros((self.nbody, 3)), xmat=np.zeros((self.nbody, 9)), geom_xpos=np.zeros((self.ngeom, 3)),
                    efc_J=np.zeros((self.MAX_EFC, nv)), efc_aref=np.zeros(self.MAX_EFC), efc_R=np.zeros(self.MAX_EFC),
-                   efc_force=np.zeros(self.MAX_EFC))
+                   efc_force=np.zeros(self.MAX_EFC), actuator_force=np.zeros(self.nu), actuator_length=np.zeros(self.nu))
         out = ForwardOut()
         for k, a in res.items():
             setattr(out, k, _p(a))
@@ -115,7 +135,8 @@ class Oracle:
         out.max_con = self.MAX_CON
         out.efc_type = etype.ctypes.data_as(C.POINTER(C.c_int))
         out.max_efc = self.MAX_EFC
-        lib().lmo_forward(self._h, _p(q), _p(v), _p(c), _p(w), C.byref(out))
+        av = np.zeros(max(self.na, 1)) if act is None else np.ascontiguousarray(act, dtype=np.float64)
+        lib().lmo_forward_act(self._h, _p(q), _p(v), _p(av), _p(c), _p(w), C.byref(out))
         ne, nc = out.nefc, out.ncon
         for k in ("efc_J", "efc_aref", "efc_R", "efc_force"):
             res[k] = res[k][:ne]

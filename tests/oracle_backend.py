@@ -19,6 +19,7 @@ class OracleBatch:
         self.qpos = np.zeros((self.n, env._model.nv))
         self.qvel = np.zeros((self.n, env._model.nv))
         self.warm = np.zeros((self.n, env._model.nv))
+        self.act = np.zeros((self.n, getattr(env._model, "na", 0)))      # muscle activations (mj_resetData zeroes them)
         self.goal = None
         self.prev_obs = None
         self.stats_log = []
@@ -27,6 +28,7 @@ class OracleBatch:
         self.qpos[:] = qpos
         self.qvel[:] = qvel
         self.warm[:] = 0
+        self.act[:] = 0
 
     def set_goal(self, goal, mask=None):
         self.goal = np.array(goal, dtype=np.float64)
@@ -48,7 +50,11 @@ class OracleBatch:
         for e in range(self.n):
             ctrl = np.zeros(env._model.nu)
             ctrl[env._action_indices] = env._preprocess_action(action[e])
-            q, v, w, st = self.oracle.step(self.qpos[e], self.qvel[e], ctrl, env._n_substeps, self.warm[e])
+            if self.act.shape[1]:
+                q, v, a, w, st = self.oracle.step_act(self.qpos[e], self.qvel[e], self.act[e], ctrl, env._n_substeps, self.warm[e])
+                self.act[e] = a
+            else:
+                q, v, w, st = self.oracle.step(self.qpos[e], self.qvel[e], ctrl, env._n_substeps, self.warm[e])
             self.qpos[e], self.qvel[e], self.warm[e] = q, v, w
             self.stats_log.append(st)
             o = self._obs(e)

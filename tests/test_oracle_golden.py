@@ -207,3 +207,63 @@ def test_humanoid_torque_full_rollout_matches_reference_test(task, speed):
         assert rows.shape == g.shape
     assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
     assert np.isclose(rewards[n - 2], np.exp(-(g[n - 2][17] - speed) ** 2))   # TargetVelocityReward on the previous observation
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HumanoidMuscle.run / .walk: pins spatial tendons (site paths, moment arms), the Hill-type muscle model
+# (force-length-velocity gain, passive bias, activation dynamics with activation-dependent time constants) and the
+# effective actuator defaults after the reference's dm_control round trip (muscle ctrlrange [0,1], range 0.65..1.05).
+# The observation holds no activations; they only depend on the action stream (act' = act + h*(ctrl-act)/tau), so
+# every golden row is still a one-control-step KAT: all 41 + 28 rows are reproduced to 1e-12. .walk rows 15-18 and
+# 22-27 additionally pin the engine's force-length fall-through for muscles shorter than lmin (oracle.c
+# muscle_gain_length): they miss by 0.4-0.8 rad/s with the textbook curve.
+# ---------------------------------------------------------------------------------------------------------------
+
+_HM_EXACT_ROWS = {"run": list(range(41)), "walk": list(range(28))}
+
+
+@pytest.mark.parametrize("task", ["run", "walk"])
+def test_humanoid_muscle_one_control_step_kats(task):
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle." + task, debug=True)
+    m = env._model
+    assert (m.nu, m.na, m.ntendon) == (92, 92, 92) and m.integrator == mjcf.INT_EULER
+    assert np.allclose(env.norm_act_mean, 0.5) and np.allclose(env.norm_act_delta, 0.5)
+    o = Oracle(pack_model(m))
+    g = GOLD["HumanoidMuscle.%s.real" % task]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    act = np.zeros(m.na)
+    exact = []
+    for k in range(len(g) - 1):
+        a = np.random.randn(92) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :17]
+        qvel[qidx] = g[k, 17:36]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, act, w, st = o.step_act(qpos, qvel, act, ctrl, nsub=10)
+        ok = np.abs(q[qidx[2:]] - g[k + 1, :17]).max() < 1e-12 and np.abs(v[qidx] - g[k + 1, 17:36]).max() < 1e-10
+        if ok:
+            exact.append(k)
+    assert exact == _HM_EXACT_ROWS[task]
+    assert 0.4 < act.mean() < 0.6                        # activations settle around ctrl = 0.5 +- 0.05
+
+
+@pytest.mark.parametrize("task", ["run", "walk"])
+def test_humanoid_muscle_full_rollout_matches_reference_test(task):
+    g = GOLD["HumanoidMuscle.%s.real" % task]
+    np.random.seed(0)
+    env = attach(LocoEnv.make("HumanoidMuscle." + task, debug=True))
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, r, absorbing, _ = env.step(np.random.randn(92) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape and np.allclose(rows, g)
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
