@@ -13,6 +13,7 @@
  *   lm_set_state        <- LocoEnv.set_sim_state: data.joint(name).qpos/qvel = value (base.py:478-497)
  *                          after mj_resetData (base.py:180): also clears the solver warm start
  *   lm_get_state        <- data.qpos / data.qvel reads (ObservationHelper._build_obs, base.py:202)
+ *   lm_set/get_activation <- data.act (muscle activation state, humanoids.py:320 HumanoidMuscle; integrated by mj_step)
  *   lm_set_goal         <- per-episode goal written into the observation
  *                          (unitreeA1.py:288-291 set_goal, :454-476 _create_observation)
  *   lm_step             <- MuJoCo.step: _preprocess_action (base.py:606-621) -> ctrl ->
@@ -46,6 +47,7 @@ typedef struct lm_batch lm_batch;
 
 typedef struct {
   int nq, nv, nu, nobs, ngoal, n_substeps, n_chains, max_chain_dofs;
+  int na;                  /* activation states per environment (muscles); 0 for torque-driven models */
 } lm_dims;
 
 typedef struct {
@@ -91,6 +93,10 @@ void lm_batch_destroy(lm_batch* b);
 int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask);
 int lm_get_state(lm_batch* b, float* qpos, float* qvel);
 int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask);
+/* muscle activations [n_envs][na] (data.act of the reference: mj_resetData zeroes it, base.py:180, so lm_set_state
+   and device-side episode restarts zero it too; these two exist for checkpointing and for parity tests) */
+int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
+int lm_get_activation(lm_batch* b, float* act);
 
 /* one control step for every environment. action in [-1,1] (normalised, base.py:606-621).
    obs [n_envs][nobs], reward [n_envs], done [n_envs] may each be NULL. Synchronous. */

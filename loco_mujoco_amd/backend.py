@@ -17,7 +17,7 @@ _D = C.POINTER(C.c_double)
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nq", "nv", "nu", "nobs", "ngoal", "n_substeps", "n_chains", "max_chain_dofs")]
+    _fields_ = [(n, C.c_int) for n in ("nq", "nv", "nu", "nobs", "ngoal", "n_substeps", "n_chains", "max_chain_dofs", "na")]
 
 
 class Stats(C.Structure):
@@ -34,7 +34,8 @@ class ForwardOut(C.Structure):
 
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
-           "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_goal", "lm_step",
+           "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
+           "lm_set_goal", "lm_step",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_forward_debug", "lm_get_stats", "lm_sync"]
 
 _lib = None
@@ -65,6 +66,8 @@ def load_library():
     lib.lm_set_state.argtypes = [C.c_void_p, _F, _F, _U8]
     lib.lm_get_state.argtypes = [C.c_void_p, _F, _F]
     lib.lm_set_goal.argtypes = [C.c_void_p, _F, _U8]
+    lib.lm_set_activation.argtypes = [C.c_void_p, _F, _U8]
+    lib.lm_get_activation.argtypes = [C.c_void_p, _F]
     lib.lm_step.argtypes = [C.c_void_p, _F, _F, _F, _U8]
     lib.lm_set_reset_table.argtypes = [C.c_void_p, _F, C.c_int, C.c_uint64, C.c_int64]
     lib.lm_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -132,6 +135,7 @@ class HipBatch:
         self._h = h
         d = model.dims
         self.nq, self.nv, self.nu, self.nobs, self.ngoal = d.nq, d.nv, d.nu, d.nobs, d.ngoal
+        self.na = d.na
 
     def close(self):
         if getattr(self, "_h", None):
@@ -150,6 +154,17 @@ class HipBatch:
         v = np.empty((self.n, self.nv), dtype=np.float32)
         _check(self._lib.lm_get_state(self._h, _fp(q), _fp(v)))
         return q, v
+
+    def set_activation(self, act, mask=None):
+        """Muscle activations [n, na] (set_state zeroes them like mj_resetData; this is for checkpoints and tests)."""
+        a = _f32(act, (self.n, self.na))
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_set_activation(self._h, _fp(a), mp))
+
+    def get_activation(self):
+        a = np.empty((self.n, self.na), dtype=np.float32)
+        _check(self._lib.lm_get_activation(self._h, _fp(a)))
+        return a
 
     def set_goal(self, goal, mask=None):
         if self.ngoal == 0:

@@ -172,8 +172,8 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
-// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18]
-template <int MC, int NS> struct LaneMem {
+// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM]
+template <int MC, int NS, int NM = 0> struct LaneMem {
   static constexpr int kSlots = 0;
   static constexpr int kMcc = NS * SL_SIZE;
   static constexpr int kMcr = kMcc + MC * (MC + 1) / 2;
@@ -182,7 +182,9 @@ template <int MC, int NS> struct LaneMem {
   static constexpr int kSc = kSr + 36;
   static constexpr int kAl = kSc + MC * 6;       // link images of the current joint-space vector (MC x 6)
   static constexpr int kFrame = kAl + MC * 6;    // link frames for the collision pass: position 3, rotation 9, velocity 6
-  static constexpr int kSize = kFrame + MC * 18;
+  static constexpr int kAct = kFrame + MC * 18;    // muscle activations of this lane's chain (NM), then their controls (NM)
+  static constexpr int kCtrl = kAct + NM;
+  static constexpr int kSize = kCtrl + NM;
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -419,10 +421,12 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // forward dynamics at (q, v): constrained acceleration in war/wac (in: warm start, out: qacc). With EULER the state
 // is also advanced by one semi-implicit Euler step (implicit joint damping), otherwise q, v are left untouched.
 // CONE: LM_CONE_PYRAMIDAL / LM_CONE_ELLIPTIC compiles the other cone's code out; -1 reads it from P.cone
-template <class Q, int MC, int NS, bool EULER, int CONE = -1>
+// NM > 0: the chain's muscles (table `mt`, lm_layout.h MT_*/MU_*) act on the chain dofs; their activations and
+// controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
+template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg) {
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
@@ -489,7 +493,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots.
   // Everything that must survive into the solver (M, twists) is parked in lane memory so that the Newton loop
   // keeps only small vectors in registers.
-  using LMm = LaneMem<MC, NS>;
+  using LMm = LaneMem<MC, NS, NM>;
 #define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
   float a0r[6], a0c[MC];
@@ -651,11 +655,103 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
     LM_TICK(1);
 
+    // ======== muscles: tendon length/velocity through the site path, force = gain(L,V)*act + bias(L), moment arms ========
+    float musc[MC];
+#pragma unroll
+    for (int k = 0; k < MC; k++) musc[k] = 0.0f;
+    if (NM > 0) {
+      Sp Fl[MC];                                   // tendon forces as wrenches about O, per link
+#pragma unroll
+      for (int k = 0; k < MC; k++) Fl[k] = sp0();
+      const int m0 = (int)mt[oz + c], nm = (int)mt[oz + LM_NCHAIN + c];
+      for (int i = 0; i < nm; i++) {
+        const float* rec = mt + oz + LM_MT_HEAD + (m0 + i) * LM_MU_SIZE;
+        const float* site = mt + oz + LM_MT_SITES + 4 * (int)rec[LM_MU_SITE_ADR];
+        const int nsite = (int)rec[LM_MU_SITE_NUM];
+        Sp Ul[MC];                                 // wrench per unit tendon force
+#pragma unroll
+        for (int k = 0; k < MC; k++) Ul[k] = sp0();
+        float len = 0.0f, vel = 0.0f;
+        V3 pp = v3(0, 0, 0), vp = v3(0, 0, 0);
+        int lp = -2;
+        for (int s = 0; s < nsite; s++) {
+          const int li = (int)site[4 * s];
+          const V3 loc = v3(site[4 * s + 1], site[4 * s + 2], site[4 * s + 3]);
+          V3 p, w, vl;
+          if (li < 0) { p = O + mul(R, loc); w = Vroot.w; vl = Vroot.v; }
+          else {
+            const int fb = LMm::kFrame + li * 18;
+            M3 Rl;
+#pragma unroll
+            for (int j = 0; j < 9; j++) Rl.a[j] = LMEM(fb + 3 + j);
+            p = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2)) + mul(Rl, loc);
+            w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); vl = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+          }
+          const V3 r = p - O;
+          const V3 pv = vl + cross(w, r);          // velocity of the path point (twists are about O)
+          if (s > 0) {
+            const V3 d = p - pp;
+            const float seg = sqrtf(dot(d, d));
+            len += seg;
+            if (li != lp && seg > 1e-12f) {        // a segment inside one body has no moment arm
+              const V3 u = (1.0f / seg) * d;
+              vel += dot(u, pv - vp);
+              // +u at this point on link li, -u at the previous point on link lp (root points move no chain dof)
+              Sp Wc; Wc.w = cross(r, u); Wc.v = u;
+              Sp Wp; Wp.w = cross(pp - O, u); Wp.v = u;
+#pragma unroll
+              for (int k = 0; k < MC; k++) {
+                if (li == k) Ul[k] = Ul[k] + Wc;
+                if (lp == k) Ul[k] = Ul[k] + (-1.0f) * Wp;
+              }
+            }
+          }
+          pp = p; vp = pv; lp = li;
+        }
+        const float gear = rec[LM_MU_GEAR];
+        const float L = fmaf(fmaf(gear, len, -rec[LM_MU_LR0]), rec[LM_MU_INV_L0], rec[LM_MU_RANGE0]);
+        const float Vn = gear * vel * rec[LM_MU_INV_L0VMAX];
+        const float lmin = rec[LM_MU_LMIN], lmax = rec[LM_MU_LMAX], fvmax = rec[LM_MU_FVMAX];
+        // force-length curve with the engine's branch order (a muscle shorter than lmin lands in the second branch)
+        const float a = 0.5f * (lmin + 1.0f), b = 0.5f * (1.0f + lmax);
+        float FL, x;
+        if (L >= lmin && L <= a) { x = (L - lmin) / fmaxf(kMinVal, a - lmin); FL = 0.5f * x * x; }
+        else if (L <= 1.0f) { x = (1.0f - L) / fmaxf(kMinVal, 1.0f - a); FL = 1.0f - 0.5f * x * x; }
+        else if (L <= b) { x = (L - 1.0f) / fmaxf(kMinVal, b - 1.0f); FL = 1.0f - 0.5f * x * x; }
+        else if (L <= lmax) { x = (lmax - L) / fmaxf(kMinVal, lmax - b); FL = 0.5f * x * x; }
+        else FL = 0.0f;
+        const float y = fvmax - 1.0f;
+        float FV;
+        if (Vn <= -1.0f) FV = 0.0f;
+        else if (Vn <= 0.0f) FV = (Vn + 1.0f) * (Vn + 1.0f);
+        else if (Vn <= y) FV = fvmax - (y - Vn) * (y - Vn) / fmaxf(kMinVal, y);
+        else FV = fvmax;
+        float FP;
+        if (L <= 1.0f) FP = 0.0f;
+        else if (L <= b) { x = (L - 1.0f) / fmaxf(kMinVal, b - 1.0f); FP = rec[LM_MU_FPMAX] * 0.5f * x * x; }
+        else { x = (L - b) / fmaxf(kMinVal, b - 1.0f); FP = rec[LM_MU_FPMAX] * (0.5f + x); }
+        const float act = LMEM(LMm::kAct + i), ctrl = LMEM(LMm::kCtrl + i);
+        const float force = -rec[LM_MU_FORCE] * fmaf(FL * FV, act, FP) * gear;
+#pragma unroll
+        for (int k = 0; k < MC; k++) Fl[k] = Fl[k] + force * Ul[k];
+        if (EULER) {
+          // activation dynamics: time constants depend on the activation, hard switch between rise and decay
+          const float cc = fminf(fmaxf(ctrl, 0.0f), 1.0f), ac_ = fminf(fmaxf(act, 0.0f), 1.0f);
+          const float dctrl = cc - act;
+          const float tau = (dctrl > 0.0f) ? rec[LM_MU_TAU_ACT] * (0.5f + 1.5f * ac_) : rec[LM_MU_TAU_DEACT] / (0.5f + 1.5f * ac_);
+          LMEM(LMm::kAct + i) = fmaf(P.h, dctrl / fmaxf(kMinVal, tau), act);
+        }
+      }
+      Sp Fs = sp0();
+#pragma unroll
+      for (int k = MC - 1; k >= 0; k--) { Fs = Fs + Fl[k]; musc[k] = spdot(Sc[k], Fs); }
+    }
+
     // ======== smooth forces, unconstrained acceleration ========
 #pragma unroll
     for (int i = 0; i < 6; i++) sm_r[i] = -RD(i, LM_D_STIFF) * qr[i] - RD(i, LM_D_DAMP) * vr[i] - bias_r[i] + actr[i];
 #pragma unroll
-    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k]) : 0.0f;
+    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k] + musc[k]) : 0.0f;
     // park M and the twists in lane memory
 #pragma unroll
     for (int i = 0; i < MC * (MC + 1) / 2; i++) LMEM(LMm::kMcc + i) = Mcc[i];
@@ -1236,11 +1332,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4, int CONE = -1>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg) {
-  if (!RK4) { forward<Q, MC, NS, true, CONE>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg); return; }
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr) {
+  static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }

@@ -45,7 +45,7 @@ int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct Task {
-  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links;
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na;
   float rp[8];
 };
 
@@ -53,6 +53,8 @@ struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iter
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
+  const float* mt;          // muscle table [LM_MT_SIZE] or null
+  float* act;               // muscle activations, SoA [na][N], or null
   float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
@@ -79,9 +81,11 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
+  __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
+  if (NM > 0) for (int i = threadIdx.x; i < LM_MT_SIZE; i += blockDim.x) mt[i] = a.mt[i];
   __shared__ float blk_stats[12];
   extern __shared__ float lane_mem[];                      // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
   for (int i = threadIdx.x; i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
@@ -156,18 +160,37 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {};
-  float* lmem = lane_mem + (threadIdx.x >> 4) * lm::LaneMem<MC, NS>::kGroup + (threadIdx.x & 15);
+  using LMm = lm::LaneMem<MC, NS, NM>;
+  float* lmem = lane_mem + (threadIdx.x >> 4) * LMm::kGroup + (threadIdx.x & 15);
   constexpr int ls = 16;
+  if (NM > 0) {
+    // this lane's muscles: activation state and un-normalised, clamped control into lane memory
+    const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+    for (int i = 0; i < nm; i++) {
+      const float* rec = mt + LM_MT_HEAD + (m0 + i) * LM_MU_SIZE;
+      const int k = (int)rec[LM_MU_ACT];
+      float u = 0.0f;
+      if (k >= 0) {
+        if (a.action_mode == 0 && a.action) u = a.action[(long long)e * a.T.nu + k];
+        else if (a.action_mode == 2) {
+          unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + a.step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+          u = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
+        }
+      }
+      lmem[(LMm::kCtrl + i) * ls] = fminf(fmaxf(fmaf(u, rec[LM_MU_ACT_DELTA], rec[LM_MU_ACT_MEAN]), rec[LM_MU_CTRL_LO]), rec[LM_MU_CTRL_HI]);
+      lmem[(LMm::kAct + i) * ls] = a.act[(long long)(int)rec[LM_MU_STATE] * N + e];
+    }
+  }
   if (FORWARD_ONLY) {
     if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
-    lm::forward<QuadDpp, MC, NS, false>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg);
+    lm::forward<QuadDpp, MC, NS, false, -1, NM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
     int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -186,6 +209,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   int step_no = a.ep_step[e] + 1;
   const bool trunc = a.horizon > 0 && step_no >= a.horizon;
   float episodes = 0.0f;
+  bool zero_act = false;                     // a restarted episode starts with zero muscle activation (mj_resetData)
   if (absorbing || trunc) {
     episodes = 1.0f;
     if (a.auto_reset && a.table_rows > 0) {
@@ -204,7 +228,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
         for (int i = 0; i < a.T.ngoal; i++) a.goal[i * N + e] = goal[i];
       }
       step_no = 0;
+      zero_act = true;
     } else if (nonfinite) {
+      zero_act = true;
       // no reset table: park the environment at rest in its last finite configuration is impossible; zero it
 #pragma unroll
       for (int i = 0; i < 6; i++) { qr[i] = 0.0f; vr[i] = 0.0f; war[i] = 0.0f; }
@@ -224,6 +250,13 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < MC; k++) if (k < nl) { a.qpos[dc[k] * N + e] = qc[k]; a.qvel[dc[k] * N + e] = vc[k]; a.warm[dc[k] * N + e] = wac[k]; }
+  if (NM > 0) {
+    const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+    for (int i = 0; i < nm; i++) {
+      const float v = lmem[(LMm::kAct + i) * ls];
+      a.act[(long long)(int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE] * N + e] = zero_act ? 0.0f : ((fabsf(v) < 1e30f) ? v : 0.0f);
+    }
+  }
   if (a.obs) {
     float* o = a.obs + (long long)e * a.T.nobs;
     if (c == 0) {
@@ -269,6 +302,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 struct lm_model {
   int device;
   float* d_cm;
+  float* d_mt;               // muscle table (models with muscles)
   lm::Params P; Task T;
   int nroot;
   std::vector<int> root_dofs;
@@ -278,6 +312,7 @@ struct lm_batch {
   lm_model* m;
   int N;
   float *qpos, *qvel, *warm, *goal, *action, *obs, *reward, *table;
+  float* act;                // muscle activations [na][N]
   unsigned char* done;
   int* ep_step; unsigned* ep_count;
   DevStats* stats;
@@ -311,6 +346,10 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
       if (!FWD && cone == LM_CONE_ELLIPTIC) launch_one(step_kernel<3, 4, false, FWD, LM_CONE_ELLIPTIC>, grid, block, lane_bytes, b, a);
       else launch_one(step_kernel<3, 4, false, FWD, -1>, grid, block, lane_bytes, b, a);
     } else launch_one(step_kernel<3, 4, true, FWD, -1>, grid, block, lane_bytes, b, a);
+  } else if (b->m->T.na > 0) {
+    // muscle-driven humanoid: Euler, muscle table in LDS, activations and controls in lane memory
+    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup * ((block.x + 15) / 16);
+    launch_one(step_kernel<5, 8, false, FWD, -1, LM_MAXMUS>, grid, block, lane_bytes, b, a);
   } else {
     const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kGroup * ((block.x + 15) / 16);
     // (a <5,8,RK4,pyramidal> specialisation was measured at +1 % and miscompared on the GPU once the collision pass
@@ -336,6 +375,10 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
   if ((int)cmod[LM_H_MAXLINKS] > 5) return fail("chains longer than 5 links are not supported");
   if ((int)cmod[LM_HEADER_SIZE + LM_R_NDOF] != 6) return fail("root body must have 6 dofs");
+  const int n_muscle = (int)cmod[LM_H_NMUSCLE];
+  if (n_muscle < 0 || n_muscle > LM_MT_MAXMUS) return fail("bad muscle count");
+  if (n_muscle > 0 && n < (size_t)(LM_HEADER_SIZE + LM_CM_SIZE + LM_MT_SIZE)) return fail("chain model lacks the muscle table");
+  if (n_muscle > 0 && (int)cmod[LM_H_INTEGRATOR] != LM_INT_EULER) return fail("muscles need the Euler integrator");
   HIPCHK(hipSetDevice(device));
   lm_model* m = new lm_model();
   m->device = device;
@@ -347,7 +390,16 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   }
   HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
   HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));
+  m->d_mt = nullptr;
+  if (n_muscle > 0) {
+    std::vector<float> mt(LM_MT_SIZE);
+    for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)cmod[LM_HEADER_SIZE + LM_CM_SIZE + i];
+    for (int c = 0; c < LM_NCHAIN; c++) if ((int)mt[LM_NCHAIN + c] > LM_MAXMUS) { delete m; return fail("too many muscles on one chain"); }
+    HIPCHK(hipMalloc(&m->d_mt, sizeof(float) * LM_MT_SIZE));
+    HIPCHK(hipMemcpy(m->d_mt, mt.data(), sizeof(float) * LM_MT_SIZE, hipMemcpyHostToDevice));
+  }
   Task& T = m->T;
+  T.na = n_muscle;
   T.nv = (int)cmod[LM_H_NV]; T.nu = (int)cmod[LM_H_NU]; T.nobs = (int)cmod[LM_H_NOBS]; T.ngoal = (int)cmod[LM_H_NGOAL];
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
   T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS];
@@ -374,12 +426,13 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
 void lm_model_destroy(lm_model* m) {
   if (!m) return;
   (void)hipFree(m->d_cm);
+  if (m->d_mt) (void)hipFree(m->d_mt);
   delete m;
 }
 
 int lm_model_dims(const lm_model* m, lm_dims* out) {
   out->nq = m->T.nv; out->nv = m->T.nv; out->nu = m->T.nu; out->nobs = m->T.nobs; out->ngoal = m->T.ngoal;
-  out->n_substeps = m->T.nsub; out->n_chains = m->T.n_chains; out->max_chain_dofs = m->T.max_links;
+  out->n_substeps = m->T.nsub; out->n_chains = m->T.n_chains; out->max_chain_dofs = m->T.max_links; out->na = m->T.na;
   return 0;
 }
 
@@ -408,6 +461,8 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
   HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
+  b->act = nullptr;
+  if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
@@ -426,7 +481,7 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   hipStreamSynchronize(b->stream);
   (void)hipFree(b->qpos); (void)hipFree(b->qvel); (void)hipFree(b->warm); (void)hipFree(b->goal); (void)hipFree(b->action); (void)hipFree(b->obs);
-  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table);
+  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table); if (b->act) (void)hipFree(b->act);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -461,7 +516,15 @@ int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_
     for (int e = 0; e < N; e++) if (mask[e]) { st[e] = 0; for (int d = 0; d < nv; d++) w[(size_t)d * N + e] = 0.0f; }
     HIPCHK(hipMemcpy(b->warm, w.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->ep_step, st.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    if (b->act) {
+      const int na = b->m->T.na;
+      std::vector<float> av((size_t)na * N);
+      HIPCHK(hipMemcpy(av.data(), b->act, sizeof(float) * na * N, hipMemcpyDeviceToHost));
+      for (int e = 0; e < N; e++) if (mask[e]) for (int d = 0; d < na; d++) av[(size_t)d * N + e] = 0.0f;
+      HIPCHK(hipMemcpy(b->act, av.data(), sizeof(float) * na * N, hipMemcpyHostToDevice));
+    }
   } else {
+    if (b->act) HIPCHK(hipMemset(b->act, 0, sizeof(float) * b->m->T.na * N));
     HIPCHK(hipMemcpy(b->warm, z.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->ep_step, zs.data(), sizeof(int) * N, hipMemcpyHostToDevice));
   }
@@ -482,6 +545,23 @@ int lm_get_state(lm_batch* b, float* qpos, float* qvel) {
   return 0;
 }
 
+int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (!b->act) return fail("model has no activation states");
+  return upload_soa(b, b->act, act, b->m->T.na, mask);
+}
+
+int lm_get_activation(lm_batch* b, float* act) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (!b->act) return fail("model has no activation states");
+  const int N = b->N, na = b->m->T.na;
+  std::vector<float> soa((size_t)na * N);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(soa.data(), b->act, sizeof(float) * na * N, hipMemcpyDeviceToHost));
+  for (int e = 0; e < N; e++) for (int d = 0; d < na; d++) act[(size_t)e * na + d] = soa[(size_t)d * N + e];
+  return 0;
+}
+
 int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->m->device));
   if (b->m->T.ngoal == 0) return 0;
@@ -491,7 +571,7 @@ int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask) {
 static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
-  a.cm = b->m->d_cm; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
   a.ep_step = b->ep_step; a.ep_count = b->ep_count;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;

@@ -109,7 +109,20 @@ HEADER_SIZE = 32
 LMC_MAGIC = 0x4C4D4331  # "LMC1"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
-H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS = 26, 27, 28, 29, 30
+H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE = 26, 27, 28, 29, 30, 31
+
+# ---- muscle table (optional; follows the constant table): MT_HEAD floats [first muscle of chain c] x NCHAIN,
+# [muscle count of chain c] x NCHAIN, then MU_SIZE floats per muscle (sorted by chain), then 4 floats per tendon
+# path entry (link index in the chain, -1 = root body; xyz in that link's frame)
+MAXMUS = 48           # muscles per chain (lane memory holds their activation and control)
+MT_MAXMUS = 96        # muscles per model
+MT_MAXSITE = 352      # tendon path entries per model
+(MU_ACT, MU_ACT_MEAN, MU_ACT_DELTA, MU_CTRL_LO, MU_CTRL_HI, MU_GEAR, MU_LR0, MU_INV_L0, MU_RANGE0, MU_FORCE, MU_LMIN,
+ MU_LMAX, MU_INV_L0VMAX, MU_FPMAX, MU_FVMAX, MU_TAU_ACT, MU_TAU_DEACT, MU_SITE_ADR, MU_SITE_NUM, MU_STATE,
+ MU_SIZE) = range(21)
+MT_HEAD = 2 * NCHAIN
+MT_SITES = MT_HEAD + MT_MAXMUS * MU_SIZE
+MT_SIZE = MT_SITES + MT_MAXSITE * 4
 SRC_ROOT_QVEL, SRC_GOAL, SRC_ROOT_QPOS = 0, 100, 200
 
 
@@ -231,7 +244,9 @@ def lower(m, task):
     act_of_dof = {int(d): a for a, d in enumerate(m.act_dof)}
     dof_to_lane = -np.ones(m.nv, dtype=np.int64)
 
-    def fill_dof(block, d, qobs, vobs):
+    dropped_root_limits = []
+
+    def fill_dof(block, d, qobs, vobs, is_root=False):
         block[D_TYPE] = m.jnt_type[d]
         block[D_AX:D_AX + 3] = m.jnt_axis[d]
         block[D_PX:D_PX + 3] = m.jnt_pos[d]
@@ -243,9 +258,21 @@ def lower(m, task):
             d0 = si[0] if not (si[0] == si[1] or si[2] <= MINVAL) else 0.5 * (si[0] + si[1])
             block[D_FLOSS_R] = max(MINVAL, (1 - d0) * m.dof_invweight0[d] / d0)
             block[D_FLOSS_B] = _kb(m.dof_solref[d], m.dof_solimp[d], m.timestep)[1]
-        block[D_LIMITED] = m.jnt_limited[d]
+        limited = bool(m.jnt_limited[d])
+        if limited and is_root:
+            # the device has no limit rows for the (replicated) root dofs. A root limit that cannot become active is
+            # dropped: translation ranges of tens of metres, or angles whose termination band (evaluated every
+            # control step) lies strictly inside the joint range.
+            lo, hi = m.jnt_range[d]
+            tlo, thi = term_q.get(int(d), (-np.inf, np.inf))
+            if (m.jnt_type[d] == 0 and min(-lo, hi) >= 50.0) or (tlo > lo and thi < hi):
+                limited = False
+                dropped_root_limits.append(int(d))
+            else:
+                raise UnsupportedModel("root joint %s has a reachable limit" % m.jnt_names[d])
+        block[D_LIMITED] = limited
         block[D_LO], block[D_HI] = m.jnt_range[d]
-        if m.jnt_limited[d]:
+        if limited:
             assert m.jnt_margin[d] == 0, "joint margin != 0 not supported on the device"
             block[D_LIM_K], block[D_LIM_B] = _kb(m.jnt_solref[d], m.jnt_solimp[d], m.timestep)
             block[D_LIM_S0:D_LIM_S0 + 5] = _clip_solimp(m.jnt_solimp[d])
@@ -336,7 +363,7 @@ def lower(m, task):
     rb[R_IXX:R_IXX + 6] = [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1], inertia[0, 2], inertia[1, 2]]
     for k in range(m.body_jntnum[root]):
         d = m.body_jntadr[root] + k
-        fill_dof(rb[R_DOFS + k * D_SIZE:R_DOFS + (k + 1) * D_SIZE], d, qobs, vobs)
+        fill_dof(rb[R_DOFS + k * D_SIZE:R_DOFS + (k + 1) * D_SIZE], d, qobs, vobs, is_root=True)
         dof_to_lane[d] = -2
     sup, unsup = geom_blocks(root, 0)
     unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
@@ -395,6 +422,67 @@ def lower(m, task):
     if (dof_to_lane == -1).any():
         raise UnsupportedModel("some dofs are outside the root+chains structure")
 
+    # ---- muscles: every tendon must run over the root body and ONE chain, so that lane c owns it
+    mt = None
+    muscles = [a for a in range(m.nu) if getattr(m, "act_kind", np.zeros(m.nu))[a] == mjcf.ACT_MUSCLE]
+    if muscles:
+        if m.integrator != mjcf.INT_EULER:
+            raise UnsupportedModel("muscle activations under RK4 are not built on the device")
+        weld_link = {root: (-1, -1)}
+        for c, chain in enumerate(chains):
+            li = -1
+            for b in chain:
+                li += m.body_jntnum[b]
+                weld_link[b] = (c, li)                       # frame after the body's last joint
+        per_chain = [[] for _ in range(NCHAIN)]
+        state_of = {a: i for i, a in enumerate(muscles)}      # activation state index = order among the muscles
+        for a in muscles:
+            t = m.act_tendon[a]
+            path = []
+            for s_id in m.wrap_site[m.tendon_adr[t]:m.tendon_adr[t] + m.tendon_num[t]]:
+                b = m.site_body[s_id]
+                w = m.body_weldid[b]
+                if w not in weld_link:
+                    raise UnsupportedModel("tendon site on a body outside the root+chains structure")
+                p, r = rel_pose(b)
+                path.append((weld_link[w], p + r @ m.site_pos[s_id]))
+            lanes = sorted(set(cl[0] for cl, _ in path if cl[0] >= 0))
+            if len(lanes) > 1:
+                raise UnsupportedModel("tendon %s spans two chains" % m.tendon_names[t])
+            if m.act_dynprm[a][2] != 0:
+                raise UnsupportedModel("smoothed muscle time constants (tausmooth) are not built on the device")
+            per_chain[lanes[0] if lanes else 0].append((a, path))
+        if max(len(x) for x in per_chain) > MAXMUS or len(muscles) > MT_MAXMUS:
+            raise UnsupportedModel("too many muscles")
+        mt = np.zeros(MT_SIZE)
+        n_mus = n_site = 0
+        for c in range(NCHAIN):
+            mt[c], mt[NCHAIN + c] = n_mus, len(per_chain[c])
+            for a, path in per_chain[c]:
+                rec = mt[MT_HEAD + n_mus * MU_SIZE:MT_HEAD + (n_mus + 1) * MU_SIZE]
+                k = action_of_act.get(a, -1)
+                rec[MU_ACT] = k
+                if k >= 0:
+                    rec[MU_ACT_MEAN], rec[MU_ACT_DELTA] = task["act_mean"][k], task["act_delta"][k]
+                lo, hi = (m.act_ctrlrange[a] if m.act_ctrllimited[a] else (-np.inf, np.inf))
+                rec[MU_CTRL_LO], rec[MU_CTRL_HI] = max(lo, -3e38), min(hi, 3e38)
+                prm, lr = m.act_gainprm[a], m.act_lengthrange[a]
+                l0 = (lr[1] - lr[0]) / max(MINVAL, prm[1] - prm[0])
+                rec[MU_GEAR], rec[MU_LR0], rec[MU_INV_L0], rec[MU_RANGE0] = m.act_gear[a], lr[0], 1.0 / max(MINVAL, l0), prm[0]
+                rec[MU_FORCE], rec[MU_LMIN], rec[MU_LMAX] = prm[2], prm[4], prm[5]
+                rec[MU_INV_L0VMAX], rec[MU_FPMAX], rec[MU_FVMAX] = 1.0 / max(MINVAL, l0 * prm[6]), prm[7], prm[8]
+                rec[MU_TAU_ACT], rec[MU_TAU_DEACT] = m.act_dynprm[a][0], m.act_dynprm[a][1]
+                rec[MU_SITE_ADR], rec[MU_SITE_NUM], rec[MU_STATE] = n_site, len(path), state_of[a]
+                if n_site + len(path) > MT_MAXSITE:
+                    raise UnsupportedModel("too many tendon path entries")
+                for (cl, li), p in path:
+                    mt[MT_SITES + 4 * n_site:MT_SITES + 4 * n_site + 4] = [li, p[0], p[1], p[2]]
+                    n_site += 1
+                n_mus += 1
+        info["muscles_per_chain"] = [len(x) for x in per_chain]
+    elif getattr(m, "na", 0):
+        raise UnsupportedModel("activation states without muscles")
+
     def src_code(obs_idx):
         kind, i = obs_src[int(obs_idx) % task["nobs"]]
         if kind == "g":
@@ -419,9 +507,10 @@ def lower(m, task):
         h[H_REWARD_P0:H_REWARD_P0 + 5] = [src_code(p) for p in rp[:5]]
     h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
     h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
-    info.update(n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
+    h[H_NMUSCLE] = len(muscles)
+    info.update(dropped_root_limits=dropped_root_limits, n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
                 self_collision_pairs=_count_self_pairs(m))
-    return np.concatenate([h, cm]), info
+    return np.concatenate([h, cm] + ([mt] if mt is not None else [])), info
 
 
 def _count_self_pairs(m):

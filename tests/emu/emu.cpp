@@ -32,13 +32,17 @@ struct QuadThreads {
 }  // namespace
 
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
-template <int MC, int NS, bool RK4>
+// act: muscle activations [n][na] double in/out (NM > 0 only)
+template <int MC, int NS, bool RK4, int NM = 0>
 static int emu_run_t(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
-                     int nsub, int debug_env, float* dbgM, float* dbg5, int* counters) {
+                     int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act = nullptr) {
   const double* H = chain_model;
   const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
   std::vector<float> cm(LM_CM_SIZE);
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)H[LM_HEADER_SIZE + i];
+  const int na = (int)H[LM_H_NMUSCLE];
+  std::vector<float> mt(NM > 0 ? LM_MT_SIZE : 1);
+  if (NM > 0) for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)H[LM_HEADER_SIZE + LM_CM_SIZE + i];
   lm::Params P;
   P.h = (float)H[LM_H_TIMESTEP]; P.g = lm::v3((float)H[LM_H_GX], (float)H[LM_H_GY], (float)H[LM_H_GZ]);
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
@@ -76,11 +80,26 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         }
       }
       lm::Counters cnt = {};
-      float lmem[lm::LaneMem<MC, NS>::kSize];
+      using LMm = lm::LaneMem<MC, NS, NM>;
+      float lmem[LMm::kSize];
+      if (NM > 0) {          // this lane's muscles: activation state and control (un-normalised, clamped) into lane memory
+        const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+        for (int i = 0; i < nm; i++) {
+          const float* rec = mt.data() + LM_MT_HEAD + (m0 + i) * LM_MU_SIZE;
+          const int k = (int)rec[LM_MU_ACT];
+          float ctrl = (k >= 0) ? (float)action[e * nu + k] * rec[LM_MU_ACT_DELTA] + rec[LM_MU_ACT_MEAN] : 0.0f;
+          lmem[LMm::kCtrl + i] = fminf(fmaxf(ctrl, rec[LM_MU_CTRL_LO]), rec[LM_MU_CTRL_HI]);
+          lmem[LMm::kAct + i] = (float)act[e * na + (int)rec[LM_MU_STATE]];
+        }
+      }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                              (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr);
+        lm::substep<QuadThreads, MC, NS, RK4, -1, NM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+                                                      (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr, mt.data());
+      if (NM > 0) {
+        const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+        for (int i = 0; i < nm; i++) act[e * na + (int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE]] = lmem[LMm::kAct + i];
+      }
       g_bar.arrive_and_wait();
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
@@ -100,7 +119,9 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
 
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
-                       int* counters /*6*/) {
+                       int* counters /*6*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
+  if ((int)chain_model[LM_H_NMUSCLE] > 0)
+    return act ? emu_run_t<5, 8, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3 || (int)chain_model[LM_H_MAXCONTACTS] > 11;
   if (!big && !rk4) return emu_run_t<3, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);

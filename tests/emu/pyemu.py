@@ -18,7 +18,7 @@ def build():
     return _LIB
 
 
-def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1):
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None):
     lib = C.CDLL(build())
     cmod = np.ascontiguousarray(chain_model, dtype=np.float64)
     nv = int(cmod[2])
@@ -31,7 +31,15 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1):
     d5 = np.zeros((5, nv), dtype=np.float32)
     cnt = np.zeros(6, dtype=np.int32)
     dp = lambda x: x.ctypes.data_as(C.c_void_p)
-    lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
-                dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt))
+    na = int(cmod[31])
+    actv = None
+    if na:
+        actv = np.zeros((n, na)) if act is None else np.array(act, dtype=np.float64).reshape(n, na)
+    rc = lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
+                     dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
+                     dp(actv) if actv is not None else None)
+    assert rc == 0
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
+    if actv is not None:
+        dbg["act"] = actv
     return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5])), dbg

@@ -83,3 +83,37 @@ def test_core_humanoids_rk4_pyramidal(task, nu, rows):
         q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10)
         assert np.abs(q10[0][qidx[2:]] - g[k + 1, :nq]).max() < 1e-5
         assert np.abs(v10[0][qidx] - g[k + 1, nq:]).max() < 1e-3
+
+
+def test_core_muscles():
+    """kernel variant <5,8,Euler,muscles>: tendon paths, muscle forces and activation dynamics in float32 vs oracle/golden."""
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.MT_SIZE
+    o = Oracle(pack_model(m))
+    g = GOLD["HumanoidMuscle.walk.real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    act = np.zeros(m.na)
+    for k in range(18):                       # rows 15-17: a muscle shorter than lmin (force-length fall-through)
+        a = np.random.randn(92) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :17]
+        qvel[qidx] = g[k, 17:36]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        if k in (0, 9, 16):
+            f = o.forward(qpos, qvel, ctrl, act=act)
+            q1, v1, w1, cnt, d = pyemu.run(cmod, qpos, qvel, a, nsub=1, debug_env=0, act=act)
+            want = f["passive"] - f["bias"] + f["actuator"]
+            assert np.abs(d["smooth"] - want).max() < 1e-3 * max(1.0, np.abs(want).max())
+            q10, v10, _, _, d10 = pyemu.run(cmod, qpos, qvel, a, nsub=10, act=act)
+            assert np.abs(q10[0][qidx[2:]] - g[k + 1, :17]).max() < 1e-5
+            assert np.abs(v10[0][qidx] - g[k + 1, 17:36]).max() < 1e-3
+        qo, vo, act_new, wo, st = o.step_act(qpos, qvel, act, ctrl, nsub=10)
+        if k in (0, 9, 16):
+            assert np.abs(d10["act"][0] - act_new).max() < 1e-5
+        act = act_new

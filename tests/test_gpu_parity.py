@@ -358,3 +358,93 @@ def test_humanoid_torque_batch_rollout_properties(humanoid):
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("HumanoidTorque 4096 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HumanoidMuscle.run / .walk (BASELINE config 5's robot): 92 Hill-type muscles on spatial tendons, 92 activation
+# states per environment, Euler; kernel variant <5,8,Euler,muscles>.
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,speed", [("run", 2.5), ("walk", 1.25)])
+def test_humanoid_muscle_one_control_step_kats(task, speed):
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle." + task, debug=True)
+    m = env._model
+    hm = HipModel(env._chain_model())
+    oracle = Oracle(pack_model(m))
+    g = GOLD["HumanoidMuscle.%s.real" % task]
+    n = len(g) - 1
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(92) * 0.1 for _ in range(n)])
+    # the observation holds no activations: replay them (they depend on the action stream only) with the oracle
+    act_rows, act = [], np.zeros(m.na)
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :17]
+    qvel[:, qidx] = g[:n, 17:36]
+    for k in range(n):
+        act_rows.append(act)
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[k])
+        act = oracle.step_act(qpos[k], qvel[k], act, ctrl, nsub=10)[2]
+    act_rows.append(act)
+    act_rows = np.array(act_rows)
+    b = HipBatch(hm, n)
+    assert b.na == 92
+    b.set_state(qpos, qvel)
+    b.set_activation(act_rows[:n])
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :17] - g[1:, :17]).max(axis=1), np.abs(obs[:, 17:36] - g[1:, 17:36]).max(axis=1)
+    ea = np.abs(b.get_activation() - act_rows[1:]).max()
+    print("HumanoidMuscle.%s KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e | act max %.2e"
+          % (task, eq.max(), np.median(eq), ev.max(), np.median(ev), ea))
+    assert eq.max() < QTOL and ev.max() < VTOL and ea < 1e-5
+    assert list(done) == [bool(env._has_fallen(g[k + 1])) for k in range(n)]
+    want = [np.exp(-(g[k][17] - speed) ** 2) for k in range(n)]
+    assert np.abs(rew - want).max() < 1e-5
+    assert b.stats()["overflow_contacts"] == 0
+    b.set_state(qpos, qvel)                                  # like mj_resetData: activations back to zero
+    assert np.abs(b.get_activation()).max() == 0
+
+
+def test_humanoid_muscle_env_rollout_follows_reference_test():
+    g = GOLD["HumanoidMuscle.run.real"]
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle.run", debug=True)
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(100):
+        if absorbing:
+            break
+        obs, r, absorbing, info = env.step(np.random.randn(92) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    assert np.abs(rows[:, :17] - g[:, :17]).max() < 5e-3
+
+
+def test_humanoid_muscle_batch_rollout_properties():
+    """2048 environments (BASELINE config 5's per-GPU share), random policy, device auto-reset."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle.run", debug=True)
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    n = 2048
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, len(tab), n)]
+    b = HipBatch(hm, n)
+    b.set_reset_table(tab, seed=1)
+    b.set_auto_reset(True, horizon=1000)
+    b.set_state(rows[:, :19], rows[:, 19:38])
+    st = b.rollout(30, action_mode=1, seed=5)
+    q, v = b.get_state()
+    act = b.get_activation()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(act).all()
+    assert act.min() >= 0 and act.max() <= 1
+    assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
+    print("HumanoidMuscle 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep %.2f"
+          % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 10)))

@@ -179,3 +179,21 @@ def test_humanoid_torque_surface():
             loco_mujoco_amd.HumanoidTorque(**kw)
     with pytest.raises(NotImplementedError):
         LocoEnv.make("HumanoidTorque.walk.perfect")
+
+
+def test_humanoid_muscle_surface():
+    np.random.seed(0)
+    e = LocoEnv.make("HumanoidMuscle.walk", debug=True)
+    assert e.info.observation_space.shape == (36,) and e.info.action_space.shape == (92,)
+    m = e._model
+    assert (m.nv, m.nu, m.na, m.ntendon) == (19, 92, 92, 92) and m.integrator == mjcf.INT_EULER
+    # muscle controls live in [0, 1]: actions in [-1, 1] are mapped onto them (base.py:122-126, 606-621)
+    assert np.allclose(e.norm_act_mean, 0.5) and np.allclose(e.norm_act_delta, 0.5)
+    assert e._action_spec[0] == "glut_med1_r" and e._action_spec[43] == "glut_med1_l" and e._action_spec[-1] == "extobl_l"
+    assert [m.act_names[i] for i in e._action_indices] == e._action_spec
+    obs = e.reset()
+    assert np.abs(obs - GOLD["HumanoidMuscle.walk.real"][0]).max() < 1e-14
+    assert "HumanoidMuscle.run.real" in loco_mujoco_amd.get_all_task_names()
+    from loco_mujoco_amd import lowering
+    cm, info = lowering.lower(m, e._device_task())
+    assert info["muscles_per_chain"] == [43, 43, 6, 0]      # every tendon runs over the pelvis and one chain
