@@ -1,7 +1,7 @@
 """
 bench.py — env-steps/s of the batched LocoEnv.step() hot path (BASELINE.json metric) on N GPUs of one node.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 4096]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 4096] [--task UnitreeA1.simple]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -11,6 +11,9 @@ device-side auto-reset on _has_fallen or after 1000 control steps. A "step" = on
 environment (= 10 physics substeps + observation + reward + termination + resets), one kernel launch.
 Environments are independent: ranks shard them (weak scaling), the only collective is the metric
 all-reduce (RCCL) at report time.
+
+`--task` switches to the other BASELINE robots for side measurements (HumanoidTorque.run / Atlas.walk /
+HumanoidMuscle.run with the device's random policy a ~ U(-1,1)); the driver's default run is the A1 line above.
 
 The timed region holds inputs resident in HBM (state lives on the device); it is bracketed by a barrier +
 device synchronisation on both sides, the maximum over ranks is taken.
@@ -35,32 +38,43 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def algorithmic_bytes_per_env_step(nq, nv, nu, nobs):
-    # state in + state out + action + obs + reward + done, plus the solver warm start in/out
-    return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv
+def algorithmic_bytes_per_env_step(nq, nv, nu, nobs, na=0):
+    # state in + state out + action + obs + reward + done, plus the solver warm start in/out and the muscle
+    # activations in/out
+    return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv + 8 * na
 
 
-def cpu_baseline(env, table, budget_s=12.0):
-    """fp64 oracle restatement, one thread, zero action, same initial-state distribution; bounded sample."""
+def cpu_baseline(env, table, task, random_policy, budget_s=12.0):
+    """fp64 oracle restatement, one thread, same policy and initial-state distribution; bounded sample."""
     from loco_mujoco_amd.model_blob import pack_model
     from oracle.pyoracle import Oracle
-    oracle = Oracle(pack_model(env._model))
+    m = env._model
+    oracle = Oracle(pack_model(m))
     rs = np.random.RandomState(0)
-    ctrl = np.zeros(env._model.nu)
+    nv, na = m.nv, getattr(m, "na", 0)
+    qi = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec[2:] if k.startswith("q_")]
+    vi = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec[2:] if k.startswith("dq_")]
     steps, t0, n_env = 0, time.perf_counter(), 0
     while time.perf_counter() - t0 < budget_s:
-        row = table[rs.randint(0, 3) * 100 + rs.randint(0, 100)]
-        q, v, w = row[:18].copy(), row[18:36].copy(), np.zeros(18)
+        row = table[rs.randint(0, len(table))]
+        q, v, w, act = row[:nv].copy(), row[nv:2 * nv].copy(), np.zeros(nv), np.zeros(na)
         n_env += 1
         for _ in range(25):
-            q, v, w, _ = oracle.step(q, v, ctrl, 10, w)
+            ctrl = np.zeros(m.nu)
+            if random_policy:
+                ctrl[env._action_indices] = env._preprocess_action(rs.uniform(-1, 1, len(env._action_indices)))
+            if na:
+                q, v, act, w, _ = oracle.step_act(q, v, act, ctrl, 10, w)
+            else:
+                q, v, w, _ = oracle.step(q, v, ctrl, 10, w)
             steps += 1
-            if env._has_fallen(np.concatenate([q[2:], v, row[36:39]])):
+            if env._has_fallen(np.concatenate([q[qi], v[vi], row[2 * nv:]])):
                 break
     dt = time.perf_counter() - t0
     return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
-                sample="%d control steps over %d episodes of UnitreeA1.simple (zero action, until fallen or 25 steps), "
-                       "fp64 C oracle restatement, 1 thread, %.1f s" % (steps, n_env, dt))
+                sample="%d control steps over %d episodes of %s (%s, until fallen or 25 steps), "
+                       "fp64 C oracle restatement, 1 thread, %.1f s"
+                       % (steps, n_env, task, "random action" if random_policy else "zero action", dt))
 
 
 def main():
@@ -70,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--task", default="UnitreeA1.simple")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -86,19 +101,27 @@ def main():
     from loco_mujoco_amd.backend import HipBatch, HipModel
 
     n = args.envs_per_gpu
+    default_task = args.task == "UnitreeA1.simple"
+    action_mode = 0 if default_task else 1            # zero action (config 2) | device random policy (configs 3-5)
     np.random.seed(0)
-    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    env = LocoEnv.make(args.task, debug=True)
     table = env._reset_table()
     hm = HipModel(env._chain_model(), device=local_rank)
     b = HipBatch(hm, n)
     offset = rank * n
+    nv = env._model.nv
     rs = np.random.RandomState(0)
-    traj, step = rs.randint(0, 3, n * world), rs.randint(0, 100, n * world)
-    rows = table[(traj * 100 + step)[offset:offset + n]]
+    if default_task:
+        traj, step = rs.randint(0, 3, n * world), rs.randint(0, 100, n * world)
+        pick = traj * 100 + step
+    else:
+        pick = rs.randint(0, len(table), n * world)
+    rows = table[pick[offset:offset + n]]
     b.set_reset_table(table, seed=0, global_env_offset=offset)
     b.set_auto_reset(True, horizon=env.info.horizon)
-    b.set_state(rows[:, :18], rows[:, 18:36])
-    b.set_goal(rows[:, 36:39])
+    b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
+    if rows.shape[1] > 2 * nv:
+        b.set_goal(rows[:, 2 * nv:])
 
     def barrier():
         b.sync()
@@ -107,11 +130,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    b.rollout(args.warmup, action_mode=0)
+    b.rollout(args.warmup, action_mode=action_mode, seed=11)
     b.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
-    st = b.rollout(args.steps, action_mode=0)
+    st = b.rollout(args.steps, action_mode=action_mode, seed=12)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -132,13 +155,15 @@ def main():
         return
     env_steps = vals[1]
     value = env_steps / elapsed
-    nq = nv = env._model.nv
-    bytes_per_launch = algorithmic_bytes_per_env_step(nq, nv, env._model.nu, 37) * n
+    m = env._model
+    forwards = 40 if m.integrator else 10             # RK4: four forward passes per substep
+    per_env_step = algorithmic_bytes_per_env_step(nv, nv, len(env._action_indices), b.nobs, getattr(m, "na", 0))
+    bytes_per_launch = per_env_step * n
     launch_s = kernel_ms * 1e-3 / args.steps
     achieved = bytes_per_launch / launch_s / 1e9
     traffic = None
     prof = os.path.join(ROOT, "profiles", "r1_pmc.json")
-    if os.path.exists(prof) and n == 4096:
+    if os.path.exists(prof) and n == 4096 and default_task:
         try:
             pmc = json.load(open(prof))["pmc"]
             # separate --pmc passes (tools/probes/prof_run.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)
@@ -150,21 +175,25 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "UnitreeA1.simple, %d envs/GPU, zero-action rollout, device-side auto-reset "
-                               "(horizon 1000), 10 physics substeps per env-step" % n,
+        "config": {"workload": "%s, %d envs/GPU, %s rollout, device-side auto-reset "
+                               "(horizon 1000), 10 physics substeps per env-step"
+                               % (args.task, n, "zero-action" if default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "kernel": "step_kernel<3,4,false>", "kernel_ms_per_launch": 1e3 * launch_s,
-                     "note": "path is VALU/latency-bound by design (SURVEY.md 8d): 636 algorithmic B per env-step; traffic = PMC bytes per launch from profiles/r1_pmc.json (same command, separate rocprofv3 --pmc passes)"},
+                     "kernel": "step_kernel", "kernel_ms_per_launch": 1e3 * launch_s,
+                     "algorithmic_bytes_per_env_step": per_env_step,
+                     "note": "path is VALU-issue/latency-bound by design (SURVEY.md 8d): %d algorithmic B per env-step; "
+                             "traffic = PMC bytes per launch from profiles/r1_pmc.json (same command, separate rocprofv3 "
+                             "--pmc passes)" % per_env_step},
         "stats": {"episodes": vals[2], "mean_reward": vals[3] / max(env_steps, 1), "nan_resets": vals[4],
                   "overflow_contacts": vals[5], "unhandled_geom_substeps": vals[6],
-                  "newton_iters_per_substep": vals[7] / max(env_steps * 10, 1),
+                  "newton_iters_per_forward_pass": vals[7] / max(env_steps * forwards, 1),
                   "physics_substeps_per_s": 10 * value},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(env, table)
+        out["cpu_baseline"] = cpu_baseline(env, table, args.task, not default_task)
         out["cpu_baseline"]["gpu_over_cpu_core"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
