@@ -13,6 +13,8 @@
  *   lm_set_state        <- LocoEnv.set_sim_state: data.joint(name).qpos/qvel = value (base.py:478-497)
  *                          after mj_resetData (base.py:180): also clears the solver warm start
  *   lm_get_state        <- data.qpos / data.qvel reads (ObservationHelper._build_obs, base.py:202)
+ *   lm_set_dof_params / lm_set_dof_randomization <- DomainRandomizationHandler.get_randomized_model
+ *                          (utils/domain_randomization.py:219-227): joint damping/stiffness/frictionloss per environment
  *   lm_set/get_activation <- data.act (muscle activation state, humanoids.py:320 HumanoidMuscle; integrated by mj_step)
  *   lm_set_goal         <- per-episode goal written into the observation
  *                          (unitreeA1.py:288-291 set_goal, :454-476 _create_observation)
@@ -95,6 +97,16 @@ int lm_get_state(lm_batch* b, float* qpos, float* qvel);
 int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask);
 /* muscle activations [n_envs][na] (data.act of the reference: mj_resetData zeroes it, base.py:180, so lm_set_state
    and device-side episode restarts zero it too; these two exist for checkpointing and for parity tests) */
+/* per-environment joint damping / stiffness / frictionloss [n_envs][nv] (NULL = leave as is) — what the reference's
+   domain randomisation changes per episode by re-compiling the model (utils/domain_randomization.py:299-383,
+   base.py:183-185). The first call allocates the arrays (initialised with the model's values) and switches the batch
+   to the kernel variant that reads them. */
+int lm_set_dof_params(lm_batch* b, const float* damping, const float* stiffness, const float* frictionloss,
+                      const uint8_t* mask);
+int lm_get_dof_params(lm_batch* b, float* damping, float* stiffness, float* frictionloss);
+/* redraw rule used when the device restarts an episode (lm_set_auto_reset): spec[3][nv][3] = (kind, a, b) per parameter
+   (damping, stiffness, frictionloss) and dof; kind 0 keep, 1 max(N(a,b),0), 2 U(a,b), 3 N(a,b). NULL disables. */
+int lm_set_dof_randomization(lm_batch* b, const float* spec);
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
 int lm_get_activation(lm_batch* b, float* act);
 

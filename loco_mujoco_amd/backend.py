@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
-           "lm_set_goal", "lm_step",
+           "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_forward_debug", "lm_get_stats", "lm_sync"]
 
 _lib = None
@@ -66,6 +66,9 @@ def load_library():
     lib.lm_set_state.argtypes = [C.c_void_p, _F, _F, _U8]
     lib.lm_get_state.argtypes = [C.c_void_p, _F, _F]
     lib.lm_set_goal.argtypes = [C.c_void_p, _F, _U8]
+    lib.lm_set_dof_params.argtypes = [C.c_void_p, _F, _F, _F, _U8]
+    lib.lm_get_dof_params.argtypes = [C.c_void_p, _F, _F, _F]
+    lib.lm_set_dof_randomization.argtypes = [C.c_void_p, _F]
     lib.lm_set_activation.argtypes = [C.c_void_p, _F, _U8]
     lib.lm_get_activation.argtypes = [C.c_void_p, _F]
     lib.lm_step.argtypes = [C.c_void_p, _F, _F, _F, _U8]
@@ -154,6 +157,25 @@ class HipBatch:
         v = np.empty((self.n, self.nv), dtype=np.float32)
         _check(self._lib.lm_get_state(self._h, _fp(q), _fp(v)))
         return q, v
+
+    def set_dof_params(self, damping=None, stiffness=None, frictionloss=None, mask=None):
+        """Per-environment joint parameters [n, nv] (domain randomisation); None leaves a parameter as it is."""
+        arrs = [None if x is None else _f32(x, (self.n, self.nv)) for x in (damping, stiffness, frictionloss)]
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_set_dof_params(self._h, *[None if x is None else _fp(x) for x in arrs], mp))
+
+    def get_dof_params(self):
+        out = [np.empty((self.n, self.nv), dtype=np.float32) for _ in range(3)]
+        _check(self._lib.lm_get_dof_params(self._h, *[_fp(x) for x in out]))
+        return dict(damping=out[0], stiffness=out[1], frictionloss=out[2])
+
+    def set_dof_randomization(self, spec):
+        """Device-side redraw rule at episode restarts: spec[3, nv, 3] = (kind, a, b); None disables."""
+        if spec is None:
+            _check(self._lib.lm_set_dof_randomization(self._h, None))
+            return
+        s = _f32(spec, (3, self.nv, 3))
+        _check(self._lib.lm_set_dof_randomization(self._h, _fp(s)))
 
     def set_activation(self, act, mask=None):
         """Muscle activations [n, na] (set_state zeroes them like mj_resetData; this is for checkpoints and tests)."""

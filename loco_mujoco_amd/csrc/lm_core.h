@@ -172,6 +172,9 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
+// per-environment joint parameters (domain randomisation): replaces the table's damping / stiffness / frictionloss
+template <int MC> struct DofPrm { float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC]; };
+
 // lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM]
 template <int MC, int NS, int NM = 0> struct LaneMem {
   static constexpr int kSlots = 0;
@@ -423,10 +426,11 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // CONE: LM_CONE_PYRAMIDAL / LM_CONE_ELLIPTIC compiles the other cone's code out; -1 reads it from P.cone
 // NM > 0: the chain's muscles (table `mt`, lm_layout.h MT_*/MU_*) act on the chain dofs; their activations and
 // controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
-template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0>
+// DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
+template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg, const float* mt = nullptr) {
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
@@ -439,6 +443,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define LX(k, f) LK(k, LM_D_SIZE + (f))
 #define GE(g, f) CH(LM_C_GEOMS + (g) * LM_G_SIZE + (f))
 #define SL(s, f) lmem[((s) * SL_SIZE + (f)) * ls]
+#define DAMP_R(i) (DR ? dp->damp_r[i] : RD(i, LM_D_DAMP))
+#define STIFF_R(i) (DR ? dp->stiff_r[i] : RD(i, LM_D_STIFF))
+#define FLOSS_R(i) (DR ? dp->floss_r[i] : RD(i, LM_D_FLOSS))
+#define DAMP_C(k) (DR ? dp->damp_c[k] : LK(k, LM_D_DAMP))
+#define STIFF_C(k) (DR ? dp->stiff_c[k] : LK(k, LM_D_STIFF))
+#define FLOSS_C(k) (DR ? dp->floss_c[k] : LK(k, LM_D_FLOSS))
   const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
   const int nl = (int)CH(LM_C_NLINKS);
   LM_TICK_INIT();
@@ -749,9 +759,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
     // ======== smooth forces, unconstrained acceleration ========
 #pragma unroll
-    for (int i = 0; i < 6; i++) sm_r[i] = -RD(i, LM_D_STIFF) * qr[i] - RD(i, LM_D_DAMP) * vr[i] - bias_r[i] + actr[i];
+    for (int i = 0; i < 6; i++) sm_r[i] = -STIFF_R(i) * qr[i] - DAMP_R(i) * vr[i] - bias_r[i] + actr[i];
 #pragma unroll
-    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-LK(k, LM_D_STIFF) * qc[k] - LK(k, LM_D_DAMP) * vc[k] - bias_c[k] + actc[k] + musc[k]) : 0.0f;
+    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-STIFF_C(k) * qc[k] - DAMP_C(k) * vc[k] - bias_c[k] + actc[k] + musc[k]) : 0.0f;
     // park M and the twists in lane memory
 #pragma unroll
     for (int i = 0; i < MC * (MC + 1) / 2; i++) LMEM(LMm::kMcc + i) = Mcc[i];
@@ -860,11 +870,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   auto cost_at = [&](const float* xr, const float* xc) -> float {
     float cost = 0, cr = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], RD(i, LM_D_FLOSS), RD(i, LM_D_FLOSS_R));
+    for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), RD(i, LM_D_FLOSS_R));
     cost = w0 * cr;
 #pragma unroll
     for (int k = 0; k < MC; k++) if (k < nl) {
-      cost += friction_cost(xc[k] - fl_aref_c[k], LK(k, LM_D_FLOSS), LK(k, LM_D_FLOSS_R));
+      cost += friction_cost(xc[k] - fl_aref_c[k], FLOSS_C(k), LK(k, LM_D_FLOSS_R));
       float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
       if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
     }
@@ -918,9 +928,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) qf_c[k] = 0;
   bool has_rows = false;
 #pragma unroll
-  for (int i = 0; i < 6; i++) has_rows = has_rows || (RD(i, LM_D_FLOSS) > 0.0f);
+  for (int i = 0; i < 6; i++) has_rows = has_rows || (FLOSS_R(i) > 0.0f);
 #pragma unroll
-  for (int k = 0; k < MC; k++) has_rows = has_rows || (k < nl && (LK(k, LM_D_FLOSS) > 0.0f || lim_s_c[k] != 0.0f));
+  for (int k = 0; k < MC; k++) has_rows = has_rows || (k < nl && (FLOSS_C(k) > 0.0f || lim_s_c[k] != 0.0f));
   has_rows = has_rows || nslot > 0;
   bool done = !(Q::sum(has_rows ? 1.0f : 0.0f) > 0.0f);   // quad-uniform: nothing to solve in this environment
   int iters = 0;
@@ -945,7 +955,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        ff_r[i] = RD(i, LM_D_FLOSS); const float Rr = RD(i, LM_D_FLOSS_R);
+        ff_r[i] = FLOSS_R(i); const float Rr = RD(i, LM_D_FLOSS_R);
         iR_r[i] = (ff_r[i] > 0.0f) ? 1.0f / Rr : 0.0f;
         const float x = ar[i] - fl_aref_r[i];
         jfr_r[i] = x;
@@ -954,7 +964,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       }
 #pragma unroll
       for (int k = 0; k < MC; k++) {
-        ff_c[k] = (k < nl) ? LK(k, LM_D_FLOSS) : 0.0f; const float Rr = (k < nl) ? LK(k, LM_D_FLOSS_R) : 1.0f;
+        ff_c[k] = (k < nl) ? FLOSS_C(k) : 0.0f; const float Rr = (k < nl) ? LK(k, LM_D_FLOSS_R) : 1.0f;
         iR_c[k] = (ff_c[k] > 0.0f) ? 1.0f / Rr : 0.0f;
         jfr_c[k] = ac[k] - fl_aref_c[k];
         jlim_c[k] = lim_s_c[k] * ac[k] - lim_aref_c[k];
@@ -1304,10 +1314,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     for (int k = 0; k < MC; k++) {
 #pragma unroll
       for (int r = 0; r < 6; r++) Hcr[k][r] = LMEM(LMm::kMcr + k * 6 + r);
-      if (k < nl) Hcc[tri(k, k)] += P.h * LK(k, LM_D_DAMP);
+      if (k < nl) Hcc[tri(k, k)] += P.h * DAMP_C(k);
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) Hrep[tri(i, i)] += P.h * RD(i, LM_D_DAMP);
+    for (int i = 0; i < 6; i++) Hrep[tri(i, i)] += P.h * DAMP_R(i);
     arrow_factor<Q, MC>(Hcc, Hcr, Hrep, zero21, Lr);
     float xr[6], xc[MC];
 #pragma unroll
@@ -1321,6 +1331,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     for (int k = 0; k < MC; k++) if (k < nl) { vc[k] = fmaf(P.h, xc[k], vc[k]); qc[k] = fmaf(P.h, vc[k], qc[k]); }
   }
   LM_TICK(9);
+#undef DAMP_R
+#undef STIFF_R
+#undef FLOSS_R
+#undef DAMP_C
+#undef STIFF_C
+#undef FLOSS_C
 #undef RD
 #undef CH
 #undef LK
@@ -1332,12 +1348,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg, const float* mt = nullptr) {
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
-  if (!RK4) { forward<Q, MC, NS, true, CONE, NM>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
@@ -1345,7 +1361,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
-    forward<Q, MC, NS, false, CONE>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr);
+    forward<Q, MC, NS, false, CONE, 0, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp);
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]
 #pragma unroll

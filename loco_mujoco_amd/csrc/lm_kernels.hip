@@ -41,6 +41,7 @@ struct QuadDpp {
 };
 
 thread_local std::string g_err;
+thread_local const char* g_launch_err = nullptr;
 int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -55,6 +56,8 @@ struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
   const float* mt;          // muscle table [LM_MT_SIZE] or null
   float* act;               // muscle activations, SoA [na][N], or null
+  float* dofprm;            // per-environment joint damping | stiffness | frictionloss, SoA [3][nv][N], or null
+  const float* drspec;      // their redraw rule at an episode restart [3][nv][3] = (kind, a, b), or null
   float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
@@ -81,7 +84,7 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __shared__ float cm[LM_CM_SIZE];
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
@@ -113,6 +116,17 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) goal[i] = (i < a.T.ngoal) ? a.goal[i * N + e] : 0.0f;
+  lm::DofPrm<MC> dofp;
+  if (DR) {
+    const long long pn = (long long)nv * N;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { dofp.damp_r[i] = a.dofprm[dr[i] * N + e]; dofp.stiff_r[i] = a.dofprm[pn + dr[i] * N + e]; dofp.floss_r[i] = a.dofprm[2 * pn + dr[i] * N + e]; }
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      dofp.damp_c[k] = (k < nl) ? a.dofprm[dc[k] * N + e] : 0.0f; dofp.stiff_c[k] = (k < nl) ? a.dofprm[pn + dc[k] * N + e] : 0.0f;
+      dofp.floss_c[k] = (k < nl) ? a.dofprm[2 * pn + dc[k] * N + e] : 0.0f;
+    }
+  }
 
   // ---- reward on the PREVIOUS observation (reference utils/reward.py:73,110-115)
   auto src = [&](float code) -> float {
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -229,6 +243,28 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       }
       step_no = 0;
       zero_act = true;
+      if (DR && a.drspec && valid) {
+        // new episode, new joint parameters (reference base.py:183-185): counter-based draws keyed like the state draw
+        auto redraw = [&](int dof, int p) {
+          const float* sp = a.drspec + ((long long)p * nv + dof) * 3;
+          const int kind = (int)sp[0];
+          if (kind == 0) return;
+          const unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ (unsigned long long)(dof * 3 + p + 1) * 0xD6E8FEB86659FD93ull);
+          const float u1 = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)((r >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);
+          float v;
+          if (kind == 2) v = sp[1] + (sp[2] - sp[1]) * u1;                          // U(a, b)
+          else {
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);        // N(a, b), kind 1 clipped at 0
+            v = fmaf(sp[2], z, sp[1]);
+            if (kind == 1) v = fmaxf(v, 0.0f);
+          }
+          a.dofprm[((long long)p * nv + dof) * N + e] = v;
+        };
+        for (int p = 0; p < 3; p++) {
+          if (c == 0) for (int i = 0; i < 6; i++) redraw(dr[i], p);
+          for (int k = 0; k < MC; k++) if (k < nl) redraw(dc[k], p);
+        }
+      }
     } else if (nonfinite) {
       zero_act = true;
       // no reset table: park the environment at rest in its last finite configuration is impossible; zero it
@@ -303,6 +339,7 @@ struct lm_model {
   int device;
   float* d_cm;
   float* d_mt;               // muscle table (models with muscles)
+  std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
   int nroot;
   std::vector<int> root_dofs;
@@ -313,6 +350,8 @@ struct lm_batch {
   int N;
   float *qpos, *qvel, *warm, *goal, *action, *obs, *reward, *table;
   float* act;                // muscle activations [na][N]
+  float* dofprm;             // per-environment joint parameters [3][nv][N] (allocated by lm_set_dof_params)
+  float* drspec;             // redraw rules [3][nv][3] (lm_set_dof_randomization)
   unsigned char* done;
   int* ep_step; unsigned* ep_count;
   DevStats* stats;
@@ -340,6 +379,20 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   const bool big = b->m->T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4;
   static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: cone read at run time
   const int cone = generic ? -2 : b->m->P.cone;
+  if (!FWD && b->dofprm) {
+    // per-environment joint parameters: the three shipped robot families have a kernel that reads them
+    if (!big && !rk4 && b->m->P.cone == LM_CONE_ELLIPTIC) {
+      const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kGroup * ((block.x + 15) / 16);
+      launch_one(step_kernel<3, 4, false, false, LM_CONE_ELLIPTIC, 0, true>, grid, block, lane_bytes, b, a);
+    } else if (big && rk4 && b->m->T.na == 0) {
+      const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kGroup * ((block.x + 15) / 16);
+      launch_one(step_kernel<5, 8, true, false, -1, 0, true>, grid, block, lane_bytes, b, a);
+    } else if (big && !rk4 && b->m->T.na > 0) {
+      const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup * ((block.x + 15) / 16);
+      launch_one(step_kernel<5, 8, false, false, -1, LM_MAXMUS, true>, grid, block, lane_bytes, b, a);
+    } else g_launch_err = "per-environment joint parameters are not compiled for this model family";
+    return;
+  }
   if (!big) {
     const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kGroup * ((block.x + 15) / 16);
     if (!rk4) {
@@ -400,6 +453,20 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   }
   Task& T = m->T;
   T.na = n_muscle;
+  {
+    const int nv = (int)cmod[LM_H_NV];
+    m->nominal.assign((size_t)3 * nv, 0.0f);
+    auto put = [&](const float* blk, int stride) {
+      const int d = (int)blk[LM_D_DOF * stride];
+      if (d < 0 || d >= nv) return;
+      m->nominal[d] = blk[LM_D_DAMP * stride]; m->nominal[nv + d] = blk[LM_D_STIFF * stride]; m->nominal[2 * nv + d] = blk[LM_D_FLOSS * stride];
+    };
+    for (int i = 0; i < 6; i++) put(cm.data() + LM_R_DOFS + i * LM_D_SIZE, 1);
+    for (int c = 0; c < LM_NCHAIN; c++) {
+      const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
+      for (int k = 0; k < nl; k++) put(cm.data() + LM_CM_CHAINS + (LM_C_LINKS + k * LM_LINK_SIZE) * LM_NCHAIN + c, LM_NCHAIN);
+    }
+  }
   T.nv = (int)cmod[LM_H_NV]; T.nu = (int)cmod[LM_H_NU]; T.nobs = (int)cmod[LM_H_NOBS]; T.ngoal = (int)cmod[LM_H_NGOAL];
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
   T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS];
@@ -461,7 +528,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
   HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
-  b->act = nullptr;
+  b->act = nullptr; b->dofprm = nullptr; b->drspec = nullptr;
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
@@ -481,7 +548,7 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   hipStreamSynchronize(b->stream);
   (void)hipFree(b->qpos); (void)hipFree(b->qvel); (void)hipFree(b->warm); (void)hipFree(b->goal); (void)hipFree(b->action); (void)hipFree(b->obs);
-  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table); if (b->act) (void)hipFree(b->act);
+  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table); if (b->act) (void)hipFree(b->act); if (b->dofprm) (void)hipFree(b->dofprm); if (b->drspec) (void)hipFree(b->drspec);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -545,6 +612,49 @@ int lm_get_state(lm_batch* b, float* qpos, float* qvel) {
   return 0;
 }
 
+int lm_set_dof_params(lm_batch* b, const float* damping, const float* stiffness, const float* frictionloss, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N, nv = b->m->T.nv;
+  if (!b->dofprm) {
+    std::vector<float> init((size_t)3 * nv * N);
+    for (int p = 0; p < 3; p++) for (int d = 0; d < nv; d++) for (int e = 0; e < N; e++) init[((size_t)p * nv + d) * N + e] = b->m->nominal[(size_t)p * nv + d];
+    HIPCHK(hipMalloc(&b->dofprm, sizeof(float) * 3 * nv * N));
+    HIPCHK(hipMemcpy(b->dofprm, init.data(), sizeof(float) * 3 * nv * N, hipMemcpyHostToDevice));
+  }
+  const float* src[3] = {damping, stiffness, frictionloss};
+  for (int p = 0; p < 3; p++) {
+    if (!src[p]) continue;
+    for (size_t i = 0; i < (size_t)N * nv; i++) if (!(src[p][i] >= 0.0f) && (!mask || mask[i / nv])) return fail("joint parameters must be non-negative");
+    if (upload_soa(b, b->dofprm + (size_t)p * nv * N, src[p], nv, mask)) return 1;
+  }
+  return 0;
+}
+
+int lm_get_dof_params(lm_batch* b, float* damping, float* stiffness, float* frictionloss) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int N = b->N, nv = b->m->T.nv;
+  float* dst[3] = {damping, stiffness, frictionloss};
+  std::vector<float> soa((size_t)nv * N);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int p = 0; p < 3; p++) {
+    if (!dst[p]) continue;
+    if (b->dofprm) HIPCHK(hipMemcpy(soa.data(), b->dofprm + (size_t)p * nv * N, sizeof(float) * nv * N, hipMemcpyDeviceToHost));
+    for (int e = 0; e < N; e++) for (int d = 0; d < nv; d++) dst[p][(size_t)e * nv + d] = b->dofprm ? soa[(size_t)d * N + e] : b->m->nominal[(size_t)p * nv + d];
+  }
+  return 0;
+}
+
+int lm_set_dof_randomization(lm_batch* b, const float* spec) {
+  HIPCHK(hipSetDevice(b->m->device));
+  const int nv = b->m->T.nv;
+  if (!spec) { if (b->drspec) { (void)hipFree(b->drspec); b->drspec = nullptr; } return 0; }
+  for (int i = 0; i < 3 * nv; i++) { const int k = (int)spec[3 * i]; if (k < 0 || k > 3) return fail("bad randomisation kind"); }
+  if (!b->dofprm && lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;
+  if (!b->drspec) HIPCHK(hipMalloc(&b->drspec, sizeof(float) * 9 * nv));
+  HIPCHK(hipMemcpy(b->drspec, spec, sizeof(float) * 9 * nv, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->m->device));
   if (!b->act) return fail("model has no activation states");
@@ -571,7 +681,7 @@ int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask) {
 static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
-  a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
   a.ep_step = b->ep_step; a.ep_count = b->ep_count;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
@@ -580,7 +690,7 @@ static KArgs make_args(lm_batch* b) {
   return a;
 }
 
-static void launch_step(lm_batch* b, const KArgs& a) { launch_variant<false>(b, a); }
+static void launch_step(lm_batch* b, const KArgs& a) { g_launch_err = nullptr; launch_variant<false>(b, a); }
 
 static int drain_stats(lm_batch* b) {
   std::vector<DevStats> s(b->nblocks);
@@ -603,6 +713,7 @@ int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t
   else a.action_mode = 1;
   a.obs = b->obs; a.reward = b->reward; a.done = b->done;
   launch_step(b, a);
+  if (g_launch_err) return fail(g_launch_err);
   HIPCHK(hipGetLastError());
   b->step_index++;
   if (obs) HIPCHK(hipMemcpyAsync(obs, b->obs, sizeof(float) * T.nobs * N, hipMemcpyDeviceToHost, b->stream));
@@ -641,6 +752,7 @@ int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stat
   for (int s = 0; s < n_steps; s++) {
     a.step_index = b->step_index++;
     launch_step(b, a);
+    if (g_launch_err) return fail(g_launch_err);
   }
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   HIPCHK(hipGetLastError());

@@ -1,7 +1,8 @@
 """
 Atlas humanoid environment — host-side mirror of the reference's
 ``loco_mujoco/environments/humanoids/atlas.py`` (+ ``base_robot_humanoid.py``) for the default configuration of
-BASELINE config 4: arms and back joints disabled (``atlas.py:275,338-364``), no carried weight.
+BASELINE config 4: arms disabled, back joints disabled by default (``atlas.py:275,338-364``; ``disable_back_joint=False``
+adds the three-joint back chain, the only joints the shipped domain-randomisation file touches), no carried weight.
 10 torque actuators (ctrl range +-0.95), 30-dim observation (14 joint positions without the two horizontal
 root coordinates, 16 joint velocities), RK4 integrator, pyramidal friction cones, box/cylinder geoms that
 collide with the floor only (``data/atlas/atlas.xml:27,65``).
@@ -35,26 +36,27 @@ class Atlas(LocoEnv):
 
     def __init__(self, disable_arms=True, disable_back_joint=True, hold_weight=False, weight_mass=None,
                  xml_path=None, timestep=0.001, **kwargs):
-        if hold_weight or not disable_arms or not disable_back_joint:
-            raise NotImplementedError("only the default Atlas configuration (arms and back joints disabled, no "
-                                      "carried weight) is built (SURVEY.md §8f rank 3)")
+        if hold_weight or not disable_arms:
+            raise NotImplementedError("Atlas with free arms or a carried weight is not built (SURVEY.md §8f rank 3): the "
+                                      "arms would hang off the end of the back chain (branching below the root)")
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, hold_weight
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
         drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
         observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
         action_spec = [a for a in self._get_action_specification() if a not in motors_to_remove]
-        model = self._load_model(xml_path, timestep, joints_to_remove, motors_to_remove)
+        model = self._load_model(xml_path, timestep, joints_to_remove, motors_to_remove,
+                                 "default" if disable_back_joint else "back")
         collision_groups = [("floor", ["floor"]), ("foot_r", ["right_foot_back"]), ("front_foot_r", ["right_foot_front"]),
                             ("foot_l", ["left_foot_back"]), ("front_foot_l", ["left_foot_front"])]
         super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
 
     @classmethod
-    def _load_model(cls, xml_path, timestep, joints_to_remove, motors_to_remove):
+    def _load_model(cls, xml_path, timestep, joints_to_remove, motors_to_remove, variant="default"):
         if xml_path is not None:
             handle = mjcf.MjcfHandle.from_path(xml_path)
             cls._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, [])
             return mjcf.compile_mjcf(handle, timestep=timestep)
-        m = mjcf.CompiledModel.load(_PKG / "assets" / "Atlas.default.model.npz")
+        m = mjcf.CompiledModel.load(_PKG / "assets" / ("Atlas.%s.model.npz" % variant))
         assert abs(m.timestep - timestep) < 1e-12
         return m
 

@@ -48,10 +48,14 @@ class LocoEnv:
         if use_foot_forces:
             raise NotImplementedError("use_foot_forces=True (ground-reaction-force observations, reference "
                                       "base.py:94-98,623-631) is not built yet")
-        if domain_randomization_config is not None:
-            raise NotImplementedError("domain randomization (reference utils/domain_randomization.py) is not "
-                                      "built yet")
         self._model = model
+        # joint-parameter randomisation per episode (reference base.py:103-107,183-185). The reference draws in worker
+        # processes, i.e. outside the main np.random stream — so does this (own RandomState, reseeded by seed()).
+        self._domain_rand = None
+        if domain_randomization_config is not None:
+            from ..utils.domain_randomization import JointRandomization
+            self._domain_rand = JointRandomization(model, domain_randomization_config)
+            self._domain_rand_rs = np.random.RandomState(0)
         assert abs(model.timestep - timestep) < 1e-12, "compile the model with the environment's timestep"
         self._timestep = timestep
         self._n_substeps = n_substeps
@@ -185,6 +189,13 @@ class LocoEnv:
             self._reset_one(e, obs)
             rows.append(self._create_observation(self.obs_helper._build_obs(self._host[e])))
         self._pending_state = True
+        self._pending_dof_params = None
+        if self._domain_rand is not None and self._domain_rand.active:
+            state = np.random.get_state()
+            np.random.set_state(self._domain_rand_rs.get_state())
+            self._pending_dof_params = self._domain_rand.sample(self.n_envs)
+            self._domain_rand_rs.set_state(np.random.get_state())
+            np.random.set_state(state)
         self._obs = np.stack(rows)
         return self._out(self._obs)
 
@@ -275,6 +286,10 @@ class LocoEnv:
         qpos = np.stack([h.qpos for h in self._host])
         qvel = np.stack([h.qvel for h in self._host])
         self._backend.set_state(qpos, qvel)
+        if getattr(self, "_pending_dof_params", None) is not None:
+            d, k, f = self._pending_dof_params
+            self._backend.set_dof_params(damping=d, stiffness=k, frictionloss=f)
+            self._pending_dof_params = None
         goal = self._goal_rows()
         if goal is not None:
             self._backend.set_goal(goal)
@@ -294,6 +309,8 @@ class LocoEnv:
             raise ValueError("auto reset needs trajectory data")
         b = self.backend
         b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset)
+        if self._domain_rand is not None and self._domain_rand.active:
+            b.set_dof_randomization(self._domain_rand.spec)
         b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)
         self._auto_reset = True
 
@@ -426,6 +443,8 @@ class LocoEnv:
 
     def seed(self, seed=None):
         np.random.seed(seed)
+        if self._domain_rand is not None:
+            self._domain_rand_rs = np.random.RandomState(seed)
 
     def play_trajectory(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
         """Kinematic replay of the loaded trajectory (reference ``base.py:314-386``): yields the observation

@@ -253,7 +253,7 @@ def lower(m, task):
         block[D_DAMP], block[D_ARM], block[D_STIFF] = m.dof_damping[d], m.dof_armature[d], m.jnt_stiffness[d]
         fl = m.dof_frictionloss[d]
         block[D_FLOSS] = fl
-        if fl > 0:
+        if fl > 0 or m.dof_invweight0[d] > 0:            # also for fl == 0: a per-environment frictionloss may switch the row on
             si = _clip_solimp(m.dof_solimp[d])
             d0 = si[0] if not (si[0] == si[1] or si[2] <= MINVAL) else 0.5 * (si[0] + si[1])
             block[D_FLOSS_R] = max(MINVAL, (1 - d0) * m.dof_invweight0[d] / d0)
@@ -408,9 +408,13 @@ def lower(m, task):
                 s, u = geom_blocks(b, li)
                 geoms += s
                 unsup += u
-        unsup = _merge_proximity_spheres(unsup, MAXG)
         if len(geoms) > MAXG:
-            raise UnsupportedModel("too many geoms on one chain")
+            # more colliders than geom slots (Atlas' upper body with its welded arms): the surplus, in model order,
+            # becomes proximity-only (bounding sphere, counted in `unhandled_geoms` when it reaches the floor)
+            info.setdefault("demoted_geoms", []).append((c, len(geoms) - MAXG))
+            unsup += [[gb[G_LINK], gb[G_PX], gb[G_PY], gb[G_PZ], gb[G_RBOUND], gb[G_MARGIN]] for gb in geoms[MAXG:]]
+            geoms = geoms[:MAXG]
+        unsup = _merge_proximity_spheres(unsup, MAXG)
         blk[C_NGEOMS], blk[C_NUNSUP] = len(geoms), len(unsup)
         max_contacts = max(max_contacts, sum({mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4}[int(gb[G_TYPE])] for gb in geoms))
         for i, gblk in enumerate(geoms):

@@ -7,9 +7,12 @@ M, sharding invariance, determinism).
 Stated fp32 tolerance: after one control step qpos Linf <= 1e-4, qvel Linf <= 1e-2.
 """
 
+import os
+
 import numpy as np
 import pytest
 
+import loco_mujoco_amd
 from loco_mujoco_amd import LocoEnv, lowering
 from loco_mujoco_amd.model_blob import pack_model
 from oracle.pyoracle import Oracle
@@ -448,3 +451,86 @@ def test_humanoid_muscle_batch_rollout_properties():
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("HumanoidMuscle 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 10)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Domain randomisation: per-environment joint damping / stiffness / frictionloss on the device.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _with_dof_params(m, damping, stiffness, frictionloss):
+    import copy
+    m2 = copy.copy(m)
+    m2.dof_damping, m2.jnt_stiffness, m2.dof_frictionloss = np.array(damping, float), np.array(stiffness, float), np.array(frictionloss, float)
+    return m2
+
+
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("Atlas.walk", 13), ("HumanoidMuscle.run", 92)])
+def test_per_environment_joint_parameters_vs_oracle(task, nu):
+    """Each environment gets its own damping/stiffness/frictionloss; one control step vs the oracle run on a model
+    compiled with exactly those values."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    kw = dict(disable_back_joint=False) if task.startswith("Atlas") else {}
+    env = LocoEnv.make(task, debug=True, **kw)
+    m = env._model
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    n = 8
+    rs = np.random.RandomState(1)
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-0.3, 0.3, (n, nu))
+    damp = np.tile(m.dof_damping, (n, 1)) * rs.uniform(0.5, 2.0, (n, m.nv)) + (m.dof_damping > 0) * rs.uniform(0, 1, (n, m.nv))
+    stiff = np.tile(m.jnt_stiffness, (n, 1)) * rs.uniform(0.5, 1.5, (n, m.nv))
+    floss = np.tile(m.dof_frictionloss, (n, 1)) * rs.uniform(0.5, 1.5, (n, m.nv))
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    if rows.shape[1] > 2 * m.nv:
+        b.set_goal(rows[:, 2 * m.nv:])
+    b.set_dof_params(damping=damp, stiffness=stiff, frictionloss=floss, mask=None)
+    got = b.get_dof_params()
+    assert np.allclose(got["damping"], damp, rtol=1e-6) and np.allclose(got["frictionloss"], floss, rtol=1e-6)
+    b.step(acts)
+    q, v = b.get_state()
+    eq, ev = [], []
+    for i in range(n):
+        o = Oracle(pack_model(_with_dof_params(m, damp[i].astype(np.float32), stiff[i].astype(np.float32), floss[i].astype(np.float32))))
+        o.set_option("disable_self_collision", 1)
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        q0, v0 = rows[i, :m.nv].astype(np.float32).astype(np.float64), rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64)
+        if m.na:
+            qo, vo = o.step_act(q0, v0, np.zeros(m.na), ctrl, nsub=10)[:2]
+        else:
+            qo, vo = o.step(q0, v0, ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
+    print("%s with per-env joint parameters vs oracle: qpos max %.2e qvel max %.2e" % (task, max(eq), max(ev)))
+    assert max(eq) < QTOL and max(ev) < VTOL
+    # the nominal kernel on the same states differs (the parameters matter)
+    b2 = HipBatch(hm, n)
+    b2.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    b2.step(acts)
+    assert np.abs(b2.get_state()[1] - v).max() > 1e-3
+
+
+def test_device_side_redraw_of_joint_parameters():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    cfg = os.path.join(os.path.dirname(loco_mujoco_amd.__file__), "environments", "data", "quadrupeds", "domain_randomization_unitree_a1.yaml")
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=512, domain_randomization_config=cfg)
+    m = env._model
+    assert env._domain_rand.active
+    env.reset()
+    env.enable_auto_reset(seed=7)
+    b = env.backend
+    env.step(np.zeros((512, 12)))                      # uploads the host-drawn parameters of the first episodes
+    p0 = b.get_dof_params()["damping"].copy()
+    i = m.jnt_id("FR_hip_joint")
+    assert p0[:, i].min() >= 0.0 and p0[:, i].max() <= 1.0 and p0[:, i].std() > 0.1          # U[0, 1] drawn on the host
+    others = [d for d in range(m.nv) if d != i]
+    assert np.allclose(p0[:, others], m.dof_damping[others])
+    st = b.rollout(60, action_mode=0)                                                       # zero action: episodes end and restart
+    assert st["episodes"] > 256
+    p1 = b.get_dof_params()["damping"]
+    changed = p1[:, i] != p0[:, i]
+    assert changed.mean() > 0.5 and p1[:, i].min() >= 0.0 and p1[:, i].max() <= 1.0
+    assert abs(p1[changed, i].mean() - 0.5) < 0.08 and np.allclose(p1[:, others], m.dof_damping[others])

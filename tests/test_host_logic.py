@@ -1,5 +1,6 @@
 """Host-side surface of the drop-in (no GPU): task registry, spaces, reset row 0, datasets, rewards."""
 
+import os
 import numpy as np
 import pytest
 
@@ -197,3 +198,50 @@ def test_humanoid_muscle_surface():
     from loco_mujoco_amd import lowering
     cm, info = lowering.lower(m, e._device_task())
     assert info["muscles_per_chain"] == [43, 43, 6, 0]      # every tendon runs over the pelvis and one chain
+
+
+def test_domain_randomization_config_and_atlas_back_chain(tmp_path):
+    from loco_mujoco_amd.utils.domain_randomization import JointRandomization, KIND_CLIPPED_NORMAL, KIND_NORMAL, KIND_UNIFORM
+    data = os.path.join(os.path.dirname(loco_mujoco_amd.__file__), "environments", "data")
+    cfg = os.path.join(data, "atlas", "domain_randomization_atlas.yaml")
+    np.random.seed(0)
+    # shipped file + default robot: the randomised back joints do not exist -> a no-op
+    e0 = LocoEnv.make("Atlas.walk", debug=True, domain_randomization_config=cfg)
+    assert not e0._domain_rand.active
+    # with the back chain: 19 dofs, 13 motors, third chain of 3 links; damping of back_bkz / back_bkx ~ U[4, 6]
+    e = LocoEnv.make("Atlas.walk", debug=True, disable_back_joint=False, domain_randomization_config=cfg)
+    m = e._model
+    assert (m.nv, m.nu) == (19, 13) and e.info.observation_space.shape == (36,)
+    from loco_mujoco_amd import lowering
+    cm, info = lowering.lower(m, e._device_task())
+    assert info["n_chains"] == 3 and sorted(len(c) for c in info["chains"]) == [3, 5, 5]
+    spec = e._domain_rand.spec
+    hit = [m.jnt_names[d] for d in np.nonzero(spec[0, :, 0])[0]]
+    assert hit == ["back_bkz", "back_bkx"] and (spec[1:, :, 0] == 0).all()
+    assert tuple(spec[0, m.jnt_id("back_bkz")]) == (KIND_UNIFORM, 4.0, 6.0)
+    state = np.random.get_state()[1].copy()
+    e.reset()
+    assert (np.random.get_state()[1] != state).any()                   # trajectory draws happened ...
+    d = e._pending_dof_params[0][0]
+    assert 4.0 <= d[m.jnt_id("back_bkz")] <= 6.0 and d[m.jnt_id("back_bky")] == m.dof_damping[m.jnt_id("back_bky")]
+    e.seed(3); e.reset(); a = e._pending_dof_params.copy()
+    e.seed(3); e.reset()
+    assert np.array_equal(a, e._pending_dof_params)                     # ... and the parameter stream is reproducible
+    # rule semantics incl. the reference's quirks (domain_randomization.py:299-383)
+    y = tmp_path / "dr.yaml"
+    y.write_text("Joints:\n  FR_hip_joint:\n    damping: {sigma: 0.5}\n    stiffness: {uniform_range: [1.0, 2.0]}\n"
+                 "  FL_hip_joint:\n    damping: {uniform_range_delta: 0.25}\n    armature: {sigma: 0.0}\n")
+    a1 = LocoEnv.make("UnitreeA1.simple", debug=True)
+    jr = JointRandomization(a1._model, str(y))
+    i, j = a1._model.jnt_id("FR_hip_joint"), a1._model.jnt_id("FL_hip_joint")
+    assert tuple(jr.spec[0, i]) == (KIND_CLIPPED_NORMAL, a1._model.dof_damping[i], 0.5)
+    assert tuple(jr.spec[1, i]) == (KIND_NORMAL, 1.0, 2.0)              # "uniform_range" on stiffness draws a normal
+    assert tuple(jr.spec[0, j]) == (KIND_UNIFORM, a1._model.dof_damping[j] - 0.25, a1._model.dof_damping[j] + 0.25)
+    s = jr.sample(2000)
+    assert s.shape == (3, 2000, 18) and s[0, :, i].min() >= 0 and abs(s[1, :, i].mean() - 1.0) < 0.2
+    y.write_text("Joints:\n  FR_hip_joint:\n    armature: {sigma: 0.1}\n")
+    with pytest.raises(NotImplementedError):
+        JointRandomization(a1._model, str(y))
+    y.write_text("Inertial:\n  trunk:\n    mass: {sigma: 0.1}\n")
+    with pytest.raises(NotImplementedError):
+        JointRandomization(a1._model, str(y))

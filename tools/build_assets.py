@@ -47,6 +47,11 @@ def main():
     m = mjcf.compile_mjcf(h, timestep=0.001)
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "Atlas.default.model.npz")
     print("Atlas: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
+    h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "atlas" / "atlas.xml")
+    Atlas._delete_from_xml_handle(h, _ARM, [j + "_actuator" for j in _ARM], [])
+    m = mjcf.compile_mjcf(h, timestep=0.001)
+    m.save(ROOT / "loco_mujoco_amd" / "assets" / "Atlas.back.model.npz")
+    print("Atlas (back joints): nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
 
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_torque.xml")
     ht = HumanoidTorque.__new__(HumanoidTorque)
@@ -63,6 +68,13 @@ def main():
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "HumanoidMuscle.default.model.npz")
     print("HumanoidMuscle: nbody %d nv %d ngeom %d nu %d na %d tendons %d path sites %d"
           % (m.nbody, m.nv, m.ngeom, m.nu, m.na, m.ntendon, len(m.wrap_site)))
+
+    # --- domain-randomisation configurations (plain YAML, copied verbatim: they are data, not code)
+    for rel in ["atlas/domain_randomization_atlas.yaml", "humanoid/domain_randomization_humanoid.yaml",
+                "quadrupeds/domain_randomization_unitree_a1.yaml"]:
+        dst = ROOT / "loco_mujoco_amd" / "environments" / "data" / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        dst.write_text((pkg / "environments" / "data" / rel).read_text())
 
     # --- mini datasets (same keys/values, re-encoded)
     for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
