@@ -131,6 +131,7 @@ struct Params {
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
+  float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
   long long t[12];
 #endif
@@ -171,7 +172,7 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // On the GPU this is an LDS array indexed [field][lane] (stride = lanes per workgroup, conflict-free); slots are
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
-       SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_SIZE };
+       SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_GRF /* force group of the chain (0/1) or -1 */, SL_SIZE };
 // per-environment joint parameters (domain randomisation): replaces the table's damping / stiffness / frictionloss
 template <int MC> struct DofPrm { float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC]; };
 
@@ -430,7 +431,8 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr) {
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
+                    bool want_grf = false) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
@@ -597,6 +599,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
           const int dim = (int)GE(g, LM_G_DIM);
           SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
+          SL(nslot, SL_GRF) = GE(g, LM_G_GRF);
           SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
           SL(nslot, SL_D) = D0;
           if (pyramidal && dim == 3) {
@@ -1271,6 +1274,35 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       }
     }
   }
+  if (want_grf) {
+    // foot forces (reference base.py:623-631,667-679): contact-frame force of the FIRST contact of each force group,
+    // from the residuals of the last gradient evaluation (= the solution)
+    bool seen0 = false, seen1 = false;
+    for (int s = 0; s < nslot; s++) {
+      const int gq = (int)SL(s, SL_GRF);
+      if (gq < 0 || (gq == 0 ? seen0 : seen1)) continue;
+      if (gq == 0) seen0 = true; else seen1 = true;
+      const int dim = (int)SL(s, SL_DIM);
+      float f[6];
+      if (pyramidal && dim == 3) {
+        float x[4], dummy = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[r] = SL(s, SL_JAR + r);
+        pyr_force(x, SL(s, SL_D), SL(s, SL_MU), f, dummy);
+      } else {
+        float jar[6], Dj[6], fr[5];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
+#pragma unroll
+        for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
+        ConeEval e = cone_eval<true>(jar, Dj, fr, SL(s, SL_MU), dim);
+#pragma unroll
+        for (int j = 0; j < 3; j++) f[j] = (j < dim) ? e.f[j] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) { if (gq == 0) cnt.grf[0][j] += f[j]; else cnt.grf[1][j] += f[j]; }
+    }
+  }
   cnt.solver_iters += (c == 0) ? iters : 0;
   if (c == 0 && iters > cnt.it_max) cnt.it_max = iters;
 
@@ -1351,9 +1383,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
-                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr) {
+                    Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
+                    bool want_grf = false) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
-  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
@@ -1361,7 +1394,8 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
-    forward<Q, MC, NS, false, CONE, 0, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp);
+    forward<Q, MC, NS, false, CONE, 0, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
+                                           want_grf && st == 3);   // the engine's data hold the 4th stage when mj_step returns
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]
 #pragma unroll

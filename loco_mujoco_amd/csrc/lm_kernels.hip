@@ -46,7 +46,7 @@ int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct Task {
-  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na;
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf;
   float rp[8];
 };
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
@@ -298,10 +298,18 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < 6; i++) { int iq = (int)RD(i, LM_D_QOBS), iv = (int)RD(i, LM_D_VOBS); if (iq >= 0) o[iq] = qr[i]; if (iv >= 0) o[iv] = vr[i]; }
-      for (int i = 0; i < a.T.ngoal; i++) o[a.T.nobs - a.T.ngoal + i] = goal[i];
+      for (int i = 0; i < a.T.ngoal; i++) o[a.T.nobs - a.T.ngrf - a.T.ngoal + i] = goal[i];
     }
 #pragma unroll
     for (int k = 0; k < MC; k++) if (k < nl) { int iq = (int)LK(k, LM_D_QOBS), iv = (int)LK(k, LM_D_VOBS); if (iq >= 0) o[iq] = qc[k]; if (iv >= 0) o[iv] = vc[k]; }
+    if (a.T.ngrf > 0) {
+      // mean contact-frame foot force over the control step's substeps, in kN (reference base.py:596-599: mean_grf / 1000);
+      // an episode that restarts in this step reports zeros like the reference's fresh running mean
+      const float scale = (step_no == 0 && episodes > 0.0f) ? 0.0f : 1.0f / (1000.0f * (float)a.T.nsub);
+      const int o0 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS0 * LM_NCHAIN + c], o1 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS1 * LM_NCHAIN + c];
+#pragma unroll
+      for (int j = 0; j < 3; j++) { if (o0 >= 0) o[o0 + j] = cnt.grf[0][j] * scale; if (o1 >= 0) o[o1 + j] = cnt.grf[1][j] * scale; }
+    }
   }
   }
 
@@ -469,7 +477,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   }
   T.nv = (int)cmod[LM_H_NV]; T.nu = (int)cmod[LM_H_NU]; T.nobs = (int)cmod[LM_H_NOBS]; T.ngoal = (int)cmod[LM_H_NGOAL];
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
-  T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS];
+  T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS]; T.ngrf = (int)cmod[LM_H_NGRF];
   if (T.ngoal > 4) { delete m; return fail("more than 4 goal entries"); }
   for (int i = 0; i < 8; i++) T.rp[i] = (float)cmod[LM_H_REWARD_P0 + i];
   lm::Params& P = m->P;

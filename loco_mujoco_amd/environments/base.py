@@ -45,9 +45,6 @@ class LocoEnv:
                  init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
                  use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
                  N_worker_per_xml_dom_rand=4, n_envs=1, device=0, **viewer_params):
-        if use_foot_forces:
-            raise NotImplementedError("use_foot_forces=True (ground-reaction-force observations, reference "
-                                      "base.py:94-98,623-631) is not built yet")
         self._model = model
         # joint-parameter randomisation per episode (reference base.py:103-107,183-185). The reference draws in worker
         # processes, i.e. outside the main np.random stream — so does this (own RandomState, reseeded by seed()).
@@ -58,8 +55,11 @@ class LocoEnv:
             self._domain_rand_rs = np.random.RandomState(0)
         assert abs(model.timestep - timestep) < 1e-12, "compile the model with the environment's timestep"
         self._timestep = timestep
+        # foot forces: the reference turns the control step into n_substeps intermediate steps of one substep each and
+        # averages the per-foot contact force over them (base.py:94-98,623-631); the device does the same inside one launch
         self._n_substeps = n_substeps
         self._n_intermediate_steps = 1
+        self._collision_groups = dict(collision_groups or [])
         self.n_envs = int(n_envs)
         self._device = device
 
@@ -74,7 +74,7 @@ class LocoEnv:
         self._mdp_info = MDPInfo(observation_space, action_space, gamma, horizon, dt=self.dt)
 
         self._reward_function = self._get_reward_function(reward_type, reward_params)
-        self._use_foot_forces = False
+        self._use_foot_forces = bool(use_foot_forces)
         self.info.observation_space = Box(*self._get_observation_space())
 
         # actions are normalised to [-1, 1] (reference base.py:122-126)
@@ -337,7 +337,16 @@ class LocoEnv:
         return np.asarray(action) * self.norm_act_delta + self.norm_act_mean
 
     def _create_observation(self, obs):
-        return np.asarray(obs)[2:].copy()
+        """Host-side observation at reset (``base.py:584-604``): the running mean of the foot forces starts at zero."""
+        obs = np.asarray(obs)[2:].copy()
+        return np.concatenate([obs, np.zeros(self._get_grf_size())]) if self._use_foot_forces else obs
+
+    def _get_grf_size(self):
+        return 12
+
+    def _grf_group_names(self):
+        """Force groups in observation order (``base.py:667-679``)."""
+        return ["foot_r", "front_foot_r", "foot_l", "front_foot_l"]
 
     def is_absorbing(self, obs):
         return self._has_fallen(obs) if self._use_absorbing_states else False
@@ -353,7 +362,12 @@ class LocoEnv:
         raise NotImplementedError
 
     def _get_observation_space(self):
-        return self.info.observation_space.low[2:], self.info.observation_space.high[2:]
+        """``base.py:566-583``: the simulator's entries without the two horizontal root coordinates [+ foot forces]."""
+        low, high = self.info.observation_space.low[2:], self.info.observation_space.high[2:]
+        if self._use_foot_forces:
+            inf = np.full(self._get_grf_size(), np.inf)
+            return np.concatenate([low, -inf]), np.concatenate([high, inf])
+        return low, high
 
     def _get_reward_function(self, reward_type, reward_params):
         if reward_type == "custom":
@@ -418,12 +432,13 @@ class LocoEnv:
             elif ot == ObservationType.JOINT_VEL:
                 qvel_idx.append(self._model.jnt_id(name))
         n_goal = self._n_goal()
-        nobs = len(qpos_idx) + len(qvel_idx) + n_goal
+        grf_groups = [list(self._collision_groups[g]) for g in self._grf_group_names()] if self._use_foot_forces else []
+        nobs = len(qpos_idx) + len(qvel_idx) + n_goal + 3 * len(grf_groups)
         assert nobs == self.info.observation_space.shape[0], "device observation layout does not match the space"
         spec = self._reward_function.device_spec()
         rtype, rparams = spec if spec is not None else (0, [])
         term = self._termination_spec() if self._use_absorbing_states else []
-        return dict(nobs=nobs, qpos_obs_idx=qpos_idx, qvel_obs_idx=qvel_idx, n_goal=n_goal,
+        return dict(nobs=nobs, qpos_obs_idx=qpos_idx, qvel_obs_idx=qvel_idx, n_goal=n_goal, grf_groups=grf_groups,
                     act_ctrl_idx=self._action_indices, act_mean=self.norm_act_mean, act_delta=self.norm_act_delta,
                     term=term, reward_type=rtype, reward_params=rparams, n_substeps=self._n_substeps)
 

@@ -155,6 +155,10 @@ class BaseHumanoid(LocoEnv):
     def _get_grf_size(self):
         return 6 if self._use_box_feet else 12
 
+    def _grf_group_names(self):
+        """``base_humanoid.py:193-209``."""
+        return ["foot_r", "foot_l"] if self._use_box_feet else ["foot_r", "front_foot_r", "foot_l", "front_foot_l"]
+
     # ------------------------------------------------------------------ task factory
     @staticmethod
     def generate(env, path, task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):

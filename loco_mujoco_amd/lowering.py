@@ -44,10 +44,12 @@ LINK_SIZE = D_SIZE + L_SIZE
 # ---- per-geom block
 (G_LINK, G_TYPE, G_PX, G_PY, G_PZ, G_AX, G_AY, G_AZ, G_RADIUS, G_HALF, G_RBOUND, G_MARGIN, G_K, G_B, G_S0, G_S1,
  G_S2, G_S3, G_S4, G_TRAN, G_DIM, G_MU, G_F0, G_F1, G_F2, G_F3, G_F4, G_RR1, G_RR2, G_RR3, G_RR4, G_RR5,
- G_SX, G_SY, G_SZ, G_R0, G_R1, G_R2, G_R3, G_R4, G_R5, G_R6, G_R7, G_R8, G_SIZE) = range(45)
+ G_SX, G_SY, G_SZ, G_R0, G_R1, G_R2, G_R3, G_R4, G_R5, G_R6, G_R7, G_R8, G_GRF, G_SIZE) = range(46)
+# G_GRF: ground-reaction-force group of this geom within its chain (0/1), -1 = not reported
 # G_TRAN: elliptic: tran (R_normal = (1-imp)/imp * tran); pyramidal: 2 mu^2 (1+mu^2) tran (shared R of all edges)
 # ---- chain block = [nlinks, ngeoms, unsupported geoms (count), links..., geoms...]
-C_NLINKS, C_NGEOMS, C_NUNSUP, C_LINKS = 0, 1, 2, 4
+C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_LINKS = 0, 1, 2, 3, 4, 6
+# C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
 C_GEOMS = C_LINKS + MAXC * LINK_SIZE
 C_UNSUP = C_GEOMS + MAXG * G_SIZE                  # unsupported geoms: (link, px,py,pz, rbound, margin) x MAXG
 U_SIZE = 6
@@ -109,7 +111,8 @@ HEADER_SIZE = 32
 LMC_MAGIC = 0x4C4D4331  # "LMC1"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
-H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE = 26, 27, 28, 29, 30, 31
+H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE = 25, 26, 27, 28, 29, 30, 31
+# H_NGRF: number of ground-reaction-force observation entries (3 per force group); they follow the goal entries
 
 # ---- muscle table (optional; follows the constant table): MT_HEAD floats [first muscle of chain c] x NCHAIN,
 # [muscle count of chain c] x NCHAIN, then MU_SIZE floats per muscle (sorted by chain), then 4 floats per tendon
@@ -292,6 +295,15 @@ def lower(m, task):
         block[D_TERM_VLO], block[D_TERM_VHI] = term_v.get(int(d), (-3e38, 3e38))
         block[D_DOF] = d
 
+    # ground-reaction-force groups (foot-force observations): geom id -> group id in observation order
+    grf_groups = task.get("grf_groups") or []
+    grf_of_geom = {}
+    for gi, names in enumerate(grf_groups):
+        for nm in names:
+            grf_of_geom[m.geom_names.index(nm)] = gi
+    n_grf = 3 * len(grf_groups)
+    grf_obs_base = task["nobs"] - n_grf
+
     def geom_blocks(w, link_index):
         """floor-collidable geoms of weld group w: (supported blocks, unsupported blocks)."""
         sup, unsup = [], []
@@ -319,6 +331,9 @@ def lower(m, task):
                 unsup.append([link_index, gpos[0], gpos[1], gpos[2], rbound, margin])
                 continue
             blk = np.zeros(G_SIZE)
+            blk[G_GRF] = -1
+            if g in grf_of_geom:
+                blk[G_GRF] = grf_of_geom[g]       # provisional: global group id, turned into the chain's slot below
             blk[G_LINK], blk[G_TYPE] = link_index, t
             blk[G_PX:G_PX + 3] = gpos
             blk[G_AX:G_AX + 3] = grot[:, 2]
@@ -366,6 +381,8 @@ def lower(m, task):
         fill_dof(rb[R_DOFS + k * D_SIZE:R_DOFS + (k + 1) * D_SIZE], d, qobs, vobs, is_root=True)
         dof_to_lane[d] = -2
     sup, unsup = geom_blocks(root, 0)
+    if any(sb[G_GRF] >= 0 for sb in sup):
+        raise UnsupportedModel("foot-force group on the root body")
     unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
     unsup = _merge_proximity_spheres(unsup, MAXRG)
     rb[R_NUNSUP] = len(unsup)
@@ -373,6 +390,8 @@ def lower(m, task):
         rb[R_UNSUP + i * U_SIZE:R_UNSUP + (i + 1) * U_SIZE] = u
 
     # ---- chains, interleaved [field][chain]
+    for c in range(NCHAIN):                      # unused lanes report no foot force
+        cm[CM_CHAINS + C_GRF_OBS0 * NCHAIN + c] = cm[CM_CHAINS + C_GRF_OBS1 * NCHAIN + c] = -1
     max_links = 0
     max_contacts = 0
     for c, chain in enumerate(chains):
@@ -408,6 +427,14 @@ def lower(m, task):
                 s, u = geom_blocks(b, li)
                 geoms += s
                 unsup += u
+        blk[C_GRF_OBS0] = blk[C_GRF_OBS1] = -1
+        chain_groups = sorted(set(int(gb[G_GRF]) for gb in geoms if gb[G_GRF] >= 0))
+        if len(chain_groups) > 2:
+            raise UnsupportedModel("more than two foot-force groups on one chain")
+        for slot, gi in enumerate(chain_groups):
+            blk[C_GRF_OBS0 + slot] = grf_obs_base + 3 * gi
+        for gb in geoms:
+            gb[G_GRF] = chain_groups.index(int(gb[G_GRF])) if gb[G_GRF] >= 0 else -1
         if len(geoms) > MAXG:
             # more colliders than geom slots (Atlas' upper body with its welded arms): the surplus, in model order,
             # becomes proximity-only (bounding sphere, counted in `unhandled_geoms` when it reaches the floor)
@@ -512,6 +539,9 @@ def lower(m, task):
     h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
     h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
     h[H_NMUSCLE] = len(muscles)
+    h[H_NGRF] = n_grf
+    if n_grf and sum(1 for c in range(len(chains)) for k in (C_GRF_OBS0, C_GRF_OBS1) if cm[CM_CHAINS + k * NCHAIN + c] >= 0) != len(grf_groups):
+        raise UnsupportedModel("a foot-force group has no geom with a device collider")
     info.update(dropped_root_limits=dropped_root_limits, n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
                 self_collision_pairs=_count_self_pairs(m))
     return np.concatenate([h, cm] + ([mt] if mt is not None else [])), info

@@ -1092,10 +1092,50 @@ int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl,
   return lmo_step_act(m, qpos, qvel, NULL, ctrl, warmstart, nsub, stats);
 }
 
+static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
+                     int nsub, lmo_stats* stats, work* w);
+
 int lmo_step_act(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
                  int nsub, lmo_stats* stats) {
   if (m->na > 0 && (!act || m->integrator != LM_INT_EULER)) return -1;
   work* w = (work*)malloc(sizeof(work));
+  int rc = step_impl(m, qpos, qvel, act, ctrl, warmstart, nsub, stats, w);
+  free(w);
+  return rc;
+}
+
+/* One substep, then the contact list of its LAST forward pass with the contact-frame force of every contact
+   (normal, tangent 1, tangent 2) — what the reference reads after each intermediate step when use_foot_forces is on
+   (mushroom-rl _get_collision_force -> mj_contactForce; reference base.py:623-631,667-679). For RK4 the engine's data
+   hold the fourth stage's evaluation when mj_step returns (unpinned: no golden rollout has foot forces).
+   out rows: geom1, geom2, f_normal, f_t1, f_t2. */
+int lmo_step_contact_forces(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl,
+                            double* warmstart, double* out, int max_con, int* ncon) {
+  if (m->na > 0 && (!act || m->integrator != LM_INT_EULER)) return -1;
+  work* w = (work*)malloc(sizeof(work));
+  int rc = step_impl(m, qpos, qvel, act, ctrl, warmstart, 1, NULL, w);
+  int n = w->ncon < max_con ? w->ncon : max_con;
+  for (int i = 0; i < n; i++) {
+    const lmo_contact* c = &w->con[i];
+    double* o = out + 5 * i;
+    o[0] = c->geom1; o[1] = c->geom2; o[2] = o[3] = o[4] = 0;
+    if (c->efc_address < 0) continue;
+    const double* f = w->force + c->efc_address;
+    if (m->cone == LM_CONE_ELLIPTIC || c->dim == 1) {
+      for (int k = 0; k < c->dim && k < 3; k++) o[2 + k] = f[k];
+    } else {                       /* pyramid edges n+mu t1, n-mu t1, n+mu t2, n-mu t2 (condim 3) */
+      o[2] = f[0] + f[1] + f[2] + f[3];
+      o[3] = c->friction[0] * (f[0] - f[1]);
+      o[4] = c->friction[1] * (f[2] - f[3]);
+    }
+  }
+  *ncon = n;
+  free(w);
+  return rc;
+}
+
+static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
+                     int nsub, lmo_stats* stats, work* w) {
   int nv = m->nv;
   if (stats) memset(stats, 0, sizeof(*stats));
   for (int s = 0; s < nsub; s++) {
@@ -1126,7 +1166,6 @@ int lmo_step_act(const lmo_model* m, double* qpos, double* qvel, double* act, co
       stats->unhandled_pairs += w->unhandled_pairs;
     }
   }
-  free(w);
   return 0;
 }
 

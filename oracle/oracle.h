@@ -53,6 +53,9 @@ int lmo_step(const lmo_model* m, double* qpos, double* qvel, const double* ctrl,
 /* same with activation states act[na] (advanced in place; explicit Euler); required when lmo_na() > 0 */
 int lmo_step_act(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl, double* warmstart,
                  int nsub, lmo_stats* stats);
+/* one substep + contact-frame forces of its last forward pass: out[max_con][5] = geom1, geom2, f_n, f_t1, f_t2 */
+int lmo_step_contact_forces(const lmo_model* m, double* qpos, double* qvel, double* act, const double* ctrl,
+                            double* warmstart, double* out, int max_con, int* ncon);
 /* one forward-dynamics pass with intermediate results */
 int lmo_forward(const lmo_model* m, const double* qpos, const double* qvel, const double* ctrl,
                 const double* warmstart, lmo_forward_out* out);

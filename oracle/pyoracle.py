@@ -60,6 +60,7 @@ def lib():
         _lib.lmo_step_act.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
         _lib.lmo_forward_act.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, C.POINTER(ForwardOut)]
         _lib.lmo_na.argtypes = [C.c_void_p]
+        _lib.lmo_step_contact_forces.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(C.c_int)]
     return _lib
 
 
@@ -114,6 +115,21 @@ class Oracle:
         if rc != 0:
             raise ValueError("oracle rejected the step (RK4 with activation states is not restated)")
         return q, v, a, w, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def step_contact_forces(self, qpos, qvel, ctrl, warmstart=None, act=None):
+        """One substep; returns (qpos, qvel, act, warmstart, contacts) with contacts = [(geom1, geom2, f[3])] of the
+        substep's last forward pass, in the engine's contact order."""
+        q = np.array(qpos, dtype=np.float64)
+        v = np.array(qvel, dtype=np.float64)
+        a = np.zeros(max(self.na, 1)) if act is None else np.array(act, dtype=np.float64)
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        w = np.zeros(self.nv) if warmstart is None else np.array(warmstart, dtype=np.float64)
+        out = np.zeros((self.MAX_CON, 5))
+        n = C.c_int(0)
+        rc = lib().lmo_step_contact_forces(self._h, _p(q), _p(v), _p(a), _p(c), _p(w), _p(out), self.MAX_CON, C.byref(n))
+        if rc != 0:
+            raise ValueError("oracle rejected the step")
+        return q, v, a[:self.na], w, [(int(r[0]), int(r[1]), r[2:5].copy()) for r in out[:n.value]]
 
     def forward(self, qpos, qvel, ctrl, warmstart=None, act=None):
         nv = self.nv

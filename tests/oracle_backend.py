@@ -50,6 +50,11 @@ class OracleBatch:
         for e in range(self.n):
             ctrl = np.zeros(env._model.nu)
             ctrl[env._action_indices] = env._preprocess_action(action[e])
+            if env._use_foot_forces:
+                obs.append(self._step_with_foot_forces(e, ctrl))
+                done.append(bool(env.is_absorbing(obs[-1])))
+                rew.append(env.reward(self.prev_obs[e], action[e], obs[-1], done[-1]))
+                continue
             if self.act.shape[1]:
                 q, v, a, w, st = self.oracle.step_act(self.qpos[e], self.qvel[e], self.act[e], ctrl, env._n_substeps, self.warm[e])
                 self.act[e] = a
@@ -63,6 +68,34 @@ class OracleBatch:
             rew.append(env.reward(self.prev_obs[e], action[e], o, done[-1]))
         self.prev_obs = np.stack(obs)
         return np.stack(obs), np.array(rew, dtype=np.float64), np.array(done)
+
+
+def _grf_step(self, e, ctrl):
+    """The reference's loop with use_foot_forces (base.py:94-98,623-631): n intermediate steps of one substep, after each
+    the contact-frame force of the first floor contact of every foot group; observation += mean / 1000."""
+    env = self.env
+    m = env._model
+    floor = m.geom_names.index("floor")
+    groups = [[m.geom_names.index(g) for g in env._collision_groups[name]] for name in env._grf_group_names()]
+    total = np.zeros((len(groups), 3))
+    for _ in range(env._n_substeps):
+        q, v, a, w, cons = self.oracle.step_contact_forces(self.qpos[e], self.qvel[e], ctrl, self.warm[e],
+                                                           self.act[e] if self.act.shape[1] else None)
+        self.qpos[e], self.qvel[e], self.warm[e] = q, v, w
+        if self.act.shape[1]:
+            self.act[e] = a
+        for gi, ids in enumerate(groups):
+            for g1, g2, f in cons:
+                if (g1 == floor and g2 in ids) or (g2 == floor and g1 in ids):
+                    total[gi] += f
+                    break
+    o = self._obs(e)
+    n_goal = 0 if self.goal is None else self.goal.shape[1]
+    grf = (total / env._n_substeps / 1000.0).ravel()
+    return np.concatenate([o, grf])
+
+
+OracleBatch._step_with_foot_forces = _grf_step
 
 
 def attach(env):

@@ -8,6 +8,7 @@ Stated fp32 tolerance: after one control step qpos Linf <= 1e-4
 """
 
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -534,3 +535,47 @@ def test_device_side_redraw_of_joint_parameters():
     changed = p1[:, i] != p0[:, i]
     assert changed.mean() > 0.5 and p1[:, i].min() >= 0.0 and p1[:, i].max() <= 1.0
     assert abs(p1[changed, i].mean() - 0.5) < 0.08 and np.allclose(p1[:, others], m.dof_damping[others])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Foot-force observations: mean contact-frame force of each foot group over the control step.
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("HumanoidTorque.walk", 13), ("Atlas.walk", 10), ("HumanoidMuscle.run", 92)])
+def test_foot_force_observations_vs_oracle(task, nu):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import attach
+    ng = 12 if task.split(".")[0] in ("UnitreeA1", "Atlas") else 6
+    np.random.seed(0)
+    dev = LocoEnv.make(task, debug=True, use_foot_forces=True)
+    np.random.seed(0)
+    ora = attach(LocoEnv.make(task, debug=True, use_foot_forces=True))
+    ora._backend.oracle.set_option("disable_self_collision", 1)       # the device simulates floor contacts only
+    assert dev.info.observation_space.shape == ora.info.observation_space.shape
+    np.random.seed(0)
+    o_dev = dev.reset()
+    np.random.seed(0)
+    o_ora = ora.reset()
+    assert np.array_equal(o_dev, o_ora) and np.all(o_dev[-ng:] == 0)            # fresh running mean
+    rs = np.random.RandomState(2)
+    worst_f = worst_q = fmax = 0.0
+    worst_at = None
+    for k in range(8):
+        a = rs.randn(nu) * 0.1
+        o_dev, r_dev, d_dev, _ = dev.step(a)
+        o_ora, r_ora, d_ora, _ = ora.step(a)
+        eq_ = np.abs(o_dev[:-ng] - o_ora[:-ng])
+        if eq_.max() > worst_q:
+            worst_q, worst_at = eq_.max(), (k, int(eq_.argmax()), float(o_dev[int(eq_.argmax())]), float(o_ora[int(eq_.argmax())]))
+        worst_f = max(worst_f, np.abs(o_dev[-ng:] - o_ora[-ng:]).max() / max(1e-3, np.abs(o_ora[-ng:]).max()))
+        fmax = max(fmax, np.abs(o_ora[-ng:]).max())
+        assert d_dev == d_ora
+        if d_ora:
+            break
+        # keep the two simulations on the same states (float32 drift would otherwise change contact timing)
+        dev._backend.set_state(ora._backend.qpos, ora._backend.qvel)
+        if dev._model.na:
+            dev._backend.set_activation(ora._backend.act)
+    print("%s foot forces vs oracle: relative error %.2e (largest component %.3f kN), state part %.2e"
+          % (task, worst_f, fmax, worst_q), worst_at)
+    assert fmax > 1e-3 and worst_f < 2e-2 and worst_q < VTOL
