@@ -1,10 +1,12 @@
 from .base import LocoEnv, ValidTaskConf
 from .unitree_a1 import UnitreeA1
 from .atlas import Atlas
-from .humanoids import BaseHumanoid, HumanoidMuscle, HumanoidTorque
+from .humanoids import BaseHumanoid, BaseHumanoid4Ages, HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque, HumanoidTorque4Ages
 from .gymnasium import GymnasiumWrapper
 
 UnitreeA1.register()
 Atlas.register()
 HumanoidTorque.register()
 HumanoidMuscle.register()
+HumanoidTorque4Ages.register()
+HumanoidMuscle4Ages.register()

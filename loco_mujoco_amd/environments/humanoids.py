@@ -21,6 +21,7 @@ import numpy as np
 
 from .. import mjcf
 from ..utils.checks import check_validity_task_mode_dataset
+from ..utils.reward import MultiTargetVelocityReward
 from .base import LocoEnv, ValidTaskConf
 from .observation import ObservationType
 
@@ -57,17 +58,18 @@ class BaseHumanoid(LocoEnv):
             handle = mjcf.MjcfHandle.from_path(xml_path)
             model = self._compile(handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet)
         else:
-            name = "HumanoidMuscle" if use_muscles else "HumanoidTorque"
-            model = mjcf.CompiledModel.load(_PKG / "assets" / (name + ".default.model.npz"))
+            model = mjcf.CompiledModel.load(_PKG / "assets" / self._asset_name())
             assert abs(model.timestep - timestep) < 1e-12
         super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
 
-    @classmethod
-    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet=0.5):
+    def _asset_name(self):
+        return ("HumanoidMuscle" if self._use_muscles else "HumanoidTorque") + ".default.model.npz"
+
+    def _compile(self, handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet=0.5):
         """The reference's constructor-time XML surgery (``base_humanoid.py:49-64``), then the mini-compiler."""
-        cls._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, equ_constr_to_remove)
-        cls._add_box_feet_to_xml_handle(handle, alpha_box_feet)
-        cls._reorient_arms(handle)
+        self._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, equ_constr_to_remove)
+        self._add_box_feet_to_xml_handle(handle, alpha_box_feet)
+        self._reorient_arms(handle)
         return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)
 
     @staticmethod
@@ -243,3 +245,188 @@ class HumanoidMuscle(BaseHumanoid):
         path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
                 "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
         return BaseHumanoid.generate(HumanoidMuscle, path, task, dataset_type, **kwargs)
+
+
+class BaseHumanoid4Ages(BaseHumanoid):
+    """The humanoid in four sizes — toddler 0.4, child 0.6, teenager 0.8, adult 1.0 — with the size indicator in the
+    observation (reference ``humanoids/base_humanoid_4_ages.py``). The reference keeps all four models in one
+    environment and samples one per episode (mode "all"); on the device one batch = one model, so only the
+    single-size modes "1".."4" are built."""
+
+    _default_scalings = [0.4, 0.6, 0.8, 1.0]
+
+    def __init__(self, scaling=None, scaling_trajectory_map=None, use_muscles=False, use_box_feet=True,
+                 disable_arms=True, alpha_box_feet=0.5, xml_path=None, timestep=0.001, **kwargs):
+        scalings = self._default_scalings if scaling is None else (list(scaling) if isinstance(scaling, (list, tuple)) else [scaling])
+        if len(scalings) != 1:
+            raise NotImplementedError('mode "all" (a different humanoid per episode) needs one model table per '
+                                      'environment on the device; use the modes "1".."4"')
+        self._scalings = scalings
+        self._scaling_trajectory_map = None
+        self._model_scale = float(scalings[0])
+        super().__init__(use_muscles=use_muscles, use_box_feet=use_box_feet, disable_arms=disable_arms,
+                         alpha_box_feet=alpha_box_feet, xml_path=xml_path, timestep=timestep, **kwargs)
+
+    def _asset_name(self):
+        return "%s.s%g.model.npz" % ("HumanoidMuscle" if self._use_muscles else "HumanoidTorque", self._model_scale)
+
+    def _compile(self, handle, timestep, joints_to_remove, motors_to_remove, equ_constr_to_remove, alpha_box_feet=0.5):
+        """Scale first, then the usual surgery with scaled box feet (``base_humanoid_4_ages.py:79-99``)."""
+        self.scale_body(handle, self._model_scale, self._use_muscles)
+        self._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, equ_constr_to_remove)
+        self._add_box_feet_to_xml_handle(handle, alpha_box_feet, self._model_scale)
+        self._reorient_arms(handle)
+        return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)
+
+    @staticmethod
+    def scale_body(xml_handle, scaling, use_muscles):
+        """Geometric similarity (``base_humanoid_4_ages.py:305-359``): lengths x s, masses x s^3, inertias x s^5, muscle
+        forces and motor gears x s^2, tendon length ranges x s; the head keeps its size."""
+        def vec(el, key, default):
+            return np.array([float(v) for v in el.get(key, default).split()])
+
+        def put(el, key, values):
+            el.set(key, " ".join(repr(float(v)) for v in np.atleast_1d(values)))
+
+        head_geoms = ["hat_skull", "hat_jaw", "hat_ribs_cap"]
+        for el in xml_handle.root.iter("mesh"):
+            if el.get("name") not in head_geoms:
+                put(el, "scale", vec(el, "scale", "1 1 1") * scaling)
+        for el in xml_handle.root.iter("geom"):
+            if el.get("name") in head_geoms:
+                put(el, "pos", [0.0, -0.5 * (1 - scaling), 0.0])
+        for el in xml_handle.root.iter("body"):
+            put(el, "pos", vec(el, "pos", "0 0 0") * scaling)
+            inertial = el.find("inertial")
+            put(inertial, "mass", float(inertial.get("mass")) * scaling ** 3)
+            full = vec(inertial, "fullinertia", "0 0 0 0 0 0") * scaling ** 5
+            assert np.array_equal(full[3:], np.zeros(3)), "off-diagonal inertia entries would need another scaling rule"
+            put(inertial, "fullinertia", full)
+            if use_muscles:
+                for site in el.findall("site"):
+                    put(site, "pos", vec(site, "pos", "0 0 0") * scaling)
+        actuators = xml_handle.root.find("actuator")
+        for el in (actuators if actuators is not None else []):
+            if use_muscles:
+                if "mot" not in el.get("name", ""):
+                    put(el, "force", float(el.get("force")) * scaling ** 2)
+                    put(el, "lengthrange", vec(el, "lengthrange", "0 0") * scaling)
+            else:
+                put(el, "gear", vec(el, "gear", "1") * scaling ** 2)
+        return xml_handle
+
+    # ------------------------------------------------------------------ observation: [humanoid obs, size indicator bits]
+    @property
+    def n_all_models(self):
+        return len(self._default_scalings)
+
+    @staticmethod
+    def _get_env_id_map(current_model_idx, n_models):
+        """Binary size indicator, most significant bit first (mushroom-rl MultiMuJoCo; the golden rollouts show
+        [0,0], [0,1], [1,0], [1,1] for the four sizes and ``utils/reward.py:90`` decodes it with bitorder='big')."""
+        bits = max(1, int(np.ceil(np.log2(max(n_models, 2)))))
+        return np.array([(current_model_idx >> (bits - 1 - i)) & 1 for i in range(bits)], dtype=np.float64)
+
+    def _env_id(self):
+        return self._get_env_id_map(self._default_scalings.index(self._model_scale), self.n_all_models)
+
+    def _get_observation_space(self):
+        low, high = super()._get_observation_space()
+        n = len(self._env_id())
+        return np.concatenate([low, np.zeros(n)]), np.concatenate([high, np.ones(n)])
+
+    def _create_observation(self, obs):
+        return np.concatenate([super()._create_observation(obs), self._env_id()])
+
+    def _n_goal(self):
+        return len(self._env_id())
+
+    def _goal_rows(self):
+        return np.tile(self._env_id(), (self.n_envs, 1))
+
+    def _reset_table(self):
+        rows = super()._reset_table()
+        return np.concatenate([rows, np.tile(self._env_id(), (len(rows), 1))], axis=1)
+
+    def _get_reward_function(self, reward_type, reward_params):
+        if reward_type == "multi_target_velocity":
+            r = MultiTargetVelocityReward(x_vel_idx=self.get_obs_idx("dq_pelvis_tx")[0], scalings=self._default_scalings,
+                                          env_id_len=len(self._env_id()), **reward_params)
+            # one size per batch: on the device this is the plain target-velocity reward with the scaled target
+            r.device_spec = lambda: (1, [r._x_vel_idx, r._target_vel * self._model_scale])
+            return r
+        return super()._get_reward_function(reward_type, reward_params)
+
+    def setup(self, obs):
+        if obs is not None:
+            raise TypeError("Initializing the environment from an observation is not allowed in this environment.")
+        super().setup(obs)
+
+    @staticmethod
+    def generate(env, path, task="walk", mode="all", dataset_type="real", n_models=None, debug=False,
+                 clip_trajectory_to_joint_ranges=False, **kwargs):
+        """``base_humanoid_4_ages.py:362-459``: dataset ``<path>_<mode>.npz``, reward ``multi_target_velocity`` with the
+        target speed scaled by the humanoid's size."""
+        if dataset_type == "perfect":
+            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
+        if mode == "all":
+            raise NotImplementedError('mode "all" samples a different humanoid per episode: not built on the device '
+                                      '(one model table per batch); use the modes "1".."4"')
+        scaling = {"1": 0.4, "2": 0.6, "3": 0.8, "4": 1.0}[mode]
+        reward_type = kwargs.pop("reward_type", "multi_target_velocity")
+        reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25 if task == "walk" else 2.5))
+        mdp = env(scaling=scaling, reward_type=reward_type, reward_params=reward_params, **kwargs)
+        path = "%s_%s.npz" % (path, mode)
+        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
+        use_mini = not (root / path).exists()
+        if debug or use_mini:
+            if use_mini and not debug:
+                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
+                              "the datasets to use this environment for imitation learning!")
+            parts = path.split("/")
+            parts.insert(3, "mini_datasets")
+            path = "/".join(parts)
+        traj_path = root / path
+        if not traj_path.exists():
+            traj_path = _PKG / path
+        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
+                                 clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+        return mdp
+
+
+class HumanoidTorque4Ages(BaseHumanoid4Ages):
+    """Reference ``humanoids.py:789-892``."""
+
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], modes=["all", "1", "2", "3", "4"], data_types=["real", "perfect"])
+
+    def __init__(self, **kwargs):
+        if "use_muscles" in kwargs:
+            assert kwargs.pop("use_muscles") is False, "Activating muscles in this environment not allowed. "
+        super().__init__(use_muscles=False, **kwargs)
+
+    @staticmethod
+    def generate(task="walk", mode="all", dataset_type="real", **kwargs):
+        check_validity_task_mode_dataset(HumanoidTorque4Ages.__name__, task, mode, dataset_type,
+                                         *HumanoidTorque4Ages.valid_task_confs.get_all())
+        path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid_POMDP",
+                "run": "datasets/humanoids/real/05-run_reduced_humanoid_POMDP"}[task]
+        return BaseHumanoid4Ages.generate(HumanoidTorque4Ages, path, task, mode, dataset_type, **kwargs)
+
+
+class HumanoidMuscle4Ages(BaseHumanoid4Ages):
+    """Reference ``humanoids.py:895-999``."""
+
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], modes=["all", "1", "2", "3", "4"], data_types=["real", "perfect"])
+
+    def __init__(self, **kwargs):
+        if "use_muscles" in kwargs:
+            assert kwargs.pop("use_muscles") is True, "Activating torque actuators in this environment not allowed. "
+        super().__init__(use_muscles=True, **kwargs)
+
+    @staticmethod
+    def generate(task="walk", mode="all", dataset_type="real", **kwargs):
+        check_validity_task_mode_dataset(HumanoidMuscle4Ages.__name__, task, mode, dataset_type,
+                                         *HumanoidMuscle4Ages.valid_task_confs.get_all())
+        path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid_POMDP",
+                "run": "datasets/humanoids/real/05-run_reduced_humanoid_POMDP"}[task]
+        return BaseHumanoid4Ages.generate(HumanoidMuscle4Ages, path, task, mode, dataset_type, **kwargs)

@@ -62,6 +62,29 @@ class TargetVelocityReward(RewardInterface):
         return 1, [self._x_vel_idx, self._target_vel]
 
 
+class MultiTargetVelocityReward(RewardInterface):
+    """exp(-(v_x - s v*)^2) with the size factor s decoded from the indicator bits at the end of the state
+    (reference ``reward.py:77-97``)."""
+
+    def __init__(self, target_velocity, x_vel_idx, env_id_len, scalings):
+        self._target_vel = target_velocity
+        self._env_id_len = env_id_len
+        self._scalings = scalings
+        self._x_vel_idx = x_vel_idx
+
+    def _scaling(self, state):
+        env_id = np.asarray(state)[..., -self._env_id_len:].astype(int)
+        ind = (env_id * (1 << np.arange(self._env_id_len)[::-1])).sum(axis=-1)
+        return np.asarray(self._scalings)[ind]
+
+    def __call__(self, state, action, next_state, absorbing):
+        x_vel = np.asarray(state)[..., self._x_vel_idx]
+        return np.exp(-np.square(x_vel - self._target_vel * self._scaling(state)))
+
+    def device_spec(self):
+        return None          # overridden per environment: a single-size batch has a constant target (see BaseHumanoid4Ages)
+
+
 class VelocityVectorReward(RewardInterface):
     """exp(-5 * || v_xy - v_goal * (cos, sin) ||)  (reference ``reward.py:100-117``)."""
 

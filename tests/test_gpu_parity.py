@@ -579,3 +579,52 @@ def test_foot_force_observations_vs_oracle(task, nu):
     print("%s foot forces vs oracle: relative error %.2e (largest component %.3f kN), state part %.2e"
           % (task, worst_f, fmax, worst_q), worst_at)
     assert fmax > 1e-3 and worst_f < 2e-2 and worst_q < VTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The humanoid in four sizes: scaled models (0.4 .. 1.0) on the device, size-indicator bits in the observation.
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,nu", [("HumanoidTorque4Ages.run.1", 13), ("HumanoidTorque4Ages.walk.2", 13),
+                                     ("HumanoidMuscle4Ages.walk.1", 92), ("HumanoidMuscle4Ages.run.3", 92)])
+def test_humanoid_4_ages_one_control_step_kats(name, nu):
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make(name, debug=True)
+    m = env._model
+    oracle = Oracle(pack_model(m))
+    hm = HipModel(env._chain_model())
+    g = GOLD[name + ".real"]
+    n = len(g) - 1
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(nu) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :17]
+    qvel[:, qidx] = g[:n, 17:36]
+    act_rows, act, pinned = [], np.zeros(m.na), []
+    for k in range(n):                          # oracle replay: activations per row, and which rows the oracle reproduces
+        act_rows.append(act)
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[k])
+        if m.na:
+            q, v, act = oracle.step_act(qpos[k], qvel[k], act, ctrl, nsub=10)[:3]
+        else:
+            q, v = oracle.step(qpos[k], qvel[k], ctrl, nsub=10)[:2]
+        pinned.append(np.abs(q[qidx[2:]] - g[k + 1, :17]).max() < 1e-12)
+    pinned = np.array(pinned)
+    b = HipBatch(hm, n)
+    b.set_state(qpos, qvel)
+    b.set_goal(np.tile(env._env_id(), (n, 1)))
+    if m.na:
+        b.set_activation(np.array(act_rows))
+    obs, rew, done = b.step(acts)
+    eq = np.abs(obs[:, :17] - g[1:, :17]).max(axis=1)[pinned]
+    ev = np.abs(obs[:, 17:36] - g[1:, 17:36]).max(axis=1)[pinned]
+    print("%s KAT errors vs golden (%d of %d rows pinned): qpos max %.2e | qvel max %.2e" % (name, pinned.sum(), n, eq.max(), ev.max()))
+    assert pinned.sum() >= 30 and eq.max() < QTOL and ev.max() < VTOL
+    assert np.array_equal(obs[:, 36:], g[1:, 36:])                                        # size-indicator bits
+    scale = [0.4, 0.6, 0.8, 1.0][int(name.split(".")[2]) - 1]
+    speed = (2.5 if ".run." in name else 1.25) * scale
+    assert np.abs(rew - np.exp(-(g[:n, 17] - speed) ** 2)).max() < 1e-5

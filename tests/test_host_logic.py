@@ -245,3 +245,28 @@ def test_domain_randomization_config_and_atlas_back_chain(tmp_path):
     y.write_text("Inertial:\n  trunk:\n    mass: {sigma: 0.1}\n")
     with pytest.raises(NotImplementedError):
         JointRandomization(a1._model, str(y))
+
+
+def test_humanoid_4_ages_surface():
+    np.random.seed(0)
+    e = LocoEnv.make("HumanoidMuscle4Ages.run.2", debug=True)
+    assert e.info.observation_space.shape == (38,) and e.info.action_space.shape == (92,)
+    assert list(e.info.observation_space.low[-2:]) == [0, 0] and list(e.info.observation_space.high[-2:]) == [1, 1]
+    assert list(e._env_id()) == [0, 1] and e._n_goal() == 2
+    m1 = LocoEnv.make("HumanoidMuscle.run", debug=True)._model
+    i = e._model.act_names.index("glut_med1_r")
+    assert np.isclose(e._model.act_gainprm[i, 2], m1.act_gainprm[i, 2] * 0.36)            # muscle force ~ s^2
+    assert np.allclose(e._model.act_lengthrange[i], m1.act_lengthrange[i] * 0.6)           # tendon range ~ s
+    t = LocoEnv.make("HumanoidTorque4Ages.walk.4", debug=True)
+    assert np.allclose(t._model.act_gear, LocoEnv.make("HumanoidTorque.walk", debug=True)._model.act_gear)
+    # reward: target speed scales with the size; on the device it is the plain target-velocity reward
+    st = np.zeros(38); st[17] = 1.5; st[-2:] = [0, 1]
+    assert np.isclose(e.reward(st, None, st, False), np.exp(-(1.5 - 2.5 * 0.6) ** 2))
+    assert e._reward_function.device_spec() == (1, [17, 2.5 * 0.6])
+    tab = e._reset_table()
+    assert tab.shape[1] == 2 * 19 + 2 and (tab[:, -2:] == [0, 1]).all()
+    assert "HumanoidTorque4Ages.walk.3.real" in loco_mujoco_amd.get_all_task_names()
+    with pytest.raises(NotImplementedError):
+        LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True)
+    with pytest.raises(TypeError):
+        e.reset(obs=np.zeros(38))

@@ -23,10 +23,12 @@ sys.path.insert(0, str(ROOT))
 from loco_mujoco_amd import mjcf                      # noqa: E402
 from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
 from loco_mujoco_amd.environments.atlas import Atlas, _ARM, _BACK   # noqa: E402
-from loco_mujoco_amd.environments.humanoids import HumanoidMuscle, HumanoidTorque   # noqa: E402
+from loco_mujoco_amd.environments.humanoids import (HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque,   # noqa: E402
+                                                    HumanoidTorque4Ages)
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
-                "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"]
+                "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"] + [
+                "Humanoid%s4Ages.%s.%d.real" % (a, t, k) for a in ("Torque", "Muscle") for t in ("run", "walk") for k in (1, 2, 3, 4)]
 
 
 def main():
@@ -56,7 +58,7 @@ def main():
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_torque.xml")
     ht = HumanoidTorque.__new__(HumanoidTorque)
     ht._use_muscles, ht._use_box_feet, ht._disable_arms = False, True, True
-    m = HumanoidTorque._compile(h, 0.001, *ht._get_xml_modifications()[:3])
+    m = ht._compile(h, 0.001, *ht._get_xml_modifications()[:3])
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "HumanoidTorque.default.model.npz")
     print("HumanoidTorque: nbody %d nv %d ngeom %d nu %d (mesh geoms kept as proximity spheres: %d)"
           % (m.nbody, m.nv, m.ngeom, m.nu, m.n_dropped_mesh_geoms))
@@ -64,10 +66,20 @@ def main():
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_muscle.xml")
     hm = HumanoidMuscle.__new__(HumanoidMuscle)
     hm._use_muscles, hm._use_box_feet, hm._disable_arms = True, True, True
-    m = HumanoidMuscle._compile(h, 0.001, *hm._get_xml_modifications()[:3])
+    m = hm._compile(h, 0.001, *hm._get_xml_modifications()[:3])
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "HumanoidMuscle.default.model.npz")
     print("HumanoidMuscle: nbody %d nv %d ngeom %d nu %d na %d tendons %d path sites %d"
           % (m.nbody, m.nv, m.ngeom, m.nu, m.na, m.ntendon, len(m.wrap_site)))
+
+    # --- the humanoid in four sizes (base_humanoid_4_ages.py): one compiled model per size and actuation
+    for cls, xml, mus in ((HumanoidTorque4Ages, "humanoid_torque.xml", False), (HumanoidMuscle4Ages, "humanoid_muscle.xml", True)):
+        for scale in (0.4, 0.6, 0.8, 1.0):
+            h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / xml)
+            e = cls.__new__(cls)
+            e._use_muscles, e._use_box_feet, e._disable_arms, e._model_scale = mus, True, True, scale
+            m = e._compile(h, 0.001, *e._get_xml_modifications()[:3])
+            m.save(ROOT / "loco_mujoco_amd" / "assets" / e._asset_name())
+            print("%s: total mass %.2f kg" % (e._asset_name(), m.body_mass.sum()))
 
     # --- domain-randomisation configurations (plain YAML, copied verbatim: they are data, not code)
     for rel in ["atlas/domain_randomization_atlas.yaml", "humanoid/domain_randomization_humanoid.yaml",
@@ -80,7 +92,9 @@ def main():
     for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_reduced_humanoid.npz",
-                "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"]:
+                "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"] + [
+                "datasets/humanoids/real/mini_datasets/%s_reduced_humanoid_POMDP_%d.npz" % (t, k)
+                for t in ("02-constspeed", "05-run") for k in (1, 2, 3, 4)]:
         src = np.load(pkg / rel, allow_pickle=True)
         dst = ROOT / "loco_mujoco_amd" / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
