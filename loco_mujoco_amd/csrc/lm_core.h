@@ -1227,11 +1227,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             mag = fabsf(g1) + fabsf(alpha * q2) + Q::sum(am + w0 * rm);
           };
           // Root of the increasing phi'. It is piecewise smooth with very different slopes: saturating friction
-          // rows give S-shapes, a stiff contact crossing its sticking sliver gives a near-jump. Newton from the
-          // current point; once the root is bracketed: Newton if it lands inside the bracket, else the secant
-          // through the bracket ends, and a bisection whenever the previous step failed to halve the bracket
-          // (that is what finds the slivers).
-          float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f, w_prev = 3.0e38f;
+          // rows give S-shapes, a stiff contact crossing its sticking sliver gives a near-jump.
+          float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f;
           line(0.0f, d1, d2, mag);
 #ifdef LM_LS_TRACE
           if (getenv("LM_SCAN")) { for (float aa = 1e-7f; aa < 2.0f; aa *= 3.0f) { float x1, x2, xm; line(aa, x1, x2, xm); if (c == 0) printf("    scan alpha %.3g d1 %.6g d2 %.6g\n", aa, x1, x2); } line(0.0f, d1, d2, mag); }
@@ -1239,6 +1236,71 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           bool ls_done = !(d1 < 0.0f && d2 > 0.0f);
           const float dref = fabsf(d1);
           dlo = d1;
+          if (Q::kPoints > 1) {
+            // ---- FOUR POINTS PER ROUND. With kRep = 4 the environment is replicated over the 4 quads of a 16-lane row
+            // (same instruction stream, idle lanes otherwise) and every replica evaluates ONE of the four step lengths,
+            // so a round costs one evaluation; with kRep = 1 (CPU emulator) the same lane evaluates all four.
+            // Round 1 spreads the Newton step geometrically (the root of a step that activates constraints is often
+            // 10-100x shorter than the Newton step); later rounds put Newton from both bracket ends, the secant and the
+            // midpoint inside the bracket.
+            float d2lo = d2, d2hi = 0.0f, best_abs = 3.0e38f;
+            float cand[4];
+            const float aN = ls_done ? 0.0f : -d1 / d2;
+            cand[0] = aN; cand[1] = 0.25f * aN; cand[2] = 0.0625f * aN; cand[3] = 0.015625f * aN;
+            for (int round = 0; round < ((P.ablate & 8) ? 0 : (P.ls_iters + 1) / 2); round++) {
+              if (!Q::any(!ls_done)) break;
+              if (!ls_done) {
+                float cd1[4], cd2[4], cmg[4];
+                if (Q::kRep == 1) {
+#pragma unroll
+                  for (int j = 0; j < 4; j++) line(cand[j], cd1[j], cd2[j], cmg[j]);
+                } else {
+                  const int r = Q::rep();
+                  const float mine = (r == 0) ? cand[0] : ((r == 1) ? cand[1] : ((r == 2) ? cand[2] : cand[3]));
+                  float x1, x2, xm;
+                  line(mine, x1, x2, xm);
+#pragma unroll
+                  for (int j = 0; j < 4; j++) { cd1[j] = Q::rep_bcast(x1, j); cd2[j] = Q::rep_bcast(x2, j); cmg[j] = Q::rep_bcast(xm, j); }
+                }
+                if (c == 0) cnt.ls_evals++;
+#ifdef LM_LS_TRACE
+                if (c == 0) for (int j = 0; j < 4; j++) printf("  ls round %d alpha %.9g d1 %.6g d2 %.6g lo %.9g hi %.9g dref %.4g\n", round, cand[j], cd1[j], cd2[j], lo, hi, dref);
+#endif
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  const float ad = fabsf(cd1[j]);
+                  if (ad < fmaxf(P.ls_tol * dref, P.ls_noise * cmg[j]) && ad < best_abs) { best_abs = ad; alpha = cand[j]; ls_done = true; }
+                }
+                if (!ls_done) {
+#pragma unroll
+                  for (int j = 0; j < 4; j++) {
+                    if (cd1[j] < 0.0f) { if (cand[j] > lo) { lo = cand[j]; dlo = cd1[j]; d2lo = cd2[j]; } }
+                    else if (hi < 0.0f || cand[j] < hi) { hi = cand[j]; dhi = cd1[j]; d2hi = cd2[j]; }
+                  }
+                  if (hi < 0.0f) {            // still descending at the longest step tried: look further out
+                    cand[0] = 2.0f * lo; cand[1] = 4.0f * lo; cand[2] = 8.0f * lo; cand[3] = 16.0f * lo;
+                    alpha = lo;
+                  } else {
+                    const float w = hi - lo;
+                    alpha = (lo * dhi - hi * dlo) / (dhi - dlo);       // secant point: the answer if the rounds run out
+                    if (!(alpha > lo && alpha < hi)) alpha = 0.5f * (lo + hi);
+                    if (w <= 1e-4f * hi) ls_done = true;
+                    else {
+                      const float in_lo = lo + 0.01f * w, in_hi = hi - 0.01f * w;
+                      float g0 = lo - dlo / d2lo, g1 = hi - dhi / d2hi;
+                      if (!(g0 > in_lo && g0 < in_hi)) g0 = lo + 0.25f * w;
+                      if (!(g1 > in_lo && g1 < in_hi)) g1 = lo + 0.75f * w;
+                      cand[0] = g0; cand[1] = g1; cand[2] = fminf(fmaxf(alpha, in_lo), in_hi); cand[3] = 0.5f * (lo + hi);
+                    }
+                  }
+                }
+              }
+            }
+          } else {
+          // ---- ONE POINT AT A TIME (full waves, no idle lanes): Newton from the current point; once the root is
+          // bracketed: Newton if it lands inside the bracket, else the secant through the bracket ends, and a bisection
+          // whenever the previous step failed to halve the bracket (that is what finds the slivers).
+          float w_prev = 3.0e38f;
           if (!ls_done) alpha = -d1 / d2;
           for (int lsi = 0; lsi < ((P.ablate & 8) ? 0 : P.ls_iters); lsi++) {
             if (!Q::any(!ls_done)) break;
@@ -1262,6 +1324,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 alpha = next;
               }
             }
+          }
           }
           if (c == 0 && !ls_done) cnt.ls_capped++;
           LM_TICK(8);

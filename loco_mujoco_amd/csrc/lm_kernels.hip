@@ -31,7 +31,17 @@ __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "
 namespace {
 
 // ---- quad policy on gfx950: DPP quad_perm butterflies, no LDS ------------------------------------------------
-struct QuadDpp {
+// REP = 4: the environment is replicated over the four quads of a 16-lane row (lanes that would idle in small batches);
+// the replicas run the same instruction stream and split the four step lengths of a line-search round between them.
+template <int REP>
+struct QuadDppT {
+  static constexpr int kRep = REP, kPoints = (REP == 4) ? 4 : 1;
+  static __device__ __forceinline__ int rep() { return (threadIdx.x >> 2) & (REP - 1); }
+  static __device__ __forceinline__ float rep_bcast(float x, int r) {
+    if (REP == 1) return x;
+    const int src = (int)((__lane_id() & ~12u) | ((unsigned)r << 2));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x)));
+  }
   static __device__ __forceinline__ float sum(float x) {
     // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
     float y = x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
@@ -39,6 +49,7 @@ struct QuadDpp {
   }
   static __device__ __forceinline__ bool any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 };
+using QuadDpp = QuadDppT<1>;
 
 thread_local std::string g_err;
 thread_local const char* g_launch_err = nullptr;
@@ -84,8 +95,9 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
+  using QuadDpp = QuadDppT<REP>;
   __shared__ float cm[LM_CM_SIZE];
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
   if (NM > 0) for (int i = threadIdx.x; i < LM_MT_SIZE; i += blockDim.x) mt[i] = a.mt[i];
@@ -95,9 +107,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 3;
-  const int e_raw = blockIdx.x * a.epb + (threadIdx.x >> 2);
-  const bool valid = e_raw < a.N;             // padding quads of the last workgroup recompute env N-1, store nothing
-  const int e = valid ? e_raw : a.N - 1;
+  const int e_local = threadIdx.x / (4 * REP);               // REP quads per environment (replicas), see QuadDppT
+  const int e_raw = blockIdx.x * a.epb + e_local;
+  // padding quads of the last workgroup recompute env N-1; they and the replicas 1..REP-1 store nothing
+  const bool valid = e_raw < a.N && QuadDpp::rep() == 0;
+  const int e = (e_raw < a.N) ? e_raw : a.N - 1;
   const int N = a.N, nv = a.T.nv;
   const float* rb = cm + LM_CM_ROOT;
 #define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
@@ -175,7 +189,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   // ---- physics
   lm::Counters cnt = {};
   using LMm = lm::LaneMem<MC, NS, NM>;
-  float* lmem = lane_mem + (threadIdx.x >> 4) * LMm::kGroup + (threadIdx.x & 15);
+  const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
+  float* lmem = lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
   constexpr int ls = 16;
   if (NM > 0) {
     // this lane's muscles: activation state and un-normalised, clamped control into lane memory
@@ -384,6 +399,25 @@ static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_bytes, lm_ba
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
+  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;                  // A/B switch
+  if (!FWD && !b->dofprm && b->epb <= 4 && !no_replicas) {
+    // small batch: at most 16 of a wave's 64 lanes carry environments -> replicate each environment over the 4 quads
+    // of its 16-lane row; the replicas share one line-search round (4 step lengths) between them
+    const bool big_ = b->m->T.max_links > 3, rk4_ = b->m->P.integrator == LM_INT_RK4;
+    dim3 block4(16 * b->epb);
+    if (!big_ && !rk4_ && b->m->P.cone == LM_CONE_ELLIPTIC) {
+      launch_one(step_kernel<3, 4, false, false, LM_CONE_ELLIPTIC, 0, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<3, 4>::kGroup, b, a);
+      return;
+    }
+    if (big_ && rk4_ && b->m->T.na == 0) {
+      launch_one(step_kernel<5, 8, true, false, -1, 0, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<5, 8>::kGroup, b, a);
+      return;
+    }
+    if (big_ && !rk4_ && b->m->T.na > 0) {
+      launch_one(step_kernel<5, 8, false, false, -1, LM_MAXMUS, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup, b, a);
+      return;
+    }
+  }
   const bool big = b->m->T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4;
   static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: cone read at run time
   const int cone = generic ? -2 : b->m->P.cone;

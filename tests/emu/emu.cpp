@@ -17,7 +17,13 @@ std::barrier<> g_bar(4);
 float g_buf[4];
 int g_ibuf[4];
 thread_local int t_lane = 0;
-struct QuadThreads {
+// POINTS = 4 runs the four-points-per-round line search of the replicated GPU layout with one replica (the lane
+// evaluates the four step lengths itself): same decisions, same results, no extra lanes needed on the CPU
+template <int POINTS>
+struct QuadThreadsT {
+  static constexpr int kRep = 1, kPoints = POINTS;
+  static int rep() { return 0; }
+  static float rep_bcast(float x, int) { return x; }
   static float sum(float x) {
     g_buf[t_lane] = x; g_bar.arrive_and_wait();
     float s = (g_buf[0] + g_buf[1]) + (g_buf[2] + g_buf[3]);
@@ -29,6 +35,10 @@ struct QuadThreads {
     g_bar.arrive_and_wait(); return r;
   }
 };
+#ifndef EMU_LS_POINTS
+#define EMU_LS_POINTS 1
+#endif
+using QuadThreads = QuadThreadsT<EMU_LS_POINTS>;
 }  // namespace
 
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)

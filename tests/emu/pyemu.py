@@ -6,20 +6,20 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libemu.so")
-
-
-def build():
+def build(ls_points=1):
+    """ls_points = 1: the one-point-at-a-time line search of full waves; 4: the four-points-per-round line search of the
+    replicated small-batch layout (evaluated by one lane here)."""
+    lib = os.path.join(_HERE, "libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points)
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
             os.path.join(_HERE, "../../include/lm_layout.h")]
-    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-o", _LIB, srcs[0]])
-    return _LIB
+                               "-DEMU_LS_POINTS=%d" % ls_points, "-o", lib, srcs[0]])
+    return lib
 
 
-def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None):
-    lib = C.CDLL(build())
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1):
+    lib = C.CDLL(build(ls_points))
     cmod = np.ascontiguousarray(chain_model, dtype=np.float64)
     nv = int(cmod[2])
     q = np.array(qpos, dtype=np.float64).reshape(-1, nv)

@@ -38,19 +38,20 @@ def test_lowering_structure(setup):
     assert sorted(int(x) for x in info["dof_to_lane"][6:]) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
 
 
-def test_core_stages_and_golden_steps(setup):
+@pytest.mark.parametrize("ls_points", [1, 4])
+def test_core_stages_and_golden_steps(setup, ls_points):
     env, cmod, info, o = setup
     g = GOLD["UnitreeA1.simple.real"]
     acts = actions(17)
     for k in (0, 3, 8, 12, 16):
         qpos, qvel = np.concatenate([[0, 0], g[k, :16]]), g[k, 16:34]
         f = o.forward(qpos, qvel, acts[k])
-        q, v, w, cnt, d = pyemu.run(cmod, qpos, qvel, acts[k], nsub=1, debug_env=0)
+        q, v, w, cnt, d = pyemu.run(cmod, qpos, qvel, acts[k], nsub=1, debug_env=0, ls_points=ls_points)
         assert cnt["ncon"] == f["ncon"] and cnt["overflow"] == 0
         assert np.abs(d["M"] - f["M"]).max() < 1e-5
         assert np.abs(d["bias"] - f["bias"]).max() < 1e-4
         assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())   # float32 Newton-decrement stop
-        q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10)
+        q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10, ls_points=ls_points)
         assert np.abs(q10[0, 2:] - g[k + 1, :16]).max() < 1e-5
         assert np.abs(v10[0] - g[k + 1, 16:34]).max() < 1e-3
 
