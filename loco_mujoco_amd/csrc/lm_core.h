@@ -677,7 +677,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
       for (int k = 0; k < MC; k++) Fl[k] = sp0();
       const int m0 = (int)mt[oz + c], nm = (int)mt[oz + LM_NCHAIN + c];
-      for (int i = 0; i < nm; i++) {
+      // the replicas of a small-batch environment (Q::kRep quads) share the chain's muscles between them: muscle i
+      // (its force and its activation state in the shared lane memory) belongs to replica i mod kRep
+      for (int i = Q::rep(); i < nm; i += Q::kRep) {
         const float* rec = mt + oz + LM_MT_HEAD + (m0 + i) * LM_MU_SIZE;
         const float* site = mt + oz + LM_MT_SITES + 4 * (int)rec[LM_MU_SITE_ADR];
         const int nsite = (int)rec[LM_MU_SITE_NUM];
@@ -757,7 +759,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       }
       Sp Fs = sp0();
 #pragma unroll
-      for (int k = MC - 1; k >= 0; k--) { Fs = Fs + Fl[k]; musc[k] = spdot(Sc[k], Fs); }
+      for (int k = MC - 1; k >= 0; k--) {
+        if (Q::kRep > 1) {      // symmetric butterfly: every replica ends up with the bit-identical total
+          Fl[k].w = v3(Q::rep_sum(Fl[k].w.x), Q::rep_sum(Fl[k].w.y), Q::rep_sum(Fl[k].w.z));
+          Fl[k].v = v3(Q::rep_sum(Fl[k].v.x), Q::rep_sum(Fl[k].v.y), Q::rep_sum(Fl[k].v.z));
+        }
+        Fs = Fs + Fl[k]; musc[k] = spdot(Sc[k], Fs);
+      }
     }
 
     // ======== smooth forces, unconstrained acceleration ========
@@ -979,9 +987,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       Sp Fl[MC];                 // contact wrench sums per link
 #pragma unroll
       for (int k = 0; k < MC; k++) Fl[k] = sp0();
+      // replicated small-batch layout: when some lane of the wave holds several contacts, the replicas of an environment
+      // take every kRep-th slot each (forces here, Hessian blocks below) and add their parts up with the symmetric
+      // butterfly, so that all replicas continue with bit-identical numbers
+      const bool split = Q::kRep > 1 && Q::any(nslot > 1);
+      const int s_first = split ? Q::rep() : 0, s_step = split ? Q::kRep : 1;
       if (nslot > 0 && !(P.ablate & 32)) {
         link_images(ar, ac);
-        for (int s = 0; s < nslot; s++) {
+        for (int s = s_first; s < nslot; s += s_step) {
           float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
@@ -1014,6 +1027,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
         }
       }
+      if (split) {
+#pragma unroll
+        for (int k = 0; k < MC; k++) {
+          Fl[k].w = v3(Q::rep_sum(Fl[k].w.x), Q::rep_sum(Fl[k].w.y), Q::rep_sum(Fl[k].w.z));
+          Fl[k].v = v3(Q::rep_sum(Fl[k].v.x), Q::rep_sum(Fl[k].v.y), Q::rep_sum(Fl[k].v.z));
+        }
+      }
       Sp Fsum = sp0();
 #pragma unroll
       for (int k = MC - 1; k >= 0; k--) { Fsum = Fsum + Fl[k]; qf_c[k] += spdot(ldS(LMm::kSc + k * 6), Fsum); }
@@ -1033,22 +1053,25 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       else {
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
         float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21], Hrep[21];
+        // when the slots are split over the replicas, only replica 0 starts from M (+ unit-row terms); the butterfly
+        // sum below then gives every replica M + all contact blocks
+        const float own = (split && Q::rep() != 0) ? 0.0f : 1.0f;
 #pragma unroll
-        for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = LMEM(LMm::kMcc + i);
+        for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = own * LMEM(LMm::kMcc + i);
 #pragma unroll
         for (int i = 0; i < 21; i++) Hrep[i] = LMEM(LMm::kMrr + i);
 #pragma unroll
         for (int k = 0; k < MC; k++) {
 #pragma unroll
-          for (int r = 0; r < 6; r++) Hcr[k][r] = LMEM(LMm::kMcr + k * 6 + r);
-          if (act_fr_c & (1u << k)) Hcc[tri(k, k)] += iR_c[k];
-          if (act_lim & (1u << k)) Hcc[tri(k, k)] += lim_D_c[k];
+          for (int r = 0; r < 6; r++) Hcr[k][r] = own * LMEM(LMm::kMcr + k * 6 + r);
+          if (act_fr_c & (1u << k)) Hcc[tri(k, k)] += own * iR_c[k];
+          if (act_lim & (1u << k)) Hcc[tri(k, k)] += own * lim_D_c[k];
         }
 #pragma unroll
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hrep[tri(i, i)] += iR_r[i];
-        for (int s = 0; s < ((P.ablate & 2) ? 0 : nslot); s++) {
+        for (int s = s_first; s < ((P.ablate & 2) ? 0 : nslot); s += s_step) {
           oz = LM_OPAQUE_ZERO();
           const int zone = (int)SL(s, SL_ZONE);
           if (zone == 0) continue;
@@ -1118,6 +1141,16 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               }
             }
           }
+        }
+        if (split) {
+#pragma unroll
+          for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Q::rep_sum(Hcc[i]);
+#pragma unroll
+          for (int k = 0; k < MC; k++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) Hcr[k][r] = Q::rep_sum(Hcr[k][r]);
+#pragma unroll
+          for (int i = 0; i < 21; i++) Hpart[i] = Q::rep_sum(Hpart[i]);
         }
         LM_TICK(5);
         float Lr[21];

@@ -42,6 +42,13 @@ struct QuadDppT {
     const int src = (int)((__lane_id() & ~12u) | ((unsigned)r << 2));
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x)));
   }
+  // sum over the replicas: butterfly over lane^4 and lane^8, the same association in every replica
+  static __device__ __forceinline__ float rep_sum(float x) {
+    if (REP == 1) return x;
+    const unsigned l = __lane_id();
+    float y = x + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 4u) << 2), __float_as_int(x)));
+    return y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 8u) << 2), __float_as_int(y)));
+  }
   static __device__ __forceinline__ float sum(float x) {
     // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
     float y = x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));

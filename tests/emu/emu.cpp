@@ -24,6 +24,7 @@ struct QuadThreadsT {
   static constexpr int kRep = 1, kPoints = POINTS;
   static int rep() { return 0; }
   static float rep_bcast(float x, int) { return x; }
+  static float rep_sum(float x) { return x; }
   static float sum(float x) {
     g_buf[t_lane] = x; g_bar.arrive_and_wait();
     float s = (g_buf[0] + g_buf[1]) + (g_buf[2] + g_buf[3]);
