@@ -550,78 +550,108 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           LMEM(LMm::kFrame + k * 18 + 15) = V.v.x; LMEM(LMm::kFrame + k * 18 + 16) = V.v.y; LMEM(LMm::kFrame + k * 18 + 17) = V.v.z;
         } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
       }
-  // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link
-      for (int g = 0; g < ng; g++) {
-        const int k = (int)GE(g, LM_G_LINK);
-        const int fb = LMm::kFrame + k * 18;
-        const V3 gl = v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ));
-        // margin-less bounding-sphere prune on the height of the geom centre (third row of the link rotation)
-        if (LMEM(fb + 2) + LMEM(fb + 9) * gl.x + LMEM(fb + 10) * gl.y + LMEM(fb + 11) * gl.z - GE(g, LM_G_RBOUND) > 0.0f) continue;
-        const V3 pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
-        M3 Rk;
-#pragma unroll
-        for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
-        Sp V; V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
-        V3 ctr = pk + mul(Rk, gl);
-        float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF), margin = GE(g, LM_G_MARGIN);
-        const int gtype = (int)GE(g, LM_G_TYPE);
-        V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
-        M3 Rg;
-        if (gtype == LM_GEOM_BOX) {
-          M3 Gr;
-#pragma unroll
-          for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
-          Rg = mul(Rk, Gr);
-        }
-        // candidate points: sphere centre | the two capsule end centres | the box corners below the box centre
-        // in bit order, at most 4 contacts per box
-        const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
+  // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link. The replicas of a
+  // small-batch environment take every kRep-th geom; in each pass they exchange how many contacts they found, so that
+  // the slot records land in lane memory in the same order (geom, then candidate point) as without replicas.
+      int n_overflow = 0, n_unhandled = 0;
+      for (int g0 = 0; g0 < ng; g0 += Q::kRep) {
+        const int g = g0 + Q::rep();
+        // ---- candidate points of my geom: sphere centre | the two capsule end centres | the box corners below the box
+        // centre in bit order, at most 4 contacts per box
         int made = 0;
-        for (int e = 0; e < npt; e++) {
-          V3 sc = ctr; float rad_e = rad;
-          if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
-          else if (gtype == LM_GEOM_BOX) {
-            V3 off = mul(Rg, v3((e & 1) ? GE(g, LM_G_SX) : -GE(g, LM_G_SX), (e & 2) ? GE(g, LM_G_SY) : -GE(g, LM_G_SY),
-                                (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
-            if (off.z > 0.0f || made >= 4) continue;
-            sc = ctr + off; rad_e = 0.0f;
+        float cx[4], cy[4], cd[4];
+        int k = 0;
+        Sp V = sp0();
+        float margin = 0.0f;
+        if (g < ng) {
+          k = (int)GE(g, LM_G_LINK);
+          const int fb = LMm::kFrame + k * 18;
+          const V3 gl = v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ));
+          // margin-less bounding-sphere prune on the height of the geom centre (third row of the link rotation)
+          if (!(LMEM(fb + 2) + LMEM(fb + 9) * gl.x + LMEM(fb + 10) * gl.y + LMEM(fb + 11) * gl.z - GE(g, LM_G_RBOUND) > 0.0f)) {
+            const V3 pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+            M3 Rk;
+#pragma unroll
+            for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
+            V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+            const V3 ctr = pk + mul(Rk, gl);
+            const float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF);
+            margin = GE(g, LM_G_MARGIN);
+            const int gtype = (int)GE(g, LM_G_TYPE);
+            const V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
+            M3 Rg;
+            if (gtype == LM_GEOM_BOX) {
+              M3 Gr;
+#pragma unroll
+              for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
+              Rg = mul(Rk, Gr);
+            }
+            const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
+            for (int e = 0; e < npt; e++) {
+              V3 sc = ctr; float rad_e = rad;
+              if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
+              else if (gtype == LM_GEOM_BOX) {
+                V3 off = mul(Rg, v3((e & 1) ? GE(g, LM_G_SX) : -GE(g, LM_G_SX), (e & 2) ? GE(g, LM_G_SY) : -GE(g, LM_G_SY),
+                                    (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
+                if (off.z > 0.0f || made >= 4) continue;
+                sc = ctr + off; rad_e = 0.0f;
+              }
+              const float dist = sc.z - rad_e;
+              if (dist >= margin) continue;
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (made == j) { cx[j] = sc.x; cy[j] = sc.y; cd[j] = dist; }
+              made++;
+            }
           }
-          float dist = sc.z - rad_e;
-          if (dist >= margin) continue;
-          made++;
-          if (nslot >= NS) { cnt.overflow++; continue; }
+        }
+        // ---- where do my contacts go: after those of the replicas with a smaller geom index in this pass
+        int before = 0, total = made;
+        if (Q::kRep > 1) {
+          total = 0;
+#pragma unroll
+          for (int r = 0; r < Q::kRep; r++) { const int n_r = (int)Q::rep_bcast((float)made, r); if (r < Q::rep()) before += n_r; total += n_r; }
+        }
+        for (int j = 0; j < made; j++) {
+          const int slot = nslot + before + j;
+          if (slot >= NS) { n_overflow++; continue; }
+          float px = cx[0], py = cy[0], dist = cd[0];
+#pragma unroll
+          for (int q = 1; q < 4; q++) if (j == q) { px = cx[q]; py = cy[q]; dist = cd[q]; }
           // contact point (midway between the surfaces) relative to O; row parameters
-          V3 cp = v3(sc.x, sc.y, 0.5f * dist) - O;
+          V3 cp = v3(px, py, 0.5f * dist) - O;
           float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
           float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
           float vel[6];
           contact_rows(V, cp, vel);
           const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
           const int dim = (int)GE(g, LM_G_DIM);
-          SL(nslot, SL_LINK) = (float)k; SL(nslot, SL_DIM) = (float)dim; SL(nslot, SL_MU) = mu;
-          SL(nslot, SL_GRF) = GE(g, LM_G_GRF);
-          SL(nslot, SL_RX) = cp.x; SL(nslot, SL_RY) = cp.y; SL(nslot, SL_RZ) = cp.z;
-          SL(nslot, SL_D) = D0;
+          SL(slot, SL_LINK) = (float)k; SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = mu;
+          SL(slot, SL_GRF) = GE(g, LM_G_GRF);
+          SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
+          SL(slot, SL_D) = D0;
           if (pyramidal && dim == 3) {
             float xv[4];
             pyr_rows(vel, mu, xv);
 #pragma unroll
-            for (int r = 0; r < 4; r++) SL(nslot, SL_AREF + r) = -B * xv[r] - Kr;
+            for (int r = 0; r < 4; r++) SL(slot, SL_AREF + r) = -B * xv[r] - Kr;
           } else {
 #pragma unroll
-            for (int j = 1; j < 6; j++) { SL(nslot, SL_D + j) = (j < dim) ? D0 / GE(g, LM_G_RR1 + j - 1) : 0.0f; SL(nslot, SL_FR + j - 1) = GE(g, LM_G_F0 + j - 1); }
+            for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / GE(g, LM_G_RR1 + j2 - 1) : 0.0f; SL(slot, SL_FR + j2 - 1) = GE(g, LM_G_F0 + j2 - 1); }
 #pragma unroll
-            for (int j = 0; j < 6; j++) SL(nslot, SL_AREF + j) = -B * vel[j] - ((j == 0) ? Kr : 0.0f);
+            for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -B * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
           }
-          nslot++;
         }
+        nslot += total;
       }
-      for (int i = 0; i < nun; i++) {
+      if (nslot > NS) nslot = NS;
+      for (int i = Q::rep(); i < nun; i += Q::kRep) {
         const int fb = LMm::kFrame + (int)CH(LM_C_UNSUP + i * LM_U_SIZE) * 18;
         const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CH(LM_C_UNSUP + i * LM_U_SIZE + 1) + LMEM(fb + 10) * CH(LM_C_UNSUP + i * LM_U_SIZE + 2)
                          + LMEM(fb + 11) * CH(LM_C_UNSUP + i * LM_U_SIZE + 3);
-        if (sz - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) cnt.unhandled++;
+        if (sz - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) n_unhandled++;
       }
+      if (Q::kRep > 1) { n_overflow = (int)Q::rep_sum((float)n_overflow); n_unhandled = (int)Q::rep_sum((float)n_unhandled); }
+      cnt.overflow += n_overflow; cnt.unhandled += n_unhandled;
     }
     cnt.ncon += nslot;
     LM_TICK(0);
