@@ -909,19 +909,23 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   };
   // lane-partial constraint cost at acceleration (xr, xc) (root rows weighted so that the quad sum counts them once)
   auto cost_at = [&](const float* xr, const float* xc) -> float {
+    // with replicas: the unit rows are counted by replica 0, the contact slots are dealt round-robin (callers add
+    // the parts up with Q::rep_sum)
     float cost = 0, cr = 0;
+    if (Q::rep() == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), RD(i, LM_D_FLOSS_R));
-    cost = w0 * cr;
+      for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), RD(i, LM_D_FLOSS_R));
+      cost = w0 * cr;
 #pragma unroll
-    for (int k = 0; k < MC; k++) if (k < nl) {
-      cost += friction_cost(xc[k] - fl_aref_c[k], FLOSS_C(k), LK(k, LM_D_FLOSS_R));
-      float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
-      if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
+      for (int k = 0; k < MC; k++) if (k < nl) {
+        cost += friction_cost(xc[k] - fl_aref_c[k], FLOSS_C(k), LK(k, LM_D_FLOSS_R));
+        float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
+        if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
+      }
     }
     if (nslot > 0) {
       link_images(xr, xc);
-      for (int s = 0; s < nslot; s++) {
+      for (int s = Q::rep(); s < nslot; s += Q::kRep) {
         float Dj[6], fr[5], jar[6];
         contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
@@ -946,14 +950,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   float ar[6], ac[MC];
   {
     // warm start: the better of (previous qacc, qacc_smooth)
-    float cost_smooth = Q::sum(cost_at(a0r, a0c));
+    float cost_smooth = Q::rep_sum(Q::sum(cost_at(a0r, a0c)));
     float yr[6], yc[MC], gauss = 0, gr = 0;
     mulM(war, wac, yr, yc);
 #pragma unroll
     for (int k = 0; k < MC; k++) gauss += 0.5f * (yc[k] - sm_c[k]) * (wac[k] - a0c[k]);
 #pragma unroll
     for (int i = 0; i < 6; i++) gr += 0.5f * (yr[i] - sm_r[i]) * (war[i] - a0r[i]);
-    float cost_warm = Q::sum(cost_at(war, wac) + gauss + w0 * gr);
+    float cost_warm = Q::rep_sum(Q::sum(cost_at(war, wac))) + Q::sum(gauss + w0 * gr);
     bool use_warm = cost_warm < cost_smooth;
 #pragma unroll
     for (int i = 0; i < 6; i++) ar[i] = use_warm ? war[i] : a0r[i];
