@@ -64,7 +64,7 @@ int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct Task {
-  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf;
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts;
   float rp[8];
 };
 
@@ -105,12 +105,13 @@ __device__ __forceinline__ float wave_sum(float x) {
 template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
-  __shared__ float cm[LM_CM_SIZE];
+  extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
+  float* cm = dyn_lds;
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
   if (NM > 0) for (int i = threadIdx.x; i < LM_MT_SIZE; i += blockDim.x) mt[i] = a.mt[i];
   __shared__ float blk_stats[12];
-  extern __shared__ float lane_mem[];                      // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
-  for (int i = threadIdx.x; i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
+  float* lane_mem = dyn_lds + a.T.cm_used;                 // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
+  for (int i = threadIdx.x; i < a.T.cm_used && i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
   for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 3;
@@ -397,67 +398,51 @@ struct lm_batch {
 // CONE = friction cone compiled in (the quadruped family gets a specialised step kernel <3,4,Euler,elliptic>;
 // everything else reads the cone at run time)
 template <class K>
-static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_bytes, lm_batch* b, const KArgs& a) {
-  // the workgroup's LDS = constant table (static) + lane memory (dynamic); opt in to more than the default cap
-  hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
-  hipLaunchKernelGGL(kernel, grid, block, lane_bytes, b->stream, a);
+static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, lm_batch* b, const KArgs& a) {
+  // the workgroup's LDS = constant table (the part the model uses) + lane memory, both dynamic; opt in to more than
+  // the default 64 KB cap
+  const size_t bytes = sizeof(float) * ((size_t)a.T.cm_used + lane_floats);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipLaunchKernelGGL(kernel, grid, block, bytes, b->stream, a);
+}
+
+// one robot family = (links per chain MC, contact slots per chain NS, integrator, compiled-in cone, muscles per chain NM).
+// Picks the layout: replicated (4 quads per environment, small workgroups of <= 4 environments), per-environment joint
+// parameters (domain randomisation), or plain.
+template <int MC, int NS, bool RK4, int CONE, int NM, bool FWD>
+static void launch_family(lm_batch* b, const KArgs& a) {
+  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;                  // A/B switch
+  const dim3 grid((b->N + b->epb - 1) / b->epb);
+  using LMm = lm::LaneMem<MC, NS, NM>;
+  if (FWD) {
+    launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
+  } else if (b->dofprm) {
+    launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
+  } else if (b->epb <= 4 && !no_replicas) {
+    launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4>, grid, dim3(16 * b->epb), (size_t)LMm::kGroup, b, a);
+  } else {
+    launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
+  }
 }
 
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
-  dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
-  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;                  // A/B switch
-  if (!FWD && !b->dofprm && b->epb <= 4 && !no_replicas) {
-    // small batch: at most 16 of a wave's 64 lanes carry environments -> replicate each environment over the 4 quads
-    // of its 16-lane row; the replicas share one line-search round (4 step lengths) between them
-    const bool big_ = b->m->T.max_links > 3, rk4_ = b->m->P.integrator == LM_INT_RK4;
-    dim3 block4(16 * b->epb);
-    if (!big_ && !rk4_ && b->m->P.cone == LM_CONE_ELLIPTIC) {
-      launch_one(step_kernel<3, 4, false, false, LM_CONE_ELLIPTIC, 0, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<3, 4>::kGroup, b, a);
-      return;
-    }
-    if (big_ && rk4_ && b->m->T.na == 0) {
-      launch_one(step_kernel<5, 8, true, false, -1, 0, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<5, 8>::kGroup, b, a);
-      return;
-    }
-    if (big_ && !rk4_ && b->m->T.na > 0) {
-      launch_one(step_kernel<5, 8, false, false, -1, LM_MAXMUS, false, 4>, grid, block4, sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup, b, a);
-      return;
-    }
-  }
-  const bool big = b->m->T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4;
-  static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: cone read at run time
-  const int cone = generic ? -2 : b->m->P.cone;
-  if (!FWD && b->dofprm) {
-    // per-environment joint parameters: the three shipped robot families have a kernel that reads them
-    if (!big && !rk4 && b->m->P.cone == LM_CONE_ELLIPTIC) {
-      const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kGroup * ((block.x + 15) / 16);
-      launch_one(step_kernel<3, 4, false, false, LM_CONE_ELLIPTIC, 0, true>, grid, block, lane_bytes, b, a);
-    } else if (big && rk4 && b->m->T.na == 0) {
-      const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kGroup * ((block.x + 15) / 16);
-      launch_one(step_kernel<5, 8, true, false, -1, 0, true>, grid, block, lane_bytes, b, a);
-    } else if (big && !rk4 && b->m->T.na > 0) {
-      const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup * ((block.x + 15) / 16);
-      launch_one(step_kernel<5, 8, false, false, -1, LM_MAXMUS, true>, grid, block, lane_bytes, b, a);
-    } else g_launch_err = "per-environment joint parameters are not compiled for this model family";
-    return;
-  }
-  if (!big) {
-    const size_t lane_bytes = sizeof(float) * lm::LaneMem<3, 4>::kGroup * ((block.x + 15) / 16);
-    if (!rk4) {
-      if (!FWD && cone == LM_CONE_ELLIPTIC) launch_one(step_kernel<3, 4, false, FWD, LM_CONE_ELLIPTIC>, grid, block, lane_bytes, b, a);
-      else launch_one(step_kernel<3, 4, false, FWD, -1>, grid, block, lane_bytes, b, a);
-    } else launch_one(step_kernel<3, 4, true, FWD, -1>, grid, block, lane_bytes, b, a);
-  } else if (b->m->T.na > 0) {
-    // muscle-driven humanoid: Euler, muscle table in LDS, activations and controls in lane memory
-    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8, LM_MAXMUS>::kGroup * ((block.x + 15) / 16);
-    launch_one(step_kernel<5, 8, false, FWD, -1, LM_MAXMUS>, grid, block, lane_bytes, b, a);
-  } else {
-    const size_t lane_bytes = sizeof(float) * lm::LaneMem<5, 8>::kGroup * ((block.x + 15) / 16);
-    // (a <5,8,RK4,pyramidal> specialisation was measured at +1 % and miscompared on the GPU once the collision pass
-    //  moved out of the link loop, while this run-time-cone kernel and the CPU lane emulator agree: not shipped)
-    if (!rk4) launch_one(step_kernel<5, 8, false, FWD, -1>, grid, block, lane_bytes, b, a);
-    else launch_one(step_kernel<5, 8, true, FWD, -1>, grid, block, lane_bytes, b, a);
+  const Task& T = b->m->T;
+  const bool big = T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
+  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 4, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped
+  else if (big && rk4 && T.na == 0 && few) launch_family<5, 4, true, -1, 0, FWD>(b, a);     // humanoid, one box foot per leg
+  else if (big && rk4 && T.na == 0) launch_family<5, 8, true, -1, 0, FWD>(b, a);            // Atlas: two boxes per foot
+  else if (big && !rk4 && T.na > 0 && few) launch_family<5, 4, false, -1, LM_MAXMUS, FWD>(b, a);   // muscle humanoid
+  else if (T.na > 0) g_launch_err = "muscle models need the <5 links, <=4 contacts per chain, Euler> family";
+  // generic fallbacks (cone read at run time; no replicated / randomised variants are compiled for them)
+  else if (b->dofprm) g_launch_err = "per-environment joint parameters are not compiled for this model family";
+  else {
+    const dim3 grid((b->N + b->epb - 1) / b->epb), block(4 * b->epb);
+    const size_t groups = (block.x + 15) / 16;
+    if (!big && !rk4) launch_one(step_kernel<3, 4, false, FWD, -1>, grid, block, (size_t)lm::LaneMem<3, 4>::kGroup * groups, b, a);
+    else if (!big) launch_one(step_kernel<3, 4, true, FWD, -1>, grid, block, (size_t)lm::LaneMem<3, 4>::kGroup * groups, b, a);
+    else if (!rk4) launch_one(step_kernel<5, 8, false, FWD, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, b, a);
+    else launch_one(step_kernel<5, 8, true, FWD, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, b, a);
   }
 }
 
@@ -519,6 +504,9 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   T.nv = (int)cmod[LM_H_NV]; T.nu = (int)cmod[LM_H_NU]; T.nobs = (int)cmod[LM_H_NOBS]; T.ngoal = (int)cmod[LM_H_NGOAL];
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
   T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS]; T.ngrf = (int)cmod[LM_H_NGRF];
+  T.max_contacts = (int)cmod[LM_H_MAXCONTACTS];
+  T.cm_used = ((int)cmod[LM_H_CM_USED] + 63) & ~63;          // keeps lane memory 256-byte aligned behind the table
+  if (T.cm_used <= 0 || T.cm_used > ((LM_CM_SIZE + 63) & ~63)) { delete m; return fail("bad constant-table extent"); }
   if (T.ngoal > 4) { delete m; return fail("more than 4 goal entries"); }
   for (int i = 0; i < 8; i++) T.rp[i] = (float)cmod[LM_H_REWARD_P0 + i];
   lm::Params& P = m->P;
@@ -558,15 +546,12 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   lm_batch* b = new lm_batch();
   memset(b, 0, sizeof(*b));
   b->m = m; b->N = n_envs;
-  // The step is latency-bound with one wave per SIMD (512-register budget), so small batches are spread
-  // over as many SIMDs as possible: fewer environments per wave until every one of the 256 CUs x 4 SIMDs
-  // has a wave (4096 envs -> 4 envs = 16 lanes per wave, 1024 waves). LM_ENVS_PER_BLOCK overrides.
+  // Four environments per workgroup: with the replicated layout that is one full wave (4 envs x 4 replicas x 4 chains),
+  // and a CU's 160 KB of LDS holds four such workgroups = one wave per SIMD. Larger batches simply run more workgroups
+  // back to back (measured: 4096 envs 1.32 ms, 16384 envs 4.0 ms, 65536 envs 13.8 ms per control step for UnitreeA1;
+  // wider workgroups without replicas were 30-50 % slower at every size). LM_ENVS_PER_BLOCK overrides.
   {
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int epb = 16;
-    while (epb > 1 && (n_envs + epb - 1) / epb < 4 * cus) epb >>= 1;
+    int epb = n_envs < 4 ? n_envs : 4;
     const char* ov = getenv("LM_ENVS_PER_BLOCK");
     if (ov && atoi(ov) >= 1 && atoi(ov) <= 16) epb = atoi(ov);
     b->epb = epb;
@@ -827,7 +812,9 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   HIPCHK(hipMemset(buf, 0, sizeof(float) * per * N));
   a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
   a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
+  g_launch_err = nullptr;
   launch_variant<true>(b, a);
+  if (g_launch_err) return fail(g_launch_err);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->stream));
   auto get = [&](float* dst, const float* src, size_t n) -> int { if (dst) HIPCHK(hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost)); return 0; };

@@ -50,10 +50,10 @@ LINK_SIZE = D_SIZE + L_SIZE
 # ---- chain block = [nlinks, ngeoms, unsupported geoms (count), links..., geoms...]
 C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_LINKS = 0, 1, 2, 3, 4, 6
 # C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
-C_GEOMS = C_LINKS + MAXC * LINK_SIZE
-C_UNSUP = C_GEOMS + MAXG * G_SIZE                  # unsupported geoms: (link, px,py,pz, rbound, margin) x MAXG
 U_SIZE = 6
-CHAIN_SIZE = C_UNSUP + MAXG * U_SIZE
+C_UNSUP = C_LINKS + MAXC * LINK_SIZE               # unsupported geoms: (link, px,py,pz, rbound, margin) x MAXG
+C_GEOMS = C_UNSUP + MAXG * U_SIZE                  # geoms LAST: a model with few geoms only ships the used part to LDS
+CHAIN_SIZE = C_GEOMS + MAXG * G_SIZE
 # ---- root block (replicated for all lanes)
 (R_NDOF, R_TX, R_TY, R_TZ, R_R0, R_R1, R_R2, R_R3, R_R4, R_R5, R_R6, R_R7, R_R8, R_MASS, R_CX, R_CY, R_CZ, R_IXX,
  R_IYY, R_IZZ, R_IXY, R_IXZ, R_IYZ, R_NUNSUP, R_DOFS) = range(25)
@@ -107,11 +107,12 @@ def _mix_with_floor(m, g, gf):
     return int(dim), np.asarray(solref, float), np.asarray(solimp, float), friction, margin, gap
 
 
-HEADER_SIZE = 32
+HEADER_SIZE = 40
 LMC_MAGIC = 0x4C4D4331  # "LMC1"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
-H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE = 25, 26, 27, 28, 29, 30, 31
+H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED = 25, 26, 27, 28, 29, 30, 31, 32
+# H_CM_USED: floats of the constant table that are actually read (up to the last used geom block)
 # H_NGRF: number of ground-reaction-force observation entries (3 per force group); they follow the goal entries
 
 # ---- muscle table (optional; follows the constant table): MT_HEAD floats [first muscle of chain c] x NCHAIN,
@@ -539,6 +540,8 @@ def lower(m, task):
     h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
     h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
     h[H_NMUSCLE] = len(muscles)
+    max_geoms = max([int(cm[CM_CHAINS + C_NGEOMS * NCHAIN + c]) for c in range(NCHAIN)])
+    h[H_CM_USED] = CM_CHAINS + (C_GEOMS + max_geoms * G_SIZE) * NCHAIN
     h[H_NGRF] = n_grf
     if n_grf and sum(1 for c in range(len(chains)) for k in (C_GRF_OBS0, C_GRF_OBS1) if cm[CM_CHAINS + k * NCHAIN + c] >= 0) != len(grf_groups):
         raise UnsupportedModel("a foot-force group has no geom with a device collider")

@@ -131,12 +131,14 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
                        int* counters /*6*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
-  if ((int)chain_model[LM_H_NMUSCLE] > 0)
-    return act ? emu_run_t<5, 8, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
+  // same family selection as the library's launch_variant()
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
-  const bool big = (int)chain_model[LM_H_MAXLINKS] > 3 || (int)chain_model[LM_H_MAXCONTACTS] > 11;
+  const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
+  if ((int)chain_model[LM_H_NMUSCLE] > 0)
+    return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
   if (!big && !rk4) return emu_run_t<3, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!rk4) return emu_run_t<5, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  if (few) return emu_run_t<5, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   return emu_run_t<5, 8, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
 }

@@ -31,7 +31,7 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     d5 = np.zeros((5, nv), dtype=np.float32)
     cnt = np.zeros(6, dtype=np.int32)
     dp = lambda x: x.ctypes.data_as(C.c_void_p)
-    na = int(cmod[31])
+    na = int(cmod[31])        # H_NMUSCLE
     actv = None
     if na:
         actv = np.zeros((n, na)) if act is None else np.array(act, dtype=np.float64).reshape(n, na)
