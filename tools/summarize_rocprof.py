@@ -27,7 +27,8 @@ with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w", newline="") as 
         w.writerow([r[0], r[1], round(r[2] * 1.0), round(r[3], 1), round(r[4], 4)])
 k = db.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, min(duration), "
                "avg(duration), max(duration), count(*) from kernels where name like '%step_kernel%'").fetchone()
-summary = dict(kernel="step_kernel<3,4,false>", vgpr=k[0], agpr=k[1], sgpr=k[2], lds_bytes=k[3], scratch_bytes=k[4],
+kname = db.execute("select name from kernels where name like '%step_kernel%' limit 1").fetchone()[0]
+summary = dict(kernel=kname.split("step_kernel")[1].split("(")[0].join(["step_kernel", ""]), vgpr=k[0], agpr=k[1], sgpr=k[2], lds_bytes=k[3], scratch_bytes=k[4],
                workgroup=k[5], grid=k[6], duration_ns=dict(min=k[7], avg=k[8], max=k[9]), dispatches=k[10])
 pmc = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
