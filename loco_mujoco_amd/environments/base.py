@@ -145,6 +145,9 @@ class LocoEnv:
             self._backend = HipBatch(self._hip_model, self.n_envs)
         return self._backend
 
+    def _select_model(self, idx):
+        """Hook of the multi-model environments: make model ``idx`` (drawn per episode, ``base.py:186-190``) current."""
+
     # ------------------------------------------------------------------ trajectories / datasets
     def load_trajectory(self, traj_params, warn=True):
         if self.trajectories is not None:
@@ -204,7 +207,7 @@ class LocoEnv:
         h.qpos[:] = self._model.qpos0          # mj_resetData
         h.qvel[:] = 0.0
         if self._random_env_reset:
-            np.random.randint(0, self._n_models)
+            self._select_model(np.random.randint(0, self._n_models))
         self._cur_env = e
         self.setup(obs)
 

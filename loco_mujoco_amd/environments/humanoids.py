@@ -249,23 +249,67 @@ class HumanoidMuscle(BaseHumanoid):
 
 class BaseHumanoid4Ages(BaseHumanoid):
     """The humanoid in four sizes — toddler 0.4, child 0.6, teenager 0.8, adult 1.0 — with the size indicator in the
-    observation (reference ``humanoids/base_humanoid_4_ages.py``). The reference keeps all four models in one
-    environment and samples one per episode (mode "all"); on the device one batch = one model, so only the
-    single-size modes "1".."4" are built."""
+    observation (reference ``humanoids/base_humanoid_4_ages.py``). Mode "all" keeps all four models in one environment
+    and draws one per episode; on the device one batch = one model table, so "all" is available for ``n_envs=1`` (one
+    device batch per size, switched at reset) while batches use the single-size modes "1".."4"."""
 
     _default_scalings = [0.4, 0.6, 0.8, 1.0]
 
     def __init__(self, scaling=None, scaling_trajectory_map=None, use_muscles=False, use_box_feet=True,
                  disable_arms=True, alpha_box_feet=0.5, xml_path=None, timestep=0.001, **kwargs):
         scalings = self._default_scalings if scaling is None else (list(scaling) if isinstance(scaling, (list, tuple)) else [scaling])
-        if len(scalings) != 1:
-            raise NotImplementedError('mode "all" (a different humanoid per episode) needs one model table per '
-                                      'environment on the device; use the modes "1".."4"')
+        if len(scalings) > 1 and kwargs.get("n_envs", 1) != 1:
+            raise NotImplementedError("several humanoid sizes in one BATCH need one model table per environment on the "
+                                      "device; use n_envs=1 or the single-size modes \"1\"..\"4\"")
         self._scalings = scalings
-        self._scaling_trajectory_map = None
+        self._scaling_trajectory_map = scaling_trajectory_map
         self._model_scale = float(scalings[0])
         super().__init__(use_muscles=use_muscles, use_box_feet=use_box_feet, disable_arms=disable_arms,
                          alpha_box_feet=alpha_box_feet, xml_path=xml_path, timestep=timestep, **kwargs)
+        # one compiled model (and, lazily, one device batch) per size; a size is drawn per episode (base.py:186-190)
+        self._models = [self._model]
+        for sc in scalings[1:]:
+            self._model_scale = float(sc)
+            if xml_path is not None:
+                j, mo, eq, _ = self._get_xml_modifications()
+                self._models.append(self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, j, mo, eq, alpha_box_feet))
+            else:
+                self._models.append(mjcf.CompiledModel.load(_PKG / "assets" / self._asset_name()))
+        self._model_scale = float(scalings[0])
+        self._n_models = len(self._models)
+        self._current_model_idx = 0
+        self._model_backends = [None] * self._n_models
+
+    def _select_model(self, idx):
+        self._model_backends[self._current_model_idx] = self._backend
+        self._current_model_idx = idx
+        self._model, self._model_scale = self._models[idx], float(self._scalings[idx])
+        self._backend = self._model_backends[idx]
+        self._hip_model = None
+
+    def setup(self, obs):
+        """``base_humanoid_4_ages.py:106-146``: with several sizes the start state is drawn from the trajectories that
+        belong to the current size."""
+        if obs is not None:
+            raise TypeError("Initializing the environment from an observation is not allowed in this environment.")
+        if self._n_models > 1 and self.trajectories is not None and self._random_start and self._scaling_trajectory_map:
+            self._reward_function.reset_state()
+            self._check_start_mode()
+            lo, hi = self._scaling_trajectory_map[self._current_model_idx]
+            self.set_sim_state(self.trajectories.reset_trajectory(traj_no=np.random.randint(lo, hi)))
+            return
+        super().setup(obs)
+
+    def load_trajectory(self, traj_params, scaling_trajectory_map=None, warn=True):
+        """``base_humanoid_4_ages.py:148-185``: default map = equally many trajectories per size, in size order."""
+        super().load_trajectory(traj_params, warn)
+        if scaling_trajectory_map is not None:
+            self._scaling_trajectory_map = scaling_trajectory_map
+        elif self._scaling_trajectory_map is None and len(self._scalings) > 1:
+            per = self.trajectories.number_of_trajectories / len(self._scalings)
+            assert float(per).is_integer(), "the number of trajectories can not be divided by the number of scalings"
+            per = int(per)
+            self._scaling_trajectory_map = [(i * per, (i + 1) * per) for i in range(self.trajectories.number_of_trajectories)]
 
     def _asset_name(self):
         return "%s.s%g.model.npz" % ("HumanoidMuscle" if self._use_muscles else "HumanoidTorque", self._model_scale)
@@ -330,6 +374,10 @@ class BaseHumanoid4Ages(BaseHumanoid):
     def _env_id(self):
         return self._get_env_id_map(self._default_scalings.index(self._model_scale), self.n_all_models)
 
+    @property
+    def more_than_one_env(self):
+        return self._n_models > 1
+
     def _get_observation_space(self):
         low, high = super()._get_observation_space()
         n = len(self._env_id())
@@ -357,11 +405,6 @@ class BaseHumanoid4Ages(BaseHumanoid):
             return r
         return super()._get_reward_function(reward_type, reward_params)
 
-    def setup(self, obs):
-        if obs is not None:
-            raise TypeError("Initializing the environment from an observation is not allowed in this environment.")
-        super().setup(obs)
-
     @staticmethod
     def generate(env, path, task="walk", mode="all", dataset_type="real", n_models=None, debug=False,
                  clip_trajectory_to_joint_ranges=False, **kwargs):
@@ -369,10 +412,7 @@ class BaseHumanoid4Ages(BaseHumanoid):
         target speed scaled by the humanoid's size."""
         if dataset_type == "perfect":
             raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
-        if mode == "all":
-            raise NotImplementedError('mode "all" samples a different humanoid per episode: not built on the device '
-                                      '(one model table per batch); use the modes "1".."4"')
-        scaling = {"1": 0.4, "2": 0.6, "3": 0.8, "4": 1.0}[mode]
+        scaling = {"all": None, "1": 0.4, "2": 0.6, "3": 0.8, "4": 1.0}[mode]
         reward_type = kwargs.pop("reward_type", "multi_target_velocity")
         reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25 if task == "walk" else 2.5))
         mdp = env(scaling=scaling, reward_type=reward_type, reward_params=reward_params, **kwargs)

@@ -99,5 +99,12 @@ OracleBatch._step_with_foot_forces = _grf_step
 
 
 def attach(env):
+    if getattr(env, "_n_models", 1) > 1:                 # one oracle per model of a multi-model environment
+        current = env._current_model_idx
+        for idx in range(env._n_models):
+            env._select_model(idx)
+            env._backend = OracleBatch(env)
+        env._select_model(current)
+        return env
     env._backend = OracleBatch(env)
     return env

@@ -628,3 +628,26 @@ def test_humanoid_4_ages_one_control_step_kats(name, nu):
     scale = [0.4, 0.6, 0.8, 1.0][int(name.split(".")[2]) - 1]
     speed = (2.5 if ".run." in name else 1.25) * scale
     assert np.abs(rew - np.exp(-(g[:n, 17] - speed) ** 2)).max() < 1e-5
+
+
+def test_humanoid_4_ages_all_mode_env_rollout():
+    """Four models in one environment (n_envs = 1): one device batch per size, switched at reset."""
+    g = GOLD["HumanoidTorque4Ages.walk.all.real"]
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True)
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(100):
+        if absorbing:
+            break
+        obs, r, absorbing, info = env.step(np.random.randn(13) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    assert np.abs(rows[:, :17] - g[:, :17]).max() < 5e-3 and np.array_equal(rows[:, 36:], g[:, 36:])
+    first = env._current_model_idx
+    for _ in range(6):                                   # other sizes get their own device batch
+        env.reset()
+        env.step(np.zeros(13))
+    assert sum(b is not None for b in env._model_backends) + (env._backend is not None and env._model_backends[env._current_model_idx] is None) >= 2

@@ -266,7 +266,20 @@ def test_humanoid_4_ages_surface():
     tab = e._reset_table()
     assert tab.shape[1] == 2 * 19 + 2 and (tab[:, -2:] == [0, 1]).all()
     assert "HumanoidTorque4Ages.walk.3.real" in loco_mujoco_amd.get_all_task_names()
+    # mode "all": four models in one environment, one drawn per episode (n_envs = 1 only)
+    np.random.seed(0)
+    a = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True)
+    assert a._n_models == 4 and a.more_than_one_env and len(a._scaling_trajectory_map) >= 4
+    seen = set()
+    for _ in range(12):
+        ob = a.reset()
+        idx = a._current_model_idx
+        seen.add(idx)
+        assert list(ob[-2:]) == [idx >> 1, idx & 1] and a._model is a._models[idx]
+        lo, hi = a._scaling_trajectory_map[idx]
+        assert lo <= a.trajectories.traj_no < hi                      # start state from the trajectories of that size
+    assert len(seen) >= 3
     with pytest.raises(NotImplementedError):
-        LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True)
+        LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)
     with pytest.raises(TypeError):
         e.reset(obs=np.zeros(38))

@@ -323,3 +323,27 @@ def test_humanoid_4_ages_golden(actuation, task, mode):
             ob, r, absorbing, _ = env.step(np.random.randn(nu) * 0.1)
             rows.append(ob)
         assert np.array(rows).shape == g.shape and np.allclose(np.array(rows), g)
+
+
+@pytest.mark.parametrize("actuation,task", [("Torque", "run"), ("Torque", "walk"), ("Muscle", "run"), ("Muscle", "walk")])
+def test_humanoid_4_ages_all_sizes_in_one_environment(actuation, task):
+    """Mode "all": the size is drawn per episode (same np.random stream as the reference), the start state comes from the
+    trajectories of that size. The rollout follows the golden file until the reference meets a bone-mesh contact."""
+    name = "Humanoid%s4Ages.%s.all" % (actuation, task)
+    g = GOLD[name + ".real"]
+    nu = 13 if actuation == "Torque" else 92
+    np.random.seed(0)
+    env = attach(LocoEnv.make(name, debug=True))
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    matched = 1
+    for k in range(len(g) - 1):
+        obs, r, absorbing, _ = env.step(np.random.randn(nu) * 0.1)
+        if np.abs(obs - g[k + 1]).max() > 1e-8:
+            assert env._backend.stats_log[-1]["unhandled_pairs"] > 0, k
+            break
+        matched += 1
+        assert absorbing == (k == len(g) - 2)
+    assert matched >= 9
+    if matched == len(g):
+        assert env._has_fallen(g[-1])

@@ -28,7 +28,7 @@ from loco_mujoco_amd.environments.humanoids import (HumanoidMuscle, HumanoidMusc
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
                 "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"] + [
-                "Humanoid%s4Ages.%s.%d.real" % (a, t, k) for a in ("Torque", "Muscle") for t in ("run", "walk") for k in (1, 2, 3, 4)]
+                "Humanoid%s4Ages.%s.%s.real" % (a, t, k) for a in ("Torque", "Muscle") for t in ("run", "walk") for k in (1, 2, 3, 4, "all")]
 
 
 def main():
@@ -93,8 +93,8 @@ def main():
                 "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_reduced_humanoid.npz",
                 "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"] + [
-                "datasets/humanoids/real/mini_datasets/%s_reduced_humanoid_POMDP_%d.npz" % (t, k)
-                for t in ("02-constspeed", "05-run") for k in (1, 2, 3, 4)]:
+                "datasets/humanoids/real/mini_datasets/%s_reduced_humanoid_POMDP_%s.npz" % (t, k)
+                for t in ("02-constspeed", "05-run") for k in (1, 2, 3, 4, "all")]:
         src = np.load(pkg / rel, allow_pickle=True)
         dst = ROOT / "loco_mujoco_amd" / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
