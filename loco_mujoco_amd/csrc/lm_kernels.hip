@@ -416,6 +416,8 @@ static void launch_family(lm_batch* b, const KArgs& a) {
   using LMm = lm::LaneMem<MC, NS, NM>;
   if (FWD) {
     launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
+  } else if (b->dofprm && b->epb <= 4 && !no_replicas) {
+    launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4>, grid, dim3(16 * b->epb), (size_t)LMm::kGroup, b, a);
   } else if (b->dofprm) {
     launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
   } else if (b->epb <= 4 && !no_replicas) {
