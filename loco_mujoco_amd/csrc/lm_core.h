@@ -124,6 +124,7 @@ struct Params {
   float ls_tol;       // line search: stop when |phi'| < ls_tol * |phi'(0)|
   int ls_iters;       // line search iteration cap
   float ls_noise;     // float32 noise floor of phi' relative to the sum of |terms|
+  float ls_grid[3];   // four-point line search: first-round step lengths as fractions of the Newton step (besides 1)
   int ablate;         // profiling only: bitmask of solver regions to skip (0 in production)
   int nv;
   int integrator;     // LM_INT_EULER (0) | LM_INT_RK4 (1)
@@ -1313,7 +1314,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             float d2lo = d2, d2hi = 0.0f, best_abs = 3.0e38f;
             float cand[4];
             const float aN = ls_done ? 0.0f : -d1 / d2;
-            cand[0] = aN; cand[1] = 0.25f * aN; cand[2] = 0.0625f * aN; cand[3] = 0.015625f * aN;
+            cand[0] = aN; cand[1] = P.ls_grid[0] * aN; cand[2] = P.ls_grid[1] * aN; cand[3] = P.ls_grid[2] * aN;
             for (int round = 0; round < ((P.ablate & 8) ? 0 : (P.ls_iters + 1) / 2); round++) {
               if (!Q::any(!ls_done)) break;
               if (!ls_done) {

@@ -520,6 +520,8 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE];
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
+  if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   if (const char* v = getenv("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
   if (const char* v = getenv("LM_ABLATE")) P.ablate = atoi(v);
   if (const char* v = getenv("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes

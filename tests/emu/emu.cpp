@@ -59,6 +59,8 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
+  if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE];
   int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int c) {
