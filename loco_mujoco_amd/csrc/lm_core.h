@@ -439,6 +439,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
   int oz = LM_OPAQUE_ZERO();
   const bool pyramidal = (CONE < 0) ? (P.cone == 0) : (CONE == 0);
+  // CONE == LM_CONE_PYRAMIDAL promises that every contact of the model is a condim-3 pyramid (checked by the launcher):
+  // the elliptic code paths then compile out
+#define PYR3(dim) (CONE == 0 || (pyramidal && (dim) == 3))
   const float* rb = cm + LM_CM_ROOT;
 #define RD(k, f) rb[oz + LM_R_DOFS + (k) * LM_D_SIZE + (f)]
 #define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
@@ -630,7 +633,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           SL(slot, SL_GRF) = GE(g, LM_G_GRF);
           SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
           SL(slot, SL_D) = D0;
-          if (pyramidal && dim == 3) {
+          if (PYR3(dim)) {
             float xv[4];
             pyr_rows(vel, mu, xv);
 #pragma unroll
@@ -930,7 +933,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         float Dj[6], fr[5], jar[6];
         contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
-        if (pyramidal && dim == 3) {
+        if (PYR3(dim)) {
           float x[4], f3[3];
           pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
@@ -1037,7 +1040,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
-          if (pyramidal && dim == 3) {
+          if (PYR3(dim)) {
             float x[4], dummy = 0;
             pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
@@ -1112,7 +1115,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           if (zone == 0) continue;
           float Dj[6], fr[5], Hc[21], jar[6];
           const int dim = (int)SL(s, SL_DIM);
-          if (pyramidal && dim == 3) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
+          if (PYR3(dim)) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
           else {
 #pragma unroll
             for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); Dj[j] = SL(s, SL_D + j); }
@@ -1133,7 +1136,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
             }
           }
-          if (dim > 3) {
+          if (CONE != 0 && dim > 3) {
 #pragma unroll
             for (int a = 0; a < 6 + MC; a++) {
               float t[6];
@@ -1224,7 +1227,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             for (int s = 0; s < nslot; s++) {
               float jv[6];
               contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
-              if (pyramidal && (int)SL(s, SL_DIM) == 3) {
+              if (PYR3((int)SL(s, SL_DIM))) {
                 float xv[4];
                 pyr_rows(jv, SL(s, SL_MU), xv);
 #pragma unroll
@@ -1271,7 +1274,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               float Dj[6], fr[5], jar[6], jv[6];
               const int dim = (int)SL(s, SL_DIM);
               float c1 = 0, c2 = 0;
-              if (pyramidal && dim == 3) {
+              if (PYR3(dim)) {
                 const float D = SL(s, SL_D);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1415,7 +1418,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (gq == 0) seen0 = true; else seen1 = true;
       const int dim = (int)SL(s, SL_DIM);
       float f[6];
-      if (pyramidal && dim == 3) {
+      if (PYR3(dim)) {
         float x[4], dummy = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) x[r] = SL(s, SL_JAR + r);
@@ -1494,6 +1497,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     for (int k = 0; k < MC; k++) if (k < nl) { vc[k] = fmaf(P.h, xc[k], vc[k]); qc[k] = fmaf(P.h, vc[k], qc[k]); }
   }
   LM_TICK(9);
+#undef PYR3
 #undef DAMP_R
 #undef STIFF_R
 #undef FLOSS_R

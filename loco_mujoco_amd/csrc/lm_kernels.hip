@@ -64,7 +64,7 @@ int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct Task {
-  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts;
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts, all_pyr3;
   float rp[8];
 };
 
@@ -431,10 +431,14 @@ template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   const Task& T = b->m->T;
   const bool big = T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
+  static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
+  const bool pyr3 = T.all_pyr3 && !generic;
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 4, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped
-  else if (big && rk4 && T.na == 0 && few) launch_family<5, 4, true, -1, 0, FWD>(b, a);     // humanoid, one box foot per leg
-  else if (big && rk4 && T.na == 0) launch_family<5, 8, true, -1, 0, FWD>(b, a);            // Atlas: two boxes per foot
-  else if (big && !rk4 && T.na > 0 && few) launch_family<5, 4, false, -1, LM_MAXMUS, FWD>(b, a);   // muscle humanoid
+  // the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked when the model is created): the
+  // elliptic code compiles out, no scratch (was 470 B per lane). NB: these kernels need -O2, see the Makefile.
+  else if (big && rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);   // one box foot per leg
+  else if (big && rk4 && T.na == 0 && pyr3) launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);          // Atlas: two boxes per foot
+  else if (big && !rk4 && T.na > 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, FWD>(b, a);   // muscle humanoid
   else if (T.na > 0) g_launch_err = "muscle models need the <5 links, <=4 contacts per chain, Euler> family";
   // generic fallbacks (cone read at run time; no replicated / randomised variants are compiled for them)
   else if (b->dofprm) g_launch_err = "per-environment joint parameters are not compiled for this model family";
@@ -507,6 +511,14 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
   T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS]; T.ngrf = (int)cmod[LM_H_NGRF];
   T.max_contacts = (int)cmod[LM_H_MAXCONTACTS];
+  {
+    // every geom with a device collider is a condim-3 contact under pyramidal cones?
+    T.all_pyr3 = (int)cmod[LM_H_CONE] == LM_CONE_PYRAMIDAL;
+    for (int c = 0; c < LM_NCHAIN && T.all_pyr3; c++) {
+      const int ng = (int)cmod[LM_HEADER_SIZE + LM_CM_CHAINS + LM_C_NGEOMS * LM_NCHAIN + c];
+      for (int g = 0; g < ng; g++) if ((int)cmod[LM_HEADER_SIZE + LM_CM_CHAINS + (LM_C_GEOMS + g * LM_G_SIZE + LM_G_DIM) * LM_NCHAIN + c] != 3) T.all_pyr3 = 0;
+    }
+  }
   T.cm_used = ((int)cmod[LM_H_CM_USED] + 63) & ~63;          // keeps lane memory 256-byte aligned behind the table
   if (T.cm_used <= 0 || T.cm_used > ((LM_CM_SIZE + 63) & ~63)) { delete m; return fail("bad constant-table extent"); }
   if (T.ngoal > 4) { delete m; return fail("more than 4 goal entries"); }
