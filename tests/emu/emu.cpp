@@ -42,6 +42,13 @@ struct QuadThreadsT {
 using QuadThreads = QuadThreadsT<EMU_LS_POINTS>;
 }  // namespace
 
+// EMU_PYRAMID_ONLY compiles the humanoid families like the library does (condim-3 pyramids only, elliptic code out)
+#ifdef EMU_PYRAMID_ONLY
+template <int MC> constexpr int kEmuCone = (MC == 5) ? 0 : -1;
+#else
+template <int MC> constexpr int kEmuCone = -1;
+#endif
+
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
 // act: muscle activations [n][na] double in/out (NM > 0 only)
 template <int MC, int NS, bool RK4, int NM = 0>
@@ -107,7 +114,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4, -1, NM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+        lm::substep<QuadThreads, MC, NS, RK4, kEmuCone<MC>, NM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                                       (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr, mt.data());
       if (NM > 0) {
         const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];

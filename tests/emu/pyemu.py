@@ -14,7 +14,7 @@ def build(ls_points=1):
             os.path.join(_HERE, "../../include/lm_layout.h")]
     if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-DEMU_LS_POINTS=%d" % ls_points, "-o", lib, srcs[0]])
+                               "-DEMU_LS_POINTS=%d" % ls_points, "-DEMU_PYRAMID_ONLY", "-o", lib, srcs[0]])
     return lib
 
 
