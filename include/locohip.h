@@ -114,6 +114,12 @@ int lm_get_activation(lm_batch* b, float* act);
    obs [n_envs][nobs], reward [n_envs], done [n_envs] may each be NULL. Synchronous. */
 int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t* done);
 
+/* the same step with DEVICE pointers (action [n_envs][nu], obs [n_envs][nobs], reward [n_envs], done [n_envs]; any may be
+   NULL) for training loops that keep policy inputs/outputs on the GPU: no PCIe traffic. `stream` = a hipStream_t to run
+   on (NULL: the library's own stream); with sync = 0 the call returns after the launch. The caller orders its own work
+   against that stream. */
+int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, void* stream, int sync);
+
 /* device-side episode handling: rows = [qpos(nq) | qvel(nv) | goal(ngoal)]; when enabled, an
    environment whose step ended absorbing (or reached `horizon` control steps, 0 = never) restarts
    from a row drawn with a counter-based RNG keyed by (seed, global env id, episode count) and the

@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
-           "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step",
+           "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_forward_debug", "lm_get_stats", "lm_sync"]
 
 _lib = None
@@ -69,6 +69,7 @@ def load_library():
     lib.lm_set_dof_params.argtypes = [C.c_void_p, _F, _F, _F, _U8]
     lib.lm_get_dof_params.argtypes = [C.c_void_p, _F, _F, _F]
     lib.lm_set_dof_randomization.argtypes = [C.c_void_p, _F]
+    lib.lm_step_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.lm_set_activation.argtypes = [C.c_void_p, _F, _U8]
     lib.lm_get_activation.argtypes = [C.c_void_p, _F]
     lib.lm_step.argtypes = [C.c_void_p, _F, _F, _F, _U8]
@@ -157,6 +158,17 @@ class HipBatch:
         v = np.empty((self.n, self.nv), dtype=np.float32)
         _check(self._lib.lm_get_state(self._h, _fp(q), _fp(v)))
         return q, v
+
+    def step_device(self, action=None, obs=None, reward=None, done=None, stream=None, sync=True):
+        """One control step on DEVICE buffers: arguments are device pointers (ints) or objects with ``data_ptr()`` such as
+        torch tensors — float32 action [n, nu], obs [n, nobs], reward [n], uint8 done [n]; None = zero action / library
+        buffers. ``stream``: raw hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        def ptr(x):
+            if x is None:
+                return None
+            return C.c_void_p(int(x.data_ptr()) if hasattr(x, "data_ptr") else int(x))
+        _check(self._lib.lm_step_device(self._h, ptr(action), ptr(obs), ptr(reward), ptr(done),
+                                        None if stream is None else C.c_void_p(int(stream)), int(bool(sync))))
 
     def set_dof_params(self, damping=None, stiffness=None, frictionloss=None, mask=None):
         """Per-environment joint parameters [n, nv] (domain randomisation); None leaves a parameter as it is."""

@@ -773,6 +773,23 @@ int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t
   return 0;
 }
 
+int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, void* stream, int sync) {
+  HIPCHK(hipSetDevice(b->m->device));
+  KArgs a = make_args(b);
+  if (d_action) { a.action = d_action; a.action_mode = 0; } else a.action_mode = 1;
+  a.obs = d_obs ? d_obs : b->obs; a.reward = d_reward ? d_reward : b->reward; a.done = d_done ? d_done : b->done;
+  hipStream_t own = b->stream;
+  if (stream) b->stream = (hipStream_t)stream;          // run on the caller's stream (e.g. torch's current stream)
+  launch_step(b, a);
+  hipStream_t used = b->stream;
+  b->stream = own;
+  if (g_launch_err) return fail(g_launch_err);
+  HIPCHK(hipGetLastError());
+  b->step_index++;
+  if (sync) HIPCHK(hipStreamSynchronize(used));
+  return 0;
+}
+
 int lm_set_reset_table(lm_batch* b, const float* rows, int n_rows, uint64_t seed, int64_t global_env_offset) {
   HIPCHK(hipSetDevice(b->m->device));
   const Task& T = b->m->T;

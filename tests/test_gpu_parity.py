@@ -651,3 +651,32 @@ def test_humanoid_4_ages_all_mode_env_rollout():
         env.reset()
         env.step(np.zeros(13))
     assert sum(b is not None for b in env._model_backends) + (env._backend is not None and env._model_backends[env._current_model_idx] is None) >= 2
+
+
+def test_step_on_device_buffers_matches_host_path():
+    """lm_step_device: torch tensors in, torch tensors out, on torch's stream — same numbers as the host-buffer step."""
+    import torch
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    n = 256
+    rs = np.random.RandomState(4)
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-1, 1, (n, 12)).astype(np.float32)
+    ref = HipBatch(hm, n)
+    ref.set_state(rows[:, :18], rows[:, 18:36]); ref.set_goal(rows[:, 36:39])
+    o_ref, r_ref, d_ref = ref.step(acts)
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :18], rows[:, 18:36]); b.set_goal(rows[:, 36:39])
+    dev = torch.device("cuda", 0)
+    a_t = torch.from_numpy(acts).to(dev)
+    o_t = torch.empty((n, 37), dtype=torch.float32, device=dev)
+    r_t = torch.empty(n, dtype=torch.float32, device=dev)
+    d_t = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b.step_device(a_t, o_t, r_t, d_t, stream=torch.cuda.current_stream().cuda_stream, sync=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_t.cpu().numpy(), o_ref) and np.array_equal(r_t.cpu().numpy(), r_ref)
+    assert np.array_equal(d_t.cpu().numpy().astype(bool), d_ref)
