@@ -2,10 +2,12 @@ from .base import LocoEnv, ValidTaskConf
 from .unitree_a1 import UnitreeA1
 from .atlas import Atlas
 from .humanoids import BaseHumanoid, BaseHumanoid4Ages, HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque, HumanoidTorque4Ages
+from .talos import Talos
 from .gymnasium import GymnasiumWrapper
 
 UnitreeA1.register()
 Atlas.register()
+Talos.register()
 HumanoidTorque.register()
 HumanoidMuscle.register()
 HumanoidTorque4Ages.register()

@@ -279,6 +279,89 @@ def _bounding_capsule(v):
     return c + 0.5 * (lo + hi) * axis, axis, r, 0.5 * (hi - lo)
 
 
+def _mesh_triangles(root, comp, base_dir):
+    """{mesh name: (ntri, 3, 3) float64 vertices, scaled} from binary STL files."""
+    out = {}
+    if base_dir is None:
+        return out
+    meshdir = comp.get("meshdir", "")
+    for el in root.iter("mesh"):
+        f = el.get("file")
+        if f is None or not f.lower().endswith(".stl"):
+            continue
+        path = os.path.join(base_dir, meshdir, f)
+        if not os.path.exists(path):
+            continue
+        raw = open(path, "rb").read()
+        ntri = int(np.frombuffer(raw[80:84], "<u4")[0])
+        if len(raw) != 84 + 50 * ntri:
+            continue
+        tri = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", 9), ("a", "<u2")]), count=ntri)
+        v = tri["v"].reshape(-1, 3, 3).astype(np.float64) * _floats(el.get("scale", "1 1 1"), 3)
+        out[el.get("name", os.path.splitext(os.path.basename(f))[0])] = v
+    return out
+
+
+def _geom_inertia(g, tris):
+    """(mass, centre, inertia about the centre) of one geom in the BODY frame; None if it carries no mass.
+    Primitives: closed formulas; meshes: the engine's pyramid sums over the triangles (see below)."""
+    density, mass_attr = g["density"], g["mass"]
+    if (mass_attr is not None and mass_attr <= 0) or (mass_attr is None and density <= 0):
+        return None
+    t, s = g["type"], g["size"]
+    r = quat_to_mat(g["quat"])
+    if t == GEOM_MESH:
+        v = tris.get(g["mesh"])
+        if v is None:
+            raise NotImplementedError("mass of mesh geom %s: mesh file not available" % g["name"])
+        # the engine's default ("legacy", exactmeshinertia=false) integration: pyramids from an apex to every
+        # triangle with |volume| — apex = area-weighted mean of the triangle centres for volume and centre,
+        # apex = that centre for the second moments. Equal to the exact integral for a convex closed mesh only.
+        a, b, c = v[:, 0], v[:, 1], v[:, 2]
+        nrm = np.cross(b - a, c - a)
+        area = 0.5 * np.linalg.norm(nrm, axis=1)
+        nrm = nrm / np.maximum(2.0 * area, 1e-300)[:, None]
+        cen = (a + b + c) / 3.0
+        facecen = (area[:, None] * cen).sum(0) / area.sum()
+        pv = np.abs(np.einsum("ij,ij->i", cen - facecen, nrm) * area / 3.0)
+        vol = pv.sum()
+        com = (pv[:, None] * (0.75 * cen + 0.25 * facecen)).sum(0) / vol
+        a, b, c = a - com, b - com, c - com
+        pv = np.abs(np.einsum("ij,ij->i", (a + b + c) / 3.0, nrm) * area / 3.0)
+        ssum = a + b + c
+        second = np.einsum("i,ijk->jk", pv / 20.0, np.einsum("ij,ik->ijk", a, a) + np.einsum("ij,ik->ijk", b, b)
+                           + np.einsum("ij,ik->ijk", c, c) + np.einsum("ij,ik->ijk", ssum, ssum))
+        inertia = np.trace(second) * np.eye(3) - second
+        # the compiler then treats the mesh geom as its equivalent inertia box (same principal axes and same
+        # inertia / mass ratio): mass = density x BOX volume, not x mesh volume (pinned by the Talos golden rollouts)
+        ev, axes = np.linalg.eigh(inertia)
+        half = np.array([np.sqrt(max(6.0 * (ev[(i + 1) % 3] + ev[(i + 2) % 3] - ev[i]) / vol, 0.0)) / 2.0 for i in range(3)])
+        m = mass_attr if mass_attr is not None else density * 8.0 * half.prod()
+        inertia = axes @ np.diag(m / 3.0 * np.array([half[1] ** 2 + half[2] ** 2, half[0] ** 2 + half[2] ** 2,
+                                                    half[0] ** 2 + half[1] ** 2])) @ axes.T
+        return m, g["pos"] + r @ com, r @ inertia @ r.T
+    if t == GEOM_SPHERE:
+        vol = 4.0 / 3.0 * np.pi * s[0] ** 3
+        diag = np.full(3, 0.4 * s[0] ** 2)
+    elif t == GEOM_BOX:
+        vol = 8.0 * s[0] * s[1] * s[2]
+        diag = np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2]) / 3.0
+    elif t == GEOM_CYLINDER:
+        vol = np.pi * s[0] ** 2 * 2 * s[1]
+        diag = np.array([(3 * s[0] ** 2 + 4 * s[1] ** 2) / 12.0, (3 * s[0] ** 2 + 4 * s[1] ** 2) / 12.0, 0.5 * s[0] ** 2])
+    elif t == GEOM_CAPSULE:
+        rad, h = s[0], 2 * s[1]
+        vc, vs = np.pi * rad ** 2 * h, 4.0 / 3.0 * np.pi * rad ** 3
+        vol = vc + vs
+        izz = (vc * 0.5 * rad ** 2 + vs * 0.4 * rad ** 2) / vol
+        ixx = (vc * (rad ** 2 / 4 + h ** 2 / 12) + vs * (0.4 * rad ** 2 + 0.375 * rad * h + h ** 2 / 4)) / vol
+        diag = np.array([ixx, ixx, izz])
+    else:
+        return None
+    m = mass_attr if mass_attr is not None else density * vol
+    return m, g["pos"].copy(), r @ np.diag(m * diag) @ r.T
+
+
 def _mesh_bounds(root, comp, base_dir):
     """{mesh name: bounding capsule (centre, axis, radius, half length)} in the mesh's own frame, from binary STL files."""
     out = {}
@@ -354,6 +437,7 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
             bodies.append(b)
             bid = len(bodies) - 1
             inertial = el.find("inertial")
+            b["explicit_inertial"] = inertial is not None
             if inertial is not None:
                 b["mass"], b["ipos"], b["inertia"] = _inertia_from_inertial(inertial.attrib)
                 # compiler bounds act on the principal moments (MuJoCo: boundmass / boundinertia / balanceinertia)
@@ -420,7 +504,8 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
                               solref=_floats(a.get("solref", "%g %g" % _DEFAULT_SOLREF), 2),
                               solimp=_pad_solimp(a.get("solimp")),
                               margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)),
-                              mesh=a.get("mesh")))
+                              mesh=a.get("mesh"), density=float(a.get("density", 1000.0)),
+                              mass=(float(a["mass"]) if "mass" in a else None)))
         for s in el.findall("site"):
             a = defaults.resolve("site", s, childclass)
             pos = _floats(a.get("pos", "0 0 0"), 3)
@@ -436,6 +521,31 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     walk_body(root.find("worldbody"), 0, None)
 
     # ---------------- bodies
+    # ---------------- bodies without <inertial>: mass, centre and inertia from their geoms (compiler inertiafromgeom="auto")
+    if comp.get("inertiafromgeom", "auto") != "false":
+        tris = None
+        for bid, b in enumerate(bodies):
+            if bid == 0 or b.get("explicit_inertial", True):
+                continue
+            parts = []
+            for gd in geoms:
+                if gd["body"] != bid:
+                    continue
+                if tris is None and gd["type"] == GEOM_MESH:
+                    tris = _mesh_triangles(root, comp, handle.base_dir)
+                part = _geom_inertia(gd, tris or {})
+                if part is not None and part[0] > 0:
+                    parts.append(part)
+            if not parts:
+                continue
+            mass = sum(p_[0] for p_ in parts)
+            com = sum(p_[0] * p_[1] for p_ in parts) / mass
+            inertia = np.zeros((3, 3))
+            for m_, c_, i_ in parts:
+                d = c_ - com
+                inertia += i_ + m_ * (d @ d * np.eye(3) - np.outer(d, d))
+            b["mass"], b["ipos"], b["inertia"] = mass, com, inertia
+
     m.nbody = len(bodies)
     m.body_names = [b["name"] for b in bodies]
     m.body_parent = np.array([b["parent"] for b in bodies], dtype=np.int32)

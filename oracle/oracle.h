@@ -6,7 +6,7 @@
 #ifndef LMO_ORACLE_H
 #define LMO_ORACLE_H
 
-#define LMO_MAXBODY 40
+#define LMO_MAXBODY 64
 #define LMO_MAXV 32
 #define LMO_MAXU 128
 #define LMO_MAXGEOM 160

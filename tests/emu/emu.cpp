@@ -147,6 +147,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
     return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
   if (!big && !rk4) return emu_run_t<3, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  if (!rk4 && few) return emu_run_t<5, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!rk4) return emu_run_t<5, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (few) return emu_run_t<5, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   return emu_run_t<5, 8, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);

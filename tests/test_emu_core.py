@@ -86,6 +86,36 @@ def test_core_humanoids_rk4_pyramidal(task, nu, rows):
         assert np.abs(v10[0][qidx] - g[k + 1, nq:]).max() < 1e-3
 
 
+@pytest.mark.parametrize("ls_points", [1, 4])
+def test_core_talos_euler_pyramidal(ls_points):
+    """kernel variant <5,4,Euler,pyramidal> (Talos: 3 chains, implicit damping, frictionloss rows) vs oracle and golden rows."""
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["n_chains"] == 3 and info["max_links"] == 5 and info["max_contacts"] == 4
+    o = Oracle(pack_model(m))
+    g = GOLD["Talos.walk.real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = [np.random.randn(12) * 0.1 for _ in range(14)]
+    for k in (0, 4, 13):
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :16]
+        qvel[qidx] = g[k, 16:34]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[k])
+        f = o.forward(qpos, qvel, ctrl)
+        q, v, w, cnt, d = pyemu.run(cmod, qpos, qvel, acts[k], nsub=1, debug_env=0, ls_points=ls_points)
+        assert cnt["ncon"] == f["ncon"] and cnt["overflow"] == 0 and cnt["unhandled"] == 0
+        assert np.abs(d["M"] - f["M"]).max() < 2e-5
+        assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())
+        q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10, ls_points=ls_points)
+        assert np.abs(q10[0][qidx[2:]] - g[k + 1, :16]).max() < 1e-5
+        assert np.abs(v10[0][qidx] - g[k + 1, 16:34]).max() < 1e-3
+
+
 def test_core_muscles():
     """kernel variant <5,8,Euler,muscles>: tendon paths, muscle forces and activation dynamics in float32 vs oracle/golden."""
     np.random.seed(0)

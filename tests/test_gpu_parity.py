@@ -270,6 +270,80 @@ def test_atlas_batch_rollout_properties(atlas):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Talos.walk: Euler + implicit damping, frictionloss rows, 3 chains (back 2, legs 5 + 5), one box foot per leg
+# (kernel variant <5,4,Euler,pyramidal>)
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def talos():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    hm = HipModel(env._chain_model())
+    return env, hm, Oracle(pack_model(env._model)), HipBatch
+
+
+def test_talos_one_control_step_kats(talos):
+    env, hm, oracle, HipBatch = talos
+    m = env._model
+    g = GOLD["Talos.walk.real"]
+    n = len(g) - 1
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(12) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :16]
+    qvel[:, qidx] = g[:n, 16:34]
+    b = HipBatch(hm, n)
+    b.set_state(qpos, qvel)
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :16] - g[1:, :16]).max(axis=1), np.abs(obs[:, 16:34] - g[1:, 16:34]).max(axis=1)
+    print("Talos KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e" % (eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL
+    assert list(done) == [False] * (n - 1) + [True]
+    want = [np.exp(-(g[k][16] - 1.25) ** 2) for k in range(n)]          # TargetVelocityReward(1.25) on the previous obs
+    assert np.abs(rew - want).max() < 1e-5
+    st = b.stats()
+    assert st["overflow_contacts"] == 0 and st["unhandled_geoms"] == 0
+
+
+def test_talos_env_rollout_follows_reference_test():
+    g = GOLD["Talos.walk.real"]
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(100):
+        if absorbing:
+            break
+        obs, r, absorbing, info = env.step(np.random.randn(12) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    assert np.abs(rows[:, :16] - g[:, :16]).max() < 5e-3
+
+
+def test_talos_batch_rollout_properties(talos):
+    env, hm, oracle, HipBatch = talos
+    tab = env._reset_table()
+    n = 4096
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, len(tab), n)]
+    b = HipBatch(hm, n)
+    b.set_reset_table(tab, seed=1)
+    b.set_auto_reset(True, horizon=1000)
+    b.set_state(rows[:, :18], rows[:, 18:36])
+    st = b.rollout(30, action_mode=1, seed=5)
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
+    print("Talos 4096 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep %.2f"
+          % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 10)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # HumanoidTorque.run / .walk (BASELINE config 3's robot): 3 chains (5, 5, 3 links), joint springs, box feet.
 # Golden rows with mesh-mesh contacts active in the reference (walk, rows >= 19) are out of scope (bones are
 # proximity-only capsules, see tests/test_oracle_golden.py).
@@ -465,7 +539,7 @@ def _with_dof_params(m, damping, stiffness, frictionloss):
     return m2
 
 
-@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("Atlas.walk", 13), ("HumanoidMuscle.run", 92)])
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("Atlas.walk", 13), ("HumanoidMuscle.run", 92), ("Talos.walk", 12)])
 def test_per_environment_joint_parameters_vs_oracle(task, nu):
     """Each environment gets its own damping/stiffness/frictionloss; one control step vs the oracle run on a model
     compiled with exactly those values."""
@@ -541,7 +615,7 @@ def test_device_side_redraw_of_joint_parameters():
 # Foot-force observations: mean contact-frame force of each foot group over the control step.
 # ---------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("HumanoidTorque.walk", 13), ("Atlas.walk", 10), ("HumanoidMuscle.run", 92)])
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("HumanoidTorque.walk", 13), ("Atlas.walk", 10), ("HumanoidMuscle.run", 92), ("Talos.walk", 12)])
 def test_foot_force_observations_vs_oracle(task, nu):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle_backend import attach

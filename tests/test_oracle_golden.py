@@ -145,6 +145,55 @@ def test_atlas_full_rollout_matches_reference_test():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Talos.walk: pins the Euler integrator with implicit joint damping, frictionloss rows on the back joints and the
+# compiler's inertia-from-geoms for a body without <inertial> (the pelvis: convex collision mesh -> equivalent inertia
+# box, mass = density x BOX volume). The mesh is float32 STL data, so rows agree to ~5e-8 instead of 1e-12.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_talos_one_control_step_kats():
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    m = env._model
+    assert abs(m.body_mass[m.body_names.index("pelvis")] - 18.828031) < 1e-5       # 1000 kg/m^3 x 8 bx by bz
+    o = Oracle(pack_model(m))
+    g = GOLD["Talos.walk.real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    contacts = 0
+    for k in range(len(g) - 1):
+        a = np.random.randn(12) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :16]
+        qvel[qidx] = g[k, 16:34]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+        assert np.abs(q[qidx[2:]] - g[k + 1, :16]).max() < 1e-9, k
+        assert np.abs(v[qidx] - g[k + 1, 16:34]).max() < 1e-7, k
+        assert st["unhandled_pairs"] == 0
+        contacts += st["ncon"]
+    assert contacts > 10
+
+
+def test_talos_full_rollout_matches_reference_test():
+    g = GOLD["Talos.walk.real"]
+    np.random.seed(0)
+    env = attach(LocoEnv.make("Talos.walk", debug=True))
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14
+    rows, absorbing = [obs], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, r, absorbing, _ = env.step(np.random.randn(12) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape and np.abs(rows - g).max() < 1e-6
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # HumanoidTorque.run / .walk: pins joint stiffness/damping under RK4, the compiler's boundinertia/balanceinertia
 # order, `euler` geoms (box feet) and the humanoid XML surgery. Bone meshes are proximity-only bounding capsules
 # (no convex-hull collider is restated): every golden row is either reproduced to 1e-12 (all 38 of .run, the first

@@ -23,11 +23,12 @@ sys.path.insert(0, str(ROOT))
 from loco_mujoco_amd import mjcf                      # noqa: E402
 from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
 from loco_mujoco_amd.environments.atlas import Atlas, _ARM, _BACK   # noqa: E402
+from loco_mujoco_amd.environments.talos import Talos   # noqa: E402
 from loco_mujoco_amd.environments.humanoids import (HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque,   # noqa: E402
                                                     HumanoidTorque4Ages)
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
-                "Atlas.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"] + [
+                "Atlas.walk.real", "Talos.walk.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"] + [
                 "Humanoid%s4Ages.%s.%s.real" % (a, t, k) for a in ("Torque", "Muscle") for t in ("run", "walk") for k in (1, 2, 3, 4, "all")]
 
 
@@ -54,6 +55,14 @@ def main():
     m = mjcf.compile_mjcf(h, timestep=0.001)
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "Atlas.back.model.npz")
     print("Atlas (back joints): nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
+
+    for variant, no_back in (("default", False), ("noback", True)):
+        t = Talos.__new__(Talos)
+        t._disable_arms, t._disable_back_joint = True, no_back
+        j, mo, _ = t._get_xml_modifications()
+        m = Talos._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "talos" / "talos.xml"), 0.001, j, mo)
+        m.save(ROOT / "loco_mujoco_amd" / "assets" / ("Talos.%s.model.npz" % variant))
+        print("Talos (%s): nbody %d nv %d ngeom %d nu %d integrator %d cone %d" % (variant, m.nbody, m.nv, m.ngeom, m.nu, m.integrator, m.cone))
 
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_torque.xml")
     ht = HumanoidTorque.__new__(HumanoidTorque)
@@ -91,6 +100,7 @@ def main():
     # --- mini datasets (same keys/values, re-encoded)
     for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz",
+                "datasets/humanoids/real/mini_datasets/02-constspeed_TALOS.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_reduced_humanoid.npz",
                 "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"] + [
                 "datasets/humanoids/real/mini_datasets/%s_reduced_humanoid_POMDP_%s.npz" % (t, k)
