@@ -17,7 +17,8 @@
 // semi-implicit Euler with implicit joint damping.
 //
 // This header has no HIP dependency: the includer defines LM_DEV (function qualifier) and supplies the quad
-// policy Q {sum(float), any(bool)}. csrc/lm_kernels.hip instantiates it with DPP intrinsics.
+// policy Q {sum(float), any(bool), kRep, kPoints, rep(), rep_bcast(x, r), rep_sum(x), fence()}.
+// csrc/lm_kernels.hip instantiates it with DPP / ds_bpermute intrinsics, tests/emu/emu.cpp with OS threads.
 #pragma once
 #include <math.h>
 #include "../../include/lm_layout.h"
@@ -648,6 +649,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         nslot += total;
       }
       if (nslot > NS) nslot = NS;
+      Q::fence();                // slot records written by one replica are read by all of them from here on
       for (int i = Q::rep(); i < nun; i += Q::kRep) {
         const int fb = LMm::kFrame + (int)CH(LM_C_UNSUP + i * LM_U_SIZE) * 18;
         const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CH(LM_C_UNSUP + i * LM_U_SIZE + 1) + LMEM(fb + 10) * CH(LM_C_UNSUP + i * LM_U_SIZE + 2)
@@ -1030,6 +1032,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // butterfly, so that all replicas continue with bit-identical numbers
       const bool split = Q::kRep > 1 && Q::any(nslot > 1);
       const int s_first = split ? Q::rep() : 0, s_step = split ? Q::kRep : 1;
+      Q::fence();
       if (nslot > 0 && !(P.ablate & 32)) {
         link_images(ar, ac);
         for (int s = s_first; s < nslot; s += s_step) {
@@ -1065,6 +1068,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
         }
       }
+      Q::fence();                  // SL_JAR / SL_ZONE of a slot are written by the replica that owns it
       if (split) {
 #pragma unroll
         for (int k = 0; k < MC; k++) {
@@ -1238,6 +1242,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               }
             }
           }
+          Q::fence();
           float Mvr[6], Mvc[MC];
           mulM(sr, sc, Mvr, Mvc);
           float q2 = 0, q2r = 0, g1 = 0, g1r = 0;    // Gauss part: phi'(a) = g1 + a*q2 with g1 = s.(Ma - f_smooth)

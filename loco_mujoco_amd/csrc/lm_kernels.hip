@@ -55,6 +55,12 @@ struct QuadDppT {
     return y + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(y), 0x4E, 0xF, 0xF, true));
   }
   static __device__ __forceinline__ bool any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+  // replicas hand records to each other through the lane memory they share (contact slots, row states). The lanes of
+  // a wave run in lock step and the LDS executes a wave's instructions in order, so no hardware wait is needed, but
+  // the COMPILER must not move or forward lane-memory accesses across the hand-over point.
+  static __device__ __forceinline__ void fence() {
+    if (REP > 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  }
 };
 using QuadDpp = QuadDppT<1>;
 
@@ -433,6 +439,10 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   const bool big = T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
   static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
   const bool pyr3 = T.all_pyr3 && !generic;
+#ifdef LM_PROBE_TALOS_ONLY          // tools/probes: a library with one kernel family builds in seconds (compiler A/B)
+  if (big && !rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);
+  else g_launch_err = "probe build: Talos family only";
+#else
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 4, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped
   // the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked when the model is created): the
   // elliptic code compiles out, no scratch (was 470 B per lane). NB: these kernels need -O2, see the Makefile.
@@ -451,6 +461,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
     else if (!rk4) launch_one(step_kernel<5, 8, false, FWD, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, b, a);
     else launch_one(step_kernel<5, 8, true, FWD, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, b, a);
   }
+#endif
 }
 
 extern "C" {

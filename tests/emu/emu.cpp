@@ -25,6 +25,7 @@ struct QuadThreadsT {
   static int rep() { return 0; }
   static float rep_bcast(float x, int) { return x; }
   static float rep_sum(float x) { return x; }
+  static void fence() {}
   static float sum(float x) {
     g_buf[t_lane] = x; g_bar.arrive_and_wait();
     float s = (g_buf[0] + g_buf[1]) + (g_buf[2] + g_buf[3]);
@@ -40,6 +41,14 @@ struct QuadThreadsT {
 #define EMU_LS_POINTS 1
 #endif
 using QuadThreads = QuadThreadsT<EMU_LS_POINTS>;
+// EMU_DR compiles the per-environment joint-parameter path (DR = true); the parameters come from emu_set_dof_params
+// ([3][n][nv]: damping, stiffness, frictionloss) or, when none are set, from the constant table (must change nothing)
+#ifdef EMU_DR
+constexpr bool kEmuDR = true;
+#else
+constexpr bool kEmuDR = false;
+#endif
+const double* g_dofprm = nullptr;
 }  // namespace
 
 // EMU_PYRAMID_ONLY compiles the humanoid families like the library does (condim-3 pyramids only, elliptic code out)
@@ -99,6 +108,21 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
           actc[k] = actuate(blk, LM_NCHAIN);
         }
       }
+      lm::DofPrm<MC> dofp = {};
+      if (kEmuDR) {
+        auto prm = [&](int which, int dof, float nominal) -> float {
+          return g_dofprm ? (float)g_dofprm[((size_t)which * n + e) * nv + dof] : nominal;
+        };
+        for (int i = 0; i < 6; i++) {
+          const float* blk = rb + LM_R_DOFS + i * LM_D_SIZE;
+          dofp.damp_r[i] = prm(0, dr[i], blk[LM_D_DAMP]); dofp.stiff_r[i] = prm(1, dr[i], blk[LM_D_STIFF]); dofp.floss_r[i] = prm(2, dr[i], blk[LM_D_FLOSS]);
+        }
+        for (int k = 0; k < MC; k++) if (k < nl) {
+          const float* blk = cm.data() + LM_CM_CHAINS + (LM_C_LINKS + k * LM_LINK_SIZE) * LM_NCHAIN + c;
+          dofp.damp_c[k] = prm(0, dc[k], blk[LM_D_DAMP * LM_NCHAIN]); dofp.stiff_c[k] = prm(1, dc[k], blk[LM_D_STIFF * LM_NCHAIN]);
+          dofp.floss_c[k] = prm(2, dc[k], blk[LM_D_FLOSS * LM_NCHAIN]);
+        }
+      }
       lm::Counters cnt = {};
       using LMm = lm::LaneMem<MC, NS, NM>;
       float lmem[LMm::kSize];
@@ -114,8 +138,8 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4, kEmuCone<MC>, NM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                                      (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr, mt.data());
+        lm::substep<QuadThreads, MC, NS, RK4, kEmuCone<MC>, NM, kEmuDR>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+                                                      (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr, mt.data(), &dofp);
       if (NM > 0) {
         const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
         for (int i = 0; i < nm; i++) act[e * na + (int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE]] = lmem[LMm::kAct + i];
@@ -136,6 +160,8 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   if (counters) memcpy(counters, cnt_tot, sizeof(cnt_tot));
   return 0;
 }
+
+extern "C" void emu_set_dof_params(const double* p) { g_dofprm = p; }
 
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,

@@ -6,20 +6,23 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-def build(ls_points=1):
+def build(ls_points=1, dr=False):
     """ls_points = 1: the one-point-at-a-time line search of full waves; 4: the four-points-per-round line search of the
     replicated small-batch layout (evaluated by one lane here)."""
-    lib = os.path.join(_HERE, "libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points)
+    lib = os.path.join(_HERE, ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so"))
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
             os.path.join(_HERE, "../../include/lm_layout.h")]
     if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-DEMU_LS_POINTS=%d" % ls_points, "-DEMU_PYRAMID_ONLY", "-o", lib, srcs[0]])
+                               "-DEMU_LS_POINTS=%d" % ls_points, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if dr else []) + ["-o", lib, srcs[0]])
     return lib
 
 
-def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1):
-    lib = C.CDLL(build(ls_points))
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False):
+    """dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
+    per-environment code path on the table's nominal values."""
+    dr = dr or dof_params is not None
+    lib = C.CDLL(build(ls_points, dr))
     cmod = np.ascontiguousarray(chain_model, dtype=np.float64)
     nv = int(cmod[2])
     q = np.array(qpos, dtype=np.float64).reshape(-1, nv)
@@ -35,6 +38,10 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     actv = None
     if na:
         actv = np.zeros((n, na)) if act is None else np.array(act, dtype=np.float64).reshape(n, na)
+    prm = None
+    if dr:
+        prm = None if dof_params is None else np.ascontiguousarray(dof_params, dtype=np.float64).reshape(3, n, nv)
+        lib.emu_set_dof_params(dp(prm) if prm is not None else None)
     rc = lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
                      dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
                      dp(actv) if actv is not None else None)

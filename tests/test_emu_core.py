@@ -116,6 +116,39 @@ def test_core_talos_euler_pyramidal(ls_points):
         assert np.abs(v10[0][qidx] - g[k + 1, 16:34]).max() < 1e-3
 
 
+def test_core_per_environment_joint_parameters():
+    """DR = true code path (damping / stiffness / frictionloss per environment) of the Talos family vs the oracle run on a
+    model compiled with those values; with the table's own values it must reproduce the nominal kernel bit for bit."""
+    import copy
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    g = GOLD["Talos.walk.real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    rs = np.random.RandomState(3)
+    n = 4
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[[0, 3, 4, 13], :16]
+    qvel[:, qidx] = g[[0, 3, 4, 13], 16:34]
+    acts = rs.uniform(-0.3, 0.3, (n, 12))
+    q0, v0, _, _, _ = pyemu.run(cmod, qpos, qvel, acts, nsub=10, ls_points=4)
+    q1, v1, _, _, _ = pyemu.run(cmod, qpos, qvel, acts, nsub=10, ls_points=4, dr=True)
+    assert np.array_equal(q0, q1) and np.array_equal(v0, v1)
+    damp = (np.tile(m.dof_damping, (n, 1)) * rs.uniform(0.5, 2.0, (n, m.nv)) + (m.dof_damping > 0) * rs.uniform(0, 1, (n, m.nv))).astype(np.float32)
+    floss = (np.tile(m.dof_frictionloss, (n, 1)) * rs.uniform(0.5, 1.5, (n, m.nv))).astype(np.float32)
+    stiff = np.tile(m.jnt_stiffness, (n, 1)).astype(np.float32)
+    q2, v2, _, _, _ = pyemu.run(cmod, qpos, qvel, acts, nsub=10, ls_points=4, dof_params=np.stack([damp, stiff, floss]))
+    assert np.abs(v2 - v0).max() > 1e-3
+    for i in range(n):
+        m2 = copy.copy(m)
+        m2.dof_damping, m2.jnt_stiffness, m2.dof_frictionloss = damp[i].astype(float), stiff[i].astype(float), floss[i].astype(float)
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo, _, _ = Oracle(pack_model(m2)).step(qpos[i], qvel[i], ctrl, nsub=10)
+        assert np.abs(q2[i] - qo).max() < 1e-5 and np.abs(v2[i] - vo).max() < 1e-3
+
+
 def test_core_muscles():
     """kernel variant <5,8,Euler,muscles>: tendon paths, muscle forces and activation dynamics in float32 vs oracle/golden."""
     np.random.seed(0)
