@@ -449,6 +449,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   else if (big && rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);   // one box foot per leg
   else if (big && rk4 && T.na == 0 && pyr3) launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);          // Atlas: two boxes per foot
   else if (big && !rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);         // Talos (Euler)
+  else if (big && !rk4 && T.na == 0 && pyr3) launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);                // Talos carrying a box
   else if (big && !rk4 && T.na > 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, FWD>(b, a);   // muscle humanoid
   else if (T.na > 0) g_launch_err = "muscle models need the <5 links, <=4 contacts per chain, Euler> family";
   // generic fallbacks (cone read at run time; no replicated / randomised variants are compiled for them)

@@ -19,6 +19,7 @@ import numpy as np
 from .. import mjcf
 from ..utils.checks import check_validity_task_mode_dataset
 from .base import LocoEnv, ValidTaskConf
+from .base_robot_humanoid import BaseRobotHumanoid
 from .observation import ObservationType
 
 _PKG = Path(__file__).resolve().parent.parent
@@ -30,35 +31,54 @@ _PELVIS = ["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", 
 _LEG = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle"]
 
 
-class Atlas(LocoEnv):
+class Atlas(BaseRobotHumanoid):
 
     valid_task_confs = ValidTaskConf(tasks=["walk", "carry"], data_types=["real", "perfect"])
 
     def __init__(self, disable_arms=True, disable_back_joint=True, hold_weight=False, weight_mass=None,
                  xml_path=None, timestep=0.001, **kwargs):
-        if hold_weight or not disable_arms:
-            raise NotImplementedError("Atlas with free arms or a carried weight is not built (SURVEY.md §8f rank 3): the "
-                                      "arms would hang off the end of the back chain (branching below the root)")
+        if not disable_arms:
+            raise NotImplementedError("Atlas with free arms is not built (SURVEY.md §8f rank 3): the arms would hang off "
+                                      "the end of the back chain (branching below the root)")
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, hold_weight
+        self._weight_mass = weight_mass
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
         drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
         observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
         action_spec = [a for a in self._get_action_specification() if a not in motors_to_remove]
-        model = self._load_model(xml_path, timestep, joints_to_remove, motors_to_remove,
-                                 "default" if disable_back_joint else "back")
+        weights = self._weight_list(hold_weight, weight_mass, kwargs.get("n_envs", 1))
+        models = [self._load_model(xml_path, timestep, joints_to_remove, motors_to_remove,
+                                   "default" if disable_back_joint else "back", w) for w in weights]
         collision_groups = [("floor", ["floor"]), ("foot_r", ["right_foot_back"]), ("front_foot_r", ["right_foot_front"]),
                             ("foot_l", ["left_foot_back"]), ("front_foot_l", ["left_foot_front"])]
-        super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+        super().__init__(models[0], action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+        self._init_weight_models(models, weights)
 
     @classmethod
-    def _load_model(cls, xml_path, timestep, joints_to_remove, motors_to_remove, variant="default"):
+    def _load_model(cls, xml_path, timestep, joints_to_remove, motors_to_remove, variant="default", weight=None):
         if xml_path is not None:
             handle = mjcf.MjcfHandle.from_path(xml_path)
             cls._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, [])
+            if weight is not None:
+                cls._add_weight(handle, weight)
             return mjcf.compile_mjcf(handle, timestep=timestep)
-        m = mjcf.CompiledModel.load(_PKG / "assets" / ("Atlas.%s.model.npz" % variant))
+        name = "Atlas.%s.model.npz" % variant if weight is None else "Atlas.carry.%s.w%g.model.npz" % (variant, weight)
+        if not (_PKG / "assets" / name).exists():
+            raise NotImplementedError("no compiled model %s in the package (shipped: no weight, or 0.1 / 1 / 5 / 10 kg with the "
+                                      "back joints disabled); pass xml_path=... to compile another one" % name)
+        m = mjcf.CompiledModel.load(_PKG / "assets" / name)
         assert abs(m.timestep - timestep) < 1e-12
         return m
+
+    @staticmethod
+    def _add_weight(xml_handle, mass, color=None):
+        """A box held in front of the robot, fixed to the upper torso; the arms are turned towards it
+        (``atlas.py:455-482``; the colour only matters to the viewer)."""
+        weight = xml_handle.add(xml_handle.find("body", "utorso"), "body", name="weight")
+        xml_handle.add(weight, "geom", type="box", size="0.1 0.27 0.1", pos="0.72 0 -0.25", group="0", mass=repr(float(mass)))
+        xml_handle.find("body", "r_clav").set("quat", "1.0 0.0 -0.35 0.0")
+        xml_handle.find("body", "l_clav").set("quat", "0.0 -0.35 0.0 1.0")
+        return xml_handle
 
     @staticmethod
     def _delete_from_xml_handle(xml_handle, joints_to_remove, motors_to_remove, equ_constraints):
@@ -110,29 +130,8 @@ class Atlas(LocoEnv):
     def generate(task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):
         """``LocoEnv.make("Atlas.walk.real")`` (``atlas.py:420-453`` -> ``base_robot_humanoid.py:145-260``)."""
         check_validity_task_mode_dataset(Atlas.__name__, task, None, dataset_type, *Atlas.valid_task_confs.get_all())
-        if task == "carry":
-            raise NotImplementedError("Atlas.carry (weight models) is not built yet (SURVEY.md §8f rank 3)")
-        if dataset_type == "perfect":
-            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
-        reward_type = kwargs.pop("reward_type", "target_velocity")
-        reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25))
-        mdp = Atlas(reward_type=reward_type, reward_params=reward_params, **kwargs)
-        path = "datasets/humanoids/real/02-constspeed_ATLAS.npz"
-        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
-        use_mini = not (root / path).exists()
-        if debug or use_mini:
-            if use_mini and not debug:
-                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
-                              "the datasets to use this environment for imitation learning!")
-            parts = path.split("/")
-            parts.insert(3, "mini_datasets")
-            path = "/".join(parts)
-        traj_path = root / path
-        if not traj_path.exists():
-            traj_path = _PKG / path
-        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
-                                 clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
-        return mdp
+        return BaseRobotHumanoid.generate(Atlas, "datasets/humanoids/real/02-constspeed_ATLAS.npz", task, dataset_type,
+                                          debug=debug, clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges, **kwargs)
 
     # ------------------------------------------------------------------ specs
     @staticmethod

@@ -145,8 +145,28 @@ class LocoEnv:
             self._backend = HipBatch(self._hip_model, self.n_envs)
         return self._backend
 
+    def _init_models(self, models):
+        """Several models in one environment (the reference's ``MultiMuJoCo``: sizes of the humanoid, carried weights).
+        One compiled model and, lazily, one device batch per model; one of them is current (``base.py:186-193``)."""
+        self._models = list(models)
+        self._n_models = len(self._models)
+        self._current_model_idx = 0
+        self._model_backends = [None] * self._n_models
+
     def _select_model(self, idx):
-        """Hook of the multi-model environments: make model ``idx`` (drawn per episode, ``base.py:186-190``) current."""
+        """Make model ``idx`` (drawn per episode, ``base.py:186-190``) current."""
+        if self._n_models <= 1:
+            return
+        self._model_backends[self._current_model_idx] = self._backend
+        self._current_model_idx = idx
+        self._model = self._models[idx]
+        self._backend = self._model_backends[idx]
+        self._hip_model = None
+
+    def _obs_perm(self):
+        """Index array that turns the device observation [q, v, constants, foot forces] into the reference's order, or
+        None when they coincide (they differ when an environment appends constants AFTER the foot forces)."""
+        return None
 
     # ------------------------------------------------------------------ trajectories / datasets
     def load_trajectory(self, traj_params, warn=True):
@@ -208,6 +228,8 @@ class LocoEnv:
         h.qvel[:] = 0.0
         if self._random_env_reset:
             self._select_model(np.random.randint(0, self._n_models))
+        elif self._n_models > 1:
+            self._select_model((self._current_model_idx + 1) % self._n_models)
         self._cur_env = e
         self.setup(obs)
 
@@ -276,6 +298,9 @@ class LocoEnv:
         prev_obs = self._obs
         obs32, rew32, done = b.step(a)
         obs = obs32.astype(np.float64)
+        perm = self._obs_perm()
+        if perm is not None:
+            obs = obs[:, perm]
         if self._reward_function.device_spec() is None:
             reward = np.asarray(self.reward(prev_obs, a, obs, done), dtype=np.float64) * np.ones(self.n_envs)
         else:

@@ -17,6 +17,7 @@ from .. import mjcf
 from ..utils.checks import check_validity_task_mode_dataset
 from .atlas import Atlas
 from .base import LocoEnv, ValidTaskConf
+from .base_robot_humanoid import BaseRobotHumanoid
 from .observation import ObservationType
 
 _PKG = Path(__file__).resolve().parent.parent
@@ -28,34 +29,60 @@ _PELVIS = ["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", 
 _LEG = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle"]
 
 
-class Talos(LocoEnv):
+class Talos(BaseRobotHumanoid):
 
-    valid_task_confs = ValidTaskConf(tasks=["walk", "carry"], data_types=["real", "perfect"])
+    valid_task_confs = ValidTaskConf(tasks=["walk", "carry"], data_types=["real", "perfect"],
+                                     non_combinable=[("carry", None, "perfect")])
 
     def __init__(self, disable_arms=True, disable_back_joint=False, hold_weight=False, weight_mass=None,
                  xml_path=None, timestep=0.001, **kwargs):
-        if hold_weight or not disable_arms:
-            raise NotImplementedError("Talos with free arms or a carried weight is not built (SURVEY.md §8f rank 3): the arms "
-                                      "would branch off the back chain")
+        if not disable_arms:
+            raise NotImplementedError("Talos with free arms is not built (SURVEY.md §8f rank 3): the arms would branch off "
+                                      "the back chain")
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, hold_weight
+        self._weight_mass = weight_mass
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
         drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
         observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
         action_spec = [a for a in self._get_action_specification() if a not in motors_to_remove]
-        if xml_path is not None:
-            model = self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, joints_to_remove, motors_to_remove)
-        else:
-            model = mjcf.CompiledModel.load(_PKG / "assets" / ("Talos.%s.model.npz" % ("noback" if disable_back_joint else "default")))
-            assert abs(model.timestep - timestep) < 1e-12
+        weights = self._weight_list(hold_weight, weight_mass, kwargs.get("n_envs", 1))
+        variant = "noback" if disable_back_joint else "default"
+        models = []
+        for w in weights:
+            if xml_path is not None:
+                models.append(self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, joints_to_remove, motors_to_remove, w))
+                continue
+            name = "Talos.%s.model.npz" % variant if w is None else "Talos.carry.%s.w%g.model.npz" % (variant, w)
+            if not (_PKG / "assets" / name).exists():
+                raise NotImplementedError("no compiled model %s in the package (shipped: no weight, or 0.1 / 1 / 5 / 10 kg with "
+                                          "the back joints); pass xml_path=... to compile another one" % name)
+            models.append(mjcf.CompiledModel.load(_PKG / "assets" / name))
+            assert abs(models[-1].timestep - timestep) < 1e-12
         collision_groups = [("floor", ["floor"]), ("foot_r", ["right_foot"]), ("foot_l", ["left_foot"])]
-        super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+        super().__init__(models[0], action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+        self._init_weight_models(models, weights)
 
     @classmethod
-    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove):
+    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, weight=None):
         Atlas._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, [])
-        cls._reorient_arms(handle)
+        if weight is not None:
+            cls._add_weight(handle, weight)
+        else:
+            cls._reorient_arms(handle)
         # the upper body's collision meshes (floor-only like every robot geom) are kept as proximity-only bounding capsules
         return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)
+
+    @staticmethod
+    def _add_weight(xml_handle, mass, color=None):
+        """A box held in front of the robot, fixed to the upper torso, elbows and wrists turned towards it
+        (``talos.py:468-500``; the colour only matters to the viewer)."""
+        weight = xml_handle.add(xml_handle.find("body", "torso_2_link"), "body", name="weight")
+        xml_handle.add(weight, "geom", type="box", size="0.1 0.25 0.1", pos="0.45 0 -0.20", group="0", mass=repr(float(mass)))
+        for body in ("arm_right_4_link", "arm_left_4_link"):
+            xml_handle.find("body", body).set("quat", "1.0 0.0 -0.65 0.0")
+        for body in ("arm_right_6_link", "arm_left_6_link"):
+            xml_handle.find("body", body).set("quat", "1.0 0.0 -0.0 1.0")
+        return xml_handle
 
     @staticmethod
     def _reorient_arms(xml_handle):
@@ -110,30 +137,9 @@ class Talos(LocoEnv):
         if "disable_arms" in kwargs:
             assert kwargs["disable_arms"] is True, "Activating the arms in the Talos environment is currently not supported."
         check_validity_task_mode_dataset(Talos.__name__, task, None, dataset_type, *Talos.valid_task_confs.get_all())
-        if task == "carry":
-            raise NotImplementedError("Talos.carry (weight models) is not built yet (SURVEY.md §8f rank 3)")
-        if dataset_type == "perfect":
-            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
-        reward_type = kwargs.pop("reward_type", "target_velocity")
-        reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25))
         clip = kwargs.pop("clip_trajectory_to_joint_ranges", True)
-        mdp = Talos(reward_type=reward_type, reward_params=reward_params, **kwargs)
-        path = "datasets/humanoids/real/02-constspeed_TALOS.npz"
-        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
-        use_mini = not (root / path).exists()
-        if debug or use_mini:
-            if use_mini and not debug:
-                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
-                              "the datasets to use this environment for imitation learning!")
-            parts = path.split("/")
-            parts.insert(3, "mini_datasets")
-            path = "/".join(parts)
-        traj_path = root / path
-        if not traj_path.exists():
-            traj_path = _PKG / path
-        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
-                                 clip_trajectory_to_joint_ranges=clip), warn=False)
-        return mdp
+        return BaseRobotHumanoid.generate(Talos, "datasets/humanoids/real/02-constspeed_TALOS.npz", task, dataset_type,
+                                          debug=debug, clip_trajectory_to_joint_ranges=clip, **kwargs)
 
     # ------------------------------------------------------------------ specs
     @staticmethod

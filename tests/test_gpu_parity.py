@@ -344,6 +344,89 @@ def test_talos_batch_rollout_properties(talos):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Atlas.carry / Talos.carry: box on the torso (kernel variants <5,8,RK4> and <5,8,Euler>), weight in the observation
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,nu", [("Atlas.carry", 10), ("Talos.carry", 12)])
+def test_carry_one_control_step_kats_and_rollout(task, nu):
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    g = GOLD[task + ".real"]
+    n = len(g) - 1
+    np.random.seed(0)
+    env = LocoEnv.make(task, debug=True, weight_mass=0.1)
+    m = env._model
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    nq = len(qidx) - 2
+    np.random.seed(0)
+    np.random.randint(0, 4), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(nu) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :nq]
+    qvel[:, qidx] = g[:n, nq:-1]
+    b = HipBatch(HipModel(env._chain_model()), n)
+    b.set_state(qpos, qvel)
+    b.set_goal(np.full((n, 1), 0.1))
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :nq] - g[1:, :nq]).max(axis=1), np.abs(obs[:, nq:-1] - g[1:, nq:-1]).max(axis=1)
+    print("%s KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e" % (task, eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL and np.all(obs[:, -1] == np.float32(0.1))
+    assert list(done) == [False] * (n - 1) + [True]
+    st = b.stats()
+    assert st["overflow_contacts"] == 0 and st["unhandled_geoms"] == 0
+    # the reference's test loop through the environment: four models, one drawn per episode
+    np.random.seed(0)
+    env = LocoEnv.make(task, debug=True)
+    o = env.reset()
+    assert np.abs(o - g[0]).max() < 1e-14 and env._current_model_idx == 0
+    rows, absorbing = [o], False
+    for _ in range(100):
+        if absorbing:
+            break
+        o, r, absorbing, info = env.step(np.random.randn(nu) * 0.1)
+        rows.append(o)
+    rows = np.array(rows)
+    assert rows.shape == g.shape, "episode must terminate at the same step as the reference"
+    assert np.abs(rows[:, :nq] - g[:, :nq]).max() < 5e-3
+    # another episode with another box: the batch of that model takes over
+    seen = {0.1}
+    for _ in range(8):
+        o = env.reset()
+        o2, _, _, _ = env.step(np.zeros(nu))
+        assert abs(o2[-1] - o[-1]) < 1e-6
+        seen.add(round(float(o[-1]), 3))
+    assert len(seen) > 1
+
+
+def test_carry_with_foot_forces_observation_order():
+    """Reference order [q, v, foot forces, weight]; the device writes [q, v, weight, foot forces]."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import attach
+    np.random.seed(0)
+    dev = LocoEnv.make("Talos.carry", debug=True, weight_mass=5.0, use_foot_forces=True)
+    np.random.seed(0)
+    ora = attach(LocoEnv.make("Talos.carry", debug=True, weight_mass=5.0, use_foot_forces=True))
+    np.random.seed(0)
+    o_dev = dev.reset()
+    np.random.seed(0)
+    o_ora = ora.reset()
+    assert np.array_equal(o_dev, o_ora) and o_dev[-1] == 5.0 and np.all(o_dev[-7:-1] == 0)
+    rs = np.random.RandomState(4)
+    fmax = 0.0
+    for k in range(6):
+        a = rs.randn(12) * 0.1
+        o_dev, _, d_dev, _ = dev.step(a)
+        o_ora, _, d_ora, _ = ora.step(a)
+        assert o_dev[-1] == 5.0 and o_ora[-1] == 5.0
+        assert np.abs(o_dev[:-7] - o_ora[:-7]).max() < VTOL
+        assert np.abs(o_dev[-7:-1] - o_ora[-7:-1]).max() < 2e-2 * max(1e-3, np.abs(o_ora[-7:-1]).max())
+        fmax = max(fmax, np.abs(o_ora[-7:-1]).max())
+        if d_ora or d_dev:
+            break
+        dev._backend.set_state(ora._backend.qpos, ora._backend.qvel)
+    assert fmax > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # HumanoidTorque.run / .walk (BASELINE config 3's robot): 3 chains (5, 5, 3 links), joint springs, box feet.
 # Golden rows with mesh-mesh contacts active in the reference (walk, rows >= 19) are out of scope (bones are
 # proximity-only capsules, see tests/test_oracle_golden.py).

@@ -194,6 +194,47 @@ def test_talos_full_rollout_matches_reference_test():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Atlas.carry / Talos.carry: a box (0.1 / 1 / 5 / 10 kg, one model each, drawn per episode) fixed to the torso, arms turned
+# towards it, its mass appended to the observation. Pins the per-episode model draw (first np.random call of reset), the
+# mass / inertia of a geom-defined body (box with `mass=`) and the re-oriented welded arms.
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,nu,tol", [("Atlas.carry", 10, 1e-11), ("Talos.carry", 12, 1e-6)])
+def test_carry_full_rollout_matches_reference_test(task, nu, tol):
+    g = GOLD[task + ".real"]
+    np.random.seed(0)
+    env = attach(LocoEnv.make(task, debug=True))
+    assert env._n_models == 4 and [float(m.body_mass[m.body_names.index("weight")]) for m in env._models] == [0.1, 1.0, 5.0, 10.0]
+    obs = env.reset()
+    assert np.abs(obs - g[0]).max() < 1e-14 and obs[-1] == 0.1
+    rows, absorbing = [obs], False
+    for _ in range(1000):
+        if absorbing:
+            break
+        obs, r, absorbing, _ = env.step(np.random.randn(nu) * 0.1)
+        rows.append(obs)
+    rows = np.array(rows)
+    assert rows.shape == g.shape and np.abs(rows - g).max() < tol
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
+    assert all(st["unhandled_pairs"] == 0 for st in env._backend.stats_log)
+
+
+def test_carry_weight_changes_the_dynamics():
+    """The same state and action under the 0.1 kg and the 10 kg box: different accelerations, heavier box -> the
+    pelvis pitches forward faster."""
+    qacc = {}
+    for w in (0.1, 10.0):
+        np.random.seed(0)
+        env = LocoEnv.make("Atlas.carry", debug=True, weight_mass=w)
+        obs = env.reset()
+        assert obs[-1] == w and env._n_models == 1
+        h = env._host[0]
+        f = Oracle(pack_model(env._model)).forward(h.qpos, h.qvel, np.zeros(env._model.nu))
+        qacc[w] = f["qacc"]
+    assert np.abs(qacc[0.1] - qacc[10.0]).max() > 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # HumanoidTorque.run / .walk: pins joint stiffness/damping under RK4, the compiler's boundinertia/balanceinertia
 # order, `euler` geoms (box feet) and the humanoid XML surgery. Bone meshes are proximity-only bounding capsules
 # (no convex-hull collider is restated): every golden row is either reproduced to 1e-12 (all 38 of .run, the first
