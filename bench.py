@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--task", default="UnitreeA1.simple")
+    ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -137,6 +138,18 @@ def main():
     st = b.rollout(args.steps, action_mode=action_mode, seed=12)
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # extra leg, reported beside `value`, never as `value`: the same number of control steps with --fuse steps per launch
+    # (lm_rollout_fused: no device-wide join between control steps; bitwise the same results). Continues from the state
+    # the timed region left, so it runs the same mixture of walking and collapsing robots.
+    fused = None
+    if args.fuse > 1:
+        b.rollout(args.fuse, action_mode=action_mode, seed=13, steps_per_launch=args.fuse)
+        barrier()
+        t1 = time.perf_counter()
+        stf = b.rollout(args.steps, action_mode=action_mode, seed=14, steps_per_launch=args.fuse)
+        barrier()
+        fused = [time.perf_counter() - t1, stf["kernel_ms"]]
 
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"]], dtype=np.float64)
@@ -193,6 +206,18 @@ def main():
                   "newton_iters_per_forward_pass": vals[7] / max(env_steps * forwards, 1),
                   "physics_substeps_per_s": 10 * value},
     }
+    if fused is not None:
+        fel = fused[0]
+        if dist is not None:
+            import torch
+            tf = torch.tensor([fel], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            fel = float(tf[0])
+        out["rollout_fused"] = {"steps_per_launch": args.fuse, "value": n * world * args.steps / fel, "unit": "env-steps/s",
+                                "ms_per_step": 1e3 * fel / args.steps,
+                                "note": "policy-free rollout with %d control steps per launch (lm_rollout_fused): every "
+                                        "environment advances on its own, results bitwise those of single-step launches; "
+                                        "a policy in the loop gets `value`" % args.fuse}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(env, table, args.task, not default_task)
         out["cpu_baseline"]["gpu_over_cpu_core"] = value / out["cpu_baseline"]["value"]

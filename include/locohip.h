@@ -131,6 +131,12 @@ int lm_set_auto_reset(lm_batch* b, int enabled, int horizon);
    the counter-based RNG. Accumulates into *stats (may be NULL). */
 int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stats* stats);
 
+/* The same rollout with `steps_per_launch` control steps per kernel launch: every environment advances on its own, without
+   the device-wide join that ends each single-step launch with its slowest environment. Bitwise the same states,
+   observations and statistics as lm_rollout (which is steps_per_launch = 1); only for the policy-free action modes, a
+   policy in the loop needs lm_step / lm_step_device. */
+int lm_rollout_fused(lm_batch* b, int n_steps, int steps_per_launch, int action_mode, uint64_t seed, lm_stats* stats);
+
 /* one forward-dynamics pass at the current state with `action`, without advancing it */
 int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out);
 

@@ -36,7 +36,7 @@ class ForwardOut(C.Structure):
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
-           "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_forward_debug", "lm_get_stats", "lm_sync"]
+           "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync"]
 
 _lib = None
 
@@ -76,6 +76,7 @@ def load_library():
     lib.lm_set_reset_table.argtypes = [C.c_void_p, _F, C.c_int, C.c_uint64, C.c_int64]
     lib.lm_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.lm_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(Stats)]
+    lib.lm_rollout_fused.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(Stats)]
     lib.lm_forward_debug.argtypes = [C.c_void_p, _F, C.POINTER(ForwardOut)]
     lib.lm_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
     lib.lm_sync.argtypes = [C.c_void_p]
@@ -223,9 +224,11 @@ class HipBatch:
     def set_auto_reset(self, enabled, horizon=0):
         _check(self._lib.lm_set_auto_reset(self._h, int(bool(enabled)), int(horizon)))
 
-    def rollout(self, n_steps, action_mode=0, seed=0):
+    def rollout(self, n_steps, action_mode=0, seed=0, steps_per_launch=1):
+        """n_steps control steps on the device with zero (0) or uniform random (1) actions. steps_per_launch > 1 fuses that
+        many control steps into one launch (same results, no device-wide join between control steps)."""
         st = Stats()
-        _check(self._lib.lm_rollout(self._h, int(n_steps), int(action_mode), int(seed), C.byref(st)))
+        _check(self._lib.lm_rollout_fused(self._h, int(n_steps), int(steps_per_launch), int(action_mode), int(seed), C.byref(st)))
         return st.as_dict()
 
     def forward_debug(self, action):

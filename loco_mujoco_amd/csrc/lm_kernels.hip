@@ -89,6 +89,7 @@ struct KArgs {
   const float* table; int table_rows;                   // reset rows [K][nq+nv+ngoal]
   unsigned long long seed; long long env_offset;
   int auto_reset, horizon, action_mode; unsigned step_index;
+  int nfused;               // control steps per launch (policy-free rollouts; 1 for lm_step*)
   int N;
   int epb;                  // environments per workgroup (workgroup = 4*epb threads)
   lm::Params P; Task T;
@@ -108,7 +109,7 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1, bool FUSED = false>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
@@ -132,6 +133,14 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #define LK(k, f) cm[LM_CM_CHAINS + (LM_C_LINKS + (k) * LM_LINK_SIZE + (f)) * LM_NCHAIN + c]
   const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
 
+  // Policy-free rollouts run `nfused` control steps in one launch: every environment advances on its own, no device-wide
+  // join between control steps (a launch otherwise ends with its slowest environment). Each control step reloads its
+  // state from global memory exactly like a launch of its own would (the lanes of an environment hand it to each
+  // other there), so the results are bitwise those of `nfused` single-step launches.
+  // (FUSED is a template parameter: the loop around the single-step kernels costs them 4-10 % in SGPR pressure)
+  for (int fused = 0; fused < (FUSED ? a.nfused : 1); fused++) {
+  if (FUSED && fused > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  const unsigned step_index = a.step_index + (unsigned)fused;
   // ---- load state (root replicated in the 4 lanes: same address -> one transaction)
   float qr[6], vr[6], war[6], qc[MC], vc[MC], wac[MC], goal[4];
   int dr[6], dc[MC];
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     float act = 0.0f;
     if (a.action_mode == 0 && a.action) act = a.action[(long long)e * a.T.nu + k];
     else if (a.action_mode == 2) {
-      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + a.step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
       act = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
     }
     float ctrl = fminf(fmaxf(fmaf(act, delta, mean), lo), hi);
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (k >= 0) {
         if (a.action_mode == 0 && a.action) u = a.action[(long long)e * a.T.nu + k];
         else if (a.action_mode == 2) {
-          unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + a.step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+          unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
           u = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
         }
       }
@@ -357,6 +366,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
 #endif
+  }
+  }  // fused control steps
+  if (a.stats) {
     __syncthreads();
     for (int i = threadIdx.x; i < 12; i += blockDim.x) {
       float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
@@ -422,6 +434,10 @@ static void launch_family(lm_batch* b, const KArgs& a) {
   using LMm = lm::LaneMem<MC, NS, NM>;
   if (FWD) {
     launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1>, grid, dim3(4 * b->epb), (size_t)LMm::kGroup * ((4 * b->epb + 15) / 16), b, a);
+  } else if (a.nfused > 1) {
+    // fused rollouts exist for the replicated layout only (lm_rollout_fused falls back to single steps otherwise)
+    if (b->dofprm) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, true>, grid, dim3(16 * b->epb), (size_t)LMm::kGroup, b, a);
+    else launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, true>, grid, dim3(16 * b->epb), (size_t)LMm::kGroup, b, a);
   } else if (b->dofprm && b->epb <= 4 && !no_replicas) {
     launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4>, grid, dim3(16 * b->epb), (size_t)LMm::kGroup, b, a);
   } else if (b->dofprm) {
@@ -445,7 +461,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
 #else
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 4, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped
   // the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked when the model is created): the
-  // elliptic code compiles out, no scratch (was 470 B per lane). NB: these kernels need -O2, see the Makefile.
+  // elliptic code compiles out, no scratch (was 470 B per lane). NB: sensitive to the optimisation level, see the Makefile.
   else if (big && rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);   // one box foot per leg
   else if (big && rk4 && T.na == 0 && pyr3) launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);          // Atlas: two boxes per foot
   else if (big && !rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);         // Talos (Euler)
@@ -749,8 +765,18 @@ static KArgs make_args(lm_batch* b) {
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
-  a.epb = b->epb; a.timers = b->timers;
+  a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
   return a;
+}
+
+static bool family_has_replicas(const lm_batch* b) {      // mirrors launch_variant: the generic fallbacks have no replicated kernels
+  const Task& T = b->m->T;
+  const bool big = T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
+  const bool pyr3 = T.all_pyr3 && getenv("LM_GENERIC_KERNELS") == nullptr;
+  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return true;
+  if (big && T.na == 0 && pyr3) return true;
+  if (big && !rk4 && T.na > 0 && few && pyr3) return true;
+  return false;
 }
 
 static void launch_step(lm_batch* b, const KArgs& a) { g_launch_err = nullptr; launch_variant<false>(b, a); }
@@ -821,16 +847,20 @@ int lm_set_auto_reset(lm_batch* b, int enabled, int horizon) {
   return 0;
 }
 
-int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stats* stats) {
+int lm_rollout_fused(lm_batch* b, int n_steps, int steps_per_launch, int action_mode, uint64_t seed, lm_stats* stats) {
   HIPCHK(hipSetDevice(b->m->device));
   if (action_mode != 0 && action_mode != 1) return fail("action_mode must be 0 (zero) or 1 (uniform random)");
+  if (steps_per_launch < 1) return fail("steps_per_launch must be >= 1");
+  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;
+  if (b->epb > 4 || no_replicas || !family_has_replicas(b)) steps_per_launch = 1;     // no fused kernels for the full-wave layout
   KArgs a = make_args(b);
   a.action = nullptr; a.action_mode = action_mode == 0 ? 1 : 2;   // kernel: 1 = zero action, 2 = random
   a.seed = b->seed ^ (seed * 0x9E3779B97F4A7C15ull);
   a.obs = b->obs; a.reward = b->reward; a.done = b->done;
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  for (int s = 0; s < n_steps; s++) {
-    a.step_index = b->step_index++;
+  for (int s = 0; s < n_steps; s += steps_per_launch) {
+    a.nfused = (n_steps - s < steps_per_launch) ? n_steps - s : steps_per_launch;
+    a.step_index = b->step_index; b->step_index += (unsigned)a.nfused;
     launch_step(b, a);
     if (g_launch_err) return fail(g_launch_err);
   }
@@ -843,6 +873,10 @@ int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stat
   b->acc.kernel_ms += ms;
   if (stats) { *stats = b->acc; stats->kernel_ms = ms; }
   return 0;
+}
+
+int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stats* stats) {
+  return lm_rollout_fused(b, n_steps, 1, action_mode, seed, stats);
 }
 
 int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {

@@ -344,6 +344,48 @@ def test_talos_batch_rollout_properties(talos):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Fused rollouts: several control steps per launch, no device-wide join between control steps
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,kw", [("UnitreeA1.simple", {}), ("HumanoidMuscle.run", {}), ("Atlas.walk", dict(dr=True))])
+def test_fused_rollout_is_bitwise_the_single_step_rollout(task, kw):
+    """20 control steps as launches of 7 + 7 + 6 vs 20 single-step launches: states, muscle activations, per-environment
+    joint parameters (redrawn at the restarts) and statistics must be identical, restarts included."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    mk = dict(disable_back_joint=False, domain_randomization_config=os.path.join(
+        os.path.dirname(loco_mujoco_amd.__file__), "environments", "data", "atlas", "domain_randomization_atlas.yaml")) if kw.get("dr") else {}
+    env = LocoEnv.make(task, debug=True, **mk)
+    m = env._model
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    n = 200
+    rows = tab[np.random.RandomState(0).randint(0, len(tab), n)]
+    out = []
+    d = env._domain_rand.sample(n) if kw.get("dr") else None
+    for fuse in (1, 7):
+        b = HipBatch(hm, n)
+        b.set_reset_table(tab, seed=3)
+        b.set_auto_reset(True, horizon=15)
+        if kw.get("dr"):
+            b.set_dof_params(damping=d[0], stiffness=d[1], frictionloss=d[2])
+            b.set_dof_randomization(env._domain_rand.spec)
+        b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+        if rows.shape[1] > 2 * m.nv:
+            b.set_goal(rows[:, 2 * m.nv:])
+        st = b.rollout(20, action_mode=1, seed=9, steps_per_launch=fuse)
+        q, v = b.get_state()
+        extra = [b.get_activation()] if m.na else []
+        if kw.get("dr"):
+            extra.append(b.get_dof_params()["damping"])
+        out.append((q, v, extra, {k: st[k] for k in ("env_steps", "episodes", "reward_sum", "solver_iters", "nan_resets")}))
+    (q1, v1, x1, s1), (q7, v7, x7, s7) = out
+    assert np.array_equal(q1, q7) and np.array_equal(v1, v7) and all(np.array_equal(a, b) for a, b in zip(x1, x7))
+    assert s1["env_steps"] == n * 20 and s1["episodes"] >= n and s1["episodes"] == s7["episodes"] and s1["solver_iters"] == s7["solver_iters"]
+    assert abs(s1["reward_sum"] - s7["reward_sum"]) <= 1e-3 * max(1.0, abs(s1["reward_sum"]))      # float32 block sums, other order
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Atlas.carry / Talos.carry: box on the torso (kernel variants <5,8,RK4> and <5,8,Euler>), weight in the observation
 # ---------------------------------------------------------------------------------------------------------------
 
