@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--task", default="UnitreeA1.simple")
+    ap.add_argument("--dr", action="store_true", help="Atlas.walk only: BASELINE config 4 — back joints kept, joint damping "
+                    "redrawn per episode from the reference's domain_randomization_atlas.yaml")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
@@ -105,7 +107,13 @@ def main():
     default_task = args.task == "UnitreeA1.simple"
     action_mode = 0 if default_task else 1            # zero action (config 2) | device random policy (configs 3-5)
     np.random.seed(0)
-    env = LocoEnv.make(args.task, debug=True)
+    make_kw = {}
+    if args.dr:
+        assert args.task == "Atlas.walk", "--dr is BASELINE config 4 (Atlas.walk)"
+        import loco_mujoco_amd
+        make_kw = dict(disable_back_joint=False, domain_randomization_config=os.path.join(
+            os.path.dirname(loco_mujoco_amd.__file__), "environments", "data", "atlas", "domain_randomization_atlas.yaml"))
+    env = LocoEnv.make(args.task, debug=True, **make_kw)
     table = env._reset_table()
     hm = HipModel(env._chain_model(), device=local_rank)
     b = HipBatch(hm, n)
@@ -123,6 +131,10 @@ def main():
     b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
     if rows.shape[1] > 2 * nv:
         b.set_goal(rows[:, 2 * nv:])
+    if args.dr:
+        d = env._domain_rand.sample(n)                       # first episode: host draw; restarts: device redraw
+        b.set_dof_params(damping=d[0], stiffness=d[1], frictionloss=d[2])
+        b.set_dof_randomization(env._domain_rand.spec)
 
     def barrier():
         b.sync()
@@ -190,7 +202,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, %d envs/GPU, %s rollout, device-side auto-reset "
                                "(horizon 1000), 10 physics substeps per env-step"
-                               % (args.task, n, "zero-action" if default_task else "random-policy"),
+                               % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else ""), n,
+                                  "zero-action" if default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

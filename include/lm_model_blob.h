@@ -14,7 +14,7 @@
 #define LM_MODEL_BLOB_H
 
 #define LM_BLOB_MAGIC 0x4C4D4231 /* "LMB1" */
-#define LM_BLOB_VERSION 2
+#define LM_BLOB_VERSION 3
 
 /* header slots (doubles) */
 enum {
@@ -28,7 +28,7 @@ enum { LM_GEOM_PLANE = 0, LM_GEOM_SPHERE, LM_GEOM_CAPSULE, LM_GEOM_CYLINDER, LM_
 enum { LM_JNT_SLIDE = 0, LM_JNT_HINGE = 1 };
 enum { LM_CONE_PYRAMIDAL = 0, LM_CONE_ELLIPTIC = 1 };
 enum { LM_INT_EULER = 0, LM_INT_RK4 = 1 };
-enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1 };
+enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1, LM_ACT_POSITION = 2 };
 
 /*
  * Array order after the header. "nb"=nbody, "nv"=number of dofs (= joints, all 1-dof), "ng"=ngeom.
@@ -47,7 +47,10 @@ enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1 };
  *  site_body[ns] site_pos[3ns] tendon_adr[nt] tendon_num[nt] wrap_site[nw]
  *  act_kind[nu] act_tendon[nu] act_dynprm[3nu] act_gainprm[9nu] act_lengthrange[2nu]
  *  (act_kind: LM_ACT_MOTOR joint torque gear*ctrl | LM_ACT_MUSCLE: activation state + force-length-velocity
- *   curves on a tendon; gainprm = range0 range1 force scale lmin lmax vmax fpmax fvmax, dynprm = tau_act tau_deact tausmooth)
+ *   curves on a tendon; gainprm = range0 range1 force scale lmin lmax vmax fpmax fvmax, dynprm = tau_act tau_deact tausmooth
+ *   | LM_ACT_POSITION: affine joint servo, force = gainprm[0]*ctrl + biasprm[0] + biasprm[1]*length + biasprm[2]*velocity)
+ *  -- version 3
+ *  act_biasprm[3nu] act_forcerange[2nu] act_forcelimited[nu]   (force clamped to forcerange when forcelimited)
  */
 
 #endif

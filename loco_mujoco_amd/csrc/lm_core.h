@@ -130,6 +130,7 @@ struct Params {
   int nv;
   int integrator;     // LM_INT_EULER (0) | LM_INT_RK4 (1)
   int cone;           // 0 pyramidal | 1 elliptic
+  int act_position;   // 1: the chain joints' actuators are position servos (torque = clamp(kp*ctrl - kp*q, force range))
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
@@ -808,7 +809,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
     for (int i = 0; i < 6; i++) sm_r[i] = -STIFF_R(i) * qr[i] - DAMP_R(i) * vr[i] - bias_r[i] + actr[i];
 #pragma unroll
-    for (int k = 0; k < MC; k++) sm_c[k] = (k < nl) ? (-STIFF_C(k) * qc[k] - DAMP_C(k) * vc[k] - bias_c[k] + actc[k] + musc[k]) : 0.0f;
+    for (int k = 0; k < MC; k++) {
+      // position servos (model-wide switch): actc = kp * ctrl, D_GEAR = kp; the engine clamps gain*ctrl + bias as a whole
+      const float act_k = (P.act_position && k < nl) ? fminf(fmaxf(fmaf(-LK(k, LM_D_GEAR), qc[k], actc[k]), LK(k, LM_D_FLO)), LK(k, LM_D_FHI)) : actc[k];
+      sm_c[k] = (k < nl) ? (-STIFF_C(k) * qc[k] - DAMP_C(k) * vc[k] - bias_c[k] + act_k + musc[k]) : 0.0f;
+    }
     // park M and the twists in lane memory
 #pragma unroll
     for (int i = 0; i < MC * (MC + 1) / 2; i++) LMEM(LMm::kMcc + i) = Mcc[i];

@@ -558,7 +558,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.iterations = (int)cmod[LM_H_ITERATIONS];
   P.tolerance = 1e-6f;      // float32 stand-in for MuJoCo's 1e-8 (the gradient itself carries ~1e-6 relative noise)
   P.nv = T.nv;
-  P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE];
+  P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE]; P.act_position = (int)cmod[LM_H_ACTMODE];
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;

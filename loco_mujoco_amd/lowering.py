@@ -36,7 +36,8 @@ MAXRG = 80        # geoms welded to the root (no device collider: proximity is c
 (D_TYPE, D_AX, D_AY, D_AZ, D_PX, D_PY, D_PZ, D_DAMP, D_ARM, D_STIFF, D_FLOSS, D_FLOSS_R, D_FLOSS_B, D_LIMITED,
  D_LO, D_HI, D_LIM_K, D_LIM_B, D_LIM_S0, D_LIM_S1, D_LIM_S2, D_LIM_S3, D_LIM_S4, D_INVW, D_GEAR, D_CTRL_LO,
  D_CTRL_HI, D_ACT, D_ACT_MEAN, D_ACT_DELTA, D_QOBS, D_VOBS, D_TERM_QLO, D_TERM_QHI, D_TERM_VLO, D_TERM_VHI, D_DOF,
- D_SIZE) = range(38)
+ D_FLO, D_FHI, D_SIZE) = range(40)
+# D_FLO / D_FHI: force range of a position servo (H_ACTMODE = 1: torque = clamp(D_GEAR * (ctrl - q), D_FLO, D_FHI))
 # ---- per-link extras (chain links only), after the dof block
 (L_HAS_T, L_TX, L_TY, L_TZ, L_R0, L_R1, L_R2, L_R3, L_R4, L_R5, L_R6, L_R7, L_R8, L_MASS, L_CX, L_CY, L_CZ,
  L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_SIZE) = range(24)
@@ -111,7 +112,8 @@ HEADER_SIZE = 40
 LMC_MAGIC = 0x4C4D4331  # "LMC1"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
-H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED = 25, 26, 27, 28, 29, 30, 31, 32
+H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED, H_ACTMODE = 25, 26, 27, 28, 29, 30, 31, 32, 33
+# H_ACTMODE: 0 = joint motors (torque = gear * ctrl), 1 = position servos on every actuated joint
 # H_CM_USED: floats of the constant table that are actually read (up to the last used geom block)
 # H_NGRF: number of ground-reaction-force observation entries (3 per force group); they follow the goal entries
 
@@ -246,6 +248,12 @@ def lower(m, task):
 
     cm = np.zeros(CM_SIZE, dtype=np.float64)
     act_of_dof = {int(d): a for a, d in enumerate(m.act_dof)}
+    kinds = set(int(k) for k, d in zip(getattr(m, "act_kind", np.zeros(m.nu)), m.act_dof) if d >= 0)
+    if kinds - {mjcf.ACT_MOTOR, mjcf.ACT_POSITION} or len(kinds) > 1:
+        raise UnsupportedModel("joint actuators must be all motors or all position servos")
+    act_mode = 1 if kinds == {mjcf.ACT_POSITION} else 0
+    if act_mode == 1 and any(act_of_dof.get(int(d), -1) >= 0 for d in range(6)):
+        raise UnsupportedModel("position servos on the root joints")
     dof_to_lane = -np.ones(m.nv, dtype=np.int64)
 
     dropped_root_limits = []
@@ -283,8 +291,17 @@ def lower(m, task):
         block[D_INVW] = m.dof_invweight0[d]
         a = act_of_dof.get(int(d), -1)
         block[D_ACT] = -1
+        block[D_FLO], block[D_FHI] = -3e38, 3e38
         if a >= 0:
             block[D_GEAR] = m.act_gear[a]
+            if act_mode == 1:
+                # position servo: force = kp * ctrl - kp * q (gain [kp], bias [0, -kp, 0]), clamped, times gear = 1
+                kp = m.act_gainprm[a][0]
+                if m.act_gear[a] != 1.0 or abs(m.act_biasprm[a][1] + kp) > 0 or m.act_biasprm[a][0] != 0 or m.act_biasprm[a][2] != 0:
+                    raise UnsupportedModel("position servo %s: only gear 1 and bias [0, -kp, 0] are lowered" % m.act_names[a])
+                block[D_GEAR] = kp
+                if m.act_forcelimited[a]:
+                    block[D_FLO], block[D_FHI] = m.act_forcerange[a]
             lo, hi = (m.act_ctrlrange[a] if m.act_ctrllimited[a] else (-np.inf, np.inf))
             block[D_CTRL_LO], block[D_CTRL_HI] = max(lo, -3e38), min(hi, 3e38)
             k = action_of_act.get(a, -1)
@@ -540,6 +557,7 @@ def lower(m, task):
     h[H_MEANINERTIA], h[H_CM_SIZE] = m.meaninertia, CM_SIZE
     h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
     h[H_NMUSCLE] = len(muscles)
+    h[H_ACTMODE] = act_mode
     max_geoms = max([int(cm[CM_CHAINS + C_NGEOMS * NCHAIN + c]) for c in range(NCHAIN)])
     h[H_CM_USED] = CM_CHAINS + (C_GEOMS + max_geoms * G_SIZE) * NCHAIN
     h[H_NGRF] = n_grf

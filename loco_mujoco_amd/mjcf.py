@@ -10,7 +10,7 @@ This module replaces both for the subset of MJCF the BASELINE models use:
 * default classes (nested ``<default class=...>``, ``childclass``), ``autolimits``,
 * bodies with hinge/slide joints, explicit ``<inertial>`` (``diaginertia``+``quat`` or ``fullinertia``),
 * primitive geoms (plane, sphere, capsule, cylinder, box; ``fromto``), sites,
-* ``<motor>`` actuators with joint transmission,
+* ``<motor>`` and ``<position>`` actuators with joint transmission,
 * ``<option>`` timestep / cone / impratio / integrator / iterations / tolerance.
 
 The result is a :class:`CompiledModel`: flat numpy arrays (body tree, joints/dofs, geoms, actuators,
@@ -33,7 +33,7 @@ GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSUL
               "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}
 JNT_SLIDE, JNT_HINGE = 0, 1
 CONE_PYRAMIDAL, CONE_ELLIPTIC = 0, 1
-ACT_MOTOR, ACT_MUSCLE = 0, 1
+ACT_MOTOR, ACT_MUSCLE, ACT_POSITION = 0, 1, 2
 INT_EULER, INT_RK4 = 0, 1
 
 _DEFAULT_SOLREF = (0.02, 1.0)
@@ -663,7 +663,7 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     act_root = root.find("actuator")
     if act_root is not None:
         for a_el in act_root:
-            if a_el.tag not in ("motor", "muscle"):
+            if a_el.tag not in ("motor", "muscle", "position"):
                 raise NotImplementedError("actuator type <%s>" % a_el.tag)
             a = defaults.resolve(a_el.tag, a_el, None)
             gear = _floats(a.get("gear", "1"))[0]
@@ -673,9 +673,19 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
             else:
                 cl = ("ctrlrange" in a) and autolimits
             act = dict(name=a.get("name", ""), kind=ACT_MOTOR, dof=-1, tendon=-1, gear=gear, ctrlrange=cr, ctrllimited=cl,
-                       dynprm=np.zeros(3), gainprm=np.zeros(9), lengthrange=np.zeros(2))
+                       dynprm=np.zeros(3), gainprm=np.zeros(9), lengthrange=np.zeros(2), biasprm=np.zeros(3),
+                       forcerange=_floats(a.get("forcerange", "0 0"), 2))
+            if "forcelimited" in a and a["forcelimited"] in ("true", "false"):
+                act["forcelimited"] = a["forcelimited"] == "true"
+            else:
+                act["forcelimited"] = ("forcerange" in a) and autolimits
             if a_el.tag == "motor":
                 act["dof"] = m.jnt_names.index(a["joint"])
+            elif a_el.tag == "position":
+                # <position kp>: force = kp * ctrl - kp * length (gain [kp, 0, 0], bias [0, -kp, 0]), clamped to forcerange
+                kp = float(a.get("kp", 1))
+                act["kind"], act["dof"] = ACT_POSITION, m.jnt_names.index(a["joint"])
+                act["gainprm"][0], act["biasprm"][1] = kp, -kp
             else:
                 # <muscle> shortcut: activation dynamics (timeconst, tausmooth) and the force-length-velocity curve
                 # parameters (range, force, scale, lmin, lmax, vmax, fpmax, fvmax), shared by gain and bias
@@ -708,6 +718,9 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.act_dynprm = np.array([a["dynprm"] for a in acts]).reshape(-1, 3)
     m.act_gainprm = np.array([a["gainprm"] for a in acts]).reshape(-1, 9)
     m.act_lengthrange = np.array([a["lengthrange"] for a in acts]).reshape(-1, 2)
+    m.act_biasprm = np.array([a["biasprm"] for a in acts]).reshape(-1, 3)
+    m.act_forcerange = np.array([a["forcerange"] for a in acts]).reshape(-1, 2)
+    m.act_forcelimited = np.array([a["forcelimited"] for a in acts], dtype=np.int32)
 
     _set_const(m)
     return m

@@ -13,7 +13,7 @@ HEADER_SIZE = 32
 def pack_model(m):
     h = np.zeros(HEADER_SIZE)
     h[0] = LM_BLOB_MAGIC
-    h[1] = 2
+    h[1] = 3
     h[2:9] = [m.nbody, m.nv, m.ngeom, m.nu, m.cone, m.integrator, m.iterations]
     h[9:12] = [m.timestep, m.impratio, m.tolerance]
     h[12:15] = m.gravity
@@ -40,5 +40,7 @@ def pack_model(m):
              m.site_body[used] if used else zeros(0), m.site_pos[used] if used else zeros(0),
              getattr(m, "tendon_adr", zeros(0)), getattr(m, "tendon_num", zeros(0)), wrap,
              getattr(m, "act_kind", zeros(nu)), getattr(m, "act_tendon", -np.ones(nu)), getattr(m, "act_dynprm", zeros(nu, 3)),
-             getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2))]
+             getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2)),
+             getattr(m, "act_biasprm", zeros(nu, 3)), getattr(m, "act_forcerange", zeros(nu, 2)),
+             getattr(m, "act_forcelimited", zeros(nu))]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

@@ -87,6 +87,7 @@ struct lmo_model {
   int nsite, ntendon, nwrap, na;
   const double *site_body, *site_pos, *tendon_adr, *tendon_num, *wrap_site;
   const double *act_kind, *act_tendon, *act_dynprm, *act_gainprm, *act_lengthrange;
+  const double *act_biasprm, *act_forcerange, *act_forcelimited;
   unsigned char affects[LMO_MAXBODY][LMO_MAXV]; /* dof d moves body b */
   /* static candidate geom pairs after type/affinity/parent filtering */
   int npair;
@@ -98,7 +99,7 @@ struct lmo_model {
 #define IDX(a, i) ((int)((a)[i]))
 
 lmo_model* lmo_model_create(const double* blob, long n) {
-  if (n < LMH_HEADER_SIZE || (unsigned)blob[LMH_MAGIC] != LM_BLOB_MAGIC) return NULL;
+  if (n < LMH_HEADER_SIZE || (unsigned)blob[LMH_MAGIC] != LM_BLOB_MAGIC || (int)blob[LMH_VERSION] != LM_BLOB_VERSION) return NULL;
   lmo_model* m = (lmo_model*)calloc(1, sizeof(lmo_model));
   m->blob = (double*)malloc(sizeof(double) * (size_t)n);
   memcpy(m->blob, blob, sizeof(double) * (size_t)n);
@@ -129,6 +130,7 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   TAKE(site_body, m->nsite); TAKE(site_pos, 3*m->nsite); TAKE(tendon_adr, m->ntendon); TAKE(tendon_num, m->ntendon);
   TAKE(wrap_site, m->nwrap);
   TAKE(act_kind, nu); TAKE(act_tendon, nu); TAKE(act_dynprm, 3*nu); TAKE(act_gainprm, 9*nu); TAKE(act_lengthrange, 2*nu);
+  TAKE(act_biasprm, 3*nu); TAKE(act_forcerange, 2*nu); TAKE(act_forcelimited, nu);
 #undef TAKE
   if (p - m->blob != n) { free(m->blob); free(m); return NULL; }
 
@@ -1052,6 +1054,16 @@ static void forward(const lmo_model* m, const double* qpos, const double* qvel, 
     double c = ctrl[a];
     if (IDX(m->act_ctrllimited, a)) { if (c < m->act_ctrlrange[2*a]) c = m->act_ctrlrange[2*a]; if (c > m->act_ctrlrange[2*a + 1]) c = m->act_ctrlrange[2*a + 1]; }
     if (IDX(m->act_kind, a) == LM_ACT_MOTOR) { w->actuator[IDX(m->act_dof, a)] += m->act_gear[a] * c; w->actuator_force[a] = c; continue; }
+    if (IDX(m->act_kind, a) == LM_ACT_POSITION) {
+      /* affine servo on a joint (mj_fwdActuation: force = gain*ctrl + bias, bias affine in actuator length / velocity,
+         clamped to forcerange; joint transmission: length = gear*q, moment = gear) */
+      const int d = IDX(m->act_dof, a);
+      const double gear = m->act_gear[a], len = gear * qpos[d], vel = gear * qvel[d];
+      double f = m->act_gainprm[9*a] * c + m->act_biasprm[3*a] + m->act_biasprm[3*a + 1] * len + m->act_biasprm[3*a + 2] * vel;
+      if (IDX(m->act_forcelimited, a)) { if (f < m->act_forcerange[2*a]) f = m->act_forcerange[2*a]; if (f > m->act_forcerange[2*a + 1]) f = m->act_forcerange[2*a + 1]; }
+      w->actuator[d] += gear * f; w->actuator_force[a] = f; w->actuator_length[a] = len; w->actuator_velocity[a] = vel;
+      continue;
+    }
     /* muscle on a tendon: length/velocity through the gear, force = gain(len, vel) * act + bias(len) */
     double moment[LMO_MAXV], gear = m->act_gear[a];
     double len = gear * tendon_length(m, w, IDX(m->act_tendon, a), moment), vel = 0;

@@ -77,7 +77,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
-  P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE];
+  P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
   int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int c) {
     t_lane = c;

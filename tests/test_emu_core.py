@@ -149,6 +149,36 @@ def test_core_per_environment_joint_parameters():
         assert np.abs(q2[i] - qo).max() < 1e-5 and np.abs(v2[i] - vo).max() < 1e-3
 
 
+def test_core_position_servos():
+    """UnitreeA1 with position servos (kp 100, force range +-33.5): device float32 code vs the oracle, one control step
+    from dataset states with actions that drive some servos into their force limit."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert cmod[lowering.H_ACTMODE] == 1
+    o = Oracle(pack_model(m))
+    o.set_option("disable_self_collision", 1)
+    tab = env._reset_table()
+    rs = np.random.RandomState(5)
+    rows = tab[rs.randint(0, len(tab), 6)]
+    sat = 0
+    for i, row in enumerate(rows):
+        qpos, qvel = row[:m.nv], row[m.nv:2 * m.nv]
+        a = np.clip((qpos[m.act_dof][np.argsort(env._action_indices)] - env.norm_act_mean) / env.norm_act_delta + rs.uniform(-0.3, 0.3, 12), -1, 1)
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        f = o.forward(qpos, qvel, ctrl)
+        sat += int((np.abs(f["actuator_force"]) == 33.5).sum())
+        q, v, w, cnt, d = pyemu.run(cmod, qpos, qvel, a, nsub=1, debug_env=0, ls_points=4)
+        assert np.abs(d["smooth"] - (f["passive"] - f["bias"] + f["actuator"])).max() < 2e-3
+        assert np.abs(d["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())
+        qo, vo, _, _ = o.step(qpos, qvel, ctrl, nsub=10)
+        q10, v10, _, _, _ = pyemu.run(cmod, qpos, qvel, a, nsub=10, ls_points=4)
+        assert np.abs(q10[0] - qo).max() < 1e-5 and np.abs(v10[0] - vo).max() < 2e-3
+    assert sat > 0
+
+
 def test_core_muscles():
     """kernel variant <5,8,Euler,muscles>: tendon paths, muscle forces and activation dynamics in float32 vs oracle/golden."""
     np.random.seed(0)

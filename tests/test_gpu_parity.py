@@ -344,6 +344,49 @@ def test_talos_batch_rollout_properties(talos):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# UnitreeA1 with position servos (action_mode="position"): affine actuator with force limit inside every substep
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_a1_position_servos_vs_oracle():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
+    m = env._model
+    oracle = Oracle(pack_model(m))
+    oracle.set_option("disable_self_collision", 1)
+    tab = env._reset_table()
+    n = 64
+    rs = np.random.RandomState(2)
+    rows = tab[rs.randint(0, len(tab), n)]
+    order = np.argsort(env._action_indices)
+    hold = (rows[:, :m.nv][:, m.act_dof][:, order] - env.norm_act_mean) / env.norm_act_delta      # "stay where you are"
+    acts = np.clip(hold + rs.uniform(-0.4, 0.4, (n, 12)), -1, 1)
+    b = HipBatch(HipModel(env._chain_model()), n)
+    b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    b.set_goal(rows[:, 2 * m.nv:])
+    b.step(acts)
+    q, v = b.get_state()
+    eq, ev, sat = [], [], 0
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        q0, v0 = rows[i, :m.nv].astype(np.float32).astype(np.float64), rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64)
+        sat += int((np.abs(oracle.forward(q0, v0, ctrl)["actuator_force"]) == 33.5).sum())
+        qo, vo = oracle.step(q0, v0, ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
+    print("A1 position servos vs oracle (%d servo-steps at the force limit): qpos max %.2e median %.2e | qvel max %.2e median %.2e"
+          % (sat, max(eq), np.median(eq), max(ev), np.median(ev)))
+    assert max(eq) < QTOL and max(ev) < VTOL and sat > 10
+    # holding the pose keeps the robot up for 30 control steps (zero torque would let it collapse within ~17)
+    env2 = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
+    o = env2.reset()
+    a = (env2._host[0].qpos[m.act_dof][order] - env2.norm_act_mean) / env2.norm_act_delta
+    for _ in range(30):
+        o, r, done, _ = env2.step(a)
+        assert not done
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Fused rollouts: several control steps per launch, no device-wide join between control steps
 # ---------------------------------------------------------------------------------------------------------------
 

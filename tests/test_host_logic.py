@@ -140,6 +140,20 @@ def test_step_without_gpu_fails_loudly():
         e.step(np.zeros(12))
 
 
+def test_a1_position_mode_surface():
+    np.random.seed(0)
+    e = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
+    m = e._model
+    assert e.info.action_space.shape == (12,) and np.all(e.info.action_space.low == -1) and np.all(e.info.action_space.high == 1)
+    lo, hi = m.act_ctrlrange[e._action_indices].T                       # joint ranges: actions are normalised onto them
+    assert np.allclose(e._preprocess_action(np.ones(12)), hi) and np.allclose(e._preprocess_action(-np.ones(12)), lo)
+    assert np.allclose(e.norm_act_mean[:3], [0.0, 1.570795, -1.806414]) and e.reset().shape == (37,)
+    e2 = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position_difference")
+    assert e2._model.act_kind.tolist() == [2] * 12
+    with pytest.raises(AssertionError):
+        LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="velocity")
+
+
 def test_atlas_surface():
     np.random.seed(0)
     e = LocoEnv.make("Atlas.walk", debug=True)

@@ -100,6 +100,39 @@ def test_oracle_solution_is_kkt_point(a1):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# UnitreeA1 with position servos (action_mode="position"): no golden rollout exists (parity unpinned); the restatement
+# follows mj_fwdActuation's affine actuator (force = kp*ctrl - kp*q clamped to forcerange) and is checked analytically.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_a1_position_servo_forces():
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
+    m = env._model
+    assert set(m.act_kind) == {2} and np.all(m.act_gainprm[:, 0] == 100) and np.all(m.act_forcelimited == 1)
+    o = Oracle(pack_model(m))
+    env.reset()
+    q, v = env._host[0].qpos.copy(), env._host[0].qvel.copy()
+    rs = np.random.RandomState(1)
+    for _ in range(5):
+        ctrl_out = q[m.act_dof] + rs.uniform(-0.6, 0.6, m.nu)              # within and beyond the force range
+        ctrl_out[:3] += rs.uniform(-1, 1, 3) * 6                            # beyond ctrlrange: clamped first
+        f = o.forward(q, v, ctrl_out)
+        want = np.clip(100.0 * (np.clip(ctrl_out, m.act_ctrlrange[:, 0], m.act_ctrlrange[:, 1]) - q[m.act_dof]), -33.5, 33.5)
+        f0 = o.forward(q, v, q[m.act_dof])                                   # servo at rest: zero actuator force
+        assert np.abs(f0["actuator"]).max() < 1e-12
+        assert np.abs(f["actuator"][m.act_dof] - want).max() < 1e-9 and np.abs(f["actuator_force"] - want).max() < 1e-9
+        assert (np.abs(want) == 33.5).any() and (np.abs(want) < 33.5).any()   # both regimes exercised
+    # a standing robot under servo control at its own pose stays up; with motors and zero torque it collapses
+    a = (q[m.act_dof] - env.norm_act_mean) / env.norm_act_delta
+    qq, vv, w = q.copy(), v.copy(), np.zeros(m.nv)
+    for _ in range(20):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        qq, vv, w, _ = o.step(qq, vv, ctrl, 10, w)
+    assert not env._has_fallen(np.concatenate([qq[2:], vv, np.zeros(3)])) and np.abs(qq[m.act_dof] - q[m.act_dof]).max() < 0.3
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Atlas.walk: pins RK4, joint-limit rows, pyramidal cones (shared regulariser Rpy = 2 mu^2 R) and the plane-box
 # collider of the oracle. 26 one-control-step KATs + the reference's full-rollout test.
 # ---------------------------------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ def main():
     m = mjcf.compile_mjcf(UnitreeA1._add_dir_vector_to_xml_handle(h), timestep=0.001)
     m.save(ROOT / "loco_mujoco_amd" / "assets" / "UnitreeA1.torque.model.npz")
     print("UnitreeA1: nbody %d nv %d ngeom %d nu %d" % (m.nbody, m.nv, m.ngeom, m.nu))
+    h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "quadrupeds" / "unitree_a1_position.xml")
+    m = mjcf.compile_mjcf(UnitreeA1._add_dir_vector_to_xml_handle(h), timestep=0.001)
+    m.save(ROOT / "loco_mujoco_amd" / "assets" / "UnitreeA1.position.model.npz")
+    print("UnitreeA1 (position servos): kp %s force range %s" % (m.act_gainprm[0, 0], m.act_forcerange[0]))
 
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "atlas" / "atlas.xml")
     Atlas._delete_from_xml_handle(h, _ARM + _BACK, [j + "_actuator" for j in _ARM + _BACK], [])
