@@ -187,12 +187,22 @@ def main():
     launch_s = kernel_ms * 1e-3 / args.steps
     achieved = bytes_per_launch / launch_s / 1e9
     traffic = None
+    valu = None
     prof = os.path.join(ROOT, "profiles", "r1_pmc.json")
     if os.path.exists(prof) and n == 4096 and default_task:
         try:
             pmc = json.load(open(prof))["pmc"]
             # separate --pmc passes (tools/probes/prof_run.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)
             traffic = pmc["FETCH_SIZE"]["bytes_per_dispatch_corrected_x2"] + pmc["WRITE_SIZE"]["bytes_per_dispatch"]
+            # what actually bounds the kernel: VALU issue. One wave64 VALU instruction holds a 16-lane SIMD for 4 cycles;
+            # SQ_WAVE_CYCLES counts in units of 4 cycles (it reproduces the mean wave time measured with s_memtime).
+            prof_ns = json.load(open(prof))["duration_ns"]["avg"]
+            valu = dict(valu_insts_per_wave=pmc["SQ_INSTS_VALU"]["per_dispatch"] / pmc["SQ_WAVES"]["per_dispatch"],
+                        valu_busy_frac_of_wave_time=pmc["SQ_INSTS_VALU"]["per_dispatch"] / pmc["SQ_WAVE_CYCLES"]["per_dispatch"],
+                        mean_wave_time_over_launch_time=4.0 * pmc["SQ_WAVE_CYCLES"]["per_dispatch"] / pmc["SQ_WAVES"]["per_dispatch"]
+                        / (prof_ns * 2.4),
+                        note="profiles/r1_pmc.json; 2.4 GHz assumed; one wave per SIMD at 4096 environments, so the SIMD's "
+                             "VALU issue rate is the product of the two fractions")
         except Exception:
             traffic = None
     out = {
@@ -219,6 +229,8 @@ def main():
                   "newton_iters_per_forward_pass": vals[7] / max(env_steps * forwards, 1),
                   "physics_substeps_per_s": 10 * value},
     }
+    if valu is not None:
+        out["roofline"]["valu"] = valu
     if fused is not None:
         fel = fused[0]
         if dist is not None:

@@ -130,7 +130,14 @@ class Atlas(BaseRobotHumanoid):
     def generate(task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):
         """``LocoEnv.make("Atlas.walk.real")`` (``atlas.py:420-453`` -> ``base_robot_humanoid.py:145-260``)."""
         check_validity_task_mode_dataset(Atlas.__name__, task, None, dataset_type, *Atlas.valid_task_confs.get_all())
-        return BaseRobotHumanoid.generate(Atlas, "datasets/humanoids/real/02-constspeed_ATLAS.npz", task, dataset_type,
+        path = "datasets/humanoids/real/02-constspeed_ATLAS.npz"
+        if dataset_type == "perfect":
+            # recorded with these settings (``atlas.py:438-451``)
+            assert kwargs.get("use_foot_forces", False) is False and kwargs.get("disable_arms", True) is True
+            assert kwargs.get("disable_back_joint", False) is False and kwargs.get("hold_weight", False) is False
+            path = {"walk": "datasets/humanoids/perfect/atlas_walk/perfect_expert_dataset_det.npz",
+                    "carry": "datasets/humanoids/perfect/atlas_carry/Atlas_carry_stochastic_dataset.npz"}[task]
+        return BaseRobotHumanoid.generate(Atlas, path, task, dataset_type,
                                           debug=debug, clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges, **kwargs)
 
     # ------------------------------------------------------------------ specs

@@ -16,14 +16,18 @@ keeps the episode bookkeeping. There is no CPU physics path in the product.
 """
 
 import copy
+import os
 import warnings
 from itertools import product
+from pathlib import Path
 
 import numpy as np
 
 from ..utils.reward import (CustomReward, NoReward, PosReward, TargetVelocityReward)
 from ..utils.trajectory import Trajectory
 from .observation import Box, MDPInfo, ObservationHelper, ObservationType
+
+_PKG = Path(__file__).resolve().parent.parent
 
 
 class _HostState:
@@ -196,6 +200,62 @@ class LocoEnv:
             self._dataset = copy.deepcopy(dataset)
             return dataset
         return copy.deepcopy(self._dataset)
+
+    def load_dataset_and_get_traj_files(self, dataset_path, freq=None):
+        """A recorded ("perfect") dataset -> per-key trajectories (reference ``base.py:499-548``). The dataset holds
+        ``states`` [n, nobs] (the observation layout: no horizontal root position), ``actions``, ``last`` ...; the two
+        missing coordinates are integrated from their velocities at ``freq`` Hz (restarting at 0 after every ``last``) or
+        left at zero without ``freq``; ``split_points`` mark the episode starts. The dataset itself becomes what
+        ``create_dataset`` returns."""
+        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
+        path = root / dataset_path
+        if not path.exists():
+            raise FileNotFoundError("dataset %s not found: the recorded datasets are downloads of the reference project; put "
+                                    "them under $LOCO_MUJOCO_AMD_DATA/datasets/... (same relative paths)" % path)
+        with np.load(str(path), allow_pickle=True) as f:
+            dataset = {k: np.asarray(f[k]) for k in f.files}
+        self._dataset = copy.deepcopy(dataset)
+        states, last = np.atleast_2d(dataset["states"]), dataset["last"]
+        keys = [spec[0] for spec in self.obs_helper.observation_spec]
+        trajectories = dict()
+        for i, key in enumerate(keys):
+            if i >= 2:
+                trajectories[key] = states[:, i - 2]
+            elif freq is None:
+                trajectories[key] = np.zeros(len(states))
+            else:
+                assert len(states) > 2
+                vel = states[:-1, keys.index("d" + key) - 2] / float(freq)
+                pos = np.zeros(len(states))
+                for j in range(1, len(states)):
+                    pos[j] = 0.0 if (last is not None and last[j - 1] == 1) else pos[j - 1] + vel[j - 1]
+                trajectories[key] = pos
+        if len(states) > 2:
+            trajectories["split_points"] = np.concatenate([[0], np.squeeze(np.argwhere(last == 1) + 1, axis=-1)])
+        return trajectories
+
+    def _load_task_trajectory(self, path, dataset_type, debug, clip_trajectory_to_joint_ranges):
+        """The trajectory part of the task factories: 500 Hz mocap files ("real", with the bundled mini files as fall-back)
+        or a recorded 100 Hz dataset ("perfect")."""
+        if dataset_type == "perfect":
+            traj_files = self.load_dataset_and_get_traj_files(path, 100)
+            self.load_trajectory(dict(traj_files=traj_files, traj_dt=1.0 / 100, control_dt=self.dt,
+                                      clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+            return
+        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
+        use_mini = not (root / path).exists()
+        if debug or use_mini:
+            if use_mini and not debug:
+                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
+                              "the datasets to use this environment for imitation learning!")
+            parts = path.split("/")
+            parts.insert(3, "mini_datasets")
+            path = "/".join(parts)
+        traj_path = root / path
+        if not traj_path.exists():
+            traj_path = _PKG / path
+        self.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=self.dt,
+                                  clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
 
     def get_all_observation_keys(self):
         return [k for k, _, _ in self.obs_helper.observation_spec]

@@ -100,26 +100,12 @@ class BaseRobotHumanoid(LocoEnv):
     # ------------------------------------------------------------------ task factory
     @staticmethod
     def generate(env, path, task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):
-        """``base_robot_humanoid.py:145-260``: walk / carry at 1.25 m/s, run at 2.5 m/s, real (mocap) trajectories."""
-        if dataset_type != "real":
-            raise NotImplementedError("perfect / preference datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
+        """``base_robot_humanoid.py:145-260``: walk / carry at 1.25 m/s, run at 2.5 m/s; "real" = 500 Hz mocap
+        trajectories, "perfect" = a recorded 100 Hz dataset (states, actions, ...: a download of the reference project)."""
         reward_type = kwargs.pop("reward_type", "target_velocity")
         reward_params = kwargs.pop("reward_params", dict(target_velocity=2.5 if task == "run" else 1.25))
         if task == "carry":
             kwargs["hold_weight"] = True
         mdp = env(reward_type=reward_type, reward_params=reward_params, **kwargs)
-        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
-        use_mini = not (root / path).exists()
-        if debug or use_mini:
-            if use_mini and not debug:
-                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
-                              "the datasets to use this environment for imitation learning!")
-            parts = path.split("/")
-            parts.insert(3, "mini_datasets")
-            path = "/".join(parts)
-        traj_path = root / path
-        if not traj_path.exists():
-            traj_path = _PKG / path
-        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
-                                 clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+        mdp._load_task_trajectory(path, dataset_type, debug, clip_trajectory_to_joint_ranges)
         return mdp

@@ -165,25 +165,10 @@ class BaseHumanoid(LocoEnv):
     @staticmethod
     def generate(env, path, task="walk", dataset_type="real", debug=False, clip_trajectory_to_joint_ranges=False, **kwargs):
         """``base_humanoid.py:211-291``: target speed 1.25 m/s (walk) or 2.5 m/s (run), 500 Hz mocap."""
-        if dataset_type == "perfect":
-            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
         reward_type = kwargs.pop("reward_type", "target_velocity")
         reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25 if task == "walk" else 2.5))
         mdp = env(reward_type=reward_type, reward_params=reward_params, **kwargs)
-        root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
-        use_mini = not (root / path).exists()
-        if debug or use_mini:
-            if use_mini and not debug:
-                warnings.warn("Datasets not found, falling back to test datasets. Please download and install "
-                              "the datasets to use this environment for imitation learning!")
-            parts = path.split("/")
-            parts.insert(3, "mini_datasets")
-            path = "/".join(parts)
-        traj_path = root / path
-        if not traj_path.exists():
-            traj_path = _PKG / path
-        mdp.load_trajectory(dict(traj_path=traj_path, traj_dt=1.0 / 500, control_dt=mdp.dt,
-                                 clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+        mdp._load_task_trajectory(path, dataset_type, debug, clip_trajectory_to_joint_ranges)
         return mdp
 
     # ------------------------------------------------------------------ specs
@@ -224,6 +209,10 @@ class HumanoidTorque(BaseHumanoid):
                                          *HumanoidTorque.valid_task_confs.get_all())
         path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
                 "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
+        if dataset_type == "perfect":
+            assert kwargs.get("use_foot_forces", False) is False and kwargs.get("disable_arms", True) is True
+            assert kwargs.get("use_box_feet", True) is True
+            path = "datasets/humanoids/perfect/humanoid_torque_%s/perfect_expert_dataset_det.npz" % task
         return BaseHumanoid.generate(HumanoidTorque, path, task, dataset_type, **kwargs)
 
 
@@ -244,6 +233,10 @@ class HumanoidMuscle(BaseHumanoid):
                                          *HumanoidMuscle.valid_task_confs.get_all())
         path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid.npz",
                 "run": "datasets/humanoids/real/05-run_reduced_humanoid.npz"}[task]
+        if dataset_type == "perfect":
+            assert kwargs.get("use_foot_forces", False) is False and kwargs.get("disable_arms", True) is True
+            assert kwargs.get("use_box_feet", True) is True
+            path = "datasets/humanoids/perfect/humanoid_muscle_%s/perfect_expert_dataset_det.npz" % task
         return BaseHumanoid.generate(HumanoidMuscle, path, task, dataset_type, **kwargs)
 
 

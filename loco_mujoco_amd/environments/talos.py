@@ -138,7 +138,12 @@ class Talos(BaseRobotHumanoid):
             assert kwargs["disable_arms"] is True, "Activating the arms in the Talos environment is currently not supported."
         check_validity_task_mode_dataset(Talos.__name__, task, None, dataset_type, *Talos.valid_task_confs.get_all())
         clip = kwargs.pop("clip_trajectory_to_joint_ranges", True)
-        return BaseRobotHumanoid.generate(Talos, "datasets/humanoids/real/02-constspeed_TALOS.npz", task, dataset_type,
+        path = "datasets/humanoids/real/02-constspeed_TALOS.npz"
+        if dataset_type == "perfect":
+            assert kwargs.get("use_foot_forces", False) is False and kwargs.get("disable_back_joint", False) is False
+            assert kwargs.get("hold_weight", False) is False
+            path = "datasets/humanoids/perfect/talos_walk/perfect_expert_dataset_det.npz"
+        return BaseRobotHumanoid.generate(Talos, path, task, dataset_type,
                                           debug=debug, clip_trajectory_to_joint_ranges=clip, **kwargs)
 
     # ------------------------------------------------------------------ specs
