@@ -6,16 +6,36 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_VARIANTS = [(1, False), (4, False), (4, True)]          # what the tests use: built together, in parallel (g++ needs ~1 min each)
+
+
+def _lib_path(ls_points, dr):
+    return os.path.join(_HERE, ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so"))
+
+
 def build(ls_points=1, dr=False):
     """ls_points = 1: the one-point-at-a-time line search of full waves; 4: the four-points-per-round line search of the
-    replicated small-batch layout (evaluated by one lane here)."""
-    lib = os.path.join(_HERE, ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so"))
+    replicated small-batch layout (evaluated by one lane here); dr: the per-environment joint-parameter code path."""
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
             os.path.join(_HERE, "../../include/lm_layout.h")]
-    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-DEMU_LS_POINTS=%d" % ls_points, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if dr else []) + ["-o", lib, srcs[0]])
-    return lib
+
+    def stale(lib):
+        return not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
+
+    want = [(ls_points, dr)] + [v for v in _VARIANTS if v != (ls_points, dr)]
+    procs = []
+    for lp, d in want:
+        lib = _lib_path(lp, d)
+        if stale(lib):
+            tmp = lib + ".tmp%d" % os.getpid()
+            procs.append((subprocess.Popen(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
+                                            "-DEMU_LS_POINTS=%d" % lp, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if d else [])
+                                           + ["-o", tmp, srcs[0]]), tmp, lib))
+    for p, tmp, lib in procs:
+        if p.wait() != 0:
+            raise RuntimeError("building %s failed" % lib)
+        os.replace(tmp, lib)
+    return _lib_path(ls_points, dr)
 
 
 def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False):
