@@ -25,16 +25,26 @@ with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w", newline="") as 
     w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
     for r in rows:
         w.writerow([r[0], r[1], round(r[2] * 1.0), round(r[3], 1), round(r[4], 4)])
-k = db.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, min(duration), "
-               "avg(duration), max(duration), count(*) from kernels where name like '%step_kernel%'").fetchone()
-kname = db.execute("select name from kernels where name like '%step_kernel%' limit 1").fetchone()[0]
-summary = dict(kernel=kname.split("step_kernel")[1].split("(")[0].join(["step_kernel", ""]), vgpr=k[0], agpr=k[1], sgpr=k[2], lds_bytes=k[3], scratch_bytes=k[4],
+# the step kernel with the most dispatches is the single-step kernel of the timed region; a fused-rollout kernel
+# (several control steps per launch, the extra leg of bench.py) is summarised separately
+names = [r[0] for r in db.execute("select name, count(*) c from kernels where name like '%step_kernel%' group by name order by c desc")]
+kname = names[0]
+def kernel_row(name):
+    return db.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, min(duration), "
+                      "avg(duration), max(duration), count(*) from kernels where name = ?", (name,)).fetchone()
+def short(name):
+    return "step_kernel" + name.split("step_kernel")[1].split("(")[0]
+k = kernel_row(kname)
+summary = dict(kernel=short(kname), vgpr=k[0], agpr=k[1], sgpr=k[2], lds_bytes=k[3], scratch_bytes=k[4],
                workgroup=k[5], grid=k[6], duration_ns=dict(min=k[7], avg=k[8], max=k[9]), dispatches=k[10])
+for other in names[1:]:
+    o = kernel_row(other)
+    summary.setdefault("other_step_kernels", []).append(dict(kernel=short(other), dispatches=o[10], duration_ns=dict(min=o[7], avg=o[8], max=o[9])))
 pmc = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
     d = sqlite3.connect(p)
     for name, total, n in d.execute("select counter_name, sum(value), count(*) from counters_collection "
-                                    "where kernel_name like '%step_kernel%' group by counter_name"):
+                                    "where kernel_name = ? group by counter_name", (kname,)):
         pmc[name] = dict(per_dispatch=total / n, dispatches=n)
 if "FETCH_SIZE" in pmc:
     pmc["FETCH_SIZE"]["unit"] = "KiB"
