@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--task", default="UnitreeA1.simple")
     ap.add_argument("--dr", action="store_true", help="Atlas.walk only: BASELINE config 4 — back joints kept, joint damping "
                     "redrawn per episode from the reference's domain_randomization_atlas.yaml")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: run all ranks on GPU 0 with the gloo backend "
+                    "(checks the multi-rank control flow on a one-GPU box; the numbers mean nothing)")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
@@ -97,8 +99,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:                 # flow test of the multi-rank path on a one-GPU box: all ranks on device 0, gloo
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from loco_mujoco_amd import LocoEnv
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -164,18 +171,21 @@ def main():
         fused = [time.perf_counter() - t1, stf["kernel_ms"]]
 
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
-                     st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"]], dtype=np.float64)
+                     st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
+                     fused[0] if fused is not None else 0.0], dtype=np.float64)
     if dist is not None:
         import torch
-        t = torch.tensor(vals, device="cuda")
+        t = torch.tensor(vals, device="cpu" if args.share_gpu else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         kernel_ms = float(tmax[8])
+        fused_elapsed = float(tmax[9])                    # every collective happens before the non-zero ranks leave
         vals = t.cpu().numpy()
     else:
         kernel_ms = vals[8]
+        fused_elapsed = vals[9]
     if rank != 0:
         return
     env_steps = vals[1]
@@ -232,12 +242,7 @@ def main():
     if valu is not None:
         out["roofline"]["valu"] = valu
     if fused is not None:
-        fel = fused[0]
-        if dist is not None:
-            import torch
-            tf = torch.tensor([fel], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-            fel = float(tf[0])
+        fel = fused_elapsed
         out["rollout_fused"] = {"steps_per_launch": args.fuse, "value": n * world * args.steps / fel, "unit": "env-steps/s",
                                 "ms_per_step": 1e3 * fel / args.steps,
                                 "note": "policy-free rollout with %d control steps per launch (lm_rollout_fused): every "
