@@ -102,6 +102,8 @@ class LocoEnv:
         self._pending_state = False
         self._auto_reset = False
         self._n_models = 1
+        self._current_model_idx = 0
+        self._blocks = False             # several models in one BATCH: contiguous blocks of environments, one per model
         self._random_env_reset = True
 
     # ------------------------------------------------------------------ registry / factory
@@ -146,7 +148,7 @@ class LocoEnv:
         if self._backend is None:
             from ..backend import HipBatch, HipModel
             self._hip_model = HipModel(self._chain_model(), self._device)
-            self._backend = HipBatch(self._hip_model, self.n_envs)
+            self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if self._blocks else self.n_envs)
         return self._backend
 
     def _init_models(self, models):
@@ -156,6 +158,25 @@ class LocoEnv:
         self._n_models = len(self._models)
         self._current_model_idx = 0
         self._model_backends = [None] * self._n_models
+        # A device batch has ONE model table. With n_envs > 1 the environments are therefore split into contiguous blocks,
+        # one block (= one device batch) per model: environment e keeps model e * n_models // n_envs for its whole life
+        # instead of drawing one per episode — the same mixture over the batch, no per-environment model table.
+        self._blocks = self.n_envs > 1 and self._n_models > 1
+        if self._blocks and self.n_envs < self._n_models:
+            raise ValueError("n_envs=%d cannot hold %d models" % (self.n_envs, self._n_models))
+        self._env_model = np.zeros(self.n_envs, dtype=np.int64)
+        if self._blocks:
+            for i in range(self._n_models):
+                self._env_model[self._model_envs(i)] = i
+
+    def _model_envs(self, idx):
+        """Environment indices of model ``idx``'s block."""
+        n, m = self.n_envs, self._n_models
+        return np.arange((idx * n + m - 1) // m, ((idx + 1) * n + m - 1) // m)
+
+    def _block_of(self, e):
+        """Model of environment ``e`` in block mode."""
+        return int(self._env_model[e])
 
     def _select_model(self, idx):
         """Make model ``idx`` (drawn per episode, ``base.py:186-190``) current."""
@@ -286,7 +307,9 @@ class LocoEnv:
         h = self._host[e]
         h.qpos[:] = self._model.qpos0          # mj_resetData
         h.qvel[:] = 0.0
-        if self._random_env_reset:
+        if self._blocks:
+            self._select_model(self._block_of(e))
+        elif self._random_env_reset:
             self._select_model(np.random.randint(0, self._n_models))
         elif self._n_models > 1:
             self._select_model((self._current_model_idx + 1) % self._n_models)
@@ -351,12 +374,21 @@ class LocoEnv:
         """
         if self._obs is None:
             raise RuntimeError("call reset() before step()")
-        b = self.backend
-        if self._pending_state:
-            self._upload_state()
         a = np.asarray(action, dtype=np.float64).reshape(self.n_envs, -1)
         prev_obs = self._obs
-        obs32, rew32, done = b.step(a)
+        if self._blocks:
+            if self._pending_state:
+                self._upload_state()
+            parts = []
+            for idx in range(self._n_models):
+                self._select_model(idx)
+                parts.append(self.backend.step(a[self._model_envs(idx)]))
+            obs32, rew32, done = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        else:
+            b = self.backend
+            if self._pending_state:
+                self._upload_state()
+            obs32, rew32, done = b.step(a)
         obs = obs32.astype(np.float64)
         perm = self._obs_perm()
         if perm is not None:
@@ -373,14 +405,19 @@ class LocoEnv:
     def _upload_state(self):
         qpos = np.stack([h.qpos for h in self._host])
         qvel = np.stack([h.qvel for h in self._host])
-        self._backend.set_state(qpos, qvel)
-        if getattr(self, "_pending_dof_params", None) is not None:
-            d, k, f = self._pending_dof_params
-            self._backend.set_dof_params(damping=d, stiffness=k, frictionloss=f)
-            self._pending_dof_params = None
-        goal = self._goal_rows()
-        if goal is not None:
-            self._backend.set_goal(goal)
+        prm = getattr(self, "_pending_dof_params", None)
+        for idx in (range(self._n_models) if self._blocks else [self._current_model_idx]):
+            envs = self._model_envs(idx) if self._blocks else np.arange(self.n_envs)
+            if self._blocks:
+                self._select_model(idx)
+            b = self.backend
+            b.set_state(qpos[envs], qvel[envs])
+            if prm is not None:
+                b.set_dof_params(damping=prm[0][envs], stiffness=prm[1][envs], frictionloss=prm[2][envs])
+            goal = self._goal_rows()
+            if goal is not None:
+                b.set_goal(goal[:len(envs)])
+        self._pending_dof_params = None
         self._pending_state = False
 
     def _goal_rows(self):
@@ -395,11 +432,15 @@ class LocoEnv:
         """
         if self.trajectories is None:
             raise ValueError("auto reset needs trajectory data")
-        b = self.backend
-        b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset)
-        if self._domain_rand is not None and self._domain_rand.active:
-            b.set_dof_randomization(self._domain_rand.spec)
-        b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)
+        for idx in (range(self._n_models) if self._blocks else [self._current_model_idx]):
+            if self._blocks:
+                self._select_model(idx)
+            b = self.backend
+            first = int(self._model_envs(idx)[0]) if self._blocks else 0
+            b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset + first)
+            if self._domain_rand is not None and self._domain_rand.active:
+                b.set_dof_randomization(self._domain_rand.spec)
+            b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)
         self._auto_reset = True
 
     def _reset_table(self):

@@ -4,8 +4,9 @@ Common part of the robot humanoids (Atlas, Talos) — host-side mirror of the re
 weight (``hold_weight``: a box fixed to the torso, its mass appended to the observation; without ``weight_mass`` one model
 per mass in 0.1 / 1 / 5 / 10 kg, one of them drawn per episode) and the task factory shared by the robots.
 
-On the device one batch = one model table, so the four-weights variant is available for ``n_envs=1`` (one device batch
-per weight, switched at reset, like the humanoid's four sizes); batches use a fixed ``weight_mass``.
+On the device one batch = one model table: with ``n_envs=1`` the four-weights variant switches between four batches at
+reset like the reference; with ``n_envs>1`` the environments form four contiguous blocks, one weight each
+(``LocoEnv._init_models``).
 """
 
 import os
@@ -31,9 +32,6 @@ class BaseRobotHumanoid(LocoEnv):
             return [None]
         if weight_mass is not None:
             return [float(weight_mass)]
-        if n_envs != 1:
-            raise NotImplementedError("the four carried weights in one BATCH need one model table per environment on the "
-                                      "device; use n_envs=1 or a fixed weight_mass")
         return list(self._valid_weights)
 
     def _init_weight_models(self, models, weights):

@@ -243,17 +243,15 @@ class HumanoidMuscle(BaseHumanoid):
 class BaseHumanoid4Ages(BaseHumanoid):
     """The humanoid in four sizes — toddler 0.4, child 0.6, teenager 0.8, adult 1.0 — with the size indicator in the
     observation (reference ``humanoids/base_humanoid_4_ages.py``). Mode "all" keeps all four models in one environment
-    and draws one per episode; on the device one batch = one model table, so "all" is available for ``n_envs=1`` (one
-    device batch per size, switched at reset) while batches use the single-size modes "1".."4"."""
+    and draws one per episode. On the device one batch = one model table: with ``n_envs=1`` the environment switches
+    between four one-environment batches at reset exactly like the reference; with ``n_envs>1`` the environments are split
+    into four contiguous blocks, one size each, for their whole life (``LocoEnv._init_models``)."""
 
     _default_scalings = [0.4, 0.6, 0.8, 1.0]
 
     def __init__(self, scaling=None, scaling_trajectory_map=None, use_muscles=False, use_box_feet=True,
                  disable_arms=True, alpha_box_feet=0.5, xml_path=None, timestep=0.001, **kwargs):
         scalings = self._default_scalings if scaling is None else (list(scaling) if isinstance(scaling, (list, tuple)) else [scaling])
-        if len(scalings) > 1 and kwargs.get("n_envs", 1) != 1:
-            raise NotImplementedError("several humanoid sizes in one BATCH need one model table per environment on the "
-                                      "device; use n_envs=1 or the single-size modes \"1\"..\"4\"")
         self._scalings = scalings
         self._scaling_trajectory_map = scaling_trajectory_map
         self._model_scale = float(scalings[0])
@@ -269,16 +267,12 @@ class BaseHumanoid4Ages(BaseHumanoid):
             else:
                 self._models.append(mjcf.CompiledModel.load(_PKG / "assets" / self._asset_name()))
         self._model_scale = float(scalings[0])
-        self._n_models = len(self._models)
-        self._current_model_idx = 0
-        self._model_backends = [None] * self._n_models
+        if len(self._models) > 1:
+            self._init_models(self._models)
 
     def _select_model(self, idx):
-        self._model_backends[self._current_model_idx] = self._backend
-        self._current_model_idx = idx
-        self._model, self._model_scale = self._models[idx], float(self._scalings[idx])
-        self._backend = self._model_backends[idx]
-        self._hip_model = None
+        super()._select_model(idx)
+        self._model_scale = float(self._scalings[self._current_model_idx])
 
     def setup(self, obs):
         """``base_humanoid_4_ages.py:106-146``: with several sizes the start state is drawn from the trajectories that
@@ -387,6 +381,11 @@ class BaseHumanoid4Ages(BaseHumanoid):
 
     def _reset_table(self):
         rows = super()._reset_table()
+        if self._n_models > 1 and self._scaling_trajectory_map:
+            # restarts of this size draw from this size's trajectories only (base_humanoid_4_ages.py:131-141)
+            lo, hi = self._scaling_trajectory_map[self._current_model_idx]
+            sp = self.trajectories.split_points
+            rows = rows[int(sp[lo]):int(sp[hi])]
         return np.concatenate([rows, np.tile(self._env_id(), (len(rows), 1))], axis=1)
 
     def _get_reward_function(self, reward_type, reward_params):

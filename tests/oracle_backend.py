@@ -12,10 +12,10 @@ from oracle.pyoracle import Oracle
 
 
 class OracleBatch:
-    def __init__(self, env):
+    def __init__(self, env, n=None):
         self.env = env
         self.oracle = Oracle(pack_model(env._model))
-        self.n = env.n_envs
+        self.n = env.n_envs if n is None else n
         self.qpos = np.zeros((self.n, env._model.nv))
         self.qvel = np.zeros((self.n, env._model.nv))
         self.warm = np.zeros((self.n, env._model.nv))
@@ -103,7 +103,7 @@ def attach(env):
         current = env._current_model_idx
         for idx in range(env._n_models):
             env._select_model(idx)
-            env._backend = OracleBatch(env)
+            env._backend = OracleBatch(env, len(env._model_envs(idx)) if env._blocks else None)
         env._select_model(current)
         return env
     env._backend = OracleBatch(env)

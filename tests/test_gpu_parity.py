@@ -387,6 +387,47 @@ def test_a1_position_servos_vs_oracle():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Several models in one batch: contiguous blocks of environments, one device batch per model
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_several_models_in_one_batch_on_the_device():
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.carry", debug=True, n_envs=22)
+    obs = env.reset()
+    assert env._blocks and obs.shape == (22, 35)
+    weights = obs[:, -1].copy()
+    assert sorted(set(weights)) == [0.1, 1.0, 5.0, 10.0]
+    rs = np.random.RandomState(3)
+    a = rs.uniform(-0.3, 0.3, (22, 12))
+    o1, r1, d1, _ = env.step(a)
+    assert np.allclose(o1[:, -1], weights) and np.isfinite(o1).all()
+    # every block equals the single-weight environment on the same states and actions (same kernels, same inputs: bitwise)
+    for idx in range(4):
+        envs = env._model_envs(idx)
+        one = LocoEnv.make("Talos.carry", debug=True, n_envs=len(envs), weight_mass=float(weights[envs[0]]))
+        one.reset()
+        for k, e in enumerate(envs):
+            one._host[k].qpos[:], one._host[k].qvel[:] = env._host[e].qpos, env._host[e].qvel
+        one._pending_state = True
+        o2, r2, d2, _ = one.step(a[envs])
+        assert np.array_equal(o2, o1[envs]) and np.array_equal(r2, r1[envs]) and np.array_equal(d2, d1[envs])
+    # the heavier the box, the more the same action sequence pitches the robot forward: the blocks really differ
+    assert np.abs(o1[env._model_envs(0)][:, :-1].mean(0) - o1[env._model_envs(3)][:, :-1].mean(0)).max() > 1e-4
+    # device-side restarts per block keep every environment on its model
+    env.enable_auto_reset(seed=5, horizon=7)
+    for _ in range(12):
+        o, r, d, _ = env.step(rs.uniform(-1, 1, (22, 12)))
+        assert np.allclose(o[:, -1], weights) and np.isfinite(o).all()
+    h = LocoEnv.make("HumanoidMuscle4Ages.run.all", debug=True, n_envs=12)
+    oh = h.reset()
+    bits = oh[:, -2:].copy()
+    h.enable_auto_reset(seed=1, horizon=5)
+    for _ in range(8):
+        oh, _, _, _ = h.step(rs.uniform(-1, 1, (12, 92)))
+        assert np.array_equal(oh[:, -2:], bits) and np.isfinite(oh).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Fused rollouts: several control steps per launch, no device-wide join between control steps
 # ---------------------------------------------------------------------------------------------------------------
 

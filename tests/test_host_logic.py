@@ -1,6 +1,7 @@
 """Host-side surface of the drop-in (no GPU): task registry, spaces, reset row 0, datasets, rewards."""
 
 import os
+import sys
 import numpy as np
 import pytest
 
@@ -176,6 +177,47 @@ def test_recorded_dataset_task(tmp_path, monkeypatch):
         LocoEnv.make("Atlas.walk.perfect", use_foot_forces=True)
 
 
+def test_several_models_in_one_batch():
+    """n_envs > 1 with several models: contiguous blocks of environments, one model (= one device batch) each."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import attach
+    np.random.seed(0)
+    env = attach(LocoEnv.make("Atlas.carry", debug=True, n_envs=10))
+    assert env._blocks and [list(env._model_envs(i)) for i in range(4)] == [[0, 1, 2], [3, 4], [5, 6, 7], [8, 9]]
+    obs = env.reset()
+    assert obs.shape == (10, 31) and obs[:, -1].tolist() == [0.1] * 3 + [1.0] * 2 + [5.0] * 3 + [10.0] * 2
+    a = np.random.uniform(-0.2, 0.2, (10, 10))
+    o1, r, d, _ = env.step(a)
+    assert o1.shape == (10, 31) and np.array_equal(o1[:, -1], obs[:, -1]) and r.shape == (10,) and d.shape == (10,)
+    # every block is the single-model environment of that weight on the same states and actions
+    for idx, w in enumerate([0.1, 1.0, 5.0, 10.0]):
+        envs = env._model_envs(idx)
+        np.random.seed(1)
+        one = attach(LocoEnv.make("Atlas.carry", debug=True, n_envs=len(envs), weight_mass=w))
+        one.reset()
+        for k, e in enumerate(envs):
+            one._host[k].qpos[:], one._host[k].qvel[:] = obs_state(env, e)
+        one._pending_state = True
+        o2, _, _, _ = one.step(a[envs])
+        assert np.abs(o2 - o1[envs]).max() < 1e-12
+    o2, _, _, _ = env.step(a)                      # a second step continues every block from its own state
+    assert not np.array_equal(o2[:, :-1], o1[:, :-1]) and np.array_equal(o2[:, -1], obs[:, -1])
+    # the humanoid's four sizes: every block restarts from its own size's trajectories and shows its size bits
+    np.random.seed(0)
+    h = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)
+    oh = h.reset()
+    assert oh.shape == (8, 38) and oh[:, -2:].tolist() == [[0, 0]] * 2 + [[0, 1]] * 2 + [[1, 0]] * 2 + [[1, 1]] * 2
+    for idx in range(4):
+        h._select_model(idx)
+        tab = h._reset_table()
+        assert len(tab) == 100 and np.all(tab[:, -2:] == h._env_id())
+
+
+def obs_state(env, e):
+    """(qpos, qvel) the multi-model environment handed to its backend for environment ``e`` at reset."""
+    return env._host[e].qpos.copy(), env._host[e].qvel.copy()
+
+
 def test_a1_position_mode_surface():
     np.random.seed(0)
     e = LocoEnv.make("UnitreeA1.simple", debug=True, action_mode="position")
@@ -250,8 +292,6 @@ def test_carry_surface():
     f = LocoEnv.make("Talos.carry", debug=True, weight_mass=1.0, use_foot_forces=True)
     assert f.info.observation_space.shape == (41,) and f._obs_perm().tolist() == list(range(34)) + list(range(35, 41)) + [34]
     assert f.reset()[-1] == 1.0
-    with pytest.raises(NotImplementedError):
-        LocoEnv.make("Atlas.carry", debug=True, n_envs=8)           # four weights in one batch
     assert LocoEnv.make("Atlas.carry", debug=True, n_envs=8, weight_mass=10.0).reset().shape == (8, 31)
     with pytest.raises(NotImplementedError):
         LocoEnv.make("Atlas.carry", debug=True, weight_mass=2.5)     # not a shipped model
@@ -380,7 +420,6 @@ def test_humanoid_4_ages_surface():
         lo, hi = a._scaling_trajectory_map[idx]
         assert lo <= a.trajectories.traj_no < hi                      # start state from the trajectories of that size
     assert len(seen) >= 3
-    with pytest.raises(NotImplementedError):
-        LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)
+    assert LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)._blocks        # batches: one block per size
     with pytest.raises(TypeError):
         e.reset(obs=np.zeros(38))
