@@ -779,7 +779,13 @@ static bool family_has_replicas(const lm_batch* b) {      // mirrors launch_vari
   return false;
 }
 
-static void launch_step(lm_batch* b, const KArgs& a) { g_launch_err = nullptr; launch_variant<false>(b, a); }
+static void launch_step(lm_batch* b, const KArgs& a) {
+  // the per-thread HIP error state is shared with whoever else uses HIP in this process (PyTorch probes peers, pointer
+  // attributes ...): drop what they left behind so that the check after the launch reports OUR launch
+  (void)hipGetLastError();
+  g_launch_err = nullptr;
+  launch_variant<false>(b, a);
+}
 
 static int drain_stats(lm_batch* b) {
   std::vector<DevStats> s(b->nblocks);
@@ -892,6 +898,7 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   HIPCHK(hipMemset(buf, 0, sizeof(float) * per * N));
   a.dM = buf; a.dbias = buf + (size_t)nv * nv * N; a.dsmooth = a.dbias + (size_t)nv * N; a.dqacc_smooth = a.dsmooth + (size_t)nv * N;
   a.dqacc = a.dqacc_smooth + (size_t)nv * N; a.dqfrc = a.dqacc + (size_t)nv * N; a.dncon = ibuf; a.diter = ibuf + N;
+  (void)hipGetLastError();
   g_launch_err = nullptr;
   launch_variant<true>(b, a);
   if (g_launch_err) return fail(g_launch_err);
