@@ -90,6 +90,7 @@ struct KArgs {
   unsigned long long seed; long long env_offset;
   int auto_reset, horizon, action_mode; unsigned step_index;
   int nfused;               // control steps per launch (policy-free rollouts; 1 for lm_step*)
+  int xcd_map;              // 1: XCD-aware workgroup -> environment mapping (see step_kernel)
   int N;
   int epb;                  // environments per workgroup (workgroup = 4*epb threads)
   lm::Params P; Task T;
@@ -123,7 +124,16 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __syncthreads();
   const int c = threadIdx.x & 3;
   const int e_local = threadIdx.x / (4 * REP);               // REP quads per environment (replicas), see QuadDppT
-  const int e_raw = blockIdx.x * a.epb + e_local;
+  // XCD-aware workgroup -> environment mapping. The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (own
+  // L2 each), while neighbouring environments share 64-byte lines of the SoA state arrays ([dof][N]: 4 environments of a
+  // workgroup use 16 B of a line). Handing every XCD a CONTIGUOUS range of environments keeps each line inside one L2:
+  // workgroup b runs on XCD b % 8 and takes the (b / 8)-th group of that XCD's range (LM_NO_XCD_MAP: A/B switch).
+  int wg = blockIdx.x;
+  if (a.xcd_map) {
+    const int nb = gridDim.x, x = wg & 7, per = nb >> 3, rem = nb & 7;
+    wg = x * per + (x < rem ? x : rem) + (wg >> 3);
+  }
+  const int e_raw = wg * a.epb + e_local;
   // padding quads of the last workgroup recompute env N-1; they and the replicas 1..REP-1 store nothing
   const bool valid = e_raw < a.N && QuadDpp::rep() == 0;
   const int e = (e_raw < a.N) ? e_raw : a.N - 1;
@@ -766,6 +776,8 @@ static KArgs make_args(lm_batch* b) {
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
+  static const bool no_xcd_map = getenv("LM_NO_XCD_MAP") != nullptr;
+  a.xcd_map = no_xcd_map ? 0 : 1;
   return a;
 }
 
