@@ -47,7 +47,13 @@ def algorithmic_bytes_per_env_step(nq, nv, nu, nobs, na=0):
 def cpu_baseline_all_cores(task, random_policy, make_kw, budget_s=8.0):
     """The same loop in one process per host core (fresh interpreters without torch / HIP), counts summed."""
     import subprocess
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                     # a container's CPU quota, not the host's core count, is what can run at once
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--task", task, "--cpu-budget", str(budget_s)]
     if make_kw:
         cmd.append("--dr")
@@ -292,7 +298,8 @@ def main():
         if allc is not None:
             out["cpu_baseline"].update(value=allc["value"], cores=allc["cores"],
                                        sample=one["sample"] + "; value = the same loop in %d processes (one per host core) for "
-                                       "%.0f s each, counts summed (%.0f env-steps/s per core under full load)"
+                                       "%.0f s each, counts summed (%.0f env-steps/s per process under full load; process count = CPU affinity "
+                                       "capped by the cgroup quota)"
                                        % (allc["cores"], 8.0, allc["per_core"]))
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
