@@ -254,6 +254,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   for (int s = 0; s < a.T.nsub; s++)
     lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
 
+  QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
+
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;
 #pragma unroll

@@ -2,7 +2,10 @@
 // loco_mujoco_amd/csrc/lm_core.h can be debugged against the fp64 oracle in a container without a GPU.
 // Four OS threads play the four lanes; the quad sum (two DPP adds on gfx950) becomes a barrier + the same
 // (x0+x1)+(x2+x3) association. Nothing in the product loads this file; it is built by tests/test_emu_core.py.
+#include <atomic>
 #include <barrier>
+#include <chrono>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -12,35 +15,88 @@
 #define LM_POW01(x, p) exp2f((p) * log2f(x))
 #include "../../loco_mujoco_amd/csrc/lm_core.h"
 
-namespace {
-std::barrier<> g_bar(4);
-float g_buf[4];
-int g_ibuf[4];
-thread_local int t_lane = 0;
-// POINTS = 4 runs the four-points-per-round line search of the replicated GPU layout with one replica (the lane
-// evaluates the four step lengths itself): same decisions, same results, no extra lanes needed on the CPU
-template <int POINTS>
-struct QuadThreadsT {
-  static constexpr int kRep = 1, kPoints = POINTS;
-  static int rep() { return 0; }
-  static float rep_bcast(float x, int) { return x; }
-  static float rep_sum(float x) { return x; }
-  static void fence() {}
-  static float sum(float x) {
-    g_buf[t_lane] = x; g_bar.arrive_and_wait();
-    float s = (g_buf[0] + g_buf[1]) + (g_buf[2] + g_buf[3]);
-    g_bar.arrive_and_wait(); return s;
-  }
-  static bool any(bool b) {
-    g_ibuf[t_lane] = b; g_bar.arrive_and_wait();
-    bool r = g_ibuf[0] | g_ibuf[1] | g_ibuf[2] | g_ibuf[3];
-    g_bar.arrive_and_wait(); return r;
-  }
-};
 #ifndef EMU_LS_POINTS
 #define EMU_LS_POINTS 1
 #endif
-using QuadThreads = QuadThreadsT<EMU_LS_POINTS>;
+#ifndef EMU_REP
+#define EMU_REP 1
+#endif
+namespace {
+// EMU_REP = 4 plays the replicated small-batch layout: 16 OS threads per environment = 4 replicas x 4 chain lanes. On the
+// GPU the replicas of a lane share one column of lane memory and run in lock step. Here every replica has a PRIVATE copy
+// of its chain's lane memory and the copies are reconciled only inside Q::fence(): whatever a replica changed since the
+// previous fence is handed to the others (two replicas changing the same word to different values is an error). A
+// hand-over that the device code does not bracket with a fence therefore reads stale data here and fails the parity
+// tests — that is how the fence placement is checked without a GPU.
+constexpr int kThreads = 4 * EMU_REP;
+std::barrier<> g_bar(kThreads);      // everybody: any(), fence(), start / end of an environment
+// the device's cross-lane operations have different participants: a quad sum joins the 4 chain lanes of ONE replica, the
+// replica operations join the EMU_REP replicas of ONE chain lane (lanes with fewer geoms / links skip them altogether)
+std::barrier<> g_bar_rep[4] = {std::barrier<>(4), std::barrier<>(4), std::barrier<>(4), std::barrier<>(4)};
+std::barrier<> g_bar_lane[4] = {std::barrier<>(EMU_REP), std::barrier<>(EMU_REP), std::barrier<>(EMU_REP), std::barrier<>(EMU_REP)};
+float g_buf[EMU_REP][4], g_rbuf[EMU_REP][4];
+int g_ibuf[kThreads];
+float* g_lmem[EMU_REP][4];          // private lane memory of (replica, chain)
+std::vector<float> g_snap[4];       // per chain: lane memory as of the last fence
+int g_lmem_size = 0, g_conflicts = 0;
+thread_local int t_lane = 0, t_rep = 0;
+int g_ops[16][5];                   // per thread: calls of sum, any, rep_bcast, rep_sum, fence (EMU_WATCHDOG diagnostics)
+#define OPC(k) (g_ops[t_rep * 4 + t_lane][k]++)
+template <int POINTS, int REP>
+struct QuadThreadsT {
+  static constexpr int kRep = REP, kPoints = (REP == 4) ? 4 : POINTS;
+  static int rep() { return t_rep; }
+  static float rep_bcast(float x, int r) {
+    if (REP == 1) return x;
+    OPC(2);
+    g_rbuf[t_rep][t_lane] = x; g_bar_lane[t_lane].arrive_and_wait();
+    float y = g_rbuf[r][t_lane];
+    g_bar_lane[t_lane].arrive_and_wait(); return y;
+  }
+  static float rep_sum(float x) {       // the device's butterfly: lane^4 then lane^8, i.e. replica^1 then replica^2
+    if (REP == 1) return x;
+    OPC(3);
+    g_rbuf[t_rep][t_lane] = x; g_bar_lane[t_lane].arrive_and_wait();
+    float y = x + g_rbuf[t_rep ^ 1][t_lane];
+    g_bar_lane[t_lane].arrive_and_wait();
+    g_rbuf[t_rep][t_lane] = y; g_bar_lane[t_lane].arrive_and_wait();
+    float z = y + g_rbuf[t_rep ^ 2][t_lane];
+    g_bar_lane[t_lane].arrive_and_wait(); return z;
+  }
+  static void fence() {
+    if (REP == 1) return;
+    OPC(4);
+    g_bar.arrive_and_wait();
+    if (t_lane == 0 && t_rep == 0) {
+      for (int c = 0; c < 4; c++) for (int i = 0; i < g_lmem_size; i++) {
+        const float old = g_snap[c][i];
+        bool have = false; float nv = old;
+        for (int r = 0; r < REP; r++) {
+          const float v = g_lmem[r][c][i];
+          if (memcmp(&v, &old, 4) == 0) continue;
+          if (have && memcmp(&v, &nv, 4) != 0) g_conflicts++;
+          have = true; nv = v;
+        }
+        if (have) { for (int r = 0; r < REP; r++) g_lmem[r][c][i] = nv; g_snap[c][i] = nv; }
+      }
+    }
+    g_bar.arrive_and_wait();
+  }
+  static float sum(float x) {
+    OPC(0);
+    g_buf[t_rep][t_lane] = x; g_bar_rep[t_rep].arrive_and_wait();
+    float s = (g_buf[t_rep][0] + g_buf[t_rep][1]) + (g_buf[t_rep][2] + g_buf[t_rep][3]);
+    g_bar_rep[t_rep].arrive_and_wait(); return s;
+  }
+  static bool any(bool b) {
+    OPC(1);
+    g_ibuf[t_rep * 4 + t_lane] = b; g_bar.arrive_and_wait();
+    bool r = false;
+    for (int i = 0; i < kThreads; i++) r = r || g_ibuf[i];
+    g_bar.arrive_and_wait(); return r;
+  }
+};
+using QuadThreads = QuadThreadsT<EMU_LS_POINTS, EMU_REP>;
 // EMU_DR compiles the per-environment joint-parameter path (DR = true); the parameters come from emu_set_dof_params
 // ([3][n][nv]: damping, stiffness, frictionloss) or, when none are set, from the constant table (must change nothing)
 #ifdef EMU_DR
@@ -79,8 +135,9 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
   int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
-  auto lane_main = [&](int c) {
-    t_lane = c;
+  auto lane_main = [&](int t) {
+    const int c = t & 3;
+    t_lane = c; t_rep = t >> 2;
     const float* rb = cm.data();
     for (int e = 0; e < n; e++) {
       float qr[6], vr[6], war[6], actr[6], qc[MC], vc[MC], wac[MC], actc[MC];
@@ -126,6 +183,14 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       lm::Counters cnt = {};
       using LMm = lm::LaneMem<MC, NS, NM>;
       float lmem[LMm::kSize];
+      // rep = 1: lane memory starts uninitialised (MemorySanitizer sees reads of never-written words); replicated: every
+      // private copy and the snapshot start as the same quiet NaN, so such a read poisons the result instead
+      const float never = __builtin_nanf("0xbad");
+      if (EMU_REP > 1) for (int i = 0; i < LMm::kSize; i++) lmem[i] = never;
+      g_lmem[t_rep][c] = lmem;
+      if (t_rep == 0) g_snap[c].assign(LMm::kSize, never);
+      g_lmem_size = LMm::kSize;
+      g_bar.arrive_and_wait();
       if (NM > 0) {          // this lane's muscles: activation state and control (un-normalised, clamped) into lane memory
         const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
         for (int i = 0; i < nm; i++) {
@@ -135,16 +200,20 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
           lmem[LMm::kCtrl + i] = fminf(fmaxf(ctrl, rec[LM_MU_CTRL_LO]), rec[LM_MU_CTRL_HI]);
           lmem[LMm::kAct + i] = (float)act[e * na + (int)rec[LM_MU_STATE]];
         }
+        if (EMU_REP > 1 && t_rep == 0) for (int i = 0; i < LMm::kSize; i++) g_snap[c][i] = lmem[i];     // all replicas start identical
+        g_bar.arrive_and_wait();
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
         lm::substep<QuadThreads, MC, NS, RK4, kEmuCone<MC>, NM, kEmuDR>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                                      (e == debug_env && s == 0 && dbgM) ? &dbg : nullptr, mt.data(), &dofp);
-      if (NM > 0) {
+                                                      (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp);
+      QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
+      if (NM > 0 && t_rep == 0) {
         const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
         for (int i = 0; i < nm; i++) act[e * na + (int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE]] = lmem[LMm::kAct + i];
       }
       g_bar.arrive_and_wait();
+      if (t_rep != 0) { g_bar.arrive_and_wait(); g_bar.arrive_and_wait(); continue; }     // replicas 1.. store nothing
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
       static int acc[4][6];
@@ -154,9 +223,24 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       g_bar.arrive_and_wait();
     }
   };
-  std::thread t1(lane_main, 1), t2(lane_main, 2), t3(lane_main, 3);
+  g_conflicts = 0;
+  memset(g_ops, 0, sizeof(g_ops));
+  std::atomic<bool> finished{false};
+  std::thread watchdog([&] {            // EMU_WATCHDOG=seconds: on a hang print how many cross-lane calls every thread made
+    const char* w = getenv("EMU_WATCHDOG");
+    if (!w) return;
+    for (int i = 0; i < atoi(w) * 10 && !finished; i++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    if (finished) return;
+    for (int t = 0; t < kThreads; t++)
+      fprintf(stderr, "emu hang: replica %d lane %d: sum %d any %d rep_bcast %d rep_sum %d fence %d\n", t >> 2, t & 3, g_ops[t][0], g_ops[t][1], g_ops[t][2], g_ops[t][3], g_ops[t][4]);
+    _exit(3);
+  });
+  std::vector<std::thread> ths;
+  for (int t = 1; t < kThreads; t++) ths.emplace_back(lane_main, t);
   lane_main(0);
-  t1.join(); t2.join(); t3.join();
+  for (auto& th : ths) th.join();
+  finished = true; watchdog.join();
+  if (g_conflicts) { fprintf(stderr, "emu: %d lane-memory words were changed to different values by two replicas between fences\n", g_conflicts); return -2; }
   if (counters) memcpy(counters, cnt_tot, sizeof(cnt_tot));
   return 0;
 }

@@ -6,14 +6,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_VARIANTS = [(1, False), (4, False), (4, True)]          # what the tests use: built together, in parallel (g++ needs ~1 min each)
+_VARIANTS = [(1, False, 1), (4, False, 1), (4, True, 1), (4, False, 4), (4, True, 4)]          # what the tests use: built together, in parallel (g++ needs ~1 min each)
 
 
-def _lib_path(ls_points, dr):
-    return os.path.join(_HERE, ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so"))
+def _lib_path(ls_points, dr, rep=1):
+    name = ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so")
+    return os.path.join(_HERE, name.replace(".so", "_rep%d.so" % rep if rep > 1 else ".so"))
 
 
-def build(ls_points=1, dr=False):
+def build(ls_points=1, dr=False, rep=1):
     """ls_points = 1: the one-point-at-a-time line search of full waves; 4: the four-points-per-round line search of the
     replicated small-batch layout (evaluated by one lane here); dr: the per-environment joint-parameter code path."""
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
@@ -22,27 +23,29 @@ def build(ls_points=1, dr=False):
     def stale(lib):
         return not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
 
-    want = [(ls_points, dr)] + [v for v in _VARIANTS if v != (ls_points, dr)]
+    want = [(ls_points, dr, rep)] + [v for v in _VARIANTS if v != (ls_points, dr, rep)]
     procs = []
-    for lp, d in want:
-        lib = _lib_path(lp, d)
+    for lp, d, rp in want:
+        lib = _lib_path(lp, d, rp)
         if stale(lib):
             tmp = lib + ".tmp%d" % os.getpid()
             procs.append((subprocess.Popen(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                                            "-DEMU_LS_POINTS=%d" % lp, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if d else [])
+                                            "-DEMU_LS_POINTS=%d" % lp, "-DEMU_REP=%d" % rp, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if d else [])
                                            + ["-o", tmp, srcs[0]]), tmp, lib))
     for p, tmp, lib in procs:
         if p.wait() != 0:
             raise RuntimeError("building %s failed" % lib)
         os.replace(tmp, lib)
-    return _lib_path(ls_points, dr)
+    return _lib_path(ls_points, dr, rep)
 
 
-def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False):
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False, rep=1):
     """dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
     per-environment code path on the table's nominal values."""
     dr = dr or dof_params is not None
-    lib = C.CDLL(build(ls_points, dr))
+    if rep > 1:
+        ls_points = 4            # the replicated layout always evaluates four step lengths per round
+    lib = C.CDLL(build(ls_points, dr, rep))
     cmod = np.ascontiguousarray(chain_model, dtype=np.float64)
     nv = int(cmod[2])
     q = np.array(qpos, dtype=np.float64).reshape(-1, nv)
@@ -65,7 +68,7 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     rc = lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
                      dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
                      dp(actv) if actv is not None else None)
-    assert rc == 0
+    assert rc == 0, "emulator returned %d (-2: two replicas changed the same lane-memory word to different values)" % rc
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
     if actv is not None:
         dbg["act"] = actv

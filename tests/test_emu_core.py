@@ -179,6 +179,54 @@ def test_core_position_servos():
     assert sat > 0
 
 
+@pytest.mark.parametrize("task,nu,row", [("UnitreeA1.simple", 12, 5), ("Talos.walk", 12, 4), ("Atlas.walk", 10, 7),
+                                         ("HumanoidTorque.run", 13, 9), ("HumanoidMuscle.walk", 92, 0)])
+def test_core_replicated_layout(task, nu, row):
+    """The small-batch layout of the GPU (4 replicas per environment: 16 threads here) with every replica on a PRIVATE copy
+    of its lane memory that is reconciled only inside Q::fence(): a hand-over between replicas that the device code does
+    not bracket with a fence reads stale (NaN-poisoned) data and fails. One control step from a golden row against the
+    golden successor and against the one-replica run (equal up to the summation order of the dealt work)."""
+    np.random.seed(0)
+    env = LocoEnv.make(task, debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    g = GOLD[task + ".real"]
+    qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    nq = len(qidx) - 2
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 3 if task.startswith("UnitreeA1") else 1), np.random.randint(0, 100)
+    acts = [np.random.randn(nu) * 0.1 for _ in range(row + 1)]
+    qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+    qpos[qidx[2:]] = g[row, :nq]
+    qvel[qidx] = g[row, nq:nq + len(qidx)]
+    act0 = np.zeros(m.na) if m.na else None
+    q1, v1, _, c1, _ = pyemu.run(cmod, qpos, qvel, acts[row], nsub=10, ls_points=4, act=act0)
+    q4, v4, _, c4, _ = pyemu.run(cmod, qpos, qvel, acts[row], nsub=10, rep=4, act=act0)
+    assert np.isfinite(q4).all() and np.isfinite(v4).all()
+    assert np.abs(q4[0][qidx[2:]] - g[row + 1, :nq]).max() < 1e-5 and np.abs(v4[0][qidx] - g[row + 1, nq:nq + len(qidx)]).max() < 1e-3
+    assert np.abs(q4 - q1).max() < 1e-6 and np.abs(v4 - v1).max() < 5e-5
+    assert c4["overflow"] == 0 and c4["ncon"] > 0
+
+
+def test_core_replicated_layout_with_per_environment_parameters():
+    """The kernel variant that tripped the -O2 build on the GPU (<5,4,Euler,pyramid,DR,4 replicas>), on the CPU."""
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    n = 3
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-0.3, 0.3, (n, 12))
+    damp = (np.tile(m.dof_damping, (n, 1)) * rs.uniform(0.5, 2.0, (n, m.nv))).astype(np.float32)
+    floss = (np.tile(m.dof_frictionloss, (n, 1)) * rs.uniform(0.5, 1.5, (n, m.nv))).astype(np.float32)
+    prm = np.stack([damp, np.zeros_like(damp), floss])
+    q1, v1, _, _, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], acts, nsub=10, ls_points=4, dof_params=prm)
+    q4, v4, _, _, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], acts, nsub=10, rep=4, dof_params=prm)
+    assert np.isfinite(v4).all() and np.abs(q4 - q1).max() < 1e-6 and np.abs(v4 - v1).max() < 5e-5
+
+
 def test_core_muscles():
     """kernel variant <5,8,Euler,muscles>: tendon paths, muscle forces and activation dynamics in float32 vs oracle/golden."""
     np.random.seed(0)

@@ -10,7 +10,7 @@ python - "$W" <<PY
 import sys, struct, numpy as np
 sys.path.insert(0, "$ROOT")
 from loco_mujoco_amd import LocoEnv, lowering
-for task, nu in [("HumanoidTorque.run", 13), ("Atlas.walk", 10), ("UnitreeA1.simple", 12), ("HumanoidMuscle.run", 92)]:
+for task, nu in [("HumanoidTorque.run", 13), ("Atlas.walk", 10), ("UnitreeA1.simple", 12), ("HumanoidMuscle.run", 92), ("Talos.walk", 12)]:
     np.random.seed(0)
     env = LocoEnv.make(task, debug=True)
     m = env._model
@@ -30,9 +30,13 @@ SRC="$ROOT/tests/emu/san_main.cpp $ROOT/tests/emu/emu.cpp"
     -DEMU_LS_POINTS=4 -DEMU_PYRAMID_ONLY -o $W/msan $SRC
 g++ -O1 -std=c++20 -pthread -ffp-contract=off -fsanitize=undefined,address -fno-sanitize-recover=undefined \
     -DEMU_LS_POINTS=4 -DEMU_PYRAMID_ONLY -o $W/asan $SRC
-for t in HumanoidTorque.run Atlas.walk UnitreeA1.simple HumanoidMuscle.run; do
+# the replicated small-batch layout: 16 threads per environment, private lane memory reconciled at Q::fence()
+g++ -O1 -std=c++20 -pthread -ffp-contract=off -fsanitize=undefined,address -fno-sanitize-recover=undefined \
+    -DEMU_LS_POINTS=4 -DEMU_REP=4 -DEMU_PYRAMID_ONLY -o $W/asan_rep4 $SRC
+for t in HumanoidTorque.run Atlas.walk UnitreeA1.simple HumanoidMuscle.run Talos.walk; do
   echo "== $t (MemorySanitizer)"; $W/msan $W/$t.bin
   echo "== $t (AddressSanitizer + UBSan)"; ASAN_OPTIONS=detect_leaks=0 $W/asan $W/$t.bin
+  echo "== $t (AddressSanitizer + UBSan, 4 replicas)"; ASAN_OPTIONS=detect_leaks=0 $W/asan_rep4 $W/$t.bin
 done
 rm -rf $W
 echo "sanitizers: clean"
