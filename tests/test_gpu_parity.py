@@ -195,6 +195,42 @@ def test_auto_reset_and_sharding_invariance(setup):
     assert np.isfinite(qa).all()
 
 
+def test_ragged_batch_sizes_and_layouts(setup):
+    """Edge cases of the launch geometry: batch sizes that are not multiples of the 4 environments of a workgroup (padding
+    quads), a single environment, sizes around the XCD count, and the full-wave layout (LM_ENVS_PER_BLOCK=16, no replicas).
+    Environment i with global id i must come out bitwise the same whatever batch it sits in (same kernel layout), and equal
+    to float32 summation order across layouts."""
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+
+    def run(n, offset, steps=12, fuse=1):
+        b = HipBatch(hm, n)
+        b.set_reset_table(tab, seed=7, global_env_offset=offset)
+        b.set_auto_reset(True, horizon=9)
+        rows = tab[(np.arange(offset, offset + n) * 37) % len(tab)]
+        b.set_state(rows[:, :18], rows[:, 18:36])
+        b.set_goal(rows[:, 36:39])
+        st = b.rollout(steps, action_mode=1, seed=3, steps_per_launch=fuse)
+        q, v = b.get_state()
+        return q, v, st
+
+    qa, va, sa = run(45, 0)
+    assert sa["env_steps"] == 45 * 12 and sa["nan_resets"] == 0 and np.isfinite(qa).all()
+    for n, off in ((1, 0), (1, 44), (2, 7), (3, 0), (5, 20), (7, 38), (9, 0), (13, 32), (33, 12)):
+        q, v, st = run(n, off)
+        assert np.array_equal(q, qa[off:off + n]) and np.array_equal(v, va[off:off + n]), (n, off)
+        assert st["env_steps"] == n * 12
+    q, v, st = run(45, 0, fuse=5)                       # fused launches of 5 + 5 + 2 control steps
+    assert np.array_equal(q, qa) and np.array_equal(v, va) and st["episodes"] == sa["episodes"]
+    os.environ["LM_ENVS_PER_BLOCK"] = "16"              # full waves: 16 environments per workgroup, one-point line search
+    try:
+        q16, v16, s16 = run(45, 0, steps=2)
+    finally:
+        del os.environ["LM_ENVS_PER_BLOCK"]
+    q2, v2, s2 = run(45, 0, steps=2)
+    assert s16["env_steps"] == 90 and np.abs(q16 - q2).max() < QTOL and np.abs(v16 - v2).max() < VTOL
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Atlas.walk (BASELINE config 4's robot): RK4, pyramidal cones, box feet, 2 chains of 5 links (kernel variant <5,8,RK4>)
 # ---------------------------------------------------------------------------------------------------------------
