@@ -27,6 +27,7 @@
  *                          (utils/trajectory.py:236-273, base.py:178-203), done on the device
  *   lm_rollout          <- the user's `for step in range(n): env.step(a)` loop
  *                          (tests/test_environments.py:15-38), kept on the device for benchmarking
+ *   lm_rollout_fused    <- the same loop with several control steps per kernel launch (policy-free only)
  *   lm_forward_debug    <- mujoco.mj_forward (base.py:362) with intermediate results, for parity tests
  *
  * All arrays at the boundary are caller-owned HOST buffers, row-major [n_envs][dim], float32.
