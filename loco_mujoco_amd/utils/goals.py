@@ -1,27 +1,31 @@
-"""Goal holder (reference: ``loco_mujoco/utils/goals.py:4``)."""
+"""Goal holder of the quadruped tasks (mirror of the reference's ``loco_mujoco/utils/goals.py:4``): desired walking
+direction (yaw, rad) and speed (m/s), handed out as copies."""
 
 import copy
 
 
 class GoalDirectionVelocity:
-    """Desired walking direction (yaw, rad) and speed (m/s)."""
+
+    _FIELDS = ("direction", "velocity")
 
     def __init__(self):
-        self._direction = None
-        self._velocity = None
+        self._goal = dict.fromkeys(self._FIELDS)
 
     def set_goal(self, direction, velocity):
-        self._direction, self._velocity = direction, velocity
+        self._goal.update(direction=direction, velocity=velocity)
 
-    def get_goal(self):
-        return self.get_direction(), self.get_velocity()
-
-    __call__ = get_goal
+    def _get(self, field):
+        value = self._goal[field]
+        assert value is not None, "goal %s was never set" % field
+        return copy.deepcopy(value)
 
     def get_direction(self):
-        assert self._direction is not None
-        return copy.deepcopy(self._direction)
+        return self._get("direction")
 
     def get_velocity(self):
-        assert self._velocity is not None
-        return copy.deepcopy(self._velocity)
+        return self._get("velocity")
+
+    def get_goal(self):
+        return tuple(self._get(f) for f in self._FIELDS)
+
+    __call__ = get_goal
