@@ -116,13 +116,14 @@ class HipModel:
         h = C.c_void_p()
         _check(lib.lm_model_create(cm.ctypes.data_as(_D), len(cm), device, C.byref(h)))
         self._h = h
+        self._lib = lib                      # kept on the object: module globals are gone when __del__ runs at interpreter exit
         d = Dims()
         _check(lib.lm_model_dims(h, C.byref(d)))
         self.dims = d
 
     def close(self):
         if getattr(self, "_h", None):
-            load_library().lm_model_destroy(self._h)
+            self._lib.lm_model_destroy(self._h)
             self._h = None
 
     __del__ = close
