@@ -269,7 +269,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "kernel": "step_kernel<3,4,Euler,elliptic,replicated>" if default_task else "step_kernel",
+                     "kernel": "step_kernel<3,5,Euler,elliptic,replicated>" if default_task else "step_kernel",
                      "kernel_ms_per_launch": 1e3 * launch_s,
                      "algorithmic_bytes_per_env_step": per_env_step,
                      "note": "path is VALU-issue/latency-bound by design (SURVEY.md 8d): %d algorithmic B per env-step; "

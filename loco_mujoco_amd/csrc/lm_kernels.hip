@@ -425,7 +425,7 @@ struct lm_batch {
 };
 
 // kernel variants: MC = links per chain the code is unrolled for, NS = contact slots per chain, RK4 = integrator,
-// CONE = friction cone compiled in (the quadruped family gets a specialised step kernel <3,4,Euler,elliptic>;
+// CONE = friction cone compiled in (the quadruped family gets a specialised step kernel <3,5,Euler,elliptic>;
 // everything else reads the cone at run time)
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, lm_batch* b, const KArgs& a) {
@@ -471,7 +471,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   if (big && !rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);
   else g_launch_err = "probe build: Talos family only";
 #else
-  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 4, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped
+  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) launch_family<3, 5, false, LM_CONE_ELLIPTIC, 0, FWD>(b, a);  // quadruped: thigh (2) + calf (2) + foot (1) contacts per leg
   // the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked when the model is created): the
   // elliptic code compiles out, no scratch (was 470 B per lane). NB: sensitive to the optimisation level, see the Makefile.
   else if (big && rk4 && T.na == 0 && few && pyr3) launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, FWD>(b, a);   // one box foot per leg

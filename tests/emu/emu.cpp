@@ -255,7 +255,7 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
     return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
-  if (!big && !rk4) return emu_run_t<3, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  if (!big && !rk4) return emu_run_t<3, 5, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!rk4 && few) return emu_run_t<5, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!rk4) return emu_run_t<5, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
