@@ -195,6 +195,24 @@ def test_auto_reset_and_sharding_invariance(setup):
     assert np.isfinite(qa).all()
 
 
+def test_a1_hard_rows_one_control_step_kats(setup):
+    """The golden rollout of UnitreeA1.hard (dataset not in the reference checkout, states are complete): 15 more KATs."""
+    env, hm, oracle, HipBatch = setup
+    g = GOLD["UnitreeA1.hard.real"]
+    n = len(g) - 1
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 8), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(12) * 0.1 for _ in range(n)])
+    b = HipBatch(hm, n)
+    b.set_state(np.concatenate([np.zeros((n, 2)), g[:n, :16]], axis=1), g[:n, 16:34])
+    b.set_goal(g[:n, 34:37])
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:, :16] - g[1:, :16]).max(axis=1), np.abs(obs[:, 16:34] - g[1:, 16:34]).max(axis=1)
+    print("UnitreeA1.hard KAT errors vs golden: qpos max %.2e median %.2e | qvel max %.2e median %.2e" % (eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL
+    assert list(done) == [False] * (n - 1) + [True]
+
+
 def test_ragged_batch_sizes_and_layouts(setup):
     """Edge cases of the launch geometry: batch sizes that are not multiples of the 4 environments of a workgroup (padding
     quads), a single environment, sizes around the XCD count, and the full-wave layout (LM_ENVS_PER_BLOCK=16, no replicas).

@@ -100,6 +100,27 @@ def test_oracle_solution_is_kkt_point(a1):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# UnitreeA1.hard: its dataset (walk_8_dir.npz) is not in the reference checkout, so the task itself cannot be built,
+# but its golden rollout holds full states: 15 more one-control-step KATs of the quadruped (other gaits, sideways and
+# backwards walking), with the action stream that follows the reset's three np.random.randint draws.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_a1_hard_rows_one_control_step_kats():
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    o = Oracle(pack_model(env._model))
+    g = GOLD["UnitreeA1.hard.real"]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 8), np.random.randint(0, 100)
+    assert not np.allclose(g[0, -3:], GOLD["UnitreeA1.simple.real"][0, -3:])          # another walking direction
+    for k in range(len(g) - 1):
+        a = np.random.randn(12) * 0.1
+        q, v, w, st = o.step(np.concatenate([[0, 0], g[k, :16]]), g[k, 16:34], a, nsub=10)
+        assert np.abs(q[2:] - g[k + 1, :16]).max() < 1e-9 and np.abs(v - g[k + 1, 16:34]).max() < 1e-8, k
+    assert env._has_fallen(g[-1]) and not any(env._has_fallen(x) for x in g[:-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # UnitreeA1 with position servos (action_mode="position"): no golden rollout exists (parity unpinned); the restatement
 # follows mj_fwdActuation's affine actuator (force = kp*ctrl - kp*q clamped to forcerange) and is checked analytically.
 # ---------------------------------------------------------------------------------------------------------------
