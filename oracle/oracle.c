@@ -94,6 +94,8 @@ struct lmo_model {
   int pair_g1[LMO_MAXPAIR], pair_g2[LMO_MAXPAIR];
   /* run-time switches (test hooks) */
   int disable_self_collision;
+  /* convex hulls attached to mesh geoms (lmo_set_mesh): hull vertices in the frame of the geom's BODY */
+  int mesh_nvert[LMO_MAXGEOM]; double* mesh_vert[LMO_MAXGEOM];
 };
 
 #define IDX(a, i) ((int)((a)[i]))
@@ -163,11 +165,25 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   return m;
 }
 
-void lmo_model_destroy(lmo_model* m) { if (m) { free(m->blob); free(m); } }
+void lmo_model_destroy(lmo_model* m) {
+  if (!m) return;
+  for (int g = 0; g < LMO_MAXGEOM; g++) free(m->mesh_vert[g]);
+  free(m->blob); free(m);
+}
 void lmo_set_option(lmo_model* m, int what, double value) {
   if (what == 0) m->disable_self_collision = (int)value;
   if (what == 1) m->iterations = (int)value;
   if (what == 2) m->tolerance = value;
+}
+
+/* attach the convex hull of mesh geom g (nv hull vertices [nv][3] in the frame of the geom's body): the geom then collides
+   with planes (one contact at the support vertex); without a hull a mesh geom is proximity-only */
+int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert) {
+  if (g < 0 || g >= m->ngeom || nv <= 0) return 1;
+  free(m->mesh_vert[g]);
+  m->mesh_nvert[g] = nv;
+  m->mesh_vert[g] = (double*)malloc(sizeof(double) * 3 * nv); memcpy(m->mesh_vert[g], vert, sizeof(double) * 3 * nv);
+  return 0;
 }
 int lmo_nv(const lmo_model* m) { return m->nv; }
 int lmo_nu(const lmo_model* m) { return m->nu; }
@@ -533,6 +549,25 @@ static void collide(const lmo_model* m, work* w) {
               add_contact(w, &tm, d3, q, n, NULL);
             }
           }
+        }
+      } else if (t2 == LM_GEOM_MESH && m->mesh_nvert[g2] > 0) {
+        /* plane vs convex hull (mjc_PlaneConvex): ONE contact, at the hull's support vertex in the direction of -normal.
+           Pinned by the UnitreeH1 golden rows: ten rows with a foot on the ground — flat on it, more than 100 hull vertices
+           below the plane, or on an edge — are reproduced to 1e-7 with exactly this, and with nothing that adds neighbouring
+           or further penetrating vertices (tests/test_oracle_golden.py). */
+        const int b2 = IDX(m->geom_body, g2), nvm = m->mesh_nvert[g2];
+        const double* V = m->mesh_vert[g2];
+        int best = -1; double dbest = 1e300;
+        for (int i = 0; i < nvm; i++) {
+          double wv[3]; mulmat3(wv, w->xmat[b2], V + 3*i); add3(wv, wv, w->xpos[b2]); sub3(wv, wv, p1);
+          double d = dot3(wv, n);
+          if (d < dbest) { dbest = d; best = i; }
+        }
+        if (dbest < margin) {
+          double wv[3], pos[3];
+          mulmat3(wv, w->xmat[b2], V + 3*best); add3(wv, wv, w->xpos[b2]);
+          copy3(pos, wv); addscl3(pos, n, -0.5 * dbest);
+          add_contact(w, &tm, dbest, pos, n, NULL);
         }
       } else if (t2 == LM_GEOM_MESH) {
         /* no convex-hull collider (not restated): count the bounding capsule coming within reach */

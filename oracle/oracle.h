@@ -42,6 +42,7 @@ typedef struct {
 lmo_model* lmo_model_create(const double* blob, long n);
 void lmo_model_destroy(lmo_model* m);
 /* what: 0 = disable self collision (value!=0), 1 = solver iterations, 2 = solver tolerance */
+int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert);
 void lmo_set_option(lmo_model* m, int what, double value);
 int lmo_nv(const lmo_model* m);
 int lmo_nu(const lmo_model* m);

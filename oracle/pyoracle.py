@@ -55,6 +55,7 @@ def lib():
         _lib.lmo_model_create.argtypes = [_DP, C.c_long]
         _lib.lmo_model_destroy.argtypes = [C.c_void_p]
         _lib.lmo_set_option.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        _lib.lmo_set_mesh.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.lmo_step.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
         _lib.lmo_forward.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, C.POINTER(ForwardOut)]
         _lib.lmo_step_act.argtypes = [C.c_void_p, _DP, _DP, _DP, _DP, _DP, C.c_int, C.POINTER(Stats)]
@@ -86,6 +87,12 @@ class Oracle:
         if getattr(self, "_h", None):
             lib().lmo_model_destroy(self._h)
             self._h = None
+
+    def set_mesh(self, geom, vert):
+        """Convex hull of a mesh geom (hull vertices [n, 3] in the frame of the geom's body): enables its plane contact."""
+        v = np.ascontiguousarray(vert, dtype=np.float64)
+        rc = lib().lmo_set_mesh(self._h, int(geom), len(v), v.ctypes.data_as(C.c_void_p))
+        assert rc == 0
 
     def set_option(self, what, value):
         lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2}[what], float(value))

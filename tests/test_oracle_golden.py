@@ -9,6 +9,8 @@ observed state under the k-th seeded action; (3) the full rollout from row 0 thr
 (4) the last row is the first terminal one.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,52 @@ def test_oracle_solution_is_kkt_point(a1):
         res = f["M"] @ f["qacc"] - f["M"] @ f["qacc_smooth"] - f["efc_J"].T @ f["efc_force"]
         assert np.abs(res).max() < 1e-6          # solver tolerance 1e-8 * meaninertia * nv
         assert f["ncon"] >= 1 and f["nefc"] >= 18
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# UnitreeH1 (not built as an environment: mesh feet, and its thigh / hip-yaw convex hulls collide). Its golden rows still pin
+# two things of the restatement: (1) the MJCF compiler and the smooth dynamics on a fifth robot (flight phases of the running
+# gait: 1e-13); (2) the engine's plane-vs-convex-mesh contact = ONE contact at the hull's support vertex: every row whose only
+# contacts are feet on the floor is reproduced to 1e-6, flat feet with > 100 penetrating hull vertices included. The remaining
+# rows carry a pure joint-space torque on hip flexion / adduction of the swinging leg (-57 N m at hip flexion 0.35 rad): the
+# thigh hull against the hip-yaw hull, a convex-convex contact that is not restated.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_h1_rows_pin_smooth_dynamics_and_plane_mesh_contact():
+    from loco_mujoco_amd import mjcf
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    m = mjcf.CompiledModel.load(os.path.join(here, "UnitreeH1.model.npz"))
+    fx = np.load(os.path.join(here, "UnitreeH1.fixture.npz"))
+    o = Oracle(pack_model(m))
+    o.set_option("disable_self_collision", 1)
+    for side in ("left", "right"):
+        o.set_mesh(m.geom_names.index(side + "_foot"), fx[side + "_foot"])
+    order = (["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", "pelvis_rotation", "back_bkz"]
+             + [j + s for s in ("_r", "_l") for j in ("hip_flexion", "hip_adduction", "hip_rotation", "knee_angle", "ankle_angle")])
+    qidx = [m.jnt_id(n) for n in order]
+    aidx = [m.act_names.index(n + "_actuator") for n in order[6:]]
+    lo, hi = m.act_ctrlrange[aidx].T
+    exact = {"run": [], "walk": []}
+    for task in ("run", "walk"):
+        g = fx[task]
+        np.random.seed(0)
+        np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+        for k in range(len(g) - 1):
+            a = np.random.randn(11) * 0.1
+            qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+            qpos[qidx[2:]] = g[k, :15]
+            qvel[qidx] = g[k, 15:32]
+            ctrl = np.zeros(m.nu)
+            ctrl[aidx] = a * (hi - lo) / 2 + (hi + lo) / 2
+            q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+            err = np.abs(v[qidx] - g[k + 1, 15:32]).max()
+            hip = max(g[k, 5], g[k, 10])                    # hip flexion of the right / left leg
+            if err < 1e-6:
+                exact[task].append(k)
+            else:
+                assert hip > 0.2 or g[k, 7] < 0 or g[k, 12] < 0, (task, k, err)      # explained by the thigh / hip-yaw contact
+    assert exact["run"] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 24, 25, 26]                  # the flight phases
+    assert exact["walk"] == [1, 2, 15, 16, 17, 18, 19, 20, 25, 26]                  # single- and double-support with feet only
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -109,6 +109,33 @@ def main():
             m.save(ROOT / "loco_mujoco_amd" / "assets" / e._asset_name())
             print("%s: total mass %.2f kg" % (e._asset_name(), m.body_mass.sum()))
 
+    # --- UnitreeH1 fixture for the oracle's plane-vs-convex-mesh contact (the robot itself is not built: its thigh and
+    #     hip-yaw hulls collide in a third of the golden rows, which needs the engine's convex-convex collider)
+    from scipy.spatial import ConvexHull
+    import struct
+    arm = ["l_arm_shy", "l_arm_shx", "l_arm_shz", "left_elbow", "r_arm_shy", "r_arm_shx", "r_arm_shz", "right_elbow"]
+    h1dir = pkg / "environments" / "data" / "unitree_h1"
+    h = mjcf.MjcfHandle.from_path(h1dir / "h1.xml")
+    Atlas._delete_from_xml_handle(h, arm, [j + "_actuator" for j in arm], [])
+    for body, quat in (("left_shoulder_pitch_link", "1.0 0.25 0.1 0.0"), ("right_elbow_link", "1.0 0.0 0.25 0.0"),
+                       ("right_shoulder_pitch_link", "1.0 -0.25 0.1 0.0"), ("left_elbow_link", "1.0 0.0 0.25 0.0")):
+        h.find("body", body).set("quat", quat)                       # unitreeH1.py:447-468
+    m = mjcf.compile_mjcf(h, timestep=0.001, drop_mesh_geoms=True)
+    m.save(ROOT / "tests" / "golden" / "UnitreeH1.model.npz")
+
+    def stl_hull(path):
+        d = open(path, "rb").read()
+        n = struct.unpack("<I", d[80:84])[0]
+        tri = np.frombuffer(d[84:84 + 50 * n], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))["v"]
+        pts = np.unique(tri.reshape(-1, 3).astype(np.float64), axis=0)
+        return pts[ConvexHull(pts).vertices]
+    np.savez_compressed(ROOT / "tests" / "golden" / "UnitreeH1.fixture.npz",
+                        left_foot=stl_hull(h1dir / "assets" / "left_ankle_link.stl"),
+                        right_foot=stl_hull(h1dir / "assets" / "right_ankle_link.stl"),
+                        walk=np.load(ref / "tests" / "test_datasets" / "UnitreeH1.walk.real.npy"),
+                        run=np.load(ref / "tests" / "test_datasets" / "UnitreeH1.run.real.npy"))
+    print("UnitreeH1 fixture: nv %d, total mass %.2f kg" % (m.nv, m.body_mass.sum()))
+
     # --- domain-randomisation configurations (plain YAML, copied verbatim: they are data, not code)
     for rel in ["atlas/domain_randomization_atlas.yaml", "humanoid/domain_randomization_humanoid.yaml",
                 "quadrupeds/domain_randomization_unitree_a1.yaml"]:
