@@ -15,6 +15,14 @@
  * Newton solver on the convex primal problem, semi-implicit Euler with implicit joint damping, RK4.
  * Parity is pinned by the reference's golden rollouts (tests/test_datasets/<task>.npy, generator
  * tests/test_environments.py:15-38,67-94) replayed one control step at a time (tests/test_oracle_golden.py).
+ * Also restated: spatial tendons through sites with Hill-type muscles and their activation states, position servos
+ * (affine actuators with a force range), plane vs convex mesh (one contact at the hull's support vertex), mass and
+ * inertia of bodies defined by their geoms (in loco_mujoco_amd/mjcf.py).
+ * Pinned / unpinned: every golden file of UnitreeA1 (.simple, .hard rows), Atlas (.walk, .carry), Talos (.walk, .carry),
+ * HumanoidTorque / HumanoidMuscle (+ the 4Ages variants) is reproduced row by row except rows with convex-convex (bone
+ * mesh) contacts, which the proximity counter flags; plane-mesh is pinned on the UnitreeH1 rows without hull-hull contact.
+ * UNPINNED (no golden row exercises them): sphere/capsule self-collisions, plane-cylinder, position servos, the muscle
+ * curve beyond lmax, the reward values, per-environment joint parameters, foot-force observations.
  *
  * Deliberately simple and dense (O(nbody*nv^2) mass matrix from body Jacobians, dense Cholesky):
  * it shares no code and no algorithmic shortcuts with the HIP path it checks.
