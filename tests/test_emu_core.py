@@ -208,6 +208,44 @@ def test_core_replicated_layout(task, nu, row):
     assert c4["overflow"] == 0 and c4["ncon"] > 0
 
 
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("Atlas.walk", 10), ("HumanoidTorque.walk", 13),
+                                     ("HumanoidMuscle.run", 92), ("Talos.carry", 12)])
+def test_core_replicated_layout_random_states(task, nu):
+    """Six dataset states per robot, full-range random actions, two control steps in the replicated layout (private lane
+    memory per replica, NaN-poisoned, reconciled at the fences only) against the fp64 oracle: contacts making and breaking,
+    several contacts per lane (the dealt gradient / Hessian paths), saturated actuators."""
+    np.random.seed(0)
+    kw = dict(weight_mass=5.0) if task.endswith("carry") else {}
+    env = LocoEnv.make(task, debug=True, **kw)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    o = Oracle(pack_model(m))
+    o.set_option("disable_self_collision", 1)
+    tab = env._reset_table()
+    rs = np.random.RandomState(11)
+    rows = tab[rs.randint(0, len(tab), 6)]
+    acts = rs.uniform(-1, 1, (2, 6, nu))
+    q, v = rows[:, :m.nv].copy(), rows[:, m.nv:2 * m.nv].copy()
+    w = np.zeros_like(q)
+    act = np.zeros((6, m.na)) if m.na else None
+    qo, vo, wo, ao = q.copy(), v.copy(), np.zeros_like(q), (np.zeros((6, m.na)) if m.na else None)
+    used = np.ones(6, dtype=bool)
+    for k in range(2):
+        q, v, w, cnt, dbg = pyemu.run(cmod, q, v, acts[k], nsub=10, rep=4, warm=w, act=act)
+        if m.na:
+            act = dbg["act"]
+        for i in range(6):
+            ctrl = np.zeros(m.nu)
+            ctrl[env._action_indices] = env._preprocess_action(acts[k, i])
+            if m.na:
+                qo[i], vo[i], ao[i], wo[i], st = o.step_act(qo[i], vo[i], ao[i], ctrl, 10, wo[i])
+            else:
+                qo[i], vo[i], wo[i], st = o.step(qo[i], vo[i], ctrl, 10, wo[i])
+            used[i] &= st["unhandled_pairs"] == 0          # a mesh / cylinder within reach of the floor: no collider on either side
+    assert np.isfinite(q).all() and np.isfinite(v).all() and used.sum() >= 3
+    assert np.abs(q - qo)[used].max() < 2e-4 and np.abs(v - vo)[used].max() < 2e-2
+
+
 def test_core_replicated_layout_with_per_environment_parameters():
     """The kernel variant that tripped the -O2 build on the GPU (<5,4,Euler,pyramid,DR,4 replicas>), on the CPU."""
     np.random.seed(0)
