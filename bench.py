@@ -44,6 +44,14 @@ def algorithmic_bytes_per_env_step(nq, nv, nu, nobs, na=0):
     return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv + 8 * na
 
 
+def baseline_metric():
+    """The headline metric, spelled exactly as /root/repo/BASELINE.json spells it."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "env-steps/sec at 4096 envs/GPU; qpos L\u221e vs CPU MuJoCo"
+
+
 def cpu_baseline_all_cores(task, random_policy, make_kw, budget_s=8.0):
     """The same loop in one process per host core (fresh interpreters without torch / HIP), counts summed."""
     import subprocess
@@ -257,7 +265,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "env-steps/sec at 4096 envs/GPU; qpos Linf vs CPU MuJoCo",
+        "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
