@@ -44,6 +44,44 @@ def algorithmic_bytes_per_env_step(nq, nv, nu, nobs, na=0):
     return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv + 8 * na
 
 
+def parity_sample(env, hm, table, random_policy, n=64):
+    """Second half of the metric: qpos / qvel L-infinity of the device against the fp64 oracle port after one control step
+    from n dataset states under the workload's policy (checker only, outside the timed region)."""
+    from loco_mujoco_amd.backend import HipBatch
+    from loco_mujoco_amd.model_blob import pack_model
+    from oracle.pyoracle import Oracle
+    m = env._model
+    nv, na = m.nv, getattr(m, "na", 0)
+    oracle = Oracle(pack_model(m))
+    oracle.set_option("disable_self_collision", 1)          # the device simulates floor contacts only
+    rs = np.random.RandomState(5)
+    rows = table[rs.randint(0, len(table), n)]
+    nu = len(env._action_indices)
+    acts = rs.uniform(-1, 1, (n, nu)) if random_policy else np.zeros((n, nu))
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
+    if rows.shape[1] > 2 * nv:
+        b.set_goal(rows[:, 2 * nv:])
+    b.step(acts)
+    q, v = b.get_state()
+    eq = ev = 0.0
+    used = 0
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        q0, v0 = rows[i, :nv].astype(np.float32).astype(np.float64), rows[i, nv:2 * nv].astype(np.float32).astype(np.float64)
+        if na:
+            qo, vo, _, _, st = oracle.step_act(q0, v0, np.zeros(na), ctrl, 10)
+        else:
+            qo, vo, _, st = oracle.step(q0, v0, ctrl, 10)
+        if st["unhandled_pairs"]:
+            continue                                         # a collider-less geom within reach of the floor on either side
+        used += 1
+        eq, ev = max(eq, np.abs(q[i] - qo).max()), max(ev, np.abs(v[i] - vo).max())
+    return dict(qpos_linf=eq, qvel_linf=ev, states=used, against="fp64 oracle port (CPU), one control step = 10 substeps, "
+                "same (qpos, qvel, ctrl)", tolerance=dict(qpos=1e-4, qvel=1e-2))
+
+
 def baseline_metric():
     """The headline metric, spelled exactly as /root/repo/BASELINE.json spells it."""
     try:
@@ -298,6 +336,7 @@ def main():
                                         "environment advances on its own, results bitwise those of single-step launches; "
                                         "a policy in the loop gets `value`" % args.fuse}
     if world == 1 and not args.no_cpu_baseline:
+        out["parity"] = parity_sample(env, hm, table, not default_task)
         one = cpu_baseline(env, table, args.task, not default_task, budget_s=6.0)
         allc = cpu_baseline_all_cores(args.task, not default_task, make_kw)
         # reported baseline = every host core running the fp64 port (falls back to the single-core sample)
