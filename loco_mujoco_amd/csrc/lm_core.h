@@ -23,6 +23,10 @@
 #include <math.h>
 #include "../../include/lm_layout.h"
 
+#ifndef LM_LMEM_T
+#define LM_LMEM_T float       // element type of lane memory (A/B probe: `volatile float`)
+#endif
+
 namespace lm {
 
 struct V3 { float x, y, z; };
@@ -433,7 +437,7 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
 template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
-                    float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
+                    float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
                     bool want_grf = false) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
@@ -1527,7 +1531,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
 template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
-                    float* war, float* wac, const float* actr, const float* actc, float* lmem, int ls,
+                    float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
                     bool want_grf = false) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");

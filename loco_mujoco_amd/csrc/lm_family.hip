@@ -1,0 +1,40 @@
+// lm_family.hip — one kernel family (LM_FAMILY) and part (LM_PART) of the step kernels; see lm_step.h.
+// The library links 14 of these objects so that `make -j` builds them in parallel.
+#include "lm_step.h"
+
+namespace lmk {
+#define LM_CAT2(a, b, c, d) a##b##c##d
+#define LM_CAT(a, b, c, d) LM_CAT2(a, b, c, d)
+
+bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a, int kind) {
+#if LM_FAMILY == 0      // quadruped: thigh (2) + calf (2) + foot (1) contacts per leg, elliptic cones
+  return launch_family<3, 5, false, LM_CONE_ELLIPTIC, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 1    // humanoid, RK4, one box foot per leg (HumanoidTorque)
+  return launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 2    // Atlas: two boxes per foot
+  return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 3    // Talos (Euler)
+  return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 4    // Talos carrying a box
+  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 5    // muscle humanoid
+  return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART>(L, a, kind);
+#else
+  // generic fallbacks (cone read at run time, plain layout only); kind = LMK_FWD or LMK_REP1; `a.T.max_links`, the
+  // integrator pick the instance. PART 0: Euler, PART 1: RK4
+  const dim3 grid((L.N + L.epb - 1) / L.epb), block(4 * L.epb);
+  const size_t groups = (block.x + 15) / 16;
+  const bool big = a.T.max_links > 3;
+  constexpr bool RK = LM_PART == 1;
+  if (kind == LMK_FWD) {
+    if (!big) launch_one(step_kernel<3, 4, RK, true, -1>, grid, block, (size_t)lm::LaneMem<3, 4>::kGroup * groups, L, a);
+    else launch_one(step_kernel<5, 8, RK, true, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, L, a);
+  } else if (kind == LMK_REP1) {
+    if (!big) launch_one(step_kernel<3, 4, RK, false, -1>, grid, block, (size_t)lm::LaneMem<3, 4>::kGroup * groups, L, a);
+    else launch_one(step_kernel<5, 8, RK, false, -1>, grid, block, (size_t)lm::LaneMem<5, 8>::kGroup * groups, L, a);
+  } else return false;
+  return true;
+#endif
+}
+
+}  // namespace lmk

@@ -1,0 +1,443 @@
+// lm_step.h — the gfx950 step kernel (one launch = one control step of a batch) and its launch helpers.
+//
+// Mapping: one 4-lane quad = one environment, lane c = chain c (lm_core.h). The default ("replicated") layout runs
+// every environment on the 4 quads of a 16-lane row: a workgroup is ONE wave = 4 environments x 4 replicas x 4 chains;
+// the replicas share their environment's lane memory in LDS and split the line-search step lengths, contact slots,
+// geoms and muscles between them. The plain layout (REP = 1) packs 16 environments into a wave. State is
+// SoA [dof][env] in HBM; per control step the kernel moves 4*(2nq+2nv+nu+nobs+2) + 8nv bytes per environment — the
+// path is VALU-issue bound, not HBM bound, so everything between the state load and the state store
+// happens in registers and LDS.
+//
+// One launch = one control step = n_substeps physics steps + observation + reward (on the previous observation) +
+// termination + optional device-side episode reset. This header is compiled once per kernel family and part
+// (lm_family.hip, -DLM_FAMILY=k -DLM_PART=p) so that the families build in parallel; lm_kernels.hip holds the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#define LM_DEV __device__ __forceinline__
+// an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
+__device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+#define LM_OPAQUE_ZERO() lm_opaque_zero()
+#define LM_POW01(x, p) __builtin_amdgcn_exp2f((p) * __builtin_amdgcn_logf(x))   // v_exp_f32(p * v_log_f32(x))
+#define LM_CLOCK() ((long long)__builtin_readcyclecounter())
+#include "lm_core.h"
+#include "../../include/locohip.h"
+
+namespace lmk {
+
+// ---- quad policy on gfx950: DPP quad_perm butterflies, no LDS ------------------------------------------------
+// REP = 4: the environment is replicated over the four quads of a 16-lane row (lanes that would idle in small batches);
+// the replicas run the same instruction stream and split the four step lengths of a line-search round between them.
+template <int REP>
+struct QuadDppT {
+  static constexpr int kRep = REP, kPoints = (REP == 4) ? 4 : 1;
+  static __device__ __forceinline__ int rep() { return (threadIdx.x >> 2) & (REP - 1); }
+  static __device__ __forceinline__ float rep_bcast(float x, int r) {
+    if (REP == 1) return x;
+    const int src = (int)((__lane_id() & ~12u) | ((unsigned)r << 2));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x)));
+  }
+  // sum over the replicas: butterfly over lane^4 and lane^8, the same association in every replica
+  static __device__ __forceinline__ float rep_sum(float x) {
+    if (REP == 1) return x;
+    const unsigned l = __lane_id();
+    float y = x + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 4u) << 2), __float_as_int(x)));
+    return y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 8u) << 2), __float_as_int(y)));
+  }
+  static __device__ __forceinline__ float sum(float x) {
+    // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
+#ifdef LM_UPDATE_DPP
+    float y = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+    return y + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x4E, 0xF, 0xF, false));
+#else
+    float y = x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+    return y + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(y), 0x4E, 0xF, 0xF, true));
+#endif
+  }
+  static __device__ __forceinline__ bool any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+  // replicas hand records to each other through the lane memory they share (contact slots, row states). The lanes of
+  // a wave run in lock step and the LDS executes a wave's instructions in order, so no hardware wait is needed, but
+  // the COMPILER must not move or forward lane-memory accesses across the hand-over point.
+  static __device__ __forceinline__ void fence() {
+    if (REP > 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  }
+};
+using QuadDpp = QuadDppT<1>;
+
+struct Task {
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts, all_pyr3;
+  float rp[8];
+};
+
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, pad0, pad1; };
+
+struct KArgs {
+  const float* cm;          // constant table [LM_CM_SIZE]
+  const float* mt;          // muscle table [LM_MT_SIZE] or null
+  float* act;               // muscle activations, SoA [na][N], or null
+  float* dofprm;            // per-environment joint damping | stiffness | frictionloss, SoA [3][nv][N], or null
+  const float* drspec;      // their redraw rule at an episode restart [3][nv][3] = (kind, a, b), or null
+  float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
+  int* ep_step; unsigned* ep_count;
+  const float* action;      // [N][nu] or null
+  float* obs; float* reward; unsigned char* done;       // [N][nobs], [N], [N] (may be null)
+  const float* table; int table_rows;                   // reset rows [K][nq+nv+ngoal]
+  unsigned long long seed; long long env_offset;
+  int auto_reset, horizon, action_mode; unsigned step_index;
+  int nfused;               // control steps per launch (policy-free rollouts; 1 for lm_step*)
+  int xcd_map;              // 1: XCD-aware workgroup -> environment mapping (see step_kernel)
+  int N;
+  int epb;                  // environments per workgroup (workgroup = 4*epb threads)
+  lm::Params P; Task T;
+  DevStats* stats;
+  unsigned long long* timers;   // LM_TIMERS builds: cycle counters per solver region (lane 0 of each workgroup)
+  // debug (forward only)
+  float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1, bool FUSED = false>
+__global__ __launch_bounds__(64) void step_kernel(KArgs a) {
+  using QuadDpp = QuadDppT<REP>;
+  extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
+  float* cm = dyn_lds;
+  __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
+  if (NM > 0) for (int i = threadIdx.x; i < LM_MT_SIZE; i += blockDim.x) mt[i] = a.mt[i];
+  __shared__ float blk_stats[12];
+  float* lane_mem = dyn_lds + a.T.cm_used;                 // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
+  for (int i = threadIdx.x; i < a.T.cm_used && i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
+  for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
+  __syncthreads();
+  const int c = threadIdx.x & 3;
+  const int e_local = threadIdx.x / (4 * REP);               // REP quads per environment (replicas), see QuadDppT
+  // XCD-aware workgroup -> environment mapping. The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (own
+  // L2 each), while neighbouring environments share 64-byte lines of the SoA state arrays ([dof][N]: 4 environments of a
+  // workgroup use 16 B of a line). Handing every XCD a CONTIGUOUS range of environments keeps each line inside one L2:
+  // workgroup b runs on XCD b % 8 and takes the (b / 8)-th group of that XCD's range (LM_NO_XCD_MAP: A/B switch).
+  int wg = blockIdx.x;
+  if (a.xcd_map) {
+    const int nb = gridDim.x, x = wg & 7, per = nb >> 3, rem = nb & 7;
+    wg = x * per + (x < rem ? x : rem) + (wg >> 3);
+  }
+  const int e_raw = wg * a.epb + e_local;
+  // padding quads of the last workgroup recompute env N-1; they and the replicas 1..REP-1 store nothing
+  const bool valid = e_raw < a.N && QuadDpp::rep() == 0;
+  const int e = (e_raw < a.N) ? e_raw : a.N - 1;
+  const int N = a.N, nv = a.T.nv;
+  const float* rb = cm + LM_CM_ROOT;
+#define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
+#define LK(k, f) cm[LM_CM_CHAINS + (LM_C_LINKS + (k) * LM_LINK_SIZE + (f)) * LM_NCHAIN + c]
+  const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
+
+  // Policy-free rollouts run `nfused` control steps in one launch: every environment advances on its own, no device-wide
+  // join between control steps (a launch otherwise ends with its slowest environment). Each control step reloads its
+  // state from global memory exactly like a launch of its own would (the lanes of an environment hand it to each
+  // other there), so the results are bitwise those of `nfused` single-step launches.
+  // (FUSED is a template parameter: the loop around the single-step kernels costs them 4-10 % in SGPR pressure)
+  for (int fused = 0; fused < (FUSED ? a.nfused : 1); fused++) {
+  if (FUSED && fused > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  const unsigned step_index = a.step_index + (unsigned)fused;
+  // ---- load state (root replicated in the 4 lanes: same address -> one transaction)
+  float qr[6], vr[6], war[6], qc[MC], vc[MC], wac[MC], goal[4];
+  int dr[6], dc[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { dr[i] = (int)RD(i, LM_D_DOF); qr[i] = a.qpos[dr[i] * N + e]; vr[i] = a.qvel[dr[i] * N + e]; war[i] = a.warm[dr[i] * N + e]; }
+#pragma unroll
+  for (int k = 0; k < MC; k++) {
+    dc[k] = (k < nl) ? (int)LK(k, LM_D_DOF) : 0;
+    qc[k] = (k < nl) ? a.qpos[dc[k] * N + e] : 0.0f; vc[k] = (k < nl) ? a.qvel[dc[k] * N + e] : 0.0f; wac[k] = (k < nl) ? a.warm[dc[k] * N + e] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) goal[i] = (i < a.T.ngoal) ? a.goal[i * N + e] : 0.0f;
+  lm::DofPrm<MC> dofp;
+  if (DR) {
+    const long long pn = (long long)nv * N;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { dofp.damp_r[i] = a.dofprm[dr[i] * N + e]; dofp.stiff_r[i] = a.dofprm[pn + dr[i] * N + e]; dofp.floss_r[i] = a.dofprm[2 * pn + dr[i] * N + e]; }
+#pragma unroll
+    for (int k = 0; k < MC; k++) {
+      dofp.damp_c[k] = (k < nl) ? a.dofprm[dc[k] * N + e] : 0.0f; dofp.stiff_c[k] = (k < nl) ? a.dofprm[pn + dc[k] * N + e] : 0.0f;
+      dofp.floss_c[k] = (k < nl) ? a.dofprm[2 * pn + dc[k] * N + e] : 0.0f;
+    }
+  }
+
+  // ---- reward on the PREVIOUS observation (reference utils/reward.py:73,110-115)
+  auto src = [&](float code) -> float {
+    int s = (int)code;
+    float v = 0;
+    if (s >= LM_SRC_ROOT_QPOS) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (s - LM_SRC_ROOT_QPOS == i) v = qr[i];
+    } else if (s >= LM_SRC_GOAL) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (s - LM_SRC_GOAL == i) v = goal[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (s == i) v = vr[i];
+    }
+    return v;
+  };
+  float reward = 0.0f;
+  if (a.T.reward_type == 1) { float d = src(a.T.rp[0]) - a.T.rp[1]; reward = expf(-d * d); }
+  else if (a.T.reward_type == 2) {
+    float gv = src(a.T.rp[4]);
+    float dx = src(a.T.rp[0]) - gv * src(a.T.rp[2]), dy = src(a.T.rp[1]) - gv * src(a.T.rp[3]);
+    reward = expf(-5.0f * sqrtf(dx * dx + dy * dy));
+  }
+
+  // ---- actuation: action in [-1,1] -> ctrl (reference base.py:606-621) -> clamp -> gear
+  const long long gid = a.env_offset + e;
+  auto actuate = [&](float kf, float delta, float mean, float lo, float hi, float gear) -> float {
+    int k = (int)kf;
+    if (k < 0) return 0.0f;
+    float act = 0.0f;
+    if (a.action_mode == 0 && a.action) act = a.action[(long long)e * a.T.nu + k];
+    else if (a.action_mode == 2) {
+      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+      act = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
+    }
+    float ctrl = fminf(fmaxf(fmaf(act, delta, mean), lo), hi);
+    return gear * ctrl;
+  };
+  float actr[6], actc[MC];
+#pragma unroll
+  for (int i = 0; i < 6; i++) actr[i] = actuate(RD(i, LM_D_ACT), RD(i, LM_D_ACT_DELTA), RD(i, LM_D_ACT_MEAN), RD(i, LM_D_CTRL_LO), RD(i, LM_D_CTRL_HI), RD(i, LM_D_GEAR));
+#pragma unroll
+  for (int k = 0; k < MC; k++) actc[k] = (k < nl) ? actuate(LK(k, LM_D_ACT), LK(k, LM_D_ACT_DELTA), LK(k, LM_D_ACT_MEAN), LK(k, LM_D_CTRL_LO), LK(k, LM_D_CTRL_HI), LK(k, LM_D_GEAR)) : 0.0f;
+
+  // ---- physics
+  lm::Counters cnt = {};
+  using LMm = lm::LaneMem<MC, NS, NM>;
+  const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
+  LM_LMEM_T* lmem = lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
+  constexpr int ls = 16;
+  if (NM > 0) {
+    // this lane's muscles: activation state and un-normalised, clamped control into lane memory
+    const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+    for (int i = 0; i < nm; i++) {
+      const float* rec = mt + LM_MT_HEAD + (m0 + i) * LM_MU_SIZE;
+      const int k = (int)rec[LM_MU_ACT];
+      float u = 0.0f;
+      if (k >= 0) {
+        if (a.action_mode == 0 && a.action) u = a.action[(long long)e * a.T.nu + k];
+        else if (a.action_mode == 2) {
+          unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 0x100000001B3ull + step_index) ^ (unsigned long long)(k + 1) * 0xD6E8FEB86659FD93ull);
+          u = (float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f;
+        }
+      }
+      lmem[(LMm::kCtrl + i) * ls] = fminf(fmaxf(fmaf(u, rec[LM_MU_ACT_DELTA], rec[LM_MU_ACT_MEAN]), rec[LM_MU_CTRL_LO]), rec[LM_MU_CTRL_HI]);
+      lmem[(LMm::kAct + i) * ls] = a.act[(long long)(int)rec[LM_MU_STATE] * N + e];
+    }
+  }
+  if (FORWARD_ONLY) {
+    if (!valid) return;
+    lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
+    lm::forward<QuadDpp, MC, NS, false, -1, NM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
+    int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
+    if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
+    return;
+  }
+  for (int s = 0; s < a.T.nsub; s++)
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
+
+  QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
+
+  // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
+  float bad = 0.0f, viol = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (!(fabsf(qr[i]) < 1e30f) || !(fabsf(vr[i]) < 1e30f)) bad = 1.0f;
+    if (qr[i] < RD(i, LM_D_TERM_QLO) || qr[i] > RD(i, LM_D_TERM_QHI) || vr[i] < RD(i, LM_D_TERM_VLO) || vr[i] > RD(i, LM_D_TERM_VHI)) viol = 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < MC; k++) if (k < nl) {
+    if (!(fabsf(qc[k]) < 1e30f) || !(fabsf(vc[k]) < 1e30f)) bad = 1.0f;
+    if (qc[k] < LK(k, LM_D_TERM_QLO) || qc[k] > LK(k, LM_D_TERM_QHI) || vc[k] < LK(k, LM_D_TERM_VLO) || vc[k] > LK(k, LM_D_TERM_VHI)) viol = 1.0f;
+  }
+  const bool nonfinite = QuadDpp::sum(bad) > 0.0f;
+  const bool absorbing = QuadDpp::sum(viol) > 0.0f || nonfinite;
+  int step_no = a.ep_step[e] + 1;
+  const bool trunc = a.horizon > 0 && step_no >= a.horizon;
+  float episodes = 0.0f;
+  bool zero_act = false;                     // a restarted episode starts with zero muscle activation (mj_resetData)
+  if (absorbing || trunc) {
+    episodes = 1.0f;
+    if (a.auto_reset && a.table_rows > 0) {
+      // restart from a trajectory sample (reference trajectory.py:236-273 + base.py:478-497), counter-based RNG
+      unsigned ec = a.ep_count[e] + 1;
+      unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32));
+      const float* row = a.table + (long long)(r % (unsigned long long)a.table_rows) * (2 * nv + a.T.ngoal);
+#pragma unroll
+      for (int i = 0; i < 6; i++) { qr[i] = row[dr[i]]; vr[i] = row[nv + dr[i]]; war[i] = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < MC; k++) if (k < nl) { qc[k] = row[dc[k]]; vc[k] = row[nv + dc[k]]; wac[k] = 0.0f; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i < a.T.ngoal) goal[i] = row[2 * nv + i];
+      if (c == 0 && valid) {
+        a.ep_count[e] = ec;
+        for (int i = 0; i < a.T.ngoal; i++) a.goal[i * N + e] = goal[i];
+      }
+      step_no = 0;
+      zero_act = true;
+      if (DR && a.drspec && valid) {
+        // new episode, new joint parameters (reference base.py:183-185): counter-based draws keyed like the state draw
+        auto redraw = [&](int dof, int p) {
+          const float* sp = a.drspec + ((long long)p * nv + dof) * 3;
+          const int kind = (int)sp[0];
+          if (kind == 0) return;
+          const unsigned long long r = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ (unsigned long long)(dof * 3 + p + 1) * 0xD6E8FEB86659FD93ull);
+          const float u1 = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)((r >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);
+          float v;
+          if (kind == 2) v = sp[1] + (sp[2] - sp[1]) * u1;                          // U(a, b)
+          else {
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);        // N(a, b), kind 1 clipped at 0
+            v = fmaf(sp[2], z, sp[1]);
+            if (kind == 1) v = fmaxf(v, 0.0f);
+          }
+          a.dofprm[((long long)p * nv + dof) * N + e] = v;
+        };
+        for (int p = 0; p < 3; p++) {
+          if (c == 0) for (int i = 0; i < 6; i++) redraw(dr[i], p);
+          for (int k = 0; k < MC; k++) if (k < nl) redraw(dc[k], p);
+        }
+      }
+    } else if (nonfinite) {
+      zero_act = true;
+      // no reset table: park the environment at rest in its last finite configuration is impossible; zero it
+#pragma unroll
+      for (int i = 0; i < 6; i++) { qr[i] = 0.0f; vr[i] = 0.0f; war[i] = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < MC; k++) { qc[k] = 0.0f; vc[k] = 0.0f; wac[k] = 0.0f; }
+    }
+  }
+
+  // ---- store state, observation [qpos[idx], qvel[idx], goal], reward, done
+  if (valid) {
+  if (c == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a.qpos[dr[i] * N + e] = qr[i]; a.qvel[dr[i] * N + e] = vr[i]; a.warm[dr[i] * N + e] = war[i]; }
+    a.ep_step[e] = step_no;
+    if (a.reward) a.reward[e] = reward;
+    if (a.done) a.done[e] = absorbing ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < MC; k++) if (k < nl) { a.qpos[dc[k] * N + e] = qc[k]; a.qvel[dc[k] * N + e] = vc[k]; a.warm[dc[k] * N + e] = wac[k]; }
+  if (NM > 0) {
+    const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+    for (int i = 0; i < nm; i++) {
+      const float v = lmem[(LMm::kAct + i) * ls];
+      a.act[(long long)(int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE] * N + e] = zero_act ? 0.0f : ((fabsf(v) < 1e30f) ? v : 0.0f);
+    }
+  }
+  if (a.obs) {
+    float* o = a.obs + (long long)e * a.T.nobs;
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) { int iq = (int)RD(i, LM_D_QOBS), iv = (int)RD(i, LM_D_VOBS); if (iq >= 0) o[iq] = qr[i]; if (iv >= 0) o[iv] = vr[i]; }
+      for (int i = 0; i < a.T.ngoal; i++) o[a.T.nobs - a.T.ngrf - a.T.ngoal + i] = goal[i];
+    }
+#pragma unroll
+    for (int k = 0; k < MC; k++) if (k < nl) { int iq = (int)LK(k, LM_D_QOBS), iv = (int)LK(k, LM_D_VOBS); if (iq >= 0) o[iq] = qc[k]; if (iv >= 0) o[iv] = vc[k]; }
+    if (a.T.ngrf > 0) {
+      // mean contact-frame foot force over the control step's substeps, in kN (reference base.py:596-599: mean_grf / 1000);
+      // an episode that restarts in this step reports zeros like the reference's fresh running mean
+      const float scale = (step_no == 0 && episodes > 0.0f) ? 0.0f : 1.0f / (1000.0f * (float)a.T.nsub);
+      const int o0 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS0 * LM_NCHAIN + c], o1 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS1 * LM_NCHAIN + c];
+#pragma unroll
+      for (int j = 0; j < 3; j++) { if (o0 >= 0) o[o0 + j] = cnt.grf[0][j] * scale; if (o1 >= 0) o[o1 + j] = cnt.grf[1][j] * scale; }
+    }
+  }
+  }
+
+  // ---- statistics: LDS adds inside the workgroup, one plain read-modify-write per workgroup slot (no global atomics)
+  if (a.stats) {
+    if (valid) {
+      if (c == 0) {
+        atomicAdd(&blk_stats[0], 1.0f); atomicAdd(&blk_stats[1], episodes); atomicAdd(&blk_stats[2], reward);
+        atomicAdd(&blk_stats[3], nonfinite ? 1.0f : 0.0f); atomicAdd(&blk_stats[4], (float)cnt.solver_iters);
+        atomicAdd(&blk_stats[7], (float)cnt.ls_evals); atomicAdd(&blk_stats[8], (float)cnt.ls_capped);
+        atomicAdd(&blk_stats[9], cnt.it_max >= 8 ? 1.0f : 0.0f);
+      }
+      if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
+      if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
+    }
+#ifdef LM_TIMERS
+    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+#endif
+  }
+  }  // fused control steps
+  if (a.stats) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 12; i += blockDim.x) {
+      float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
+      *dst += blk_stats[i];
+    }
+  }
+#undef RD
+#undef LK
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------------
+struct LaunchCtx { hipStream_t stream; int N, epb; };
+
+// kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
+enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_NKINDS };
+constexpr int LMK_NFAMILY = 7;      // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic
+
+template <class K>
+static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
+  // the workgroup's LDS = constant table (the part the model uses) + lane memory, both dynamic; opt in to more than
+  // the default 64 KB cap
+  const size_t bytes = sizeof(float) * ((size_t)a.T.cm_used + lane_floats);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipLaunchKernelGGL(kernel, grid, block, bytes, L.stream, a);
+}
+
+// one robot family = (links per chain MC, contact slots per chain NS, integrator, compiled-in cone, muscles per chain NM)
+template <int MC, int NS, bool RK4, int CONE, int NM, int PART>
+static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
+  const dim3 grid((L.N + L.epb - 1) / L.epb);
+  using LMm = lm::LaneMem<MC, NS, NM>;
+  const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
+  if (PART == 0) {
+    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1>, grid, dim3(4 * L.epb), plain, L, a);
+    else return false;
+  } else {
+    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, true>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, true>, grid, dim3(16 * L.epb), rep, L, a);
+    else return false;
+  }
+  return true;
+}
+
+// defined in the lm_family.hip objects; false = this family/part has no kernel of that kind
+typedef bool (*family_fn)(const LaunchCtx&, const KArgs&, int kind);
+bool launch_f0p0(const LaunchCtx&, const KArgs&, int); bool launch_f0p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f1p0(const LaunchCtx&, const KArgs&, int); bool launch_f1p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f2p0(const LaunchCtx&, const KArgs&, int); bool launch_f2p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f3p0(const LaunchCtx&, const KArgs&, int); bool launch_f3p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int);
+
+}  // namespace lmk
