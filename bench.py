@@ -53,7 +53,6 @@ def parity_sample(env, hm, table, random_policy, n=64):
     m = env._model
     nv, na = m.nv, getattr(m, "na", 0)
     oracle = Oracle(pack_model(m))
-    oracle.set_option("disable_self_collision", 1)          # the device simulates floor contacts only
     rs = np.random.RandomState(5)
     rows = table[rs.randint(0, len(table), n)]
     nu = len(env._action_indices)

@@ -65,6 +65,9 @@ typedef struct {
   double linesearch_capped;/* line searches that ran into the iteration cap */
   double steps_with_8plus_iters; /* env-steps in which some substep needed >= 8 Newton iterations */
   double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
+  double self_proximity;   /* forward passes x geom pairs WITHOUT a collider (a box / cylinder against another geom of the robot)
+                              within the contact margin: the state was outside the validated collision domain */
+  double self_contacts;    /* self-contacts (sphere / capsule pairs of two links) simulated, summed over the forward passes */
 } lm_stats;
 
 typedef struct {

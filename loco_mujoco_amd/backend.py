@@ -22,7 +22,8 @@ class Dims(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("env_steps", "episodes", "reward_sum", "nan_resets", "solver_iters",
-                                          "overflow_contacts", "unhandled_geoms", "linesearch_evals", "linesearch_capped", "steps_with_8plus_iters", "kernel_ms")]
+                                          "overflow_contacts", "unhandled_geoms", "linesearch_evals", "linesearch_capped", "steps_with_8plus_iters", "kernel_ms",
+                                          "self_proximity", "self_contacts")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -215,7 +216,10 @@ class HipBatch:
         rew = np.empty(self.n, dtype=np.float32)
         done = np.empty(self.n, dtype=np.uint8)
         _check(self._lib.lm_step(self._h, _fp(a), _fp(obs), _fp(rew), done.ctypes.data_as(_U8)))
-        return obs, rew, done.astype(bool)
+        # done byte: bit 0 = absorbing state, bit 1 = the device ended the episode in this step (restarted it from the
+        # reset table, or the horizon was reached)
+        self.last_restarted = (done & 2) != 0
+        return obs, rew, (done & 1) != 0
 
     def set_reset_table(self, rows, seed=0, global_env_offset=0):
         r = _f32(rows)

@@ -135,9 +135,16 @@ struct Params {
   int integrator;     // LM_INT_EULER (0) | LM_INT_RK4 (1)
   int cone;           // 0 pyramidal | 1 elliptic
   int act_position;   // 1: the chain joints' actuators are position servos (torque = clamp(kp*ctrl - kp*q, force range))
+  int off_runsup, off_cunsup, off_prune;   // tail lists of the constant table (lm_layout.h LM_H_OFF_*)
+  int off_lgroup;     // geom groups per link with their bounding spheres (constant-table tail, LM_H_OFF_LGROUP)
+  int off_lpair;      // link-pair list of the self-collision broad phase (constant-table tail, LM_H_OFF_LPAIR)
+  const float* gpt;   // geom-pair table (global memory): records of LM_GPAIR_SIZE floats, read when a link pair is within reach
+  const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
+  int selfprox;      // forward passes x geom pairs without a collider (box / cylinder against something) within the margin
+  int selfcon;       // self-contacts simulated, summed over the forward passes
   float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
   long long t[12];
@@ -180,13 +187,18 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_GRF /* force group of the chain (0/1) or -1 */, SL_SIZE };
+// pair extension of a slot record (kernels with self-collisions, PAIRS): SL_PART = 0 for a floor contact, else
+// sign * (1 + partner lane * 8 + partner link), partner link 7 = the root body; sign = +1 when this lane's body carries the
+// contact's SECOND geom (the normal points from geom 1 to geom 2). Then the unit normal and the first tangent, world axes.
+enum { SL_PART = SL_SIZE, SL_NX, SL_NY, SL_NZ, SL_T1X, SL_T1Y, SL_T1Z, SL_SIZE_PAIRS };
 // per-environment joint parameters (domain randomisation): replaces the table's damping / stiffness / frictionloss
 template <int MC> struct DofPrm { float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC]; };
 
-// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM]
-template <int MC, int NS, int NM = 0> struct LaneMem {
+// lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM][link bounding-sphere centres MCx3 (PAIRS)]
+template <int MC, int NS, int NM = 0, bool PAIRS = false> struct LaneMem {
+  static constexpr int kSlot = PAIRS ? (int)SL_SIZE_PAIRS : (int)SL_SIZE;
   static constexpr int kSlots = 0;
-  static constexpr int kMcc = NS * SL_SIZE;
+  static constexpr int kMcc = NS * kSlot;
   static constexpr int kMcr = kMcc + MC * (MC + 1) / 2;
   static constexpr int kMrr = kMcr + MC * 6;
   static constexpr int kSr = kMrr + 21;
@@ -195,7 +207,8 @@ template <int MC, int NS, int NM = 0> struct LaneMem {
   static constexpr int kFrame = kAl + MC * 6;    // link frames for the collision pass: position 3, rotation 9, velocity 6
   static constexpr int kAct = kFrame + MC * 18;    // muscle activations of this lane's chain (NM), then their controls (NM)
   static constexpr int kCtrl = kAct + NM;
-  static constexpr int kSize = kCtrl + NM;
+  static constexpr int kBS = kCtrl + NM;         // world centres of the links' bounding spheres (self-collision broad phase)
+  static constexpr int kSize = kBS + (PAIRS ? MC * 3 : 0);
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -414,6 +427,195 @@ LM_DEV void arrow_solve(const float* Lcc, const float (*W)[6], const float* Lrr,
   }
 }
 
+// ---- arrow factorisation with ONE cross block per lane (self-collisions between two chains) --------------------------
+// A contact between links of chains a < b couples their blocks: H_ab = X (MC x MC, kept by lane a). Elimination order
+// a, b, (other chains), root:  Y = L_a^-1 X;  H_bb -= Y^T Y;  H_br -= Y^T W_a;  then b factors what is left. `role`: 0 = no
+// cross block on this lane, 1 = lane a (X: in the cross block, out Y), 2 = lane b (X: out the partner's Y); `partner` = the
+// other lane of the pair. `any_cross` is quad-uniform; without it this is arrow_factor. The lanes of a quad run the same
+// instructions: the second pass (lane b) costs every lane of the quad one more chain-block factorisation.
+template <class Q, int MC>
+LM_DEV void arrow_factor_x(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, const float* Hrr_part, float* Lrr,
+                           float (*X)[MC], int role, int partner, bool any_cross) {
+  for (int pass = 0; pass < (any_cross ? 2 : 1); pass++) {
+    if (pass == 1) {
+      float Ya[MC][MC], Wa[MC][6];
+#pragma unroll
+      for (int k = 0; k < MC; k++) {
+#pragma unroll
+        for (int j = 0; j < MC; j++) Ya[k][j] = Q::quad_read(X[k][j], partner);
+#pragma unroll
+        for (int r = 0; r < 6; r++) Wa[k][r] = Q::quad_read(Hcr[k][r], partner);
+      }
+      if (role == 2) {
+#pragma unroll
+        for (int i = 0; i < MC; i++) {
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            float t = Hcc[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < MC; k++) t = fmaf(-Ya[k][i], Ya[k][j], t);
+            Hcc[tri(i, j)] = t;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            float t = Hcr[i][r];
+#pragma unroll
+            for (int k = 0; k < MC; k++) t = fmaf(-Ya[k][i], Wa[k][r], t);
+            Hcr[i][r] = t;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < MC; k++)
+#pragma unroll
+          for (int j = 0; j < MC; j++) X[k][j] = Ya[k][j];
+      }
+    }
+    const bool mine = (role == 2) ? (pass == 1) : (pass == 0);
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < MC; j++) {
+        float sd = Hcc[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) sd = fmaf(-Hcc[tri(j, k)], Hcc[tri(j, k)], sd);
+        float d = sqrtf(fmaxf(sd, 1e-30f)), id = 1.0f / d;
+        Hcc[tri(j, j)] = d;
+#pragma unroll
+        for (int i = j + 1; i < MC; i++) {
+          float t = Hcc[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; k++) t = fmaf(-Hcc[tri(i, k)], Hcc[tri(j, k)], t);
+          Hcc[tri(i, j)] = t * id;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+        const float idg = 1.0f / Hcc[tri(i, i)];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          float t = Hcr[i][r];
+#pragma unroll
+          for (int k = 0; k < i; k++) t = fmaf(-Hcc[tri(i, k)], Hcr[k][r], t);
+          Hcr[i][r] = t * idg;
+        }
+        if (role == 1) {
+#pragma unroll
+          for (int j = 0; j < MC; j++) {
+            float t = X[i][j];
+#pragma unroll
+            for (int k = 0; k < i; k++) t = fmaf(-Hcc[tri(i, k)], X[k][j], t);
+            X[i][j] = t * idg;
+          }
+        }
+      }
+    }
+  }
+  float S[21];
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      float t = Hrr_part[tri(a, b)];
+#pragma unroll
+      for (int k = 0; k < MC; k++) t = fmaf(-Hcr[k][a], Hcr[k][b], t);
+      S[tri(a, b)] = Q::sum(t) + Hrr_rep[tri(a, b)];
+    }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float sd = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) sd = fmaf(-Lrr[tri(j, k)], Lrr[tri(j, k)], sd);
+    float d = sqrtf(fmaxf(sd, 1e-30f)), id = 1.0f / d;
+    Lrr[tri(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float t = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fmaf(-Lrr[tri(i, k)], Lrr[tri(j, k)], t);
+      Lrr[tri(i, j)] = t * id;
+    }
+  }
+}
+
+// solve with the factors of arrow_factor_x (Y in X for both lanes of a pair)
+template <class Q, int MC>
+LM_DEV void arrow_solve_x(const float* Lcc, const float (*W)[6], const float* Lrr, const float (*Y)[MC], int role, int partner,
+                          bool any_cross, float* xc, float* xr) {
+  // forward: a (and the chains without a cross block), then b with its right-hand side reduced by Y^T y_a
+  for (int pass = 0; pass < (any_cross ? 2 : 1); pass++) {
+    if (pass == 1) {
+      float t[MC];
+#pragma unroll
+      for (int k = 0; k < MC; k++) t[k] = Q::quad_read(xc[k], partner);
+      if (role == 2) {
+#pragma unroll
+        for (int i = 0; i < MC; i++)
+#pragma unroll
+          for (int k = 0; k < MC; k++) xc[i] = fmaf(-Y[k][i], t[k], xc[i]);
+      }
+    }
+    const bool mine = (role == 2) ? (pass == 1) : (pass == 0);
+    if (mine) {
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+        float t = xc[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t = fmaf(-Lcc[tri(i, k)], xc[k], t);
+        xc[i] = t / Lcc[tri(i, i)];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float t = 0;
+#pragma unroll
+    for (int k = 0; k < MC; k++) t = fmaf(W[k][r], xc[k], t);
+    xr[r] -= Q::sum(t);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t = fmaf(-Lrr[tri(i, k)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t = fmaf(-Lrr[tri(k, i)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+  // backward: b (and the chains without a cross block), then a with Y x_b taken off
+  for (int pass = 0; pass < (any_cross ? 2 : 1); pass++) {
+    float t[MC];
+#pragma unroll
+    for (int k = 0; k < MC; k++) t[k] = 0.0f;
+    if (pass == 1) {
+#pragma unroll
+      for (int k = 0; k < MC; k++) t[k] = Q::quad_read(xc[k], partner);
+    }
+    const bool mine = (role == 1) ? (pass == 1) : (pass == 0);
+    if (mine) {
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) xc[i] = fmaf(-W[i][r], xr[r], xc[i]);
+        if (role == 1) {
+#pragma unroll
+          for (int j = 0; j < MC; j++) xc[i] = fmaf(-Y[i][j], t[j], xc[i]);
+        }
+      }
+#pragma unroll
+      for (int i = MC - 1; i >= 0; i--) {
+        float tt = xc[i];
+#pragma unroll
+        for (int k = i + 1; k < MC; k++) tt = fmaf(-Lcc[tri(k, i)], xc[k], tt);
+        xc[i] = tt / Lcc[tri(i, i)];
+      }
+    }
+  }
+}
+
 // contact-frame components (n=+z, t1=+y, t2=-x; then the same for rotation) of motion S at r
 LM_DEV void contact_rows(Sp S, V3 r, float* out) {
   V3 u = S.v + cross(S.w, r);
@@ -423,6 +625,35 @@ LM_DEV void contact_rows(Sp S, V3 r, float* out) {
 LM_DEV Sp contact_wrench(const float* f, V3 r) {
   V3 lin = v3(-f[2], f[1], f[0]), tor = v3(-f[5], f[4], f[3]);
   Sp F; F.v = lin; F.w = tor + cross(r, lin); return F;
+}
+
+// the same for a contact frame (n, t1, t2) in general position (self-collisions)
+LM_DEV void frame_rows(Sp S, V3 r, V3 n, V3 t1, V3 t2, float* out) {
+  V3 u = S.v + cross(S.w, r);
+  out[0] = dot(n, u); out[1] = dot(t1, u); out[2] = dot(t2, u); out[3] = dot(n, S.w); out[4] = dot(t1, S.w); out[5] = dot(t2, S.w);
+}
+LM_DEV Sp frame_wrench(const float* f, V3 r, V3 n, V3 t1, V3 t2) {
+  V3 lin = f[0] * n + f[1] * t1 + f[2] * t2, tor = f[3] * n + f[4] * t1 + f[5] * t2;
+  Sp F; F.v = lin; F.w = tor + cross(r, lin); return F;
+}
+// tangents of a contact frame from its unit normal (engine: mju_makeFrame): the second axis starts from +y, or +z when the
+// normal is within 60 degrees of +-y, and is made orthogonal to the normal; third = first x second
+LM_DEV void make_frame(V3 n, V3& t1, V3& t2) {
+  V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
+  y = y + (-dot(n, y)) * n;
+  t1 = (1.0f / sqrtf(fmaxf(dot(y, y), 1e-30f))) * y;
+  t2 = cross(n, t1);
+}
+// closest points of two segments p1 + s d1 (|s| <= h1), p2 + t d2 (|t| <= h2), unit directions (a sphere is h = 0)
+LM_DEV void segment_closest(V3 p1, V3 d1, float h1, V3 p2, V3 d2, float h2, float& s_out, float& t_out) {
+  const V3 r = p1 - p2;
+  const float b = dot(d1, d2), cc = dot(d1, r), f = dot(d2, r), den = 1.0f - b * b;
+  float s = 0.0f;
+  if (den > 1e-12f) s = fminf(fmaxf((b * f - cc) / den, -h1), h1);
+  float t = b * s + f;
+  if (t < -h2) { t = -h2; s = fminf(fmaxf(b * t - cc, -h1), h1); }
+  else if (t > h2) { t = h2; s = fminf(fmaxf(b * t - cc, -h1), h1); }
+  s_out = s; t_out = t;
 }
 
 // ---- the substep ---------------------------------------------------------------------------------------------
@@ -435,7 +666,7 @@ LM_DEV Sp contact_wrench(const float* f, V3 r) {
 // NM > 0: the chain's muscles (table `mt`, lm_layout.h MT_*/MU_*) act on the chain dofs; their activations and
 // controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
 // DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
-template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false>
+template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false, bool PAIRS = false>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
@@ -453,8 +684,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
 #define LK(k, f) CH(LM_C_LINKS + (k) * LM_LINK_SIZE + (f))
 #define LX(k, f) LK(k, LM_D_SIZE + (f))
-#define GE(g, f) CH(LM_C_GEOMS + (g) * LM_G_SIZE + (f))
-#define SL(s, f) lmem[((s) * SL_SIZE + (f)) * ls]
+#define GE(g, f) P.gt[((g) * LM_G_SIZE + (f)) * LM_NCHAIN + c]
+#define GP(g, f) cm[oz + P.off_prune + ((g) * LM_P_SIZE + (f)) * LM_NCHAIN + c]
+#define CU(i, f) cm[oz + P.off_cunsup + ((i) * LM_U_SIZE + (f)) * LM_NCHAIN + c]
+#define SL(s, f) lmem[((s) * LMm::kSlot + (f)) * ls]
+#define PEER(dl, i) Q::peer(lmem, ls, (i), (dl))
 #define DAMP_R(i) (DR ? dp->damp_r[i] : RD(i, LM_D_DAMP))
 #define STIFF_R(i) (DR ? dp->stiff_r[i] : RD(i, LM_D_STIFF))
 #define FLOSS_R(i) (DR ? dp->floss_r[i] : RD(i, LM_D_FLOSS))
@@ -506,7 +740,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   {
     int nu = (int)rb[LM_R_NUNSUP];
     for (int i = c; i < nu; i += 4) {            // the quad's lanes share the list
-      const float* u = rb + LM_R_UNSUP + i * LM_U_SIZE;
+      const float* u = rb + P.off_runsup + i * LM_U_SIZE;
       const float sz = O.z + R.a[6] * u[1] + R.a[7] * u[2] + R.a[8] * u[3];
       if (sz - u[4] < u[5]) cnt.unhandled++;
     }
@@ -515,12 +749,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots.
   // Everything that must survive into the solver (M, twists) is parked in lane memory so that the Newton loop
   // keeps only small vectors in registers.
-  using LMm = LaneMem<MC, NS, NM>;
+  using LMm = LaneMem<MC, NS, NM, PAIRS>;
 #define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
   float a0r[6], a0c[MC];
   float sm_r[6], sm_c[MC];
   int nslot = 0;
+  int pair_mask_out = 0;           // partner lanes of this lane's cross-chain contact slots (PAIRS)
   {
     Sp Sc[MC];
     float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
@@ -529,7 +764,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     {
       M3 Rk = R; V3 pk = O;
       Sp V = Vroot, A = Aroot;
-      const int ng = (int)CH(LM_C_NGEOMS), nun = (int)CH(LM_C_NUNSUP);
+      const int nun = (int)CH(LM_C_NUNSUP);
 #pragma unroll
       for (int k = 0; k < MC; k++) {
         if (k < nl) {
@@ -564,8 +799,23 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // small-batch environment take every kRep-th geom; in each pass they exchange how many contacts they found, so that
   // the slot records land in lane memory in the same order (geom, then candidate point) as without replicas.
       int n_overflow = 0, n_unhandled = 0;
-      for (int g0 = 0; g0 < ng; g0 += Q::kRep) {
+      // two levels: the geoms of a link (or of the root body: link -1, this lane's share) form a group with a bounding sphere;
+      // a link high above the floor costs one test per pass
+      const int ngroups = (int)CH(LM_C_NLGROUP);
+      for (int gi = 0; gi < ngroups; gi++) {
+#define LG(f) cm[oz + P.off_lgroup + (gi * LM_LG_SIZE + (f)) * LM_NCHAIN + c]
+        const int glink = (int)LG(0), gfirst = (int)LG(1), gend = gfirst + (int)LG(2);
+        {
+          const int fbg = LMm::kFrame + (glink < 0 ? 0 : glink) * 18;
+          const V3 gc = v3(LG(3), LG(4), LG(5));
+          const float zg = (glink < 0) ? O.z + R.a[6] * gc.x + R.a[7] * gc.y + R.a[8] * gc.z
+                                       : LMEM(fbg + 2) + LMEM(fbg + 9) * gc.x + LMEM(fbg + 10) * gc.y + LMEM(fbg + 11) * gc.z;
+          if (zg - LG(6) > 0.0f) continue;
+        }
+#undef LG
+      for (int g0 = gfirst; g0 < gend; g0 += Q::kRep) {
         const int g = g0 + Q::rep();
+        const int ng = gend;
         // ---- candidate points of my geom: sphere centre | the two capsule end centres | the box corners below the box
         // centre in bit order, at most 4 contacts per box
         int made = 0;
@@ -574,29 +824,50 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         Sp V = sp0();
         float margin = 0.0f;
         if (g < ng) {
-          k = (int)GE(g, LM_G_LINK);
-          const int fb = LMm::kFrame + k * 18;
-          const V3 gl = v3(GE(g, LM_G_PX), GE(g, LM_G_PY), GE(g, LM_G_PZ));
-          // margin-less bounding-sphere prune on the height of the geom centre (third row of the link rotation)
-          if (!(LMEM(fb + 2) + LMEM(fb + 9) * gl.x + LMEM(fb + 10) * gl.y + LMEM(fb + 11) * gl.z - GE(g, LM_G_RBOUND) > 0.0f)) {
-            const V3 pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
-            M3 Rk;
+          k = (int)GP(g, 0);               // link of the geom; -1: a geom of the root body, dealt to this chain's lane
+          const int fb = LMm::kFrame + (k < 0 ? 0 : k) * 18;
+          const V3 gl = v3(GP(g, 1), GP(g, 2), GP(g, 3));
+          // margin-less bounding-sphere prune on the height of the geom centre (third row of the link rotation); only a
+          // geom that passes it reads its full record from the geom table
+          const float zc = (k < 0) ? O.z + R.a[6] * gl.x + R.a[7] * gl.y + R.a[8] * gl.z
+                                   : LMEM(fb + 2) + LMEM(fb + 9) * gl.x + LMEM(fb + 10) * gl.y + LMEM(fb + 11) * gl.z;
+          if (!(zc - GP(g, 4) > 0.0f)) {
+            V3 pk = O;
+            M3 Rk = R;
+            V = Vroot;
+            if (k >= 0) {
+              pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
 #pragma unroll
-            for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
-            V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+              for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
+              V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+            }
             const V3 ctr = pk + mul(Rk, gl);
             const float rad = GE(g, LM_G_RADIUS), half = GE(g, LM_G_HALF);
             margin = GE(g, LM_G_MARGIN);
             const int gtype = (int)GE(g, LM_G_TYPE);
             const V3 ax = mul(Rk, v3(GE(g, LM_G_AX), GE(g, LM_G_AY), GE(g, LM_G_AZ)));
             M3 Rg;
-            if (gtype == LM_GEOM_BOX) {
+            if (gtype == LM_GEOM_BOX || gtype == LM_GEOM_CYLINDER) {
               M3 Gr;
 #pragma unroll
               for (int i = 0; i < 9; i++) Gr.a[i] = GE(g, LM_G_R0 + i);
               Rg = mul(Rk, Gr);
             }
-            const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : 1);
+            // plane vs cylinder (engine: mjc_PlaneCylinder): deepest rim point of the cap facing the plane, the rim point
+            // below it on the other cap, and two more points of the near cap's rim at +-120 degrees
+            V3 cax = ax, cvec = v3(0, 0, 0), cv1 = v3(0, 0, 0);
+            if (gtype == LM_GEOM_CYLINDER) {
+              float prj = cax.z;
+              if (prj > 0.0f) { cax = -1.0f * cax; prj = -prj; }
+              cvec = v3(cax.x * prj, cax.y * prj, cax.z * prj - 1.0f);
+              const float l2 = dot(cvec, cvec);
+              if (l2 >= 1e-30f) cvec = (rad / sqrtf(l2)) * cvec;
+              else cvec = rad * v3(Rg.a[0], Rg.a[3], Rg.a[6]);        // disk parallel to the plane: the geom's x axis
+              cax = half * cax;
+              V3 side = cross(cvec, cax);
+              cv1 = (rad * 0.8660254037844386f / sqrtf(fmaxf(dot(side, side), 1e-30f))) * side;
+            }
+            const int npt = (gtype == LM_GEOM_CAPSULE) ? 2 : ((gtype == LM_GEOM_BOX) ? 8 : ((gtype == LM_GEOM_CYLINDER) ? 4 : 1));
             for (int e = 0; e < npt; e++) {
               V3 sc = ctr; float rad_e = rad;
               if (gtype == LM_GEOM_CAPSULE) sc = ctr + ((e == 0) ? half : -half) * ax;
@@ -605,6 +876,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                                     (e & 4) ? GE(g, LM_G_SZ) : -GE(g, LM_G_SZ)));
                 if (off.z > 0.0f || made >= 4) continue;
                 sc = ctr + off; rad_e = 0.0f;
+              } else if (gtype == LM_GEOM_CYLINDER) {
+                rad_e = 0.0f;
+                if (e == 0) sc = ctr + cvec + cax;
+                else if (made == 0) break;                             // the deepest point is out of reach: no contact at all
+                else if (e == 1) sc = ctr + cvec + (-1.0f) * cax;
+                else sc = ctr + cax + (-0.5f) * cvec + ((e == 2) ? 1.0f : -1.0f) * cv1;
               }
               const float dist = sc.z - rad_e;
               if (dist >= margin) continue;
@@ -637,6 +914,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const int dim = (int)GE(g, LM_G_DIM);
           SL(slot, SL_LINK) = (float)k; SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = mu;
           SL(slot, SL_GRF) = GE(g, LM_G_GRF);
+          if (PAIRS) SL(slot, SL_PART) = 0.0f;
           SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
           SL(slot, SL_D) = D0;
           if (PYR3(dim)) {
@@ -653,19 +931,115 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         nslot += total;
       }
+      }
       if (nslot > NS) nslot = NS;
       Q::fence();                // slot records written by one replica are read by all of them from here on
       for (int i = Q::rep(); i < nun; i += Q::kRep) {
-        const int fb = LMm::kFrame + (int)CH(LM_C_UNSUP + i * LM_U_SIZE) * 18;
-        const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CH(LM_C_UNSUP + i * LM_U_SIZE + 1) + LMEM(fb + 10) * CH(LM_C_UNSUP + i * LM_U_SIZE + 2)
-                         + LMEM(fb + 11) * CH(LM_C_UNSUP + i * LM_U_SIZE + 3);
-        if (sz - CH(LM_C_UNSUP + i * LM_U_SIZE + 4) < CH(LM_C_UNSUP + i * LM_U_SIZE + 5)) n_unhandled++;
+        const int fb = LMm::kFrame + (int)CU(i, 0) * 18;
+        const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CU(i, 1) + LMEM(fb + 10) * CU(i, 2) + LMEM(fb + 11) * CU(i, 3);
+        if (sz - CU(i, 4) < CU(i, 5)) n_unhandled++;
       }
       if (Q::kRep > 1) { n_overflow = (int)Q::rep_sum((float)n_overflow); n_unhandled = (int)Q::rep_sum((float)n_unhandled); }
       cnt.overflow += n_overflow; cnt.unhandled += n_unhandled;
     }
+    // ======== self-collisions (PAIRS): sphere / capsule pairs between links of different chains or a link and the root ========
+    // Broad phase per forward pass: bounding spheres of the two links (list in the constant-table tail, one entry per link
+    // pair and lane involved). A pair within reach walks its geom pairs in the geom-pair table (global memory): closest
+    // points of the two capsule segments, one contact when closer than the margin. BOTH lanes of a cross-chain pair run the
+    // same arithmetic on the same numbers and each records the contact as a slot of its own ("mirror" slots: same point,
+    // frame and parameters, opposite sign); every replica records all of them (identical words to identical addresses).
+    // Geom pairs without a collider (a box or a cylinder against something) are tested as bounding capsules and counted.
+    int pair_mask = 0;               // partner lanes of this lane's cross-chain slots
+    if (PAIRS) {
+#pragma unroll
+      for (int k = 0; k < MC; k++) if (k < nl) {
+        const int fb = LMm::kFrame + k * 18;
+        const V3 bl = v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ));
+        LMEM(LMm::kBS + k * 3 + 0) = LMEM(fb + 0) + LMEM(fb + 3) * bl.x + LMEM(fb + 4) * bl.y + LMEM(fb + 5) * bl.z;
+        LMEM(LMm::kBS + k * 3 + 1) = LMEM(fb + 1) + LMEM(fb + 6) * bl.x + LMEM(fb + 7) * bl.y + LMEM(fb + 8) * bl.z;
+        LMEM(LMm::kBS + k * 3 + 2) = LMEM(fb + 2) + LMEM(fb + 9) * bl.x + LMEM(fb + 10) * bl.y + LMEM(fb + 11) * bl.z;
+      }
+      Q::quad_sync();                // the peers' frames and sphere centres are read below
+      const V3 rootc = O + mul(R, v3(rb[LM_R_BSX], rb[LM_R_BSY], rb[LM_R_BSZ]));
+      const int nlp = (int)CH(LM_C_NLPAIR);
+      int n_over = 0;
+      for (int i = 0; i < nlp; i++) {
+        const int code = (int)cm[oz + P.off_lpair + (i * LM_LP_SIZE + 0) * LM_NCHAIN + c];
+        const int ka = code & 7, kb = (code >> 3) & 7, lb = (code >> 6) & 3, own_q = (code >> 8) & 1, dl = lb - c;
+        const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
+        const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
+        const V3 dc = cb - ca;
+        if (!(dot(dc, dc) < cm[oz + P.off_lpair + (i * LM_LP_SIZE + 2) * LM_NCHAIN + c])) continue;
+        // ---- narrow phase over the geom pairs of this link pair
+        const int rng = (int)cm[oz + P.off_lpair + (i * LM_LP_SIZE + 1) * LM_NCHAIN + c], first = rng & 4095, npairs = rng >> 12;
+        V3 po, pp = O; M3 Ro, Rp = R; Sp Vo, Vp = Vroot;       // own / partner link frame and velocity
+        {
+          const int fb = LMm::kFrame + ka * 18;
+          po = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+#pragma unroll
+          for (int j = 0; j < 9; j++) Ro.a[j] = LMEM(fb + 3 + j);
+          Vo.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); Vo.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+        }
+        if (kb != 7) {
+          const int fb = LMm::kFrame + kb * 18;
+          pp = v3(PEER(dl, fb), PEER(dl, fb + 1), PEER(dl, fb + 2));
+#pragma unroll
+          for (int j = 0; j < 9; j++) Rp.a[j] = PEER(dl, fb + 3 + j);
+          Vp.w = v3(PEER(dl, fb + 12), PEER(dl, fb + 13), PEER(dl, fb + 14)); Vp.v = v3(PEER(dl, fb + 15), PEER(dl, fb + 16), PEER(dl, fb + 17));
+        }
+        for (int j = 0; j < npairs; j++) {
+          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
+          const bool g1own = ((int)rec[LM_GP_G1Q] == own_q);        // geom 1 sits on my link
+          const V3 p1 = g1own ? po : pp, p2 = g1own ? pp : po;
+          const M3& R1 = g1own ? Ro : Rp; const M3& R2 = g1own ? Rp : Ro;
+          const V3 c1 = p1 + mul(R1, v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2]));
+          const V3 a1 = mul(R1, v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
+          const V3 c2 = p2 + mul(R2, v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2]));
+          const V3 a2 = mul(R2, v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
+          const float r1 = rec[LM_GP_R1], r2 = rec[LM_GP_R2];
+          float sa, ta;
+          segment_closest(c1, a1, rec[LM_GP_H1], c2, a2, rec[LM_GP_H2], sa, ta);
+          const V3 q1 = c1 + sa * a1, q2 = c2 + ta * a2, dq = q2 - q1;
+          const float dd = sqrtf(dot(dq, dq)), dist = dd - r1 - r2, pmargin = rec[LM_GP_MARGIN];
+          if (!(dist < pmargin)) continue;
+          if (rec[LM_GP_KIND] != 0.0f) {                            // no collider for this pair of geom types: counted (once)
+            if ((g1own || kb == 7) && Q::rep() == 0) cnt.selfprox++;
+            continue;
+          }
+          if (nslot >= NS) { n_over++; continue; }
+          const V3 nrm = (dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / dd) * dq;
+          V3 t1, t2;
+          make_frame(nrm, t1, t2);
+          const V3 cp = q1 + (r1 + 0.5f * dist) * nrm - O;
+          const int slot = nslot++;
+          SL(slot, SL_LINK) = (float)ka; SL(slot, SL_GRF) = -1.0f;
+          SL(slot, SL_PART) = (g1own ? -1.0f : 1.0f) * (float)(1 + ((kb == 7) ? 0 : lb) * 8 + kb);
+          SL(slot, SL_NX) = nrm.x; SL(slot, SL_NY) = nrm.y; SL(slot, SL_NZ) = nrm.z;
+          SL(slot, SL_T1X) = t1.x; SL(slot, SL_T1Y) = t1.y; SL(slot, SL_T1Z) = t1.z;
+          SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
+          if (kb != 7) pair_mask |= 1 << lb;
+          // relative velocity of body 2 against body 1 at the contact point, in the contact frame
+          Sp Vrel = g1own ? (Vp + (-1.0f) * Vo) : (Vo + (-1.0f) * Vp);
+          float vel[6];
+          frame_rows(Vrel, cp, nrm, t1, t2, vel);
+          const float imp = impedance(rec + LM_GP_S0, 1, dist, pmargin);
+          const float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * rec[LM_GP_TRAN]);
+          const float Bp = rec[LM_GP_B], Kr = rec[LM_GP_K] * imp * (dist - pmargin);
+          const int dim = (int)rec[LM_GP_DIM];
+          SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = rec[LM_GP_MU]; SL(slot, SL_D) = D0;
+#pragma unroll
+          for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / rec[LM_GP_RR1 + j2 - 1] : 0.0f; SL(slot, SL_FR + j2 - 1) = rec[LM_GP_F0 + j2 - 1]; }
+#pragma unroll
+          for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -Bp * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
+          if (Q::rep() == 0 && (g1own || kb == 7)) cnt.selfcon++;
+        }
+      }
+      if (Q::rep() == 0) cnt.overflow += n_over;
+      Q::fence();
+    }
     cnt.ncon += nslot;
     LM_TICK(0);
+    pair_mask_out = pair_mask;
 
     // ======== inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) ========
     SpI comp = spi0();
@@ -849,6 +1223,25 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       arrow_solve<Q, MC>(Mcc, Mcr, Lrr, a0c, a0r);
     }
   }
+  // cross-chain contacts: who is coupled with whom (quad-uniform). The factorisation handles a MATCHING (every chain coupled
+  // with at most one other chain); anything else falls back to a block-diagonal majorant of the cross terms (the Newton
+  // direction is then inexact, the solution is not: more iterations) and is counted with the dropped contacts.
+  bool any_pair = false;
+  int xrole = 0, xpartner = 0;       // 1: lower lane of a coupled pair (keeps the cross block), 2: upper lane
+  bool xmajor = false;
+  if (PAIRS) {
+    const int all = (int)(Q::sum((float)(pair_mask_out << (4 * c))) + 0.5f);
+    any_pair = all != 0;
+    if (any_pair) {
+      bool matching = true;
+#pragma unroll
+      for (int l = 0; l < 4; l++) { const int row = (all >> (4 * l)) & 15; if (row & (row - 1)) matching = false; }
+      if (matching) {
+        const int row = (all >> (4 * c)) & 15;
+        if (row) { xpartner = (row & 1) ? 0 : ((row & 2) ? 1 : ((row & 4) ? 2 : 3)); xrole = (xpartner > c) ? 1 : 2; }
+      } else { xmajor = true; if (c == 0 && Q::rep() == 0) cnt.overflow++; }
+    }
+  }
   auto ldS = [&](int base) -> Sp {       // twist from lane memory
     Sp S; S.w = v3(LMEM(base), LMEM(base + 1), LMEM(base + 2)); S.v = v3(LMEM(base + 3), LMEM(base + 4), LMEM(base + 5)); return S;
   };
@@ -903,18 +1296,50 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   };
   // spatial image of joint-space vector x on every link of this chain: Al[k] = sum_root x_r S_r + sum_{j<=k} x_j S_j
   // (kept in lane memory: a register array indexed by the contact's link number ends up in scratch)
+  Sp img_root = sp0();             // root image of the vector last handed to link_images (contacts of root geoms, trunk pairs)
   auto link_images = [&](const float* xr, const float* xc) {
     Sp A = sp0();
 #pragma unroll
     for (int r = 0; r < 6; r++) A = A + xr[r] * ldS(LMm::kSr + r * 6);
+    img_root = A;
 #pragma unroll
     for (int k = 0; k < MC; k++) {
       A = A + xc[k] * ldS(LMm::kSc + k * 6);
       LMEM(LMm::kAl + k * 6 + 0) = A.w.x; LMEM(LMm::kAl + k * 6 + 1) = A.w.y; LMEM(LMm::kAl + k * 6 + 2) = A.w.z;
       LMEM(LMm::kAl + k * 6 + 3) = A.v.x; LMEM(LMm::kAl + k * 6 + 4) = A.v.y; LMEM(LMm::kAl + k * 6 + 5) = A.v.z;
     }
+    if (PAIRS && any_pair) Q::quad_sync();     // mirror slots read the partner lane's images
   };
-  auto pick = [&](int link) -> Sp { return ldS(LMm::kAl + link * 6); };
+  auto pick = [&](int link) -> Sp { return (link < 0) ? img_root : ldS(LMm::kAl + (link < 0 ? 0 : link) * 6); };
+  // ---- slots of self-contacts (PAIRS): the row space is the motion of body 2 against body 1, the frame is the slot's own
+  auto slot_sign = [&](int s) -> float { return PAIRS ? SL(s, SL_PART) : 0.0f; };                 // 0: floor contact
+  auto slot_frame = [&](int s, V3& n, V3& t1, V3& t2) {
+    n = v3(SL(s, SL_NX), SL(s, SL_NY), SL(s, SL_NZ)); t1 = v3(SL(s, SL_T1X), SL(s, SL_T1Y), SL(s, SL_T1Z)); t2 = cross(n, t1);
+  };
+  auto peer_twist = [&](int dl, int base) -> Sp {
+    Sp S; S.w = v3(PEER(dl, base), PEER(dl, base + 1), PEER(dl, base + 2)); S.v = v3(PEER(dl, base + 3), PEER(dl, base + 4), PEER(dl, base + 5)); return S;
+  };
+  // contact-frame components of the current link images for slot s
+  auto slot_rows_of_images = [&](int s, float* out) {
+    const int link = (int)SL(s, SL_LINK);
+    const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
+    const float part = slot_sign(s);
+    if (PAIRS && part != 0.0f) {
+      const int code = (int)fabsf(part) - 1, pl = code & 7, dl = (code >> 3) - c;
+      const Sp B = (pl == 7) ? img_root : peer_twist(dl, LMm::kAl + pl * 6);
+      const float sg = (part > 0.0f) ? 1.0f : -1.0f;
+      const Sp A = sg * (pick(link) + (-1.0f) * B);
+      V3 n, t1, t2;
+      slot_frame(s, n, t1, t2);
+      frame_rows(A, rc, n, t1, t2, out);
+    } else contact_rows(pick(link), rc, out);
+  };
+  // a contact between two chains has a slot in both lanes: each of them carries half of its cost
+  auto slot_weight = [&](int s) -> float {
+    if (!PAIRS) return 1.0f;
+    const float part = slot_sign(s);
+    return (part != 0.0f && (((int)fabsf(part) - 1) & 7) != 7) ? 0.5f : 1.0f;
+  };
   auto friction_cost = [&](float x, float f, float Rr) -> float {
     if (f <= 0.0f) return 0.0f;
     float Rf = Rr * f;
@@ -938,11 +1363,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
       }
     }
-    if (nslot > 0) {
+    if (nslot > 0 || any_pair) {
       link_images(xr, xc);
       for (int s = Q::rep(); s < nslot; s += Q::kRep) {
         float Dj[6], fr[5], jar[6];
-        contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
+        slot_rows_of_images(s, jar);
         const int dim = (int)SL(s, SL_DIM);
         if (PYR3(dim)) {
           float x[4], f3[3];
@@ -955,9 +1380,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
 #pragma unroll
           for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
-          cost += cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
+          cost += slot_weight(s) * cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
         }
       }
+      if (PAIRS && any_pair) Q::quad_sync();        // ... before the next link_images overwrites them
     }
     return cost;
   };
@@ -1042,13 +1468,17 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       const bool split = Q::kRep > 1 && Q::any(nslot > 1);
       const int s_first = split ? Q::rep() : 0, s_step = split ? Q::kRep : 1;
       Q::fence();
-      if (nslot > 0 && !(P.ablate & 32)) {
+      Sp Frt = sp0();              // wrench of the contacts of root geoms held by this lane
+      Sp Fp[PAIRS ? MC : 1];       // wrenches of the self-contacts per link: they act on the chain dofs only (the opposite
+#pragma unroll                     // wrench on the other body cancels them on the root)
+      for (int k = 0; k < (PAIRS ? MC : 1); k++) Fp[k] = sp0();
+      if ((nslot > 0 || any_pair) && !(P.ablate & 32)) {
         link_images(ar, ac);
         for (int s = s_first; s < nslot; s += s_step) {
           float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
-          contact_rows(pick(link), rc, jar);
+          slot_rows_of_images(s, jar);
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
@@ -1071,11 +1501,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
           SL(s, SL_ZONE) = (float)zone;
           if (zone) {
-            Sp Fw = contact_wrench(fc, rc);
+            const float part = slot_sign(s);
+            if (PAIRS && part != 0.0f) {
+              V3 n, t1, t2;
+              slot_frame(s, n, t1, t2);
+              const Sp Fw = ((part > 0.0f) ? 1.0f : -1.0f) * frame_wrench(fc, rc, n, t1, t2);
 #pragma unroll
-            for (int k = 0; k < MC; k++) if (link == k) Fl[k] = Fl[k] + Fw;
+              for (int k = 0; k < MC; k++) if (link == k) Fp[k] = Fp[k] + Fw;
+            } else {
+              Sp Fw = contact_wrench(fc, rc);
+              if (link < 0) Frt = Frt + Fw;
+#pragma unroll
+              for (int k = 0; k < MC; k++) if (link == k) Fl[k] = Fl[k] + Fw;
+            }
           }
         }
+        if (PAIRS && any_pair) Q::quad_sync();
       }
       Q::fence();                  // SL_JAR / SL_ZONE of a slot are written by the replica that owns it
       if (split) {
@@ -1083,11 +1524,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int k = 0; k < MC; k++) {
           Fl[k].w = v3(Q::rep_sum(Fl[k].w.x), Q::rep_sum(Fl[k].w.y), Q::rep_sum(Fl[k].w.z));
           Fl[k].v = v3(Q::rep_sum(Fl[k].v.x), Q::rep_sum(Fl[k].v.y), Q::rep_sum(Fl[k].v.z));
+          if (PAIRS) {
+            Fp[k].w = v3(Q::rep_sum(Fp[k].w.x), Q::rep_sum(Fp[k].w.y), Q::rep_sum(Fp[k].w.z));
+            Fp[k].v = v3(Q::rep_sum(Fp[k].v.x), Q::rep_sum(Fp[k].v.y), Q::rep_sum(Fp[k].v.z));
+          }
         }
+        Frt.w = v3(Q::rep_sum(Frt.w.x), Q::rep_sum(Frt.w.y), Q::rep_sum(Frt.w.z));
+        Frt.v = v3(Q::rep_sum(Frt.v.x), Q::rep_sum(Frt.v.y), Q::rep_sum(Frt.v.z));
       }
-      Sp Fsum = sp0();
+      Sp Fsum = sp0(), Psum = sp0();
 #pragma unroll
-      for (int k = MC - 1; k >= 0; k--) { Fsum = Fsum + Fl[k]; qf_c[k] += spdot(ldS(LMm::kSc + k * 6), Fsum); }
+      for (int k = MC - 1; k >= 0; k--) {
+        Fsum = Fsum + Fl[k];
+        if (PAIRS) Psum = Psum + Fp[k];
+        qf_c[k] += spdot(ldS(LMm::kSc + k * 6), PAIRS ? Fsum + Psum : Fsum);
+      }
+      Fsum = Fsum + Frt;           // what the root dofs feel: the chain's floor contacts and the root geoms' contacts
       float gc[MC], gr_[6], g2 = 0;
 #pragma unroll
       for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; g2 = fmaf(gc[k], gc[k], g2); }
@@ -1104,6 +1556,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       else {
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
         float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21], Hrep[21];
+        float Xc[PAIRS ? MC : 1][PAIRS ? MC : 1];      // cross block H_ab of a pair of coupled chains (kept by the lower lane a)
+#pragma unroll
+        for (int i = 0; i < (PAIRS ? MC : 1); i++)
+#pragma unroll
+          for (int j = 0; j < (PAIRS ? MC : 1); j++) Xc[i][j] = 0.0f;
         // when the slots are split over the replicas, only replica 0 starts from M (+ unit-row terms); the butterfly
         // sum below then gives every replica M + all contact blocks
         const float own = (split && Q::rep() != 0) ? 0.0f : 1.0f;
@@ -1139,14 +1596,53 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
           const int link = (int)SL(s, SL_LINK);
           float Jc[6 + MC][6];
+          float Jp[PAIRS ? MC : 1][6];      // the PARTNER chain's columns of a cross-chain contact (lower lane of the pair only)
+          bool cross = false;
+          const float part = slot_sign(s);
+          if (PAIRS && part != 0.0f) {
+            // self-contact: the row space is the motion of body 2 against body 1 -> the root columns vanish, my chain's
+            // columns carry my sign, the partner chain's columns the opposite one
+            const int code = (int)fabsf(part) - 1, pl = code & 7, pc = code >> 3, dl = pc - c;
+            const float sg = (part > 0.0f) ? 1.0f : -1.0f;
+            V3 n, t1, t2;
+            slot_frame(s, n, t1, t2);
 #pragma unroll
-          for (int r = 0; r < 6; r++) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
+            for (int r = 0; r < 6; r++)
 #pragma unroll
-          for (int k = 0; k < MC; k++) {
-            if (k <= link) contact_rows(ldS(LMm::kSc + k * 6), rc, Jc[6 + k]);
-            else {
+              for (int j = 0; j < 6; j++) Jc[r][j] = 0;
 #pragma unroll
-              for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
+            for (int k = 0; k < MC; k++) {
+              if (k <= link) frame_rows(sg * ldS(LMm::kSc + k * 6), rc, n, t1, t2, Jc[6 + k]);
+              else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
+              }
+            }
+            if (pl != 7 && xmajor) {              // no exact cross block: twice my own block majorises the pair's Hessian
+#pragma unroll
+              for (int i = 0; i < 21; i++) Hc[i] *= 2.0f;
+            }
+            cross = pl != 7 && xrole == 1 && pc == xpartner;
+            if (cross) {
+#pragma unroll
+              for (int k = 0; k < MC; k++) {
+                if (k <= pl) frame_rows((-sg) * peer_twist(dl, LMm::kSc + k * 6), rc, n, t1, t2, Jp[k]);
+                else {
+#pragma unroll
+                  for (int j = 0; j < 6; j++) Jp[k][j] = 0;
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 6; r++) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
+#pragma unroll
+            for (int k = 0; k < MC; k++) {
+              if (k <= link) contact_rows(ldS(LMm::kSc + k * 6), rc, Jc[6 + k]);
+              else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
+              }
             }
           }
           if (CONE != 0 && dim > 3) {
@@ -1169,6 +1665,15 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 else if (b < 6) Hcr[a - 6][b] += d;
                 else Hcc[tri(a - 6, b - 6)] += d;
               }
+              if (PAIRS && cross && a >= 6) {
+#pragma unroll
+                for (int b = 0; b < MC; b++) {
+                  float d = 0;
+#pragma unroll
+                  for (int j = 0; j < 6; j++) d = fmaf(t[j], Jp[b][j], d);
+                  Xc[a - 6][b] += d;
+                }
+              }
             }
           } else {
 #pragma unroll
@@ -1190,10 +1695,26 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 else if (b < 6) Hcr[a - 6][b] += d;
                 else Hcc[tri(a - 6, b - 6)] += d;
               }
+              if (PAIRS && cross && a >= 6) {
+#pragma unroll
+                for (int b = 0; b < MC; b++) {
+                  float d = 0;
+#pragma unroll
+                  for (int j = 0; j < 3; j++) d = fmaf(t[j], Jp[b][j], d);
+                  Xc[a - 6][b] += d;
+                }
+              }
             }
           }
         }
+        if (PAIRS && any_pair) Q::quad_sync();
         if (split) {
+          if (PAIRS && any_pair) {
+#pragma unroll
+            for (int i = 0; i < MC; i++)
+#pragma unroll
+              for (int j = 0; j < MC; j++) Xc[i][j] = Q::rep_sum(Xc[i][j]);
+          }
 #pragma unroll
           for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Q::rep_sum(Hcc[i]);
 #pragma unroll
@@ -1211,8 +1732,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
         if (!(P.ablate & 4)) {
-          arrow_factor<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr);
-          arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+          if constexpr (PAIRS) {
+            const bool coupled = any_pair && !xmajor;
+            arrow_factor_x<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, xrole, xpartner, coupled);
+            arrow_solve_x<Q, MC>(Hcc, Hcr, Lr, Xc, xrole, xpartner, coupled, sc, sr);
+          } else {
+            arrow_factor<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr);
+            arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+          }
         }
 
         LM_TICK(6);
@@ -1235,11 +1762,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int i = 0; i < 6; i++) jv_r[i] = sr[i];
 #pragma unroll
           for (int k = 0; k < MC; k++) { jv_c[k] = sc[k]; jvlim_c[k] = lim_s_c[k] * sc[k]; }
-          if (nslot > 0) {
+          if (nslot > 0 || any_pair) {
             link_images(sr, sc);
             for (int s = 0; s < nslot; s++) {
               float jv[6];
-              contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
+              slot_rows_of_images(s, jv);
               if (PYR3((int)SL(s, SL_DIM))) {
                 float xv[4];
                 pyr_rows(jv, SL(s, SL_MU), xv);
@@ -1250,6 +1777,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
               }
             }
+            if (PAIRS && any_pair) Q::quad_sync();
           }
           Q::fence();
           float Mvr[6], Mvc[MC];
@@ -1305,6 +1833,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #ifdef LM_LS_TRACE
               if (getenv("LM_ROWS")) printf("      lane %d slot %d alpha %.6g c1 %.6g c2 %.6g\n", c, s, alpha, c1, c2);
 #endif
+              if (PAIRS) { const float wgt = slot_weight(s); c1 *= wgt; c2 *= wgt; }      // mirror slots: half each
               a1 += c1; a2 += c2; am += fabsf(c1);
             }
             d1 = g1 + alpha * q2 + Q::sum(a1 + w0 * r1);
@@ -1523,19 +2052,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #undef LK
 #undef LX
 #undef GE
+#undef GP
+#undef CU
 #undef SL
+#undef PEER
 #undef LMEM
 }
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false, bool PAIRS = false>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
                     bool want_grf = false) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
-  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
@@ -1543,7 +2075,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
-    forward<Q, MC, NS, false, CONE, 0, DR>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
+    forward<Q, MC, NS, false, CONE, 0, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
                                            want_grf && st == 3);   // the engine's data hold the 4th stage when mj_step returns
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]

@@ -2,6 +2,7 @@
 // launches of the step kernels. The kernels themselves live in lm_step.h / lm_core.h and are compiled per family in
 // lm_family.hip (one object per family and part, so the library builds in parallel).
 #include "lm_step.h"
+#include <memory>
 
 using lmk::KArgs; using lmk::Task; using lmk::DevStats; using lmk::LaunchCtx;
 
@@ -19,7 +20,9 @@ int fail(const std::string& m) { g_err = m; return 1; }
 struct lm_model {
   int device;
   float* d_cm;
+  float* d_gt;               // geom table: full records of the geoms with a collider
   float* d_mt;               // muscle table (models with muscles)
+  float* d_gpt;              // geom-pair table of the self-collision path
   std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
   int nroot;
@@ -42,6 +45,7 @@ struct lm_batch {
   hipStream_t stream;
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 5 slots, Euler, elliptic>; the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked
@@ -99,32 +103,41 @@ int lm_device_count(void) {
   return n;
 }
 
+void lm_model_destroy(lm_model* m);
+
 int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
-  if (!cmod || n < LM_HEADER_SIZE + LM_CM_SIZE) return fail("chain model too short");
+  if (!cmod || n < LM_HEADER_SIZE + LM_CM_SIZE + LM_GT_SIZE) return fail("chain model too short");
   if ((unsigned)cmod[LM_H_MAGIC] != (unsigned)LM_LMC_MAGIC) return fail("bad chain-model magic");
-  if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
+  if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE || (int)cmod[LM_H_GT_SIZE] != LM_GT_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
   if ((int)cmod[LM_H_MAXLINKS] > 5) return fail("chains longer than 5 links are not supported");
   if ((int)cmod[LM_HEADER_SIZE + LM_R_NDOF] != 6) return fail("root body must have 6 dofs");
   const int n_muscle = (int)cmod[LM_H_NMUSCLE];
   if (n_muscle < 0 || n_muscle > LM_MT_MAXMUS) return fail("bad muscle count");
-  if (n_muscle > 0 && n < (size_t)(LM_HEADER_SIZE + LM_CM_SIZE + LM_MT_SIZE)) return fail("chain model lacks the muscle table");
+  if (n_muscle > 0 && n < (size_t)(LM_HEADER_SIZE + LM_CM_SIZE + LM_GT_SIZE + LM_MT_SIZE)) return fail("chain model lacks the muscle table");
   if (n_muscle > 0 && (int)cmod[LM_H_INTEGRATOR] != LM_INT_EULER) return fail("muscles need the Euler integrator");
   HIPCHK(hipSetDevice(device));
-  lm_model* m = new lm_model();
+  std::unique_ptr<lm_model, void (*)(lm_model*)> guard(new lm_model(), lm_model_destroy);      // freed on every error path
+  lm_model* m = guard.get();
   m->device = device;
   std::vector<float> cm(LM_CM_SIZE);
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)cmod[LM_HEADER_SIZE + i];
   for (int i = 0; i < 6; i++) {
     const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
-    if (blk[LM_D_LIMITED] != 0.0f) { delete m; return fail("limited root joints are not supported"); }
+    if (blk[LM_D_LIMITED] != 0.0f) { return fail("limited root joints are not supported"); }
   }
   HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
   HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));
+  {
+    std::vector<float> gt(LM_GT_SIZE);
+    for (int i = 0; i < LM_GT_SIZE; i++) gt[i] = (float)cmod[LM_HEADER_SIZE + LM_CM_SIZE + i];
+    HIPCHK(hipMalloc(&m->d_gt, sizeof(float) * LM_GT_SIZE));
+    HIPCHK(hipMemcpy(m->d_gt, gt.data(), sizeof(float) * LM_GT_SIZE, hipMemcpyHostToDevice));
+  }
   m->d_mt = nullptr;
   if (n_muscle > 0) {
     std::vector<float> mt(LM_MT_SIZE);
-    for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)cmod[LM_HEADER_SIZE + LM_CM_SIZE + i];
-    for (int c = 0; c < LM_NCHAIN; c++) if ((int)mt[LM_NCHAIN + c] > LM_MAXMUS) { delete m; return fail("too many muscles on one chain"); }
+    for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)cmod[LM_HEADER_SIZE + LM_CM_SIZE + LM_GT_SIZE + i];
+    for (int c = 0; c < LM_NCHAIN; c++) if ((int)mt[LM_NCHAIN + c] > LM_MAXMUS) { return fail("too many muscles on one chain"); }
     HIPCHK(hipMalloc(&m->d_mt, sizeof(float) * LM_MT_SIZE));
     HIPCHK(hipMemcpy(m->d_mt, mt.data(), sizeof(float) * LM_MT_SIZE, hipMemcpyHostToDevice));
   }
@@ -153,12 +166,12 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     T.all_pyr3 = (int)cmod[LM_H_CONE] == LM_CONE_PYRAMIDAL;
     for (int c = 0; c < LM_NCHAIN && T.all_pyr3; c++) {
       const int ng = (int)cmod[LM_HEADER_SIZE + LM_CM_CHAINS + LM_C_NGEOMS * LM_NCHAIN + c];
-      for (int g = 0; g < ng; g++) if ((int)cmod[LM_HEADER_SIZE + LM_CM_CHAINS + (LM_C_GEOMS + g * LM_G_SIZE + LM_G_DIM) * LM_NCHAIN + c] != 3) T.all_pyr3 = 0;
+      for (int g = 0; g < ng; g++) if ((int)cmod[LM_HEADER_SIZE + LM_CM_SIZE + (g * LM_G_SIZE + LM_G_DIM) * LM_NCHAIN + c] != 3) T.all_pyr3 = 0;
     }
   }
   T.cm_used = ((int)cmod[LM_H_CM_USED] + 63) & ~63;          // keeps lane memory 256-byte aligned behind the table
-  if (T.cm_used <= 0 || T.cm_used > ((LM_CM_SIZE + 63) & ~63)) { delete m; return fail("bad constant-table extent"); }
-  if (T.ngoal > 4) { delete m; return fail("more than 4 goal entries"); }
+  if (T.cm_used <= 0 || T.cm_used > ((LM_CM_SIZE + 63) & ~63)) { return fail("bad constant-table extent"); }
+  if (T.ngoal > 4) { return fail("more than 4 goal entries"); }
   for (int i = 0; i < 8; i++) T.rp[i] = (float)cmod[LM_H_REWARD_P0 + i];
   lm::Params& P = m->P;
   P.h = (float)cmod[LM_H_TIMESTEP];
@@ -168,6 +181,18 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.nv = T.nv;
   P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE]; P.act_position = (int)cmod[LM_H_ACTMODE];
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
+  P.off_runsup = (int)cmod[LM_H_OFF_RUNSUP]; P.off_cunsup = (int)cmod[LM_H_OFF_CUNSUP]; P.off_prune = (int)cmod[LM_H_OFF_PRUNE];
+  P.gt = m->d_gt;
+  P.off_lgroup = (int)cmod[LM_H_OFF_LGROUP]; P.off_lpair = (int)cmod[LM_H_OFF_LPAIR];
+  {
+    const size_t ngp = (size_t)cmod[LM_H_NGPAIR], off = (size_t)cmod[LM_H_OFF_GPT];
+    if (ngp > 0 && n < off + ngp * LM_GPAIR_SIZE) return fail("chain model lacks the geom-pair table");
+    std::vector<float> gpt(ngp * LM_GPAIR_SIZE + 1, 0.0f);
+    for (size_t i = 0; i < ngp * LM_GPAIR_SIZE; i++) gpt[i] = (float)cmod[off + i];
+    HIPCHK(hipMalloc(&m->d_gpt, sizeof(float) * gpt.size()));
+    HIPCHK(hipMemcpy(m->d_gpt, gpt.data(), sizeof(float) * gpt.size(), hipMemcpyHostToDevice));
+    P.gpt = m->d_gpt;
+  }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
@@ -176,13 +201,15 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   if (const char* v = getenv("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes
   if (const char* v = getenv("LM_LS_TOL")) P.ls_tol = (float)atof(v);
   if (const char* v = getenv("LM_LS_ITERS")) P.ls_iters = atoi(v);
-  *out = m;
+  *out = guard.release();
   return 0;
 }
 
 void lm_model_destroy(lm_model* m) {
   if (!m) return;
-  (void)hipFree(m->d_cm);
+  if (m->d_cm) (void)hipFree(m->d_cm);
+  if (m->d_gt) (void)hipFree(m->d_gt);
+  if (m->d_gpt) (void)hipFree(m->d_gpt);
   if (m->d_mt) (void)hipFree(m->d_mt);
   delete m;
 }
@@ -193,31 +220,17 @@ int lm_model_dims(const lm_model* m, lm_dims* out) {
   return 0;
 }
 
-int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
-  if (n_envs <= 0) return fail("n_envs must be positive");
-  HIPCHK(hipSetDevice(m->device));
-  lm_batch* b = new lm_batch();
-  memset(b, 0, sizeof(*b));
-  b->m = m; b->N = n_envs;
-  // Four environments per workgroup: with the replicated layout that is one full wave (4 envs x 4 replicas x 4 chains),
-  // and a CU's 160 KB of LDS holds four such workgroups = one wave per SIMD. Larger batches simply run more workgroups
-  // back to back (measured: 4096 envs 1.32 ms, 16384 envs 4.0 ms, 65536 envs 13.8 ms per control step for UnitreeA1;
-  // wider workgroups without replicas were 30-50 % slower at every size). LM_ENVS_PER_BLOCK overrides.
-  {
-    int epb = n_envs < 4 ? n_envs : 4;
-    const char* ov = getenv("LM_ENVS_PER_BLOCK");
-    if (ov && atoi(ov) >= 1 && atoi(ov) <= 16) epb = atoi(ov);
-    b->epb = epb;
-  }
-  const int N = n_envs, nv = m->T.nv;
+void lm_batch_destroy(lm_batch* b);
+
+static int batch_alloc(lm_batch* b) {
+  lm_model* m = b->m;
+  const int N = b->N, nv = m->T.nv;
   HIPCHK(hipMalloc(&b->qpos, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->qvel, sizeof(float) * nv * N));
   HIPCHK(hipMalloc(&b->warm, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->goal, sizeof(float) * 4 * N));
   HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
   HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
-  b->act = nullptr; b->dofprm = nullptr; b->drspec = nullptr;
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
-  b->nblocks = (n_envs + b->epb - 1) / b->epb;
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
@@ -225,7 +238,27 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
   HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * 16)); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * 16));
   HIPCHK(hipStreamCreate(&b->stream));
-  HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
+  HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); HIPCHK(hipEventCreateWithFlags(&b->ev_ext, hipEventDisableTiming));
+  return 0;
+}
+
+int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
+  if (n_envs <= 0) return fail("n_envs must be positive");
+  HIPCHK(hipSetDevice(m->device));
+  lm_batch* b = new lm_batch();
+  memset(b, 0, sizeof(*b));
+  b->m = m; b->N = n_envs;
+  // Four environments per workgroup: with the replicated layout that is one full wave (4 envs x 4 replicas x 4 chains).
+  // Larger batches simply run more workgroups back to back (wider workgroups without replicas were 30-50 % slower at
+  // every size, profiles/r1_ab_probes.md). LM_ENVS_PER_BLOCK overrides.
+  {
+    int epb = n_envs < 4 ? n_envs : 4;
+    const char* ov = getenv("LM_ENVS_PER_BLOCK");
+    if (ov && atoi(ov) >= 1 && atoi(ov) <= 16) epb = atoi(ov);
+    b->epb = epb;
+  }
+  b->nblocks = (n_envs + b->epb - 1) / b->epb;
+  if (batch_alloc(b)) { lm_batch_destroy(b); return 1; }     // g_err holds the failed call; nothing leaks
   *out = b;
   return 0;
 }
@@ -233,10 +266,14 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
 void lm_batch_destroy(lm_batch* b) {
   if (!b) return;
   hipSetDevice(b->m->device);
-  hipStreamSynchronize(b->stream);
-  (void)hipFree(b->qpos); (void)hipFree(b->qvel); (void)hipFree(b->warm); (void)hipFree(b->goal); (void)hipFree(b->action); (void)hipFree(b->obs);
-  (void)hipFree(b->reward); (void)hipFree(b->done); (void)hipFree(b->ep_step); (void)hipFree(b->ep_count); (void)hipFree(b->stats); (void)hipFree(b->table); if (b->act) (void)hipFree(b->act); if (b->dofprm) (void)hipFree(b->dofprm); if (b->drspec) (void)hipFree(b->drspec);
-  (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); (void)hipStreamDestroy(b->stream);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->ep_step, b->ep_count, b->stats,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers};
+  for (void* p : bufs) if (p) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev_ext) (void)hipEventDestroy(b->ev_ext);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
 
@@ -396,6 +433,7 @@ static int drain_stats(lm_batch* b) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
     b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
     b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals; b->acc.linesearch_capped += x.ls_capped; b->acc.steps_with_8plus_iters += x.it_ge8;
+    b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon;
   }
   return 0;
 }
@@ -424,12 +462,17 @@ int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_re
   if (d_action) { a.action = d_action; a.action_mode = 0; } else a.action_mode = 1;
   a.obs = d_obs ? d_obs : b->obs; a.reward = d_reward ? d_reward : b->reward; a.done = d_done ? d_done : b->done;
   hipStream_t own = b->stream;
-  if (stream) b->stream = (hipStream_t)stream;          // run on the caller's stream (e.g. torch's current stream)
+  hipStream_t used = stream ? (hipStream_t)stream : own;       // the caller's stream (e.g. torch's current stream)
+  // a launch on a foreign stream is ordered on BOTH sides against the library's own stream: it waits for what the
+  // library has queued (state uploads, earlier steps), and whatever the library queues next (lm_get_state, lm_get_stats,
+  // lm_rollout ...) waits for it
+  if (used != own) { HIPCHK(hipEventRecord(b->ev_ext, own)); HIPCHK(hipStreamWaitEvent(used, b->ev_ext, 0)); }
+  b->stream = used;
   launch_step(b, a);
-  hipStream_t used = b->stream;
   b->stream = own;
   if (g_launch_err) return fail(g_launch_err);
   HIPCHK(hipGetLastError());
+  if (used != own) { HIPCHK(hipEventRecord(b->ev_ext, used)); HIPCHK(hipStreamWaitEvent(own, b->ev_ext, 0)); }
   b->step_index++;
   if (sync) HIPCHK(hipStreamSynchronize(used));
   return 0;

@@ -62,6 +62,15 @@ struct QuadDppT {
 #endif
   }
   static __device__ __forceinline__ bool any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+  // the four lanes of a quad (self-collisions between two chains): the partner lane's column of lane memory is `dl` floats
+  // away ([field][16 lanes] groups); a value of a named lane of the quad; and the point where lane memory written by the
+  // quad's other lanes becomes readable — lock step and the in-order LDS make that a compiler-only fence, like fence()
+  static __device__ __forceinline__ float peer(const LM_LMEM_T* lmem, int ls, int i, int dl) { return lmem[i * ls + dl]; }
+  static __device__ __forceinline__ float quad_read(float x, int src) {
+    const int lane = (int)((__lane_id() & ~3u) | (unsigned)src);
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(x)));
+  }
+  static __device__ __forceinline__ void quad_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   // replicas hand records to each other through the lane memory they share (contact slots, row states). The lanes of
   // a wave run in lock step and the LDS executes a wave's instructions in order, so no hardware wait is needed, but
   // the COMPILER must not move or forward lane-memory accesses across the hand-over point.
@@ -76,7 +85,7 @@ struct Task {
   float rp[8];
 };
 
-struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, pad0, pad1; };
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, selfprox, selfcon; };
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
@@ -112,7 +121,7 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1, bool FUSED = false>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1, bool FUSED = false, bool PAIRS = false>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {};
-  using LMm = lm::LaneMem<MC, NS, NM>;
+  using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
   const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
   LM_LMEM_T* lmem = lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
   constexpr int ls = 16;
@@ -248,13 +257,13 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   if (FORWARD_ONLY) {
     if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
-    lm::forward<QuadDpp, MC, NS, false, -1, NM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
+    lm::forward<QuadDpp, MC, NS, false, -1, NM, false, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
     int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
 
   QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
 
@@ -276,8 +285,12 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   const bool trunc = a.horizon > 0 && step_no >= a.horizon;
   float episodes = 0.0f;
   bool zero_act = false;                     // a restarted episode starts with zero muscle activation (mj_resetData)
+  // done byte: bit 0 = absorbing state; bit 1 = the episode ended in this step on the device's side (restarted from the
+  // reset table — the observation written below is then the first of the NEW episode — or the horizon was reached)
+  const unsigned char done_byte = (unsigned char)((absorbing ? 1 : 0) | ((trunc || (absorbing && a.auto_reset && a.table_rows > 0)) ? 2 : 0));
   if (absorbing || trunc) {
-    episodes = 1.0f;
+    // without device-side restarts an episode that runs past its horizon (or stays absorbed) is counted once
+    episodes = (a.auto_reset && a.table_rows > 0) || step_no == a.horizon || (absorbing && !trunc) ? 1.0f : 0.0f;
     if (a.auto_reset && a.table_rows > 0) {
       // restart from a trajectory sample (reference trajectory.py:236-273 + base.py:478-497), counter-based RNG
       unsigned ec = a.ep_count[e] + 1;
@@ -306,9 +319,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
           float v;
           if (kind == 2) v = sp[1] + (sp[2] - sp[1]) * u1;                          // U(a, b)
           else {
-            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);        // N(a, b), kind 1 clipped at 0
-            v = fmaf(sp[2], z, sp[1]);
-            if (kind == 1) v = fmaxf(v, 0.0f);
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);        // N(a, b)
+            v = fmaxf(fmaf(sp[2], z, sp[1]), 0.0f);      // both normal kinds are clipped at 0 (a joint parameter cannot be negative)
           }
           a.dofprm[((long long)p * nv + dof) * N + e] = v;
         };
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     for (int i = 0; i < 6; i++) { a.qpos[dr[i] * N + e] = qr[i]; a.qvel[dr[i] * N + e] = vr[i]; a.warm[dr[i] * N + e] = war[i]; }
     a.ep_step[e] = step_no;
     if (a.reward) a.reward[e] = reward;
-    if (a.done) a.done[e] = absorbing ? 1 : 0;
+    if (a.done) a.done[e] = done_byte;
   }
 #pragma unroll
   for (int k = 0; k < MC; k++) if (k < nl) { a.qpos[dc[k] * N + e] = qc[k]; a.qvel[dc[k] * N + e] = vc[k]; a.warm[dc[k] * N + e] = wac[k]; }
@@ -376,6 +388,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       }
       if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
+      if (PAIRS && cnt.selfprox) atomicAdd(&blk_stats[10], (float)cnt.selfprox);
+      if (PAIRS && cnt.selfcon) atomicAdd(&blk_stats[11], (float)cnt.selfcon);
     }
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
@@ -410,21 +424,21 @@ static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, cons
 }
 
 // one robot family = (links per chain MC, contact slots per chain NS, integrator, compiled-in cone, muscles per chain NM)
-template <int MC, int NS, bool RK4, int CONE, int NM, int PART>
+template <int MC, int NS, bool RK4, int CONE, int NM, int PART, bool PAIRS = false>
 static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const dim3 grid((L.N + L.epb - 1) / L.epb);
-  using LMm = lm::LaneMem<MC, NS, NM>;
+  using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
-  if (PART == 0) {
-    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1>, grid, dim3(4 * L.epb), plain, L, a);
-    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1>, grid, dim3(4 * L.epb), plain, L, a);
+  if constexpr (PART == 0) {
+    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
     else return false;
   } else {
-    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1>, grid, dim3(4 * L.epb), plain, L, a);
-    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, true>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, true>, grid, dim3(16 * L.epb), rep, L, a);
+    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
     else return false;
   }
   return true;

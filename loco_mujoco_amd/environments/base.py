@@ -393,14 +393,36 @@ class LocoEnv:
         perm = self._obs_perm()
         if perm is not None:
             obs = obs[:, perm]
-        if self._reward_function.device_spec() is None:
-            reward = np.asarray(self.reward(prev_obs, a, obs, done), dtype=np.float64) * np.ones(self.n_envs)
+        if self._reward_device_spec() is None:
+            # host-side functors (custom callbacks, ...) see what the reference's see (mushroom-rl MuJoCo.step ->
+            # reward(cur_obs, action, obs, absorbing)): ONE environment's 1-D state and the UN-normalised action of
+            # _preprocess_action (base.py:606-621), environment by environment
+            ctrl = self._preprocess_action(a)
+            reward = np.array([float(self.reward(prev_obs[e], ctrl[e], obs[e], bool(done[e]))) for e in range(self.n_envs)], dtype=np.float64)
         else:
             reward = rew32.astype(np.float64)
         self._obs = obs
+        # episode boundaries the DEVICE crossed in this step (auto reset: the observation already belongs to the new
+        # episode; horizon reached): reported so that a learner does not bootstrap across them. Empty like the
+        # reference's info dict otherwise.
+        restarted = self._restarted_flags()
+        info = {} if restarted is None or not restarted.any() else {"episode_restarted": restarted if self.n_envs > 1 else bool(restarted[0])}
         if self.n_envs == 1:
-            return obs[0].copy(), float(reward[0]), bool(done[0]), {}
-        return obs.copy(), reward, done, {}
+            return obs[0].copy(), float(reward[0]), bool(done[0]), info
+        return obs.copy(), reward, done, info
+
+    def _restarted_flags(self):
+        """bit 1 of the device's done byte per environment (episode restarted / horizon reached in the last step)."""
+        if self._blocks:
+            flags = []
+            for idx in range(self._n_models):
+                self._select_model(idx)
+                f = getattr(self.backend, "last_restarted", None)
+                if f is None:
+                    return None
+                flags.append(f)
+            return np.concatenate(flags)
+        return getattr(self.backend, "last_restarted", None)
 
     def _upload_state(self):
         qpos = np.stack([h.qpos for h in self._host])
@@ -564,12 +586,28 @@ class LocoEnv:
         grf_groups = [list(self._collision_groups[g]) for g in self._grf_group_names()] if self._use_foot_forces else []
         nobs = len(qpos_idx) + len(qvel_idx) + n_goal + 3 * len(grf_groups)
         assert nobs == self.info.observation_space.shape[0], "device observation layout does not match the space"
-        spec = self._reward_function.device_spec()
+        spec = self._reward_device_spec(nobs, 3 * len(grf_groups))
         rtype, rparams = spec if spec is not None else (0, [])
         term = self._termination_spec() if self._use_absorbing_states else []
         return dict(nobs=nobs, qpos_obs_idx=qpos_idx, qvel_obs_idx=qvel_idx, n_goal=n_goal, grf_groups=grf_groups,
                     act_ctrl_idx=self._action_indices, act_mean=self.norm_act_mean, act_delta=self.norm_act_delta,
                     term=term, reward_type=rtype, reward_params=rparams, n_substeps=self._n_substeps)
+
+    def _reward_device_spec(self, nobs=None, n_grf=None):
+        """The reward functor's device form, or None when it has to run on the host. With ``use_foot_forces`` the foot
+        forces END the observation, so the reference's negative indices (UnitreeA1's velocity-vector reward reads
+        ``state[-3:]``, ``unitreeA1.py:491-497``) land on foot-force entries: that quirk is reproduced by evaluating the
+        functor on the host — the kernel's reward only reads joint and goal entries."""
+        spec = self._reward_function.device_spec()
+        if spec is None:
+            return None
+        if nobs is None:
+            nobs = self.info.observation_space.shape[0]
+            n_grf = self._get_grf_size() if self._use_foot_forces else 0
+        idx = {1: spec[1][:1], 2: spec[1][:5]}.get(spec[0], [])
+        if n_grf and any(int(i) % nobs >= nobs - n_grf for i in idx):
+            return None
+        return spec
 
     def _chain_model(self):
         from ..lowering import lower

@@ -29,7 +29,7 @@ from . import mjcf
 MAXC = 5          # links per chain the table has room for
 NCHAIN = 4
 NROOT = 6
-MAXG = 12         # floor-collidable geoms per chain (with / without a device collider, each)
+MAXG = 40         # floor-collidable geoms per chain (with / without a device collider, each)
 MAXRG = 80        # geoms welded to the root (no device collider: proximity is counted)
 
 # ---- per-dof parameter block (used for root dofs and chain links)
@@ -40,7 +40,8 @@ MAXRG = 80        # geoms welded to the root (no device collider: proximity is c
 # D_FLO / D_FHI: force range of a position servo (H_ACTMODE = 1: torque = clamp(D_GEAR * (ctrl - q), D_FLO, D_FHI))
 # ---- per-link extras (chain links only), after the dof block
 (L_HAS_T, L_TX, L_TY, L_TZ, L_R0, L_R1, L_R2, L_R3, L_R4, L_R5, L_R6, L_R7, L_R8, L_MASS, L_CX, L_CY, L_CZ,
- L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_SIZE) = range(24)
+ L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_BSX, L_BSY, L_BSZ, L_SIZE) = range(27)
+# L_BS*: centre of the link's bounding sphere in the link frame (self-collision broad phase)
 LINK_SIZE = D_SIZE + L_SIZE
 # ---- per-geom block
 (G_LINK, G_TYPE, G_PX, G_PY, G_PZ, G_AX, G_AY, G_AZ, G_RADIUS, G_HALF, G_RBOUND, G_MARGIN, G_K, G_B, G_S0, G_S1,
@@ -48,24 +49,41 @@ LINK_SIZE = D_SIZE + L_SIZE
  G_SX, G_SY, G_SZ, G_R0, G_R1, G_R2, G_R3, G_R4, G_R5, G_R6, G_R7, G_R8, G_GRF, G_SIZE) = range(46)
 # G_GRF: ground-reaction-force group of this geom within its chain (0/1), -1 = not reported
 # G_TRAN: elliptic: tran (R_normal = (1-imp)/imp * tran); pyramidal: 2 mu^2 (1+mu^2) tran (shared R of all edges)
-# ---- chain block = [nlinks, ngeoms, unsupported geoms (count), links..., geoms...]
-C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_LINKS = 0, 1, 2, 3, 4, 6
+# ---- chain block (LDS, interleaved [field][chain]) = [nlinks, ngeoms, unsupported geoms (count), force-group slots, links...]
+C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_LINKS = 0, 1, 2, 3, 4, 5, 6, 7
+# C_NLPAIR: link-pair entries of the self-collision broad phase that involve this chain
 # C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
-U_SIZE = 6
-C_UNSUP = C_LINKS + MAXC * LINK_SIZE               # unsupported geoms: (link, px,py,pz, rbound, margin) x MAXG
-C_GEOMS = C_UNSUP + MAXG * U_SIZE                  # geoms LAST: a model with few geoms only ships the used part to LDS
-CHAIN_SIZE = C_GEOMS + MAXG * G_SIZE
+CHAIN_SIZE = C_LINKS + MAXC * LINK_SIZE
+U_SIZE = 6        # collider-less ("unsupported") geom: (link, px,py,pz, rbound, margin)
+P_SIZE = 5        # prune record of a geom with a collider: (link, px,py,pz, rbound) — the full record is in the geom table
+LG_SIZE = 7       # geoms of one link as a group: (link, first geom, count, bounding sphere cx,cy,cz, r); link -1 = root body
+MAXLG = MAXC + 1
 # ---- root block (replicated for all lanes)
 (R_NDOF, R_TX, R_TY, R_TZ, R_R0, R_R1, R_R2, R_R3, R_R4, R_R5, R_R6, R_R7, R_R8, R_MASS, R_CX, R_CY, R_CZ, R_IXX,
- R_IYY, R_IZZ, R_IXY, R_IXZ, R_IYZ, R_NUNSUP, R_DOFS) = range(25)
-R_UNSUP = R_DOFS + NROOT * D_SIZE
-ROOT_SIZE = R_UNSUP + MAXRG * U_SIZE
-# ---- whole table: root block, then the chain blocks interleaved [field][chain]
+ R_IYY, R_IZZ, R_IXY, R_IXZ, R_IYZ, R_NUNSUP, R_BSX, R_BSY, R_BSZ, R_DOFS) = range(28)
+ROOT_SIZE = R_DOFS + NROOT * D_SIZE
+# ---- the LDS constant table: root block, the chain blocks interleaved [field][chain], then a TAIL whose offsets are
+# header fields (H_OFF_*): it starts right behind the last link slot the model uses, so a robot with 3-link chains and a
+# few geoms ships a short table: [root unsupported geoms x U_SIZE][chain unsupported geoms, interleaved][prune records]
 CM_ROOT = 0
 CM_CHAINS = ROOT_SIZE
-CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN
+# ---- self-collisions (kernels compiled with PAIRS): per lane a list of link pairs (LP_SIZE floats each, interleaved
+# [entry][field][chain] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane + 256 * (own link
+# is the pair's SECOND link), range = first geom pair + 4096 * number of geom pairs, squared reach of the two bounding spheres
+MAXLP = 48
+LP_SIZE = 3
+# geom-pair records (global memory): kind (0 sphere/capsule pair with a collider, 1 counted only: bounding capsules of a box /
+# cylinder pair), geom 1 on the pair's second link?, geom 1 / geom 2 as capsules in their link frames (centre, axis, half length,
+# radius), then the contact parameters after the engine's mixing rules
+(GP_KIND, GP_G1Q, GP_P1, GP_P1Y, GP_P1Z, GP_A1, GP_A1Y, GP_A1Z, GP_H1, GP_R1, GP_P2, GP_P2Y, GP_P2Z, GP_A2, GP_A2Y, GP_A2Z, GP_H2,
+ GP_R2, GP_MARGIN, GP_K, GP_B, GP_S0, GP_S1, GP_S2, GP_S3, GP_S4, GP_TRAN, GP_DIM, GP_MU, GP_F0, GP_F1, GP_F2, GP_F3, GP_F4,
+ GP_RR1, GP_RR2, GP_RR3, GP_RR4, GP_RR5, GPAIR_SIZE) = range(40)
+CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN + MAXRG * U_SIZE + MAXG * (U_SIZE + P_SIZE) * NCHAIN + MAXLG * LG_SIZE * NCHAIN + MAXLP * LP_SIZE * NCHAIN
+# ---- the geom table (global memory, read when a geom's bounding sphere reaches the floor): full records interleaved
+# [geom][field][chain]
+GT_SIZE = MAXG * G_SIZE * NCHAIN
 
-GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX)
+GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX, mjcf.GEOM_CYLINDER)
 MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
 
 
@@ -108,13 +126,16 @@ def _mix_with_floor(m, g, gf):
     return int(dim), np.asarray(solref, float), np.asarray(solimp, float), friction, margin, gap
 
 
-HEADER_SIZE = 40
-LMC_MAGIC = 0x4C4D4331  # "LMC1"
+HEADER_SIZE = 48
+LMC_MAGIC = 0x4C4D4332  # "LMC2"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
 H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED, H_ACTMODE = 25, 26, 27, 28, 29, 30, 31, 32, 33
+H_OFF_RUNSUP, H_OFF_CUNSUP, H_OFF_PRUNE, H_GT_SIZE, H_OFF_LPAIR, H_NGPAIR, H_OFF_GPT, H_OFF_LGROUP = 34, 35, 36, 37, 38, 39, 40, 41
+# H_NGPAIR geom-pair records start H_OFF_GPT floats into the chain-model array (behind the geom table and the muscle table)
+# H_OFF_*: offsets (floats from the start of the constant table) of the tail lists, see CM_SIZE
 # H_ACTMODE: 0 = joint motors (torque = gear * ctrl), 1 = position servos on every actuated joint
-# H_CM_USED: floats of the constant table that are actually read (up to the last used geom block)
+# H_CM_USED: floats of the constant table that are actually read (through the tail lists)
 # H_NGRF: number of ground-reaction-force observation entries (3 per force group); they follow the goal entries
 
 # ---- muscle table (optional; follows the constant table): MT_HEAD floats [first muscle of chain c] x NCHAIN,
@@ -177,13 +198,16 @@ def lower(m, task):
         obs_src[i] = ("q", d)
     for d, i in vobs.items():
         obs_src[i] = ("v", d)
+    n_grf_obs = 3 * len(task.get("grf_groups") or [])        # foot forces end the observation, the goal sits before them
     for i in range(task["n_goal"]):
-        obs_src[task["nobs"] - task["n_goal"] + i] = ("g", i)
+        obs_src[task["nobs"] - n_grf_obs - task["n_goal"] + i] = ("g", i)
+    for i in range(n_grf_obs):
+        obs_src[task["nobs"] - n_grf_obs + i] = ("f", i)
     term_q, term_v = {}, {}
     for idx, lo, hi in task["term"]:
         kind, d = obs_src[int(idx)]
-        if kind == "g":
-            raise UnsupportedModel("termination on a goal entry")
+        if kind in ("g", "f"):
+            raise UnsupportedModel("termination on a goal / foot-force entry")
         (term_q if kind == "q" else term_v)[d] = (max(lo, -3e38), min(hi, 3e38))
     nb = m.nbody
     jointed = [b for b in range(1, nb) if m.body_jntnum[b] > 0]
@@ -357,7 +381,7 @@ def lower(m, task):
             blk[G_AX:G_AX + 3] = grot[:, 2]
             blk[G_SX:G_SX + 3] = size
             blk[G_R0:G_R0 + 9] = grot.reshape(9)
-            blk[G_RADIUS], blk[G_HALF], blk[G_RBOUND], blk[G_MARGIN] = size[0], (size[1] if t == mjcf.GEOM_CAPSULE else 0), rbound, margin
+            blk[G_RADIUS], blk[G_HALF], blk[G_RBOUND], blk[G_MARGIN] = size[0], (size[1] if t in (mjcf.GEOM_CAPSULE, mjcf.GEOM_CYLINDER) else 0), rbound, margin
             blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
             blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
             tran = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
@@ -401,17 +425,18 @@ def lower(m, task):
     sup, unsup = geom_blocks(root, 0)
     if any(sb[G_GRF] >= 0 for sb in sup):
         raise UnsupportedModel("foot-force group on the root body")
-    unsup += [[0, s[G_PX], s[G_PY], s[G_PZ], s[G_RBOUND], s[G_MARGIN]] for s in sup]   # root geoms: no device collider
-    unsup = _merge_proximity_spheres(unsup, MAXRG)
-    rb[R_NUNSUP] = len(unsup)
-    for i, u in enumerate(unsup):
-        rb[R_UNSUP + i * U_SIZE:R_UNSUP + (i + 1) * U_SIZE] = u
+    root_geoms = sup                   # colliders of the root body: dealt to the chains' lanes below (link -1)
+    for gb in root_geoms:
+        gb[G_LINK] = -1
+    root_unsup = unsup                 # + colliders that find no geom slot (below); merged when the tail is written
+    gt = np.zeros(GT_SIZE, dtype=np.float64)
+    chain_unsup, chain_prune, chain_groups_tab = [[] for _ in range(NCHAIN)], [[] for _ in range(NCHAIN)], [[] for _ in range(NCHAIN)]
 
     # ---- chains, interleaved [field][chain]
     for c in range(NCHAIN):                      # unused lanes report no foot force
         cm[CM_CHAINS + C_GRF_OBS0 * NCHAIN + c] = cm[CM_CHAINS + C_GRF_OBS1 * NCHAIN + c] = -1
     max_links = 0
-    max_contacts = 0
+    standing = []
     for c, chain in enumerate(chains):
         blk = np.zeros(CHAIN_SIZE)
         links = []
@@ -445,6 +470,7 @@ def lower(m, task):
                 s, u = geom_blocks(b, li)
                 geoms += s
                 unsup += u
+        geoms += root_geoms[c::len(chains)]          # this lane's share of the root body's colliders (after the chain's own)
         blk[C_GRF_OBS0] = blk[C_GRF_OBS1] = -1
         chain_groups = sorted(set(int(gb[G_GRF]) for gb in geoms if gb[G_GRF] >= 0))
         if len(chain_groups) > 2:
@@ -454,18 +480,44 @@ def lower(m, task):
         for gb in geoms:
             gb[G_GRF] = chain_groups.index(int(gb[G_GRF])) if gb[G_GRF] >= 0 else -1
         if len(geoms) > MAXG:
-            # more colliders than geom slots (Atlas' upper body with its welded arms): the surplus, in model order,
-            # becomes proximity-only (bounding sphere, counted in `unhandled_geoms` when it reaches the floor)
+            # more colliders than geom slots: the surplus, in model order, becomes proximity-only (bounding sphere,
+            # counted in `unhandled_geoms` when it reaches the floor)
             info.setdefault("demoted_geoms", []).append((c, len(geoms) - MAXG))
-            unsup += [[gb[G_LINK], gb[G_PX], gb[G_PY], gb[G_PZ], gb[G_RBOUND], gb[G_MARGIN]] for gb in geoms[MAXG:]]
+            unsup += [[gb[G_LINK], gb[G_PX], gb[G_PY], gb[G_PZ], gb[G_RBOUND], gb[G_MARGIN]] for gb in geoms[MAXG:] if gb[G_LINK] >= 0]
+            root_unsup += [[0, gb[G_PX], gb[G_PY], gb[G_PZ], gb[G_RBOUND], gb[G_MARGIN]] for gb in geoms[MAXG:] if gb[G_LINK] < 0]
             geoms = geoms[:MAXG]
         unsup = _merge_proximity_spheres(unsup, MAXG)
         blk[C_NGEOMS], blk[C_NUNSUP] = len(geoms), len(unsup)
-        max_contacts = max(max_contacts, sum({mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4}[int(gb[G_TYPE])] for gb in geoms))
+        # contact slots the chain needs in regular operation: what the geoms that stand on the floor in the reference pose
+        # (qpos0; bottom of the bounding sphere within 3 cm of the lowest one of the model) can produce. Geoms further up
+        # only reach the floor once the robot has fallen; contacts beyond the kernel's slots are dropped and counted in
+        # `overflow_contacts`
+        for gb in geoms:
+            cap = {mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4, mjcf.GEOM_CYLINDER: 4}[int(gb[G_TYPE])]
+            b = links[int(gb[G_LINK])][0] if gb[G_LINK] >= 0 else root
+            rot = kin["xmat"][b] @ gb[G_R0:G_R0 + 9].reshape(3, 3)            # geom axes in the world at qpos0
+            t, size = int(gb[G_TYPE]), gb[G_SX:G_SX + 3]
+            reach = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1] * abs(rot[2, 2]),
+                     mjcf.GEOM_CYLINDER: size[1] * abs(rot[2, 2]) + size[0] * np.sqrt(max(0.0, 1 - rot[2, 2] ** 2)),
+                     mjcf.GEOM_BOX: float(np.abs(rot[2]) @ size)}[t]
+            bottom = (kin["xpos"][b] + kin["xmat"][b] @ gb[G_PX:G_PX + 3])[2] - reach
+            standing.append((c, bottom, cap))
         for i, gblk in enumerate(geoms):
-            blk[C_GEOMS + i * G_SIZE:C_GEOMS + (i + 1) * G_SIZE] = gblk
-        for i, u in enumerate(unsup):
-            blk[C_UNSUP + i * U_SIZE:C_UNSUP + (i + 1) * U_SIZE] = u
+            gt[(i * G_SIZE + np.arange(G_SIZE)) * NCHAIN + c] = gblk
+            chain_prune[c].append([gblk[G_LINK], gblk[G_PX], gblk[G_PY], gblk[G_PZ], gblk[G_RBOUND]])
+        # the geoms of one link form a group with a bounding sphere: a link far above the floor costs one test per pass
+        i = 0
+        while i < len(geoms):
+            j = i
+            while j < len(geoms) and geoms[j][G_LINK] == geoms[i][G_LINK]:
+                j += 1
+            ctr = np.mean([gb[G_PX:G_PX + 3] for gb in geoms[i:j]], axis=0)
+            rad = max(np.linalg.norm(gb[G_PX:G_PX + 3] - ctr) + gb[G_RBOUND] for gb in geoms[i:j])
+            chain_groups_tab[c].append([geoms[i][G_LINK], i, j - i, ctr[0], ctr[1], ctr[2], rad])
+            i = j
+        assert len(chain_groups_tab[c]) <= MAXLG
+        blk[C_NLGROUP] = len(chain_groups_tab[c])
+        chain_unsup[c] = unsup
         cm[CM_CHAINS + np.arange(CHAIN_SIZE) * NCHAIN + c] = blk
 
     if (dof_to_lane == -1).any():
@@ -532,10 +584,15 @@ def lower(m, task):
     elif getattr(m, "na", 0):
         raise UnsupportedModel("activation states without muscles")
 
+    lowest = min([b for _, b, _ in standing], default=0.0)
+    max_contacts = max([sum(cap for c2, b, cap in standing if c2 == c and b <= lowest + 0.03) for c in range(NCHAIN)], default=0)
+
     def src_code(obs_idx):
         kind, i = obs_src[int(obs_idx) % task["nobs"]]
         if kind == "g":
             return SRC_GOAL + i
+        if kind == "f":
+            raise UnsupportedModel("device reward reads a foot-force entry (evaluate it on the host)")
         k = i - m.body_jntadr[root]
         if not (0 <= k < m.body_jntnum[root]):
             raise UnsupportedModel("device reward reads a non-root dof")
@@ -558,14 +615,171 @@ def lower(m, task):
     h[H_INTEGRATOR], h[H_CONE], h[H_MAXCONTACTS] = m.integrator, m.cone, max_contacts
     h[H_NMUSCLE] = len(muscles)
     h[H_ACTMODE] = act_mode
-    max_geoms = max([int(cm[CM_CHAINS + C_NGEOMS * NCHAIN + c]) for c in range(NCHAIN)])
-    h[H_CM_USED] = CM_CHAINS + (C_GEOMS + max_geoms * G_SIZE) * NCHAIN
+    # ---- the tail of the constant table, right behind the last link slot in use
+    off = CM_CHAINS + (C_LINKS + max_links * LINK_SIZE) * NCHAIN
+    h[H_OFF_RUNSUP] = off
+    root_unsup = _merge_proximity_spheres(root_unsup, MAXRG)
+    rb[R_NUNSUP] = len(root_unsup)
+    for i, u in enumerate(root_unsup):
+        cm[off + i * U_SIZE:off + (i + 1) * U_SIZE] = u
+    off += len(root_unsup) * U_SIZE
+    h[H_OFF_CUNSUP] = off
+    nmax = max(len(u) for u in chain_unsup)
+    for c in range(NCHAIN):
+        for i, u in enumerate(chain_unsup[c]):
+            cm[off + (i * U_SIZE + np.arange(U_SIZE)) * NCHAIN + c] = u
+    off += nmax * U_SIZE * NCHAIN
+    h[H_OFF_PRUNE] = off
+    nmax = max(len(u) for u in chain_prune)
+    for c in range(NCHAIN):
+        for i, u in enumerate(chain_prune[c]):
+            cm[off + (i * P_SIZE + np.arange(P_SIZE)) * NCHAIN + c] = u
+    off += nmax * P_SIZE * NCHAIN
+    h[H_OFF_LGROUP] = off
+    nmax = max(len(u) for u in chain_groups_tab)
+    for c in range(NCHAIN):
+        for i, u in enumerate(chain_groups_tab[c]):
+            cm[off + (i * LG_SIZE + np.arange(LG_SIZE)) * NCHAIN + c] = u
+    off += nmax * LG_SIZE * NCHAIN
+    # self-collisions: the quadruped family's kernels (<= 3 links per chain, Euler, elliptic cones, no muscles) are compiled
+    # with the pair path; the other robots of the suite have no self-collision pair with a collider
+    pairs_on = (m.cone == mjcf.CONE_ELLIPTIC and max_links <= 3 and m.integrator == mjcf.INT_EULER and not muscles
+                and task.get("self_collisions", True))
+    pair_tab = _self_collision_tables(m, root, chains, kin) if pairs_on else None
+    h[H_OFF_LPAIR] = off
+    gpt = np.zeros(0)
+    if pair_tab is not None:
+        lanes_lp, gpt, spheres = pair_tab
+        for c in range(NCHAIN):
+            cm[CM_CHAINS + C_NLPAIR * NCHAIN + c] = len(lanes_lp[c])
+            for i, e in enumerate(lanes_lp[c]):
+                cm[off + (i * LP_SIZE + np.arange(LP_SIZE)) * NCHAIN + c] = e
+        off += max(len(x) for x in lanes_lp) * LP_SIZE * NCHAIN
+        for (cl, li), ctr in spheres.items():
+            if cl < 0:
+                rb[R_BSX:R_BSX + 3] = ctr
+            else:
+                cm[CM_CHAINS + (C_LINKS + li * LINK_SIZE + D_SIZE + L_BSX + np.arange(3)) * NCHAIN + cl] = ctr
+        info["self_collision_tables"] = dict(link_pairs=[len(x) for x in lanes_lp], geom_pairs=len(gpt) // GPAIR_SIZE)
+    assert off <= CM_SIZE
+    h[H_CM_USED] = off
+    h[H_GT_SIZE] = GT_SIZE
     h[H_NGRF] = n_grf
     if n_grf and sum(1 for c in range(len(chains)) for k in (C_GRF_OBS0, C_GRF_OBS1) if cm[CM_CHAINS + k * NCHAIN + c] >= 0) != len(grf_groups):
         raise UnsupportedModel("a foot-force group has no geom with a device collider")
     info.update(dropped_root_limits=dropped_root_limits, n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
                 self_collision_pairs=_count_self_pairs(m))
-    return np.concatenate([h, cm] + ([mt] if mt is not None else [])), info
+    h[H_NGPAIR] = len(gpt) // GPAIR_SIZE
+    h[H_OFF_GPT] = HEADER_SIZE + CM_SIZE + GT_SIZE + (MT_SIZE if mt is not None else 0)
+    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt]), info
+
+
+def _self_collision_tables(m, root, chains, kin):
+    """
+    Tables of the self-collision path (kernels compiled with PAIRS; elliptic cones): candidate geom pairs after the engine's
+    filters (different weld groups, not parent and child, contype / conaffinity — the floor is handled elsewhere), grouped by
+    link pair. Sphere / capsule pairs get a collider; pairs with a box or a cylinder are kept as bounding capsules and only
+    COUNTED when they come within the margin (``self_proximity`` statistic).
+    Returns (per-lane link-pair entries [code, range, reach^2], geom-pair records (flat), {(lane, link): sphere centre}).
+    """
+    if m.cone != mjcf.CONE_ELLIPTIC:
+        raise UnsupportedModel("self-collisions are built for elliptic cones only")
+    nb = m.nbody
+    where = {root: (-1, 7)}                                   # weld group -> (lane, link index after its last joint)
+    for c, chain in enumerate(chains):
+        li = -1
+        for b in chain:
+            li += m.body_jntnum[b]
+            where[b] = (c, li)
+
+    def rel_pose(b):
+        w = m.body_weldid[b]
+        rw = kin["xmat"][w]
+        return rw.T @ (kin["xpos"][b] - kin["xpos"][w]), rw.T @ kin["xmat"][b]
+
+    def capsule_of(g):
+        """(centre, axis, half, radius, rbound) of geom g in the frame of its weld body; exact for spheres and capsules."""
+        p, r = rel_pose(m.geom_body[g])
+        pos, rot = p + r @ m.geom_pos[g], r @ mjcf.quat_to_mat(m.geom_quat[g])
+        t, size = m.geom_type[g], m.geom_size[g]
+        if t == mjcf.GEOM_SPHERE:
+            return pos, rot[:, 2], 0.0, size[0], size[0]
+        if t == mjcf.GEOM_BOX:
+            k = int(np.argmax(size))
+            rad = float(np.sqrt(sum(size[j] ** 2 for j in range(3) if j != k)))
+            return pos, rot[:, k], size[k], rad, size[k] + rad
+        return pos, rot[:, 2], size[1], size[0], size[0] + size[1]        # capsule, cylinder, mesh (bounding capsule)
+
+    by_links = {}
+    for g1 in range(m.ngeom):
+        for g2 in range(g1 + 1, m.ngeom):
+            b1, b2 = m.geom_body[g1], m.geom_body[g2]
+            w1, w2 = m.body_weldid[b1], m.body_weldid[b2]
+            if w1 == 0 or w2 == 0 or w1 == w2:
+                continue
+            p1, p2 = m.body_weldid[m.body_parent[w1]], m.body_weldid[m.body_parent[w2]]
+            if w1 == p2 or w2 == p1:
+                continue
+            if not ((m.geom_contype[g1] & m.geom_conaffinity[g2]) or (m.geom_contype[g2] & m.geom_conaffinity[g1])):
+                continue
+            a, b = (g1, g2) if m.geom_type[g1] <= m.geom_type[g2] else (g2, g1)      # the engine's order: lower type first
+            by_links.setdefault((min(w1, w2), max(w1, w2)), []).append((a, b))
+    handled = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE)
+    lanes_lp = [[] for _ in range(NCHAIN)]
+    records, spheres_r = [], {}
+    # bounding sphere per weld group over the geoms that take part in any pair
+    members = {}
+    for (wp, wq), pairs in by_links.items():
+        for a, b in pairs:
+            members.setdefault(m.body_weldid[m.geom_body[a]], set()).add(a)
+            members.setdefault(m.body_weldid[m.geom_body[b]], set()).add(b)
+    sphere = {}
+    for w, gs in members.items():
+        caps = [capsule_of(g) for g in gs]
+        ctr = np.mean([cp[0] for cp in caps], axis=0)
+        sphere[w] = (ctr, max(np.linalg.norm(cp[0] - ctr) + cp[4] for cp in caps))
+    for (wp, wq), pairs in sorted(by_links.items()):
+        if wp not in where or wq not in where:
+            raise UnsupportedModel("self-collision pair outside the root+chains structure")
+        (lp, kp), (lq, kq) = where[wp], where[wq]
+        first = len(records)
+        margin_max = 0.0
+        for a, b in pairs:
+            dim, solref, solimp, fr, margin, gap = _mix_with_floor(m, a, b)
+            assert gap == 0
+            kind = 0 if (m.geom_type[a] in handled and m.geom_type[b] in handled) else 1
+            if kind == 0 and lp == lq:
+                raise UnsupportedModel("self-collision between two links of one chain")
+            rec = np.zeros(GPAIR_SIZE)
+            rec[GP_KIND], rec[GP_G1Q] = kind, float(m.body_weldid[m.geom_body[a]] == wq)
+            for base, g in ((GP_P1, a), (GP_P2, b)):
+                pos, axis, half, rad, _ = capsule_of(g)
+                rec[base:base + 3], rec[base + 3:base + 6], rec[base + 6], rec[base + 7] = pos, axis, half, rad
+            rec[GP_MARGIN] = margin
+            rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)
+            rec[GP_S0:GP_S0 + 5] = _clip_solimp(solimp)
+            rec[GP_TRAN] = m.body_invweight0[m.geom_body[a], 0] + m.body_invweight0[m.geom_body[b], 0]
+            if dim not in (1, 3, 4, 6):
+                raise UnsupportedModel("condim %d" % dim)
+            rec[GP_DIM] = dim
+            rec[GP_F0:GP_F0 + 5] = fr
+            rec[GP_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
+            rr1 = 1.0 / max(MINVAL, m.impratio)
+            rec[GP_RR1], rec[GP_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
+            rec[GP_RR3:GP_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+            records.append(rec)
+            margin_max = max(margin_max, margin)
+        n = len(records) - first
+        assert first < 4096 and n < 4096
+        reach2 = (sphere[wp][1] + sphere[wq][1] + margin_max) ** 2
+        if lp >= 0:
+            lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 4096 * n, reach2])
+        if lq >= 0 and lq != lp:
+            lanes_lp[lq].append([kq + 8 * kp + 64 * max(lp, 0) + 256, first + 4096 * n, reach2])
+        spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp][0], sphere[wq][0]
+    if max(len(x) for x in lanes_lp) > MAXLP:
+        raise UnsupportedModel("too many self-collision link pairs")
+    return lanes_lp, (np.concatenate(records) if records else np.zeros(0)), spheres_r
 
 
 def _count_self_pairs(m):

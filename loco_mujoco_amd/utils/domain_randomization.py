@@ -99,5 +99,7 @@ class JointRandomization:
                 elif kind == KIND_UNIFORM:
                     out[p, :, d] = np.random.uniform(a, b, n)
                 else:
-                    out[p, :, d] = np.random.normal(a, b, n)
+                    # the reference's N(a, b) quirk can draw negative values, which no joint parameter may take: clipped at 0
+                    # here and in the kernel's redraw
+                    out[p, :, d] = np.clip(np.random.normal(a, b, n), 0.0, np.inf)
         return out

@@ -470,17 +470,41 @@ static double rbound(int type, const double* size) {
   }
 }
 
+/* bounding capsule (centre, unit axis, half length, radius) of a geom: sphere / capsule exact, cylinder and box conservative */
+static void bounding_capsule(int type, const double* size, const double* pos, const double* R, double* c, double* a,
+                             double* half, double* rad) {
+  copy3(c, pos);
+  int k = 2;
+  if (type == LM_GEOM_BOX) { k = 0; if (size[1] > size[k]) k = 1; if (size[2] > size[k]) k = 2; }
+  a[0] = R[k]; a[1] = R[3 + k]; a[2] = R[6 + k];
+  switch (type) {
+    case LM_GEOM_SPHERE: *half = 0; *rad = size[0]; break;
+    case LM_GEOM_BOX: { double o2 = 0; for (int j = 0; j < 3; j++) if (j != k) o2 += size[j] * size[j]; *half = size[k]; *rad = sqrt(o2); break; }
+    default: *half = size[1]; *rad = size[0]; break;      /* capsule, cylinder, mesh (its bounding capsule) */
+  }
+}
+
 static void collide(const lmo_model* m, work* w) {
   w->ncon = 0; w->unhandled_pairs = 0;
   for (int pi = 0; pi < m->npair; pi++) {
     int g1 = m->pair_g1[pi], g2 = m->pair_g2[pi];
     int t1 = IDX(m->geom_type, g1), t2 = IDX(m->geom_type, g2);
-    lmo_contact tm; memset(&tm, 0, sizeof(tm));
-    contact_params(m, g1, g2, &tm);
     const double *p1 = w->gpos[g1], *R1 = w->gmat[g1], *s1 = m->geom_size + 3*g1;
     const double *p2 = w->gpos[g2], *R2 = w->gmat[g2], *s2 = m->geom_size + 3*g2;
-    double margin = tm.margin;
     double rb2 = rbound(t2, s2);
+    /* margin-less bounding-sphere prune first (see below): most pairs end here, before their contact parameters are mixed */
+    {
+      double rel[3]; sub3(rel, p2, p1);
+      if (t1 == LM_GEOM_PLANE) { double n[3] = { R1[2], R1[5], R1[8] }; if (dot3(rel, n) - rb2 > 0) continue; }
+      else {
+        if (m->disable_self_collision) continue;
+        double rr = rbound(t1, s1) + rb2;
+        if (dot3(rel, rel) > rr * rr) continue;
+      }
+    }
+    lmo_contact tm; memset(&tm, 0, sizeof(tm));
+    contact_params(m, g1, g2, &tm);
+    double margin = tm.margin;
     if (t1 == LM_GEOM_PLANE) {
       double n[3] = { R1[2], R1[5], R1[8] };           /* plane normal = its z axis */
       double rel[3];
@@ -615,11 +639,18 @@ static void collide(const lmo_model* m, work* w) {
          (3 + 3 face normals, 9 edge cross products) keeps the boxes more than `margin` apart */
       if (box_box_gap(p1, R1, s1, p2, R2, s2) < margin) w->unhandled_pairs++;
     } else {
-      /* box / cylinder vs other non-plane geoms: not restated. Count the pair if bounding spheres overlap
-         so that a test can assert the situation never arises on the workloads it checks. */
-      double ra = rbound(t1, s1), rb = rb2;
-      double rel[3]; sub3(rel, p2, p1);
-      if (norm3(rel) - ra - rb < margin) w->unhandled_pairs++;
+      /* box / cylinder vs other non-plane geoms (the engine: native capsule-box / sphere-box colliders, libccd for
+         everything with a cylinder): not restated. The pair is COUNTED when the geoms' bounding capsules (cylinder (r, h) ->
+         capsule (r, h); box -> capsule along its longest edge, radius = half diagonal of the cross-section) come within
+         the margin — conservative: no count means the engine has no contact there either, so a test that sees a zero
+         count compares against complete physics. */
+      double ca[3], aa[3], ha, ra, cb[3], ab[3], hb, rb, sa, ta;
+      bounding_capsule(t1, s1, p1, R1, ca, aa, &ha, &ra);
+      bounding_capsule(t2, s2, p2, R2, cb, ab, &hb, &rb);
+      segment_closest(ca, aa, ha, cb, ab, hb, &sa, &ta);
+      double c1[3], c2[3], dd[3]; copy3(c1, ca); addscl3(c1, aa, sa); copy3(c2, cb); addscl3(c2, ab, ta);
+      sub3(dd, c2, c1);
+      if (norm3(dd) - ra - rb < margin) w->unhandled_pairs++;
     }
   }
 }

@@ -88,6 +88,14 @@ struct QuadThreadsT {
     float s = (g_buf[t_rep][0] + g_buf[t_rep][1]) + (g_buf[t_rep][2] + g_buf[t_rep][3]);
     g_bar_rep[t_rep].arrive_and_wait(); return s;
   }
+  // the lanes of one quad (replica): peers' lane memory, values of a named lane, a join before / after peer reads
+  static void quad_sync() { g_bar_rep[t_rep].arrive_and_wait(); }
+  static float peer(const float* /*lmem*/, int /*ls*/, int i, int dl) { return g_lmem[t_rep][t_lane + dl][i]; }
+  static float quad_read(float x, int src) {
+    g_buf[t_rep][t_lane] = x; g_bar_rep[t_rep].arrive_and_wait();
+    float y = g_buf[t_rep][src];
+    g_bar_rep[t_rep].arrive_and_wait(); return y;
+  }
   static bool any(bool b) {
     OPC(1);
     g_ibuf[t_rep * 4 + t_lane] = b; g_bar.arrive_and_wait();
@@ -116,7 +124,7 @@ template <int MC> constexpr int kEmuCone = -1;
 
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
 // act: muscle activations [n][na] double in/out (NM > 0 only)
-template <int MC, int NS, bool RK4, int NM = 0>
+template <int MC, int NS, bool RK4, int NM = 0, bool PAIRS = false>
 static int emu_run_t(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                      int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act = nullptr) {
   const double* H = chain_model;
@@ -125,7 +133,9 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)H[LM_HEADER_SIZE + i];
   const int na = (int)H[LM_H_NMUSCLE];
   std::vector<float> mt(NM > 0 ? LM_MT_SIZE : 1);
-  if (NM > 0) for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)H[LM_HEADER_SIZE + LM_CM_SIZE + i];
+  if (NM > 0) for (int i = 0; i < LM_MT_SIZE; i++) mt[i] = (float)H[LM_HEADER_SIZE + LM_CM_SIZE + LM_GT_SIZE + i];
+  std::vector<float> gt(LM_GT_SIZE);
+  for (int i = 0; i < LM_GT_SIZE; i++) gt[i] = (float)H[LM_HEADER_SIZE + LM_CM_SIZE + i];
   lm::Params P;
   P.h = (float)H[LM_H_TIMESTEP]; P.g = lm::v3((float)H[LM_H_GX], (float)H[LM_H_GY], (float)H[LM_H_GZ]);
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
@@ -134,7 +144,12 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
-  int cnt_tot[6] = {0, 0, 0, 0, 0, 0};
+  P.off_runsup = (int)H[LM_H_OFF_RUNSUP]; P.off_cunsup = (int)H[LM_H_OFF_CUNSUP]; P.off_prune = (int)H[LM_H_OFF_PRUNE]; P.gt = gt.data();
+  P.off_lgroup = (int)H[LM_H_OFF_LGROUP]; P.off_lpair = (int)H[LM_H_OFF_LPAIR];
+  std::vector<float> gpt((size_t)H[LM_H_NGPAIR] * LM_GPAIR_SIZE + 1);
+  for (size_t i = 0; i + 1 < gpt.size(); i++) gpt[i] = (float)H[(size_t)H[LM_H_OFF_GPT] + i];
+  P.gpt = gpt.data();
+  int cnt_tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int t) {
     const int c = t & 3;
     t_lane = c; t_rep = t >> 2;
@@ -181,7 +196,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         }
       }
       lm::Counters cnt = {};
-      using LMm = lm::LaneMem<MC, NS, NM>;
+      using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
       float lmem[LMm::kSize];
       // rep = 1: lane memory starts uninitialised (MemorySanitizer sees reads of never-written words); replicated: every
       // private copy and the snapshot start as the same quiet NaN, so such a read poisons the result instead
@@ -205,7 +220,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4, kEmuCone<MC>, NM, kEmuDR>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+        lm::substep<QuadThreads, MC, NS, RK4, PAIRS ? 1 : kEmuCone<MC>, NM, kEmuDR, PAIRS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                                       (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
       if (NM > 0 && t_rep == 0) {
@@ -216,10 +231,10 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       if (t_rep != 0) { g_bar.arrive_and_wait(); g_bar.arrive_and_wait(); continue; }     // replicas 1.. store nothing
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
-      static int acc[4][6];
-      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped;
+      static int acc[4][8];
+      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped; acc[c][6] = cnt.selfprox; acc[c][7] = cnt.selfcon;
       g_bar.arrive_and_wait();
-      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 6; j++) cnt_tot[j] += acc[l][j];
+      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 8; j++) cnt_tot[j] += acc[l][j];
       g_bar.arrive_and_wait();
     }
   };
@@ -249,12 +264,13 @@ extern "C" void emu_set_dof_params(const double* p) { g_dofprm = p; }
 
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
-                       int* counters /*6*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
+                       int* counters /*8*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
   // same family selection as the library's launch_variant()
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
     return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
+  if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, 6, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!big && !rk4) return emu_run_t<3, 5, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
   if (!rk4 && few) return emu_run_t<5, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);

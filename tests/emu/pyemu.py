@@ -55,7 +55,7 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     a = np.ascontiguousarray(action, dtype=np.float64).reshape(n, -1)
     M = np.zeros((nv, nv), dtype=np.float32)
     d5 = np.zeros((5, nv), dtype=np.float32)
-    cnt = np.zeros(6, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.int32)
     dp = lambda x: x.ctypes.data_as(C.c_void_p)
     na = int(cmod[31])        # H_NMUSCLE
     actv = None
@@ -72,4 +72,4 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
     if actv is not None:
         dbg["act"] = actv
-    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5])), dbg
+    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5]), selfprox=int(cnt[6]), selfcon=int(cnt[7])), dbg

@@ -21,7 +21,6 @@ def setup():
     env = LocoEnv.make("UnitreeA1.simple", debug=True)
     cmod, info = lowering.lower(env._model, env._device_task())
     o = Oracle(pack_model(env._model))
-    o.set_option("disable_self_collision", 1)
     return env, cmod, info, o
 
 
@@ -34,7 +33,7 @@ def actions(n):
 def test_lowering_structure(setup):
     env, cmod, info, o = setup
     assert info["n_chains"] == 4 and info["max_links"] == 3
-    assert len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE
+    assert len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.GPAIR_SIZE * int(cmod[lowering.H_NGPAIR])
     assert sorted(int(x) for x in info["dof_to_lane"][6:]) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
 
 
@@ -158,7 +157,6 @@ def test_core_position_servos():
     cmod, info = lowering.lower(m, env._device_task())
     assert cmod[lowering.H_ACTMODE] == 1
     o = Oracle(pack_model(m))
-    o.set_option("disable_self_collision", 1)
     tab = env._reset_table()
     rs = np.random.RandomState(5)
     rows = tab[rs.randint(0, len(tab), 6)]
@@ -220,7 +218,6 @@ def test_core_replicated_layout_random_states(task, nu):
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
     o = Oracle(pack_model(m))
-    o.set_option("disable_self_collision", 1)
     tab = env._reset_table()
     rs = np.random.RandomState(11)
     rows = tab[rs.randint(0, len(tab), 6)]
@@ -271,7 +268,7 @@ def test_core_muscles():
     env = LocoEnv.make("HumanoidMuscle.walk", debug=True)
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
-    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.MT_SIZE
+    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE
     o = Oracle(pack_model(m))
     g = GOLD["HumanoidMuscle.walk.real"]
     qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
@@ -297,3 +294,75 @@ def test_core_muscles():
         if k in (0, 9, 16):
             assert np.abs(d10["act"][0] - act_new).max() < 1e-5
         act = act_new
+
+
+def test_core_plane_cylinder_contacts():
+    """Plane vs cylinder on the device code (engine: mjc_PlaneCylinder — deepest rim point of the near cap, the rim point
+    under it on the far cap, two more points of the near cap at +-120 degrees): Atlas states with a thigh / shin cylinder on
+    the floor (tests/golden/atlas_cylinder_states.npz, found with the oracle by lowering tilted, folded robots onto the
+    floor), one forward pass and then three control steps against the fp64 oracle, which restates the same construction
+    (unpinned: no golden rollout of the reference has a cylinder on the floor)."""
+    np.random.seed(0)
+    env = LocoEnv.make("Atlas.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    o = Oracle(pack_model(m))
+    d = np.load(__file__.replace("test_emu_core.py", "golden/atlas_cylinder_states.npz"))
+    pick = [0, 3, 11, 40, 77, 120, 180, 212]
+    n_multi = 0
+    for i in pick:
+        q, v = d["q"][i].copy(), d["v"][i].copy()
+        ctrl = np.zeros(m.nu)
+        f = o.forward(q, v, ctrl)
+        assert any(m.geom_type[c["geom2"]] == 3 for c in f["contacts"])
+        _, _, _, cnt, dbg = pyemu.run(cmod, q, v, np.zeros(10), nsub=1, debug_env=0, ls_points=4)
+        assert 4 * f["ncon"] <= cnt["ncon"] <= 4 * f["ncon"] + 3 and cnt["overflow"] == 0, (i, cnt, f["ncon"])     # RK4: four passes, contacts may join in the later ones
+        assert np.abs(dbg["qacc"] - f["qacc"]).max() < 2e-4 * max(1.0, np.abs(f["qacc"]).max()), i
+        qe, ve, we, qo, vo, wo = q[None], v[None], None, q.copy(), v.copy(), np.zeros(m.nv)
+        ok = True
+        for k in range(3):
+            qe, ve, we, cnt, _ = pyemu.run(cmod, qe, ve, np.zeros(10), nsub=10, rep=4, warm=we)
+            qo, vo, wo, st = o.step(qo, vo, ctrl, 10, wo)
+            n_multi += st["ncon"] >= 2
+            if cnt["overflow"] or cnt["unhandled"] or st["unhandled_pairs"]:
+                ok = False          # a ninth contact on a leg, or the pelvis / torso (root geoms: no collider) reached the floor
+                break
+            assert np.abs(qe[0] - qo).max() < 2e-4 and np.abs(ve[0] - vo).max() < 2e-2, (i, k, np.abs(qe[0] - qo).max(), np.abs(ve[0] - vo).max())
+    assert n_multi >= 4
+
+
+@pytest.mark.parametrize("rep", [1, 4])
+def test_core_self_contacts(rep):
+    """Sphere / capsule contacts between two legs of the quadruped (and a leg and the trunk) on the device code: broad phase
+    over link bounding spheres, closest points of the capsule segments, contact frame in general position, "mirror" slots in
+    the two chain lanes, cross block between the two chains in the Newton factorisation. States of oracle rollouts under
+    full-range random torques at the moment two legs touch (tests/golden/a1_self_contact_states.npz: 1..9 self-contacts, up
+    to three pairs of legs at once), one forward pass and one control step against the fp64 oracle WITH self-collisions.
+    Unpinned: no golden rollout of the reference has a self-contact (the oracle restates mjc_CapsuleCapsule / mjc_SphereCapsule)."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["self_collision_tables"]["geom_pairs"] > 300
+    o = Oracle(pack_model(m))
+    d = np.load(__file__.replace("test_emu_core.py", "golden/a1_self_contact_states.npz"))
+    pick = [0, 26, 65, 104, 143, 195, 208, 247] if rep == 1 else [65, 143, 247]
+    seen_multi = 0
+    for i in pick:
+        q, v, a, w = d["q"][i], d["v"][i], d["a"][i], d["w"][i]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        f = o.forward(q, v, ctrl, w)
+        nself = sum(1 for c in f["contacts"] if m.geom_type[c["geom1"]] != 0)
+        assert nself == d["nself"][i] and f["unhandled_pairs"] == 0
+        _, _, _, cnt, dbg = pyemu.run(cmod, q, v, a, nsub=1, debug_env=0, ls_points=4, warm=w, rep=rep)
+        assert cnt["selfcon"] == nself and cnt["overflow"] == 0 and cnt["selfprox"] == 0
+        assert cnt["ncon"] == f["ncon"] + nself          # a contact between two chains occupies a slot in both lanes
+        assert np.abs(dbg["qacc"] - f["qacc"]).max() < 2e-5 * max(1.0, np.abs(f["qacc"]).max()), i
+        assert abs(cnt["solver_iters"] - f["solver_iter"]) <= 2        # the cross block makes the Newton step exact
+        qo, vo, wo, st = o.step(q, v, ctrl, 10, w)
+        qe, ve, we, cnt10, _ = pyemu.run(cmod, q, v, a, nsub=10, ls_points=4, warm=w, rep=rep)
+        assert cnt10["overflow"] == 0 and st["unhandled_pairs"] == 0
+        assert np.abs(qe[0] - qo).max() < 1e-4 and np.abs(ve[0] - vo).max() < 1e-2, (i, np.abs(qe[0] - qo).max(), np.abs(ve[0] - vo).max())
+        seen_multi += d["npairs"][i] > 1
+    assert seen_multi >= 2

@@ -116,7 +116,6 @@ def test_h1_rows_pin_smooth_dynamics_and_plane_mesh_contact():
     m = mjcf.CompiledModel.load(os.path.join(here, "UnitreeH1.model.npz"))
     fx = np.load(os.path.join(here, "UnitreeH1.fixture.npz"))
     o = Oracle(pack_model(m))
-    o.set_option("disable_self_collision", 1)
     for side in ("left", "right"):
         o.set_mesh(m.geom_names.index(side + "_foot"), fx[side + "_foot"])
     order = (["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", "pelvis_rotation", "back_bkz"]
