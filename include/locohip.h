@@ -141,6 +141,12 @@ int lm_rollout(lm_batch* b, int n_steps, int action_mode, uint64_t seed, lm_stat
    policy in the loop needs lm_step / lm_step_device. */
 int lm_rollout_fused(lm_batch* b, int n_steps, int steps_per_launch, int action_mode, uint64_t seed, lm_stats* stats);
 
+/* Validity flags of the LAST control step, one byte per environment: 1 = a contact was dropped (the chain's contact slots were
+ * full), 2 = two geoms of the robot WITHOUT a pair collider (a box or cylinder against another geom) came within the contact
+ * margin, 4 = a geom without a floor collider (mesh without hull) reached the floor. 0 = the step stayed inside the collision model
+ * that the parity tests validate. No counterpart in the reference (MuJoCo collides everything): statistics of THIS path. */
+int lm_get_flags(lm_batch* b, uint8_t* out);
+
 /* one forward-dynamics pass at the current state with `action`, without advancing it */
 int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out);
 

@@ -37,7 +37,8 @@ class ForwardOut(C.Structure):
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
-           "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync"]
+           "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
+           "lm_get_flags"]
 
 _lib = None
 
@@ -81,6 +82,7 @@ def load_library():
     lib.lm_forward_debug.argtypes = [C.c_void_p, _F, C.POINTER(ForwardOut)]
     lib.lm_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
     lib.lm_sync.argtypes = [C.c_void_p]
+    lib.lm_get_flags.argtypes = [C.c_void_p, _U8]
     _lib = lib
     return lib
 
@@ -257,6 +259,13 @@ class HipBatch:
         st = Stats()
         _check(self._lib.lm_get_stats(self._h, C.byref(st), int(reset)))
         return st.as_dict()
+
+    def flags(self):
+        """Validity flags of the last control step per environment (``lm_get_flags``): 1 dropped contact, 2 self pair without a
+        collider in reach, 4 collider-less geom at the floor."""
+        out = np.empty(self.n, dtype=np.uint8)
+        _check(self._lib.lm_get_flags(self._h, out.ctypes.data_as(_U8)))
+        return out
 
     def sync(self):
         _check(self._lib.lm_sync(self._h))

@@ -23,6 +23,7 @@
 #include <math.h>
 #include "../../include/lm_layout.h"
 
+#define LM_PAIR_PAD 0.03f     // metres added to the reach of the link-pair list (lowering.PAIR_PAD)
 #ifndef LM_LMEM_T
 #define LM_LMEM_T float       // element type of lane memory (A/B probe: `volatile float`)
 #endif
@@ -145,6 +146,7 @@ struct Params {
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
   int selfprox;      // forward passes x geom pairs without a collider (box / cylinder against something) within the margin
   int selfcon;       // self-contacts simulated, summed over the forward passes
+  int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
   float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
   long long t[12];
@@ -670,7 +672,7 @@ template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool D
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
-                    bool want_grf = false) {
+                    bool want_grf = false, float* pair_slack = nullptr) {
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
@@ -756,6 +758,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   float sm_r[6], sm_c[MC];
   int nslot = 0;
   int pair_mask_out = 0;           // partner lanes of this lane's cross-chain contact slots (PAIRS)
+  int nrootslot = 0, npairslot = 0; // slots of root-body geoms / of self-contacts held by this lane
   {
     Sp Sc[MC];
     float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
@@ -950,15 +953,35 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     // frame and parameters, opposite sign); every replica records all of them (identical words to identical addresses).
     // Geom pairs without a collider (a box or a cylinder against something) are tested as bounding capsules and counted.
     int pair_mask = 0;               // partner lanes of this lane's cross-chain slots
+    // The pass is SKIPPED while it provably cannot find anything: `pair_slack` is the smallest gap (distance minus margin)
+    // over all pairs of this quad at the last detection, less the distance the links can have travelled since — per substep
+    // h x (bound on the speed of my links against the root + the largest such bound in the quad); with semi-implicit Euler
+    // the positions of a substep move by exactly h x the velocities this pass starts from. In a normal gait only the
+    // trunk-thigh pairs are a few centimetres apart: one detection every 5-10 substeps.
+    bool detect = PAIRS;
+    float gap_min = 3.0e38f;
     if (PAIRS) {
+      float s_own = 0.0f;
 #pragma unroll
       for (int k = 0; k < MC; k++) if (k < nl) {
         const int fb = LMm::kFrame + k * 18;
         const V3 bl = v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ));
-        LMEM(LMm::kBS + k * 3 + 0) = LMEM(fb + 0) + LMEM(fb + 3) * bl.x + LMEM(fb + 4) * bl.y + LMEM(fb + 5) * bl.z;
-        LMEM(LMm::kBS + k * 3 + 1) = LMEM(fb + 1) + LMEM(fb + 6) * bl.x + LMEM(fb + 7) * bl.y + LMEM(fb + 8) * bl.z;
-        LMEM(LMm::kBS + k * 3 + 2) = LMEM(fb + 2) + LMEM(fb + 9) * bl.x + LMEM(fb + 10) * bl.y + LMEM(fb + 11) * bl.z;
+        const V3 cw = v3(LMEM(fb + 0) + LMEM(fb + 3) * bl.x + LMEM(fb + 4) * bl.y + LMEM(fb + 5) * bl.z,
+                         LMEM(fb + 1) + LMEM(fb + 6) * bl.x + LMEM(fb + 7) * bl.y + LMEM(fb + 8) * bl.z,
+                         LMEM(fb + 2) + LMEM(fb + 9) * bl.x + LMEM(fb + 10) * bl.y + LMEM(fb + 11) * bl.z);
+        LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z;
+        // speed of the link's points against the root body: |v_c| + |w| r with the twist relative to the root
+        const V3 wr = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)) - Vroot.w;
+        const V3 vc = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17)) - Vroot.v + cross(wr, cw - O);
+        s_own = fmaxf(s_own, sqrtf(dot(vc, vc)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
       }
+      const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
+      float slack = (pair_slack ? *pair_slack : 0.0f) - P.h * (s_own + s_quad);
+      detect = Q::sum((slack <= 0.0f) ? 1.0f : 0.0f) > 0.0f;          // quad-uniform: mirror slots need both lanes
+      if (pair_slack) *pair_slack = slack;
+    }
+    if (PAIRS && detect) {
+      if (c == 0 && Q::rep() == 0) cnt.pair_passes++;
       Q::quad_sync();                // the peers' frames and sphere centres are read below
       const V3 rootc = O + mul(R, v3(rb[LM_R_BSX], rb[LM_R_BSY], rb[LM_R_BSZ]));
       const int nlp = (int)CH(LM_C_NLPAIR);
@@ -969,7 +992,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
         const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
         const V3 dc = cb - ca;
-        if (!(dot(dc, dc) < cm[oz + P.off_lpair + (i * LM_LP_SIZE + 2) * LM_NCHAIN + c])) continue;
+        const float d2c = dot(dc, dc), thr2 = cm[oz + P.off_lpair + (i * LM_LP_SIZE + 2) * LM_NCHAIN + c];
+        // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
+        if (!(d2c < thr2)) { gap_min = fminf(gap_min, sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD); continue; }
         // ---- narrow phase over the geom pairs of this link pair
         const int rng = (int)cm[oz + P.off_lpair + (i * LM_LP_SIZE + 1) * LM_NCHAIN + c], first = rng & 4095, npairs = rng >> 12;
         V3 po, pp = O; M3 Ro, Rp = R; Sp Vo, Vp = Vroot;       // own / partner link frame and velocity
@@ -1001,10 +1026,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           segment_closest(c1, a1, rec[LM_GP_H1], c2, a2, rec[LM_GP_H2], sa, ta);
           const V3 q1 = c1 + sa * a1, q2 = c2 + ta * a2, dq = q2 - q1;
           const float dd = sqrtf(dot(dq, dq)), dist = dd - r1 - r2, pmargin = rec[LM_GP_MARGIN];
+          // only pairs WITH a collider hold the next detection back: the bounding capsules of the counted-only pairs (trunk
+          // cylinders against the thighs ...) sit millimetres apart in every gait; they are looked at when a detection runs
+#ifdef LM_PAIR_TRACE
+          if (Q::rep() == 0 && dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f (d %.7f r1 %.4f r2 %.4f) s %.5f t %.5f\n", c, i, first + j, rec[LM_GP_KIND], dist, dd, r1, r2, sa, ta);
+#endif
+          if (rec[LM_GP_KIND] == 0.0f) gap_min = fminf(gap_min, dist - pmargin);
           if (!(dist < pmargin)) continue;
           if (rec[LM_GP_KIND] != 0.0f) {                            // no collider for this pair of geom types: counted (once)
             if ((g1own || kb == 7) && Q::rep() == 0) cnt.selfprox++;
             continue;
+          }
+          // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
+          // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
+          {
+            const V3 cc = c2 - c1;
+            if (sqrtf(dot(cc, cc)) - (rec[LM_GP_H1] + r1) - (rec[LM_GP_H2] + r2) > 0.0f) continue;
           }
           if (nslot >= NS) { n_over++; continue; }
           const V3 nrm = (dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / dd) * dq;
@@ -1035,11 +1072,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
       }
       if (Q::rep() == 0) cnt.overflow += n_over;
+      if (pair_slack) *pair_slack = gap_min;
       Q::fence();
     }
     cnt.ncon += nslot;
     LM_TICK(0);
     pair_mask_out = pair_mask;
+    for (int s2 = 0; s2 < nslot; s2++) { if ((int)SL(s2, SL_LINK) < 0) nrootslot++; if (PAIRS && SL(s2, SL_PART) != 0.0f) npairslot++; }
 
     // ======== inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) ========
     SpI comp = spi0();
@@ -1524,13 +1563,15 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int k = 0; k < MC; k++) {
           Fl[k].w = v3(Q::rep_sum(Fl[k].w.x), Q::rep_sum(Fl[k].w.y), Q::rep_sum(Fl[k].w.z));
           Fl[k].v = v3(Q::rep_sum(Fl[k].v.x), Q::rep_sum(Fl[k].v.y), Q::rep_sum(Fl[k].v.z));
-          if (PAIRS) {
+          if (PAIRS && npairslot > 0) {       // the replicas of a lane agree on its slot list: a uniform branch for them
             Fp[k].w = v3(Q::rep_sum(Fp[k].w.x), Q::rep_sum(Fp[k].w.y), Q::rep_sum(Fp[k].w.z));
             Fp[k].v = v3(Q::rep_sum(Fp[k].v.x), Q::rep_sum(Fp[k].v.y), Q::rep_sum(Fp[k].v.z));
           }
         }
-        Frt.w = v3(Q::rep_sum(Frt.w.x), Q::rep_sum(Frt.w.y), Q::rep_sum(Frt.w.z));
-        Frt.v = v3(Q::rep_sum(Frt.v.x), Q::rep_sum(Frt.v.y), Q::rep_sum(Frt.v.z));
+        if (nrootslot > 0) {
+          Frt.w = v3(Q::rep_sum(Frt.w.x), Q::rep_sum(Frt.w.y), Q::rep_sum(Frt.w.z));
+          Frt.v = v3(Q::rep_sum(Frt.v.x), Q::rep_sum(Frt.v.y), Q::rep_sum(Frt.v.z));
+        }
       }
       Sp Fsum = sp0(), Psum = sp0();
 #pragma unroll
@@ -2065,9 +2106,9 @@ template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR 
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
-                    bool want_grf = false) {
+                    bool want_grf = false, float* pair_slack = nullptr) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
-  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf, pair_slack); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }

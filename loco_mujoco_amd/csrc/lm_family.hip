@@ -8,7 +8,13 @@ namespace lmk {
 
 bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a, int kind) {
 #if LM_FAMILY == 0      // quadruped: thigh (2) + calf (2) + foot (1) floor contacts per leg + one for a self-contact, elliptic cones
-  return launch_family<3, 6, false, LM_CONE_ELLIPTIC, 0, LM_PART, true>(L, a, kind);
+#ifndef LM_A1_NS
+#define LM_A1_NS 6
+#endif
+#ifndef LM_A1_PAIRS
+#define LM_A1_PAIRS true
+#endif
+  return launch_family<3, LM_A1_NS, false, LM_CONE_ELLIPTIC, 0, LM_PART, LM_A1_PAIRS>(L, a, kind);
 #elif LM_FAMILY == 1    // humanoid, RK4, one box foot per leg (HumanoidTorque)
   return launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
 #elif LM_FAMILY == 2    // Atlas: two boxes per foot

@@ -37,6 +37,7 @@ struct lm_batch {
   float* dofprm;             // per-environment joint parameters [3][nv][N] (allocated by lm_set_dof_params)
   float* drspec;             // redraw rules [3][nv][3] (lm_set_dof_randomization)
   unsigned char* done;
+  unsigned char* flags;      // validity flags of the last control step per environment (lm_get_flags)
   int* ep_step; unsigned* ep_count;
   DevStats* stats;
   int table_rows; unsigned long long seed; long long env_offset; int auto_reset, horizon; unsigned step_index;
@@ -121,6 +122,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   m->device = device;
   std::vector<float> cm(LM_CM_SIZE);
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)cmod[LM_HEADER_SIZE + i];
+  if (getenv("LM_NO_PAIRS")) for (int c = 0; c < LM_NCHAIN; c++) cm[LM_CM_CHAINS + LM_C_NLPAIR * LM_NCHAIN + c] = 0.0f;      // A/B: self-collision broad phase off
   for (int i = 0; i < 6; i++) {
     const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
     if (blk[LM_D_LIMITED] != 0.0f) { return fail("limited root joints are not supported"); }
@@ -229,6 +231,7 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->warm, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->goal, sizeof(float) * 4 * N));
   HIPCHK(hipMalloc(&b->action, sizeof(float) * m->T.nu * N)); HIPCHK(hipMalloc(&b->obs, sizeof(float) * m->T.nobs * N));
   HIPCHK(hipMalloc(&b->reward, sizeof(float) * N)); HIPCHK(hipMalloc(&b->done, N));
+  HIPCHK(hipMalloc(&b->flags, N)); HIPCHK(hipMemset(b->flags, 0, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
@@ -267,7 +270,7 @@ void lm_batch_destroy(lm_batch* b) {
   if (!b) return;
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
-  void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->ep_step, b->ep_count, b->stats,
+  void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
                   b->table, b->act, b->dofprm, b->drspec, b->timers};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -406,7 +409,7 @@ static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
-  a.ep_step = b->ep_step; a.ep_count = b->ep_count;
+  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
@@ -553,6 +556,13 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   if (out->ncon) HIPCHK(hipMemcpy(out->ncon, a.dncon, sizeof(int) * N, hipMemcpyDeviceToHost));
   if (out->solver_iter) HIPCHK(hipMemcpy(out->solver_iter, a.diter, sizeof(int) * N, hipMemcpyDeviceToHost));
   HIPCHK(hipFree(buf)); HIPCHK(hipFree(ibuf));
+  return 0;
+}
+
+int lm_get_flags(lm_batch* b, uint8_t* out) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->flags, b->N, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -97,6 +97,7 @@ struct KArgs {
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
   float* obs; float* reward; unsigned char* done;       // [N][nobs], [N], [N] (may be null)
+  unsigned char* flags;     // [N] per control step: 1 contact dropped (slots full) | 2 self pair without a collider in reach | 4 collider-less geom at the floor
   const float* table; int table_rows;                   // reset rows [K][nq+nv+ngoal]
   unsigned long long seed; long long env_offset;
   int auto_reset, horizon, action_mode; unsigned step_index;
@@ -262,10 +263,17 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
+  float pair_slack = 0.0f;            // self-collision detection is due in the first pass of every control step (lm_core.h)
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0, &pair_slack);
 
   QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
+
+  // ---- validity flags of this control step: where the device left its collision model (tests and statistics)
+  {
+    const float f_over = QuadDpp::sum((float)cnt.overflow), f_prox = QuadDpp::sum((float)cnt.selfprox), f_unh = QuadDpp::sum((float)cnt.unhandled);
+    if (a.flags && c == 0 && valid) a.flags[e] = (unsigned char)((f_over > 0.0f ? 1 : 0) | (f_prox > 0.0f ? 2 : 0) | (f_unh > 0.0f ? 4 : 0));
+  }
 
   // ---- termination (reference _has_fallen via per-dof bounds), non-finite guard
   float bad = 0.0f, viol = 0.0f;

@@ -40,8 +40,8 @@ MAXRG = 80        # geoms welded to the root (no device collider: proximity is c
 # D_FLO / D_FHI: force range of a position servo (H_ACTMODE = 1: torque = clamp(D_GEAR * (ctrl - q), D_FLO, D_FHI))
 # ---- per-link extras (chain links only), after the dof block
 (L_HAS_T, L_TX, L_TY, L_TZ, L_R0, L_R1, L_R2, L_R3, L_R4, L_R5, L_R6, L_R7, L_R8, L_MASS, L_CX, L_CY, L_CZ,
- L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_BSX, L_BSY, L_BSZ, L_SIZE) = range(27)
-# L_BS*: centre of the link's bounding sphere in the link frame (self-collision broad phase)
+ L_IXX, L_IYY, L_IZZ, L_IXY, L_IXZ, L_IYZ, L_BSX, L_BSY, L_BSZ, L_BSR, L_SIZE) = range(28)
+# L_BS*: centre and radius of the link's bounding sphere in the link frame (self-collision broad phase)
 LINK_SIZE = D_SIZE + L_SIZE
 # ---- per-geom block
 (G_LINK, G_TYPE, G_PX, G_PY, G_PZ, G_AX, G_AY, G_AZ, G_RADIUS, G_HALF, G_RBOUND, G_MARGIN, G_K, G_B, G_S0, G_S1,
@@ -71,6 +71,7 @@ CM_CHAINS = ROOT_SIZE
 # [entry][field][chain] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane + 256 * (own link
 # is the pair's SECOND link), range = first geom pair + 4096 * number of geom pairs, squared reach of the two bounding spheres
 MAXLP = 48
+PAIR_PAD = 0.03   # metres: link pairs closer than touching + PAIR_PAD go through the narrow phase (csrc/lm_core.h LM_PAIR_PAD)
 LP_SIZE = 3
 # geom-pair records (global memory): kind (0 sphere/capsule pair with a collider, 1 counted only: bounding capsules of a box /
 # cylinder pair), geom 1 on the pair's second link?, geom 1 / geom 2 as capsules in their link frames (centre, axis, half length,
@@ -657,9 +658,9 @@ def lower(m, task):
         off += max(len(x) for x in lanes_lp) * LP_SIZE * NCHAIN
         for (cl, li), ctr in spheres.items():
             if cl < 0:
-                rb[R_BSX:R_BSX + 3] = ctr
+                rb[R_BSX:R_BSX + 3] = ctr[0]
             else:
-                cm[CM_CHAINS + (C_LINKS + li * LINK_SIZE + D_SIZE + L_BSX + np.arange(3)) * NCHAIN + cl] = ctr
+                cm[CM_CHAINS + (C_LINKS + li * LINK_SIZE + D_SIZE + L_BSX + np.arange(4)) * NCHAIN + cl] = list(ctr[0]) + [ctr[1]]
         info["self_collision_tables"] = dict(link_pairs=[len(x) for x in lanes_lp], geom_pairs=len(gpt) // GPAIR_SIZE)
     assert off <= CM_SIZE
     h[H_CM_USED] = off
@@ -771,12 +772,12 @@ def _self_collision_tables(m, root, chains, kin):
             margin_max = max(margin_max, margin)
         n = len(records) - first
         assert first < 4096 and n < 4096
-        reach2 = (sphere[wp][1] + sphere[wq][1] + margin_max) ** 2
+        reach2 = (sphere[wp][1] + sphere[wq][1] + margin_max + PAIR_PAD) ** 2
         if lp >= 0:
             lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 4096 * n, reach2])
         if lq >= 0 and lq != lp:
             lanes_lp[lq].append([kq + 8 * kp + 64 * max(lp, 0) + 256, first + 4096 * n, reach2])
-        spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp][0], sphere[wq][0]
+        spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp], sphere[wq]
     if max(len(x) for x in lanes_lp) > MAXLP:
         raise UnsupportedModel("too many self-collision link pairs")
     return lanes_lp, (np.concatenate(records) if records else np.zeros(0)), spheres_r

@@ -219,9 +219,10 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         g_bar.arrive_and_wait();
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
+      float pair_slack = 0.0f;
       for (int s = 0; s < nsub; s++)
         lm::substep<QuadThreads, MC, NS, RK4, PAIRS ? 1 : kEmuCone<MC>, NM, kEmuDR, PAIRS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                                      (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp);
+                                                      (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, &pair_slack);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
       if (NM > 0 && t_rep == 0) {
         const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
@@ -232,7 +233,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
       for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
       static int acc[4][8];
-      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped; acc[c][6] = cnt.selfprox; acc[c][7] = cnt.selfcon;
+      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped; acc[c][6] = cnt.selfprox; acc[c][7] = cnt.selfcon; if (getenv("EMU_PAIR_TRACE") && c == 0) fprintf(stderr, "env %d: pair detection passes %d, slack at the end %.4f\n", e, cnt.pair_passes, pair_slack);
       g_bar.arrive_and_wait();
       if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 8; j++) cnt_tot[j] += acc[l][j];
       g_bar.arrive_and_wait();
