@@ -21,6 +21,7 @@
 // csrc/lm_kernels.hip instantiates it with DPP / ds_bpermute intrinsics, tests/emu/emu.cpp with OS threads.
 #pragma once
 #include <math.h>
+#include <type_traits>
 #include "../../include/lm_layout.h"
 
 #define LM_PAIR_PAD 0.03f     // metres added to the reach of the link-pair list (lowering.PAIR_PAD)
@@ -759,6 +760,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   int nslot = 0;
   int pair_mask_out = 0;           // partner lanes of this lane's cross-chain contact slots (PAIRS)
   int nrootslot = 0, npairslot = 0; // slots of root-body geoms / of self-contacts held by this lane
+  int nfloor = 0;                   // slots [0, nfloor) are floor contacts, [nfloor, nslot) self-contacts: the loops over the
+                                    // slots run the lean floor code first and the general-frame code for the rest
   {
     Sp Sc[MC];
     float Mcc[MC * (MC + 1) / 2], Mcr[MC][6], Mrr[21];
@@ -958,7 +961,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     // h x (bound on the speed of my links against the root + the largest such bound in the quad); with semi-implicit Euler
     // the positions of a substep move by exactly h x the velocities this pass starts from. In a normal gait only the
     // trunk-thigh pairs are a few centimetres apart: one detection every 5-10 substeps.
-    bool detect = PAIRS;
+    nfloor = nslot;
+    bool detect = PAIRS, first_detect = true;
     float gap_min = 3.0e38f;
     if (PAIRS) {
       float s_own = 0.0f;
@@ -976,10 +980,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         s_own = fmaxf(s_own, sqrtf(dot(vc, vc)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
       }
       const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
+      first_detect = !pair_slack || *pair_slack == 0.0f;        // the first pass of a control step (the caller starts it at 0)
       float slack = (pair_slack ? *pair_slack : 0.0f) - P.h * (s_own + s_quad);
       detect = Q::sum((slack <= 0.0f) ? 1.0f : 0.0f) > 0.0f;          // quad-uniform: mirror slots need both lanes
       if (pair_slack) *pair_slack = slack;
     }
+#ifdef LM_NO_DETECT
+    detect = false;
+#endif
     if (PAIRS && detect) {
       if (c == 0 && Q::rep() == 0) cnt.pair_passes++;
       Q::quad_sync();                // the peers' frames and sphere centres are read below
@@ -1012,51 +1020,73 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int j = 0; j < 9; j++) Rp.a[j] = PEER(dl, fb + 3 + j);
           Vp.w = v3(PEER(dl, fb + 12), PEER(dl, fb + 13), PEER(dl, fb + 14)); Vp.v = v3(PEER(dl, fb + 15), PEER(dl, fb + 16), PEER(dl, fb + 17));
         }
-        for (int j = 0; j < npairs; j++) {
-          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
-          const bool g1own = ((int)rec[LM_GP_G1Q] == own_q);        // geom 1 sits on my link
-          const V3 p1 = g1own ? po : pp, p2 = g1own ? pp : po;
-          const M3& R1 = g1own ? Ro : Rp; const M3& R2 = g1own ? Rp : Ro;
-          const V3 c1 = p1 + mul(R1, v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2]));
+        // geometry of geom pair j: closest points of the two capsule segments (same arithmetic in both lanes of a cross pair)
+        struct PairGeom { V3 c1, c2, q1, dq; float r1, r2, dd, dist; bool g1own; };
+        auto pair_geom = [&](const float* rec) -> PairGeom {
+          PairGeom G;
+          G.g1own = ((int)rec[LM_GP_G1Q] == own_q);        // geom 1 sits on my link
+          const V3 p1 = G.g1own ? po : pp, p2 = G.g1own ? pp : po;
+          const M3& R1 = G.g1own ? Ro : Rp; const M3& R2 = G.g1own ? Rp : Ro;
+          G.c1 = p1 + mul(R1, v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2]));
           const V3 a1 = mul(R1, v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
-          const V3 c2 = p2 + mul(R2, v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2]));
+          G.c2 = p2 + mul(R2, v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2]));
           const V3 a2 = mul(R2, v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
-          const float r1 = rec[LM_GP_R1], r2 = rec[LM_GP_R2];
+          G.r1 = rec[LM_GP_R1]; G.r2 = rec[LM_GP_R2];
           float sa, ta;
-          segment_closest(c1, a1, rec[LM_GP_H1], c2, a2, rec[LM_GP_H2], sa, ta);
-          const V3 q1 = c1 + sa * a1, q2 = c2 + ta * a2, dq = q2 - q1;
-          const float dd = sqrtf(dot(dq, dq)), dist = dd - r1 - r2, pmargin = rec[LM_GP_MARGIN];
-          // only pairs WITH a collider hold the next detection back: the bounding capsules of the counted-only pairs (trunk
-          // cylinders against the thighs ...) sit millimetres apart in every gait; they are looked at when a detection runs
+          segment_closest(G.c1, a1, rec[LM_GP_H1], G.c2, a2, rec[LM_GP_H2], sa, ta);
+          G.q1 = G.c1 + sa * a1;
+          G.dq = G.c2 + ta * a2 - G.q1;
+          G.dd = sqrtf(dot(G.dq, G.dq)); G.dist = G.dd - G.r1 - G.r2;
+          return G;
+        };
+        // ---- phase 1, dealt to the replicas (the records come from global memory: latency-bound): which geom pairs are within
+        // their margin? Bit j of `hit`. Only pairs WITH a collider hold the next detection back (gap_min): the bounding capsules
+        // of the counted-only pairs (trunk cylinders against the thighs ...) sit millimetres apart in every gait; those are
+        // looked at in the first pass of a control step only.
+        float hit = 0.0f;
+        for (int j = Q::rep(); j < npairs; j += Q::kRep) {
+          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
+          const bool counted_only = rec[LM_GP_KIND] != 0.0f;
+          if (counted_only && !first_detect) continue;
+          const PairGeom G = pair_geom(rec);
+          const float pmargin = rec[LM_GP_MARGIN];
 #ifdef LM_PAIR_TRACE
-          if (Q::rep() == 0 && dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f (d %.7f r1 %.4f r2 %.4f) s %.5f t %.5f\n", c, i, first + j, rec[LM_GP_KIND], dist, dd, r1, r2, sa, ta);
+          if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f\n", c, i, first + j, rec[LM_GP_KIND], G.dist);
 #endif
-          if (rec[LM_GP_KIND] == 0.0f) gap_min = fminf(gap_min, dist - pmargin);
-          if (!(dist < pmargin)) continue;
+          if (!counted_only) gap_min = fminf(gap_min, G.dist - pmargin);
+          if (G.dist < pmargin) hit += (float)(1 << j);
+        }
+        if (Q::kRep > 1) hit = Q::rep_sum(hit);                  // disjoint bits: the sum is the union (npairs <= 24: exact)
+        // ---- phase 2, every replica: record the contacts (rare)
+        for (int hm = (int)hit, j = 0; hm != 0; hm >>= 1, j++) {
+          if (!(hm & 1)) continue;
+          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
+          const PairGeom G = pair_geom(rec);
+          const float pmargin = rec[LM_GP_MARGIN], dist = G.dist;
           if (rec[LM_GP_KIND] != 0.0f) {                            // no collider for this pair of geom types: counted (once)
-            if ((g1own || kb == 7) && Q::rep() == 0) cnt.selfprox++;
+            if ((G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
             continue;
           }
           // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
           // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
           {
-            const V3 cc = c2 - c1;
-            if (sqrtf(dot(cc, cc)) - (rec[LM_GP_H1] + r1) - (rec[LM_GP_H2] + r2) > 0.0f) continue;
+            const V3 cc = G.c2 - G.c1;
+            if (sqrtf(dot(cc, cc)) - (rec[LM_GP_H1] + G.r1) - (rec[LM_GP_H2] + G.r2) > 0.0f) continue;
           }
           if (nslot >= NS) { n_over++; continue; }
-          const V3 nrm = (dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / dd) * dq;
+          const V3 nrm = (G.dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / G.dd) * G.dq;
           V3 t1, t2;
           make_frame(nrm, t1, t2);
-          const V3 cp = q1 + (r1 + 0.5f * dist) * nrm - O;
+          const V3 cp = G.q1 + (G.r1 + 0.5f * dist) * nrm - O;
           const int slot = nslot++;
           SL(slot, SL_LINK) = (float)ka; SL(slot, SL_GRF) = -1.0f;
-          SL(slot, SL_PART) = (g1own ? -1.0f : 1.0f) * (float)(1 + ((kb == 7) ? 0 : lb) * 8 + kb);
+          SL(slot, SL_PART) = (G.g1own ? -1.0f : 1.0f) * (float)(1 + ((kb == 7) ? 0 : lb) * 8 + kb);
           SL(slot, SL_NX) = nrm.x; SL(slot, SL_NY) = nrm.y; SL(slot, SL_NZ) = nrm.z;
           SL(slot, SL_T1X) = t1.x; SL(slot, SL_T1Y) = t1.y; SL(slot, SL_T1Z) = t1.z;
           SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
           if (kb != 7) pair_mask |= 1 << lb;
           // relative velocity of body 2 against body 1 at the contact point, in the contact frame
-          Sp Vrel = g1own ? (Vp + (-1.0f) * Vo) : (Vo + (-1.0f) * Vp);
+          Sp Vrel = G.g1own ? (Vp + (-1.0f) * Vo) : (Vo + (-1.0f) * Vp);
           float vel[6];
           frame_rows(Vrel, cp, nrm, t1, t2, vel);
           const float imp = impedance(rec + LM_GP_S0, 1, dist, pmargin);
@@ -1068,9 +1098,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / rec[LM_GP_RR1 + j2 - 1] : 0.0f; SL(slot, SL_FR + j2 - 1) = rec[LM_GP_F0 + j2 - 1]; }
 #pragma unroll
           for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -Bp * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
-          if (Q::rep() == 0 && (g1own || kb == 7)) cnt.selfcon++;
+          if (Q::rep() == 0 && (G.g1own || kb == 7)) cnt.selfcon++;
         }
       }
+      if (Q::kRep > 1) gap_min = fminf(fminf(Q::rep_bcast(gap_min, 0), Q::rep_bcast(gap_min, 1)), fminf(Q::rep_bcast(gap_min, 2), Q::rep_bcast(gap_min, 3)));
       if (Q::rep() == 0) cnt.overflow += n_over;
       if (pair_slack) *pair_slack = gap_min;
       Q::fence();
@@ -1373,6 +1404,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       frame_rows(A, rc, n, t1, t2, out);
     } else contact_rows(pick(link), rc, out);
   };
+  auto aligned_from = [&](int lo, int first, int step) -> int { int r = (first - lo) % step; if (r < 0) r += step; return lo + r; };
   // a contact between two chains has a slot in both lanes: each of them carries half of its cost
   auto slot_weight = [&](int s) -> float {
     if (!PAIRS) return 1.0f;
@@ -1404,9 +1436,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
     if (nslot > 0 || any_pair) {
       link_images(xr, xc);
-      for (int s = Q::rep(); s < nslot; s += Q::kRep) {
+      auto cost_slot = [&](int s, auto is_pair) {
+        constexpr bool IP = decltype(is_pair)::value;
         float Dj[6], fr[5], jar[6];
-        slot_rows_of_images(s, jar);
+        if constexpr (IP) slot_rows_of_images(s, jar);
+        else contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
         if (PYR3(dim)) {
           float x[4], f3[3];
@@ -1419,8 +1453,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
 #pragma unroll
           for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
-          cost += slot_weight(s) * cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
+          cost += (IP ? slot_weight(s) : 1.0f) * cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
         }
+      };
+      for (int s = Q::rep(); s < nfloor; s += Q::kRep) cost_slot(s, std::false_type{});
+      if constexpr (PAIRS) {
+        if (nslot > nfloor) for (int s = aligned_from(nfloor, Q::rep(), Q::kRep); s < nslot; s += Q::kRep) cost_slot(s, std::true_type{});
       }
       if (PAIRS && any_pair) Q::quad_sync();        // ... before the next link_images overwrites them
     }
@@ -1513,11 +1551,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       for (int k = 0; k < (PAIRS ? MC : 1); k++) Fp[k] = sp0();
       if ((nslot > 0 || any_pair) && !(P.ablate & 32)) {
         link_images(ar, ac);
-        for (int s = s_first; s < nslot; s += s_step) {
+        auto grad_slot = [&](int s, auto is_pair) {
+          constexpr bool IP = decltype(is_pair)::value;
           float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
-          slot_rows_of_images(s, jar);
+          if constexpr (IP) slot_rows_of_images(s, jar);
+          else contact_rows(pick(link), rc, jar);
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
@@ -1540,11 +1580,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
           SL(s, SL_ZONE) = (float)zone;
           if (zone) {
-            const float part = slot_sign(s);
-            if (PAIRS && part != 0.0f) {
+            if constexpr (IP) {
               V3 n, t1, t2;
               slot_frame(s, n, t1, t2);
-              const Sp Fw = ((part > 0.0f) ? 1.0f : -1.0f) * frame_wrench(fc, rc, n, t1, t2);
+              const Sp Fw = ((slot_sign(s) > 0.0f) ? 1.0f : -1.0f) * frame_wrench(fc, rc, n, t1, t2);
 #pragma unroll
               for (int k = 0; k < MC; k++) if (link == k) Fp[k] = Fp[k] + Fw;
             } else {
@@ -1554,6 +1593,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               for (int k = 0; k < MC; k++) if (link == k) Fl[k] = Fl[k] + Fw;
             }
           }
+        };
+        for (int s = s_first; s < nfloor; s += s_step) grad_slot(s, std::false_type{});
+        if constexpr (PAIRS) {
+          if (nslot > nfloor) for (int s = aligned_from(nfloor, s_first, s_step); s < nslot; s += s_step) grad_slot(s, std::true_type{});
         }
         if (PAIRS && any_pair) Q::quad_sync();
       }
@@ -1620,10 +1663,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hrep[tri(i, i)] += iR_r[i];
-        for (int s = s_first; s < ((P.ablate & 2) ? 0 : nslot); s += s_step) {
+        auto hess_slot = [&](int s, auto is_pair) {
+          constexpr bool IP = decltype(is_pair)::value;
           oz = LM_OPAQUE_ZERO();
           const int zone = (int)SL(s, SL_ZONE);
-          if (zone == 0) continue;
+          if (zone == 0) return;
           float Dj[6], fr[5], Hc[21], jar[6];
           const int dim = (int)SL(s, SL_DIM);
           if (PYR3(dim)) pyr_hessian((unsigned)zone, SL(s, SL_D), SL(s, SL_MU), Hc);
@@ -1639,8 +1683,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           float Jc[6 + MC][6];
           float Jp[PAIRS ? MC : 1][6];      // the PARTNER chain's columns of a cross-chain contact (lower lane of the pair only)
           bool cross = false;
-          const float part = slot_sign(s);
-          if (PAIRS && part != 0.0f) {
+          if constexpr (IP) {
+            const float part = slot_sign(s);
             // self-contact: the row space is the motion of body 2 against body 1 -> the root columns vanish, my chain's
             // columns carry my sign, the partner chain's columns the opposite one
             const int code = (int)fabsf(part) - 1, pl = code & 7, pc = code >> 3, dl = pc - c;
@@ -1706,7 +1750,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 else if (b < 6) Hcr[a - 6][b] += d;
                 else Hcc[tri(a - 6, b - 6)] += d;
               }
-              if (PAIRS && cross && a >= 6) {
+              if constexpr (IP) if (cross && a >= 6) {
 #pragma unroll
                 for (int b = 0; b < MC; b++) {
                   float d = 0;
@@ -1736,7 +1780,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 else if (b < 6) Hcr[a - 6][b] += d;
                 else Hcc[tri(a - 6, b - 6)] += d;
               }
-              if (PAIRS && cross && a >= 6) {
+              if constexpr (IP) if (cross && a >= 6) {
 #pragma unroll
                 for (int b = 0; b < MC; b++) {
                   float d = 0;
@@ -1746,6 +1790,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 }
               }
             }
+          }
+        };
+        if (!(P.ablate & 2)) {
+          for (int s = s_first; s < nfloor; s += s_step) hess_slot(s, std::false_type{});
+          if constexpr (PAIRS) {
+            if (nslot > nfloor) for (int s = aligned_from(nfloor, s_first, s_step); s < nslot; s += s_step) hess_slot(s, std::true_type{});
           }
         }
         if (PAIRS && any_pair) Q::quad_sync();
@@ -1773,11 +1823,15 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
         if (!(P.ablate & 4)) {
+          bool coupled = false;
+          if constexpr (PAIRS) coupled = any_pair && !xmajor;
           if constexpr (PAIRS) {
-            const bool coupled = any_pair && !xmajor;
-            arrow_factor_x<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, xrole, xpartner, coupled);
-            arrow_solve_x<Q, MC>(Hcc, Hcr, Lr, Xc, xrole, xpartner, coupled, sc, sr);
-          } else {
+            if (coupled) {
+              arrow_factor_x<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, xrole, xpartner, true);
+              arrow_solve_x<Q, MC>(Hcc, Hcr, Lr, Xc, xrole, xpartner, true, sc, sr);
+            }
+          }
+          if (!coupled) {
             arrow_factor<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr);
             arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
           }
@@ -1805,9 +1859,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int k = 0; k < MC; k++) { jv_c[k] = sc[k]; jvlim_c[k] = lim_s_c[k] * sc[k]; }
           if (nslot > 0 || any_pair) {
             link_images(sr, sc);
-            for (int s = 0; s < nslot; s++) {
+            auto jv_slot = [&](int s, auto is_pair) {
+              constexpr bool IP = decltype(is_pair)::value;
               float jv[6];
-              slot_rows_of_images(s, jv);
+              if constexpr (IP) slot_rows_of_images(s, jv);
+              else contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jv);
               if (PYR3((int)SL(s, SL_DIM))) {
                 float xv[4];
                 pyr_rows(jv, SL(s, SL_MU), xv);
@@ -1817,7 +1873,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
                 for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
               }
-            }
+            };
+            for (int s = 0; s < nfloor; s++) jv_slot(s, std::false_type{});
+            if constexpr (PAIRS) for (int s = nfloor; s < nslot; s++) jv_slot(s, std::true_type{});
             if (PAIRS && any_pair) Q::quad_sync();
           }
           Q::fence();

@@ -771,7 +771,7 @@ def _self_collision_tables(m, root, chains, kin):
             records.append(rec)
             margin_max = max(margin_max, margin)
         n = len(records) - first
-        assert first < 4096 and n < 4096
+        assert first < 4096 and n <= 24           # the device exchanges the hits of a link pair as a 24-bit mask
         reach2 = (sphere[wp][1] + sphere[wq][1] + margin_max + PAIR_PAD) ** 2
         if lp >= 0:
             lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 4096 * n, reach2])

@@ -140,10 +140,24 @@ def test_random_states_one_step_vs_oracle(setup):
         eq.append(np.abs(q1[k] - q).max())
         ev.append(np.abs(v1[k] - v).max())
     eq, ev = np.array(eq), np.array(ev)
-    print("random states: qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e"
-          % (eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev)))
+    # knife-edge states (a contact switching on within a hair of a substep boundary: the fp64 oracle itself jumps when its
+    # input moves by float32-sized noise) and states with a dropped contact are reported, not held to the tolerance
+    flags = b.flags()
+    keep = np.ones(n, dtype=bool)
+    prs = np.random.RandomState(5)
+    for k in np.nonzero((eq > QTOL) | (ev > VTOL))[0]:
+        q0, v0 = qpos[k].astype(np.float32).astype(np.float64), qvel[k].astype(np.float32).astype(np.float64)
+        qo, vo, _, _ = oracle.step(q0, v0, acts[k].astype(np.float32), 10)
+        for e in (1e-7, 1e-7, 1e-6, 1e-6, 1e-6, 1e-6):
+            qp, vp, _, _ = oracle.step(q0 + e * prs.uniform(-1, 1, 18), v0 + e * prs.uniform(-1, 1, 18), acts[k].astype(np.float32), 10)
+            if np.abs(qp - qo).max() > QTOL or np.abs(vp - vo).max() > VTOL or flags[k]:
+                keep[k] = False
+    print("random states: qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e | %d knife-edge / dropped-contact states left out of the max: max %.2e / %.2e"
+          % (eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev), (~keep).sum(), eq[keep].max(), ev[keep].max()))
     assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
-    assert eq.max() < 10 * QTOL and ev.max() < 10 * VTOL
+    # (these start states are NOT reachable: trajectory states with every joint moved by up to 0.03 rad and the trunk pushed up to
+    # 3 cm into the floor — the stiffest contacts of the suite; the reachable-state distributions are in test_4096_...)
+    assert eq[keep].max() <= 2 * QTOL and ev[keep].max() <= 2 * VTOL and keep.sum() >= n - 4
     st = b.stats()
     assert st["overflow_contacts"] == 0
 
@@ -466,7 +480,7 @@ def test_error_distribution_three_control_steps_vs_oracle(task, nu):
         b.step(acts[k])
     q, v = b.get_state()
     act_dev = b.get_activation() if m.na else None
-    eq, ev, ea = [], [], []
+    eq, ev, ea, n_jump = [], [], [], 0
     for i in range(n):
         qo, vo = rows[i, :m.nv].astype(np.float32).astype(np.float64), rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64)
         w, ao, flagged = np.zeros(m.nv), np.zeros(m.na), 0
@@ -480,17 +494,34 @@ def test_error_distribution_three_control_steps_vs_oracle(task, nu):
             flagged += st["unhandled_pairs"]
         if flagged:
             continue
+        # knife-edge states (see test_4096_reachable_states...): the oracle itself jumps when its start state moves by 1e-6 / 1e-5
+        jump = False
+        prs = np.random.RandomState(1000 + i)
+        for e in (1e-6, 1e-6, 1e-5, 1e-5):
+            qp = rows[i, :m.nv].astype(np.float32).astype(np.float64) + e * prs.uniform(-1, 1, m.nv)
+            vp = rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64) + e * prs.uniform(-1, 1, m.nv)
+            wp, ap = np.zeros(m.nv), np.zeros(m.na)
+            for k in range(3):
+                ctrl = np.zeros(m.nu)
+                ctrl[env._action_indices] = env._preprocess_action(acts[k, i])
+                if m.na:
+                    qp, vp, ap, wp, _ = oracle.step_act(qp, vp, ap, ctrl, 10, wp)
+                else:
+                    qp, vp, wp, _ = oracle.step(qp, vp, ctrl, 10, wp)
+            jump = jump or np.abs(qp - qo).max() > 3 * QTOL or np.abs(vp - vo).max() > 3 * VTOL
+        if jump:
+            n_jump += 1
+            continue
         eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
         if m.na:
             ea.append(np.abs(act_dev[i] - ao).max())
     eq, ev = np.array(eq), np.array(ev)
-    print("%s, 3 control steps, %d/%d states: qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e%s"
-          % (task, len(eq), n, eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev),
+    print("%s, 3 control steps, %d/%d states (%d knife-edge states left out): qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e%s"
+          % (task, len(eq), n, n_jump, eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev),
              (" | act max %.2e" % max(ea)) if ea else ""))
     assert len(eq) >= n // 2
-    # tolerance of ONE control step scaled by the three steps taken here
-    assert np.percentile(eq, 99) < 3 * QTOL and np.percentile(ev, 99) < 3 * VTOL
-    assert eq.max() < 30 * QTOL and ev.max() < 30 * VTOL
+    # the tolerance of ONE control step holds after three: worst case, not a percentile
+    assert eq.max() < QTOL and ev.max() < VTOL and n_jump <= n // 8
     assert b.stats()["overflow_contacts"] == 0
 
 
@@ -1175,21 +1206,23 @@ def test_atlas_cylinder_states_vs_oracle(atlas):
 
 
 def _worker_oracle_steps(args):
-    """one process of the oracle pool: (task, kwargs, indices, q, v, act, actions) -> results per state"""
-    task, kw, q, v, act, actions, eps = args
-    np.random.seed(0)
-    env = LocoEnv.make(task, debug=True, **kw)
-    oracle = Oracle(pack_model(env._model))
+    """one THREAD of the oracle pool (the oracle's C code runs without the GIL and allocates its work area per call; no
+    fork: a forked child of a process that holds a HIP context is undefined behaviour): results per state"""
+    env, oracle, q, v, act, actions, eps = args
     out = []
     rs = np.random.RandomState(12345)
     for i in range(len(q)):
         a0 = None if act is None else act[i]
         qo, vo, ao, st = _oracle_step(env, oracle, q[i], v[i], actions[i], a0)
-        # conditioning probe: the same step from a state moved by float32 rounding noise
-        dq = q[i] + eps * rs.uniform(-1, 1, q[i].shape) * np.maximum(1.0, np.abs(q[i]))
-        dv = v[i] + eps * rs.uniform(-1, 1, v[i].shape) * np.maximum(1.0, np.abs(v[i]))
-        qp, vp, _, _ = _oracle_step(env, oracle, dq, dv, actions[i], a0)
-        out.append((qo, vo, ao, st["unhandled_pairs"], np.abs(qp - qo).max(), np.abs(vp - vo).max()))
+        # conditioning probes: the same step from the state moved by float32-sized noise (a knife-edge state — a contact
+        # or a joint limit that switches on within a hair of a substep boundary — shows a JUMP in one of them)
+        sq = sv = 0.0
+        for e in eps:
+            dq = q[i] + e * rs.uniform(-1, 1, q[i].shape) * np.maximum(1.0, np.abs(q[i]))
+            dv = v[i] + e * rs.uniform(-1, 1, v[i].shape) * np.maximum(1.0, np.abs(v[i]))
+            qp, vp, _, _ = _oracle_step(env, oracle, dq, dv, actions[i], a0)
+            sq, sv = max(sq, np.abs(qp - qo).max()), max(sv, np.abs(vp - vo).max())
+        out.append((qo, vo, ao, st["unhandled_pairs"], sq, sv))
     return out
 
 
@@ -1203,12 +1236,13 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     fp64 oracle (all cores), no collision mask on either side. Reported: median / p99 / max. Asserted: max <= the stated
     tolerance (qpos 1e-4, qvel 1e-2) over every state where the comparison is meaningful — not meaningful are states (counted
     and reported) where (i) the oracle has no collider for a geom pair in reach (`unhandled_pairs`), (ii) a lane ran out of
-    contact slots on the device, (iii) the fp64 oracle ITSELF moves by more than the tolerance when its input is disturbed
-    by float32 rounding noise (1e-7 relative): a contact making or breaking inside the step — no float32 code can be held
-    to 1e-4 there. The humanoid's bone meshes collide as convex hulls in the reference (libccd); neither side restates that:
+    contact slots on the device, (iii) the fp64 oracle ITSELF jumps by more than the tolerance when its input is disturbed
+    by float32-sized noise (four probes, 1e-7 and 1e-6 relative): a contact or a joint limit that switches on within a hair
+    of a substep boundary — the engine's contact damping acts at full strength from the first pass in which dist < margin,
+    so a foot arriving at 2 m/s gains or loses ~0.05 m/s with the pass in which it is first seen, in float64 as in float32. The humanoid's bone meshes collide as convex hulls in the reference (libccd); neither side restates that:
     a humanoid that has folded up under 12 steps of random torques has bone pairs in reach in most states (`min_ok`), which is
     why it is also run after 3 steps."""
-    import multiprocessing as mp
+    from multiprocessing.pool import ThreadPool
     from loco_mujoco_amd.backend import HipBatch, HipModel
     np.random.seed(0)
     env = LocoEnv.make(task, debug=True, **kw)
@@ -1236,9 +1270,10 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     st = b.stats()
     ncpu = min(16, len(os.sched_getaffinity(0)))
     chunks = np.array_split(np.arange(n), ncpu * 4)
-    jobs = [(task, kw, q0[c].astype(np.float64), v0[c].astype(np.float64), None if act0 is None else act0[c].astype(np.float64),
-             actions[c].astype(np.float64), 1e-7) for c in chunks]
-    with mp.get_context("fork").Pool(ncpu) as pool:
+    oracle = Oracle(pack_model(m))
+    jobs = [(env, oracle, q0[c].astype(np.float64), v0[c].astype(np.float64), None if act0 is None else act0[c].astype(np.float64),
+             actions[c].astype(np.float64), (1e-7, 1e-7, 1e-6, 1e-6)) for c in chunks]
+    with ThreadPool(ncpu) as pool:
         res = [r for chunk in pool.map(_worker_oracle_steps, jobs) for r in chunk]
     eq = np.array([np.abs(q1[i] - res[i][0]).max() for i in range(n)])
     ev = np.array([np.abs(v1[i] - res[i][1]).max() for i in range(n)])
