@@ -10,7 +10,7 @@ zero action, initial states = the 300 samples of the bundled mini dataset drawn 
 device-side auto-reset on _has_fallen or after 1000 control steps. A "step" = one control step of every
 environment (= 10 physics substeps + observation + reward + termination + resets), one kernel launch.
 Environments are independent: ranks shard them (weak scaling), the only collective is the metric
-all-reduce (RCCL) at report time.
+all-reduce at report time: ncclAllReduce on librccl.so through ctypes (loco_mujoco_amd/utils/collective.py).
 
 `--task` switches to the other BASELINE robots for side measurements (HumanoidTorque.run / Atlas.walk /
 HumanoidMuscle.run with the device's random policy a ~ U(-1,1)); the driver's default run is the A1 line above.
@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--cpu-random-policy", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help="testing only: run all ranks on GPU 0 with the gloo backend "
                     "(checks the multi-rank control flow on a one-GPU box; the numbers mean nothing)")
+    ap.add_argument("--dump-states", default=None, help=argparse.SUPPRESS)              # tests: <prefix>.rank<r>.npz with the final states
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
@@ -181,17 +182,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.share_gpu:                 # flow test of the multi-rank path on a one-GPU box: all ranks on device 0, gloo
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # the only collective of the path: the metric all-reduce at report time — ncclAllReduce on librccl.so through ctypes
+    # (loco_mujoco_amd/utils/collective.py; no PyTorch anywhere in this file). --share-gpu: all ranks on GPU 0 and the
+    # reduction over the rendezvous sockets (RCCL refuses two ranks on one device)
+    from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
+    if args.share_gpu:
+        local_rank = 0
+    coll = Collective(backend="tcp" if args.share_gpu else "rccl", rank=rank, world=world, device=local_rank)
 
     from loco_mujoco_amd import LocoEnv
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -230,11 +227,9 @@ def main():
         b.set_dof_randomization(env._domain_rand.spec)
 
     def barrier():
+        b.sync()                       # device synchronisation of this rank's stream ...
+        coll.barrier()                 # ... then every rank has arrived (no-op for one rank)
         b.sync()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
 
     b.rollout(args.warmup, action_mode=action_mode, seed=11)
     b.stats(reset=True)
@@ -258,20 +253,14 @@ def main():
 
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
-                     fused[0] if fused is not None else 0.0], dtype=np.float64)
-    if dist is not None:
-        import torch
-        t = torch.tensor(vals, device="cpu" if args.share_gpu else "cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        kernel_ms = float(tmax[8])
-        fused_elapsed = float(tmax[9])                    # every collective happens before the non-zero ranks leave
-        vals = t.cpu().numpy()
-    else:
-        kernel_ms = vals[8]
-        fused_elapsed = vals[9]
+                     fused[0] if fused is not None else 0.0, st["self_proximity"], st["self_contacts"]], dtype=np.float64)
+    tmax = coll.all_reduce(vals, MAX)
+    vals = coll.all_reduce(vals, SUM)
+    elapsed, kernel_ms, fused_elapsed = float(tmax[0]), float(tmax[8]), float(tmax[9])
+    if args.dump_states:                                      # tests: this rank's final states, to compare partitions
+        q_fin, v_fin = b.get_state()
+        np.savez(args.dump_states + ".rank%d.npz" % rank, qpos=q_fin, qvel=v_fin, offset=offset)
+    coll.close()                                              # every collective happens before the non-zero ranks leave
     if rank != 0:
         return
     env_steps = vals[1]
@@ -284,8 +273,18 @@ def main():
     achieved = bytes_per_launch / launch_s / 1e9
     traffic = None
     valu = None
-    prof = os.path.join(ROOT, "profiles", "r1_pmc.json")
-    if os.path.exists(prof) and n == 4096 and default_task:
+    # counters of the committed profile (tools/probes/prof_run.sh: the same command under rocprofv3, separate --pmc passes).
+    # They are only quoted when the profile was taken on THIS build of the library (sha256 of liblocohip.so stamped into it):
+    # after a kernel change they go stale, and stale numbers are dropped (null) rather than reported.
+    import hashlib
+    from loco_mujoco_amd import backend as _backend
+    lib_sha = hashlib.sha256(open(_backend.LIB_PATH, "rb").read()).hexdigest()[:16]
+    prof = os.path.join(ROOT, "profiles", "r2_pmc.json")
+    prof_note = "no committed profile for this workload"
+    if os.path.exists(prof) and n == 4096 and default_task and json.load(open(prof)).get("lib_sha16") != lib_sha:
+        prof_note = "profiles/r2_pmc.json was taken on another build of liblocohip.so (%s, this one is %s): counters not quoted" % (json.load(open(prof)).get("lib_sha16"), lib_sha)
+    elif os.path.exists(prof) and n == 4096 and default_task:
+        prof_note = "profiles/r2_pmc.json, taken on this build (liblocohip.so sha256[:16] = %s)" % lib_sha
         try:
             pmc = json.load(open(prof))["pmc"]
             # separate --pmc passes (tools/probes/prof_run.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)
@@ -297,7 +296,7 @@ def main():
                         valu_busy_frac_of_wave_time=pmc["SQ_INSTS_VALU"]["per_dispatch"] / pmc["SQ_WAVE_CYCLES"]["per_dispatch"],
                         mean_wave_time_over_launch_time=4.0 * pmc["SQ_WAVE_CYCLES"]["per_dispatch"] / pmc["SQ_WAVES"]["per_dispatch"]
                         / (prof_ns * 2.4),
-                        note="profiles/r1_pmc.json; 2.4 GHz assumed; one wave per SIMD at 4096 environments, so the SIMD's "
+                        note="profiles/r2_pmc.json; 2.4 GHz assumed; one wave per SIMD at 4096 environments, so the SIMD's "
                              "VALU issue rate is the product of the two fractions")
         except Exception:
             traffic = None
@@ -314,14 +313,18 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "kernel": "step_kernel<3,5,Euler,elliptic,replicated>" if default_task else "step_kernel",
+                     "kernel": "step_kernel<3 links,6 slots,Euler,elliptic,self-collisions,4 replicas>" if default_task else "step_kernel",
+                     "profile": prof_note, "lib_sha16": lib_sha,
                      "kernel_ms_per_launch": 1e3 * launch_s,
                      "algorithmic_bytes_per_env_step": per_env_step,
                      "note": "path is VALU-issue/latency-bound by design (SURVEY.md 8d): %d algorithmic B per env-step; "
-                             "traffic = PMC bytes per launch from profiles/r1_pmc.json (same command, separate rocprofv3 "
-                             "--pmc passes)" % per_env_step},
+                             "traffic = PMC bytes per launch from the committed profile (same command, separate rocprofv3 "
+                             "--pmc passes), null when that profile is not of this build" % per_env_step},
         "stats": {"episodes": vals[2], "mean_reward": vals[3] / max(env_steps, 1), "nan_resets": vals[4],
                   "overflow_contacts": vals[5], "unhandled_geom_substeps": vals[6],
+                  # where the device left its validated collision model (all ranks): forward passes x geom pairs of the robot
+                  # without a pair collider (box / cylinder) within the margin, and self-contacts it did simulate
+                  "self_proximity": vals[10], "self_contacts": vals[11],
                   "newton_iters_per_forward_pass": vals[7] / max(env_steps * forwards, 1),
                   "physics_substeps_per_s": 10 * value},
     }

@@ -54,3 +54,41 @@ def test_partition_and_metric_reduction_world2(tmp_path):
     rs = np.random.RandomState(0)
     traj, step = rs.randint(0, 3, 16), rs.randint(0, 100, 16)
     assert sum(res["rows"], []) == (traj * 100 + step).tolist()      # the union of the shards is the global assignment
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The product's own collective (loco_mujoco_amd/utils/collective.py; bench.py uses it, no PyTorch): world size 2 on the CPU
+# through the launcher the driver uses. The "tcp" backend carries the reduction over the rendezvous sockets; the "rccl"
+# backend needs GPUs and is exercised by the driver's multi-GPU runs.
+# ---------------------------------------------------------------------------------------------------------------------
+WORKER2 = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
+    coll = Collective(backend="tcp")
+    rank, world = coll.rank, coll.world
+    vals = np.array([1.0 + rank, 800.0, 3.0 + rank, 0.25 * (rank + 1)])
+    tmax = coll.all_reduce(vals, MAX)
+    tsum = coll.all_reduce(vals, SUM)
+    coll.barrier()
+    coll.close()
+    if rank == 0:
+        print(json.dumps(dict(world=world, tmax=tmax.tolist(), tsum=tsum.tolist())))
+""") % ROOT
+
+
+def test_product_collective_world2_through_the_launcher(tmp_path):
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["world"] == 2
+    assert res["tmax"] == [2.0, 800.0, 4.0, 0.5] and res["tsum"] == [3.0, 1600.0, 7.0, 0.75]

@@ -1290,3 +1290,35 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     assert ok.sum() >= min_ok * n
     assert ((flags & 2) != 0).sum() <= unhandled.sum() + 8      # the device's own proximity flag fires no more often than the oracle's
     assert eq[ok].max() <= QTOL and ev[ok].max() <= VTOL
+
+
+def test_bench_two_ranks_on_one_gpu_shard_invariance(tmp_path):
+    """The multi-rank flow of bench.py on a one-GPU box (`--share-gpu`: both ranks on device 0, the metric reduction over the
+    rendezvous sockets instead of RCCL, which refuses two ranks on one device), launched the way the driver launches it. Rank
+    r owns the global environments [256 r, 256 (r + 1)): the final states of rank 1 are BITWISE those of environments
+    256..511 of a one-rank run with 512 environments (reset RNG and random actions are keyed by the global id)."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--fuse", "0"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--envs-per-gpu", "256",
+                          "--dump-states", str(tmp_path / "two")] + common, capture_output=True, text=True, timeout=400, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--envs-per-gpu", "512", "--dump-states", str(tmp_path / "one")] + common,
+                         capture_output=True, text=True, timeout=400, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["global_envs"] == 512 and line2["scaling"] == "weak"
+    assert line2["stats"]["episodes"] == line1["stats"]["episodes"]                     # summed over the ranks
+    assert abs(line2["stats"]["mean_reward"] - line1["stats"]["mean_reward"]) < 1e-6
+    whole = np.load(str(tmp_path / "one") + ".rank0.npz")
+    for r in (0, 1):
+        part = np.load(str(tmp_path / "two") + ".rank%d.npz" % r)
+        assert int(part["offset"]) == 256 * r
+        assert np.array_equal(part["qpos"], whole["qpos"][256 * r:256 * (r + 1)]) and np.array_equal(part["qvel"], whole["qvel"][256 * r:256 * (r + 1)])
