@@ -1542,7 +1542,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // replicated small-batch layout: when some lane of the wave holds several contacts, the replicas of an environment
       // take every kRep-th slot each (forces here, Hessian blocks below) and add their parts up with the symmetric
       // butterfly, so that all replicas continue with bit-identical numbers
-      const bool split = Q::kRep > 1 && Q::any(nslot > 1);
+      // decided per ENVIRONMENT (quad), not per wave: the arithmetic of an environment must not depend on which other
+      // environments share its wave (ragged batches and shards of any size agree bitwise)
+      const bool split = Q::kRep > 1 && Q::sum((nslot > 1) ? 1.0f : 0.0f) > 0.0f;
       const int s_first = split ? Q::rep() : 0, s_step = split ? Q::kRep : 1;
       Q::fence();
       Sp Frt = sp0();              // wrench of the contacts of root geoms held by this lane

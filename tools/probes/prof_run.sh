@@ -12,6 +12,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM 
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_FLAT SQ_IFETCH SQ_WAIT_INST_LDS -d $OUT/pmc2 -o pmc2 -- $CMD > /dev/null 2> $OUT/pmc2.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $CMD > /dev/null 2> $OUT/pmc3.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $CMD > /dev/null 2> $OUT/pmc4.err
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES -d $OUT/pmc5 -o pmc5 -- $CMD > /dev/null 2> $OUT/pmc5.err
 cd $OUT
 find . -name "*.csv" | head -30
 python - <<'PY'
@@ -19,7 +20,7 @@ import csv, glob, collections, json, os
 res = {}
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     res["kernel_stats"] = list(csv.DictReader(open(f)))
-for tag in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for tag in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
     for f in glob.glob(tag + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
@@ -29,3 +30,5 @@ for tag in ("pmc1", "pmc2", "pmc3", "pmc4"):
 json.dump(res, open("summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
 PY
+
+cd $GRAFT_REPO_ROOT && python tools/summarize_rocprof.py gpurun_out/prof_$TAG $TAG > /dev/null 2>&1 && mkdir -p gpurun_out/profiles && cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc.json gpurun_out/profiles/

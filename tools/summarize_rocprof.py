@@ -59,5 +59,10 @@ if os.path.exists(bench):
         summary["bench_line_under_trace"] = json.loads(open(bench).read().strip().splitlines()[-1])
     except Exception:
         pass
+# the build these counters belong to: bench.py quotes them only when the library it loads has the same hash
+import hashlib
+lib = os.path.join(root, "loco_mujoco_amd", "csrc", "liblocohip.so")
+if os.path.exists(lib):
+    summary["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
 json.dump(summary, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
