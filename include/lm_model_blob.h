@@ -14,13 +14,13 @@
 #define LM_MODEL_BLOB_H
 
 #define LM_BLOB_MAGIC 0x4C4D4231 /* "LMB1" */
-#define LM_BLOB_VERSION 3
+#define LM_BLOB_VERSION 4
 
 /* header slots (doubles) */
 enum {
   LMH_MAGIC = 0, LMH_VERSION, LMH_NBODY, LMH_NV, LMH_NGEOM, LMH_NU, LMH_CONE, LMH_INTEGRATOR,
   LMH_ITERATIONS, LMH_TIMESTEP, LMH_IMPRATIO, LMH_TOLERANCE, LMH_GRAV_X, LMH_GRAV_Y, LMH_GRAV_Z,
-  LMH_MEANINERTIA, LMH_NSITE, LMH_NTENDON, LMH_NWRAP, LMH_NA, LMH_HEADER_SIZE = 32
+  LMH_MEANINERTIA, LMH_NSITE, LMH_NTENDON, LMH_NWRAP, LMH_NA, LMH_NHULLVERT, LMH_HEADER_SIZE = 32
 };
 
 /* geom types / joint types / cones / integrators (private numbering of this framework) */
@@ -51,6 +51,8 @@ enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1, LM_ACT_POSITION = 2 };
  *   | LM_ACT_POSITION: affine joint servo, force = gainprm[0]*ctrl + biasprm[0] + biasprm[1]*length + biasprm[2]*velocity)
  *  -- version 3
  *  act_biasprm[3nu] act_forcerange[2nu] act_forcelimited[nu]   (force clamped to forcerange when forcelimited)
+ *  -- version 4: convex hulls of the mesh geoms (nh = LMH_NHULLVERT vertices in all, each in the frame of its geom's BODY)
+ *  geom_hull_adr[ng] (-1: none) geom_hull_num[ng] hull_vert[3nh]   (plane vs mesh: one contact at the hull's support vertex)
  */
 
 #endif

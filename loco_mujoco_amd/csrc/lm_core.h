@@ -140,6 +140,7 @@ struct Params {
   int off_runsup, off_cunsup, off_prune;   // tail lists of the constant table (lm_layout.h LM_H_OFF_*)
   int off_lgroup;     // geom groups per link with their bounding spheres (constant-table tail, LM_H_OFF_LGROUP)
   int off_lpair;      // link-pair list of the self-collision broad phase (constant-table tail, LM_H_OFF_LPAIR)
+  const float* meshv; // hull vertices of the mesh colliders (global memory, 4 floats per vertex, link frame)
   const float* gpt;   // geom-pair table (global memory): records of LM_GPAIR_SIZE floats, read when a link pair is within reach
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
 };
@@ -760,6 +761,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   int nslot = 0;
   int pair_mask_out = 0;           // partner lanes of this lane's cross-chain contact slots (PAIRS)
   int nrootslot = 0, npairslot = 0; // slots of root-body geoms / of self-contacts held by this lane
+  float pair_speed = 0.0f;          // largest speed of a point of this chain's links against the root body (PAIRS)
   int nfloor = 0;                   // slots [0, nfloor) are floor contacts, [nfloor, nslot) self-contacts: the loops over the
                                     // slots run the lean floor code first and the general-frame code for the rest
   {
@@ -799,12 +801,48 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int i = 0; i < 9; i++) LMEM(LMm::kFrame + k * 18 + 3 + i) = Rk.a[i];
           LMEM(LMm::kFrame + k * 18 + 12) = V.w.x; LMEM(LMm::kFrame + k * 18 + 13) = V.w.y; LMEM(LMm::kFrame + k * 18 + 14) = V.w.z;
           LMEM(LMm::kFrame + k * 18 + 15) = V.v.x; LMEM(LMm::kFrame + k * 18 + 16) = V.v.y; LMEM(LMm::kFrame + k * 18 + 17) = V.v.z;
+          if (PAIRS) {
+            // self-collision broad phase: world centre of the link's bounding sphere, and the speed of the link's points
+            // against the root body, |v_c| + |w| r with the twist relative to the root (the detection's travel bound)
+            const V3 cw = pk + mul(Rk, v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ)));
+            LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z;
+            const V3 wr = V.w - Vroot.w;
+            const V3 vcr = V.v - Vroot.v + cross(wr, cw - O);
+            pair_speed = fmaxf(pair_speed, sqrtf(dot(vcr, vcr)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
+          }
         } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
       }
   // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link. The replicas of a
   // small-batch environment take every kRep-th geom; in each pass they exchange how many contacts they found, so that
   // the slot records land in lane memory in the same order (geom, then candidate point) as without replicas.
       int n_overflow = 0, n_unhandled = 0;
+      // one floor contact of geom g (link k, twist V) at (px, py), `dist` above the plane -> slot record
+      auto emit_floor_slot = [&](int slot, int g, int k, const Sp& V, float margin, float px, float py, float dist) {
+          // contact point (midway between the surfaces) relative to O; row parameters
+          V3 cp = v3(px, py, 0.5f * dist) - O;
+          float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
+          float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
+          float vel[6];
+          contact_rows(V, cp, vel);
+          const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
+          const int dim = (int)GE(g, LM_G_DIM);
+          SL(slot, SL_LINK) = (float)k; SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = mu;
+          SL(slot, SL_GRF) = GE(g, LM_G_GRF);
+          if (PAIRS) SL(slot, SL_PART) = 0.0f;
+          SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
+          SL(slot, SL_D) = D0;
+          if (PYR3(dim)) {
+            float xv[4];
+            pyr_rows(vel, mu, xv);
+#pragma unroll
+            for (int r = 0; r < 4; r++) SL(slot, SL_AREF + r) = -B * xv[r] - Kr;
+          } else {
+#pragma unroll
+            for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / GE(g, LM_G_RR1 + j2 - 1) : 0.0f; SL(slot, SL_FR + j2 - 1) = GE(g, LM_G_F0 + j2 - 1); }
+#pragma unroll
+            for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -B * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
+          }
+      };
       // two levels: the geoms of a link (or of the root body: link -1, this lane's share) form a group with a bounding sphere;
       // a link high above the floor costs one test per pass
       const int ngroups = (int)CH(LM_C_NLGROUP);
@@ -829,7 +867,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         int k = 0;
         Sp V = sp0();
         float margin = 0.0f;
-        if (g < ng) {
+        if (g < ng && (int)GP(g, 5) != LM_GEOM_MESH) {
           k = (int)GP(g, 0);               // link of the geom; -1: a geom of the root body, dealt to this chain's lane
           const int fb = LMm::kFrame + (k < 0 ? 0 : k) * 18;
           const V3 gl = v3(GP(g, 1), GP(g, 2), GP(g, 3));
@@ -910,32 +948,51 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           float px = cx[0], py = cy[0], dist = cd[0];
 #pragma unroll
           for (int q = 1; q < 4; q++) if (j == q) { px = cx[q]; py = cy[q]; dist = cd[q]; }
-          // contact point (midway between the surfaces) relative to O; row parameters
-          V3 cp = v3(px, py, 0.5f * dist) - O;
-          float imp = impedance(&GE(g, LM_G_S0), LM_NCHAIN, dist, margin);
-          float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * GE(g, LM_G_TRAN));
-          float vel[6];
-          contact_rows(V, cp, vel);
-          const float B = GE(g, LM_G_B), Kr = GE(g, LM_G_K) * imp * (dist - margin), mu = GE(g, LM_G_MU);
-          const int dim = (int)GE(g, LM_G_DIM);
-          SL(slot, SL_LINK) = (float)k; SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = mu;
-          SL(slot, SL_GRF) = GE(g, LM_G_GRF);
-          if (PAIRS) SL(slot, SL_PART) = 0.0f;
-          SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
-          SL(slot, SL_D) = D0;
-          if (PYR3(dim)) {
-            float xv[4];
-            pyr_rows(vel, mu, xv);
-#pragma unroll
-            for (int r = 0; r < 4; r++) SL(slot, SL_AREF + r) = -B * xv[r] - Kr;
-          } else {
-#pragma unroll
-            for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / GE(g, LM_G_RR1 + j2 - 1) : 0.0f; SL(slot, SL_FR + j2 - 1) = GE(g, LM_G_F0 + j2 - 1); }
-#pragma unroll
-            for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -B * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
-          }
+          emit_floor_slot(slot, g, k, V, margin, px, py, dist);
         }
         nslot += total;
+      }
+      // ---- convex meshes of the group (plane vs hull: ONE contact, at the support vertex — pinned by the UnitreeH1 golden
+      // rows): every replica takes the same geom and a quarter of its hull vertices (mesh-vertex table, global
+      // memory, link frame); the lowest vertex wins, ties go to the first in the table like a sequential search
+      for (int g = gfirst; g < gend; g++) {
+        if ((int)GP(g, 5) != LM_GEOM_MESH) continue;
+        const int k = (int)GP(g, 0);
+        const int fb = LMm::kFrame + (k < 0 ? 0 : k) * 18;
+        const V3 gl = v3(GP(g, 1), GP(g, 2), GP(g, 3));
+        V3 pk = O; M3 Rk = R; Sp V = Vroot;
+        if (k >= 0) {
+          pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+#pragma unroll
+          for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
+          V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+        }
+        if (pk.z + Rk.a[6] * gl.x + Rk.a[7] * gl.y + Rk.a[8] * gl.z - GP(g, 4) > 0.0f) continue;      // bounding sphere above the floor
+        const int v0 = (int)GE(g, LM_G_SX), nvert = (int)GE(g, LM_G_SY);
+        const V3 nl = v3(Rk.a[6], Rk.a[7], Rk.a[8]);       // the plane normal in the link frame (third row of the rotation)
+        float best = 3.0e38f; int ibest = 0x7fffffff;
+        for (int i = Q::rep(); i < nvert; i += Q::kRep) {
+          const float* vp = P.meshv + 4 * (v0 + i);
+          const float d = nl.x * vp[0] + nl.y * vp[1] + nl.z * vp[2];
+          if (d < best) { best = d; ibest = i; }
+        }
+        if (Q::kRep > 1) {
+          float gb = best; int gi = ibest;
+#pragma unroll
+          for (int r = 0; r < Q::kRep; r++) {
+            const float bd = Q::rep_bcast(best, r); const int bi = (int)Q::rep_bcast((float)ibest, r);
+            if (bd < gb || (bd == gb && bi < gi)) { gb = bd; gi = bi; }
+          }
+          best = gb; ibest = gi;
+        }
+        if (ibest >= nvert) continue;
+        const float* vp = P.meshv + 4 * (v0 + ibest);
+        const V3 sv = pk + mul(Rk, v3(vp[0], vp[1], vp[2]));
+        const float margin = GE(g, LM_G_MARGIN);
+        if (!(sv.z < margin)) continue;
+        if (nslot >= NS) { n_overflow += (Q::rep() == 0) ? 1 : 0; continue; }
+        emit_floor_slot(nslot, g, k, V, margin, sv.x, sv.y, sv.z);
+        nslot++;
       }
       }
       if (nslot > NS) nslot = NS;
@@ -965,20 +1022,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     bool detect = PAIRS, first_detect = true;
     float gap_min = 3.0e38f;
     if (PAIRS) {
-      float s_own = 0.0f;
-#pragma unroll
-      for (int k = 0; k < MC; k++) if (k < nl) {
-        const int fb = LMm::kFrame + k * 18;
-        const V3 bl = v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ));
-        const V3 cw = v3(LMEM(fb + 0) + LMEM(fb + 3) * bl.x + LMEM(fb + 4) * bl.y + LMEM(fb + 5) * bl.z,
-                         LMEM(fb + 1) + LMEM(fb + 6) * bl.x + LMEM(fb + 7) * bl.y + LMEM(fb + 8) * bl.z,
-                         LMEM(fb + 2) + LMEM(fb + 9) * bl.x + LMEM(fb + 10) * bl.y + LMEM(fb + 11) * bl.z);
-        LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z;
-        // speed of the link's points against the root body: |v_c| + |w| r with the twist relative to the root
-        const V3 wr = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)) - Vroot.w;
-        const V3 vc = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17)) - Vroot.v + cross(wr, cw - O);
-        s_own = fmaxf(s_own, sqrtf(dot(vc, vc)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
-      }
+      const float s_own = pair_speed;
       const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
       first_detect = !pair_slack || *pair_slack == 0.0f;        // the first pass of a control step (the caller starts it at 0)
       float slack = (pair_slack ? *pair_slack : 0.0f) - P.h * (s_own + s_quad);

@@ -23,6 +23,7 @@ struct lm_model {
   float* d_gt;               // geom table: full records of the geoms with a collider
   float* d_mt;               // muscle table (models with muscles)
   float* d_gpt;              // geom-pair table of the self-collision path
+  float* d_meshv;            // hull vertices of the mesh colliders
   std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
   int nroot;
@@ -195,6 +196,15 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     HIPCHK(hipMemcpy(m->d_gpt, gpt.data(), sizeof(float) * gpt.size(), hipMemcpyHostToDevice));
     P.gpt = m->d_gpt;
   }
+  {
+    const size_t nmv = (size_t)cmod[LM_H_NMESHV], off = (size_t)cmod[LM_H_OFF_MESHV];
+    if (nmv > 0 && n < off + 4 * nmv) return fail("chain model lacks the mesh-vertex table");
+    std::vector<float> mv(4 * nmv + 4, 0.0f);
+    for (size_t i = 0; i < 4 * nmv; i++) mv[i] = (float)cmod[off + i];
+    HIPCHK(hipMalloc(&m->d_meshv, sizeof(float) * mv.size()));
+    HIPCHK(hipMemcpy(m->d_meshv, mv.data(), sizeof(float) * mv.size(), hipMemcpyHostToDevice));
+    P.meshv = m->d_meshv;
+  }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
@@ -212,6 +222,7 @@ void lm_model_destroy(lm_model* m) {
   if (m->d_cm) (void)hipFree(m->d_cm);
   if (m->d_gt) (void)hipFree(m->d_gt);
   if (m->d_gpt) (void)hipFree(m->d_gpt);
+  if (m->d_meshv) (void)hipFree(m->d_meshv);
   if (m->d_mt) (void)hipFree(m->d_mt);
   delete m;
 }

@@ -55,7 +55,7 @@ C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_LIN
 # C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
 CHAIN_SIZE = C_LINKS + MAXC * LINK_SIZE
 U_SIZE = 6        # collider-less ("unsupported") geom: (link, px,py,pz, rbound, margin)
-P_SIZE = 5        # prune record of a geom with a collider: (link, px,py,pz, rbound) — the full record is in the geom table
+P_SIZE = 6        # prune record of a geom with a collider: (link, px,py,pz, rbound, type) — the full record is in the geom table
 LG_SIZE = 7       # geoms of one link as a group: (link, first geom, count, bounding sphere cx,cy,cz, r); link -1 = root body
 MAXLG = MAXC + 1
 # ---- root block (replicated for all lanes)
@@ -84,7 +84,7 @@ CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN + MAXRG * U_SIZE + MAXG * (U_SIZE + P_
 # [geom][field][chain]
 GT_SIZE = MAXG * G_SIZE * NCHAIN
 
-GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX, mjcf.GEOM_CYLINDER)
+GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX, mjcf.GEOM_CYLINDER)     # + meshes that come with a convex hull
 MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
 
 
@@ -127,12 +127,37 @@ def _mix_with_floor(m, g, gf):
     return int(dim), np.asarray(solref, float), np.asarray(solimp, float), friction, margin, gap
 
 
+def _fill_contact_params(blk, m, b, dim, fr):
+    """cone-dependent floor-contact constants of a geom on body ``b`` (G_DIM, G_F*, G_MU, G_TRAN, G_RR*)."""
+    tran = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
+    blk[G_DIM] = dim
+    blk[G_F0:G_F0 + 5] = fr
+    if m.cone == mjcf.CONE_ELLIPTIC:
+        if dim not in (1, 3, 4, 6):
+            raise UnsupportedModel("condim %d" % dim)
+        blk[G_TRAN] = tran
+        blk[G_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
+        rr1 = 1.0 / max(MINVAL, m.impratio)
+        blk[G_RR1], blk[G_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
+        blk[G_RR3:G_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+    else:
+        if dim not in (1, 3):
+            raise UnsupportedModel("pyramidal condim %d is not built on the device" % dim)
+        if fr[0] != fr[1]:
+            raise UnsupportedModel("anisotropic sliding friction")
+        mu = fr[0]
+        blk[G_MU] = mu
+        # every edge of the pyramid: diagApprox = (1+mu^2) tran, shared regulariser Rpy = 2 mu^2 R
+        blk[G_TRAN] = 2 * mu * mu * (1 + mu * mu) * tran if dim == 3 else tran
+        blk[G_RR1:G_RR1 + 5] = 1.0
+
+
 HEADER_SIZE = 48
 LMC_MAGIC = 0x4C4D4332  # "LMC2"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
 H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED, H_ACTMODE = 25, 26, 27, 28, 29, 30, 31, 32, 33
-H_OFF_RUNSUP, H_OFF_CUNSUP, H_OFF_PRUNE, H_GT_SIZE, H_OFF_LPAIR, H_NGPAIR, H_OFF_GPT, H_OFF_LGROUP = 34, 35, 36, 37, 38, 39, 40, 41
+H_OFF_RUNSUP, H_OFF_CUNSUP, H_OFF_PRUNE, H_GT_SIZE, H_OFF_LPAIR, H_NGPAIR, H_OFF_GPT, H_OFF_LGROUP, H_NMESHV, H_OFF_MESHV = 34, 35, 36, 37, 38, 39, 40, 41, 42, 43
 # H_NGPAIR geom-pair records start H_OFF_GPT floats into the chain-model array (behind the geom table and the muscle table)
 # H_OFF_*: offsets (floats from the start of the constant table) of the tail lists, see CM_SIZE
 # H_ACTMODE: 0 = joint motors (torque = gear * ctrl), 1 = position servos on every actuated joint
@@ -364,6 +389,25 @@ def lower(m, task):
             t, size = m.geom_type[g], m.geom_size[g]
             rbound = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1], mjcf.GEOM_MESH: size[0] + size[1],
                       mjcf.GEOM_CYLINDER: np.hypot(size[0], size[1]), mjcf.GEOM_BOX: np.linalg.norm(size)}[t]
+            hull_n = int(getattr(m, "geom_hull_num", np.zeros(m.ngeom, int))[g])
+            if t == mjcf.GEOM_MESH and hull_n > 0:
+                # plane vs convex hull: one contact at the support vertex. The hull's vertices go into the
+                # mesh-vertex table in the frame of the LINK; the prune sphere is the hull's bounding sphere
+                hv = p + m.hull_vert[m.geom_hull_adr[g]:m.geom_hull_adr[g] + hull_n].astype(np.float64) @ r.T
+                ctr = 0.5 * (hv.min(0) + hv.max(0))
+                blk = np.zeros(G_SIZE)
+                blk[G_GRF] = grf_of_geom.get(g, -1)
+                blk[G_LINK], blk[G_TYPE] = link_index, t
+                blk[G_PX:G_PX + 3] = ctr
+                blk[G_R0:G_R0 + 9] = np.eye(3).reshape(9)
+                blk[G_RBOUND], blk[G_MARGIN] = float(np.linalg.norm(hv - ctr, axis=1).max()) * (1 + 1e-6), margin
+                blk[G_SX], blk[G_SY] = len(mesh_verts), hull_n           # first vertex, vertex count in the mesh-vertex table
+                mesh_verts.extend(hv.tolist())
+                blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
+                blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
+                _fill_contact_params(blk, m, b, dim, fr)
+                sup.append(blk)
+                continue
             if t == mjcf.GEOM_MESH:
                 # proximity-only bounding capsule (mjcf.compile_mjcf): the floor is within reach of a capsule exactly
                 # when it is within reach of one of its two end spheres
@@ -385,31 +429,12 @@ def lower(m, task):
             blk[G_RADIUS], blk[G_HALF], blk[G_RBOUND], blk[G_MARGIN] = size[0], (size[1] if t in (mjcf.GEOM_CAPSULE, mjcf.GEOM_CYLINDER) else 0), rbound, margin
             blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
             blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
-            tran = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
-            blk[G_DIM] = dim
-            blk[G_F0:G_F0 + 5] = fr
-            if m.cone == mjcf.CONE_ELLIPTIC:
-                if dim not in (1, 3, 4, 6):
-                    raise UnsupportedModel("condim %d" % dim)
-                blk[G_TRAN] = tran
-                blk[G_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
-                rr1 = 1.0 / max(MINVAL, m.impratio)
-                blk[G_RR1], blk[G_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
-                blk[G_RR3:G_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
-            else:
-                if dim not in (1, 3):
-                    raise UnsupportedModel("pyramidal condim %d is not built on the device" % dim)
-                if fr[0] != fr[1]:
-                    raise UnsupportedModel("anisotropic sliding friction")
-                mu = fr[0]
-                blk[G_MU] = mu
-                # every edge of the pyramid: diagApprox = (1+mu^2) tran, shared regulariser Rpy = 2 mu^2 R
-                blk[G_TRAN] = 2 * mu * mu * (1 + mu * mu) * tran if dim == 3 else tran
-                blk[G_RR1:G_RR1 + 5] = 1.0
+            _fill_contact_params(blk, m, b, dim, fr)
             sup.append(blk)
         return sup, unsup
 
     info = dict(root=root, chains=chains)
+    mesh_verts = []                    # hull vertices of the mesh colliders, link frame (device table, global memory)
 
     # ---- root block
     rb = cm[CM_ROOT:CM_ROOT + ROOT_SIZE]
@@ -494,18 +519,22 @@ def lower(m, task):
         # only reach the floor once the robot has fallen; contacts beyond the kernel's slots are dropped and counted in
         # `overflow_contacts`
         for gb in geoms:
-            cap = {mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4, mjcf.GEOM_CYLINDER: 4}[int(gb[G_TYPE])]
+            cap = {mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4, mjcf.GEOM_CYLINDER: 4, mjcf.GEOM_MESH: 1}[int(gb[G_TYPE])]
             b = links[int(gb[G_LINK])][0] if gb[G_LINK] >= 0 else root
             rot = kin["xmat"][b] @ gb[G_R0:G_R0 + 9].reshape(3, 3)            # geom axes in the world at qpos0
             t, size = int(gb[G_TYPE]), gb[G_SX:G_SX + 3]
-            reach = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1] * abs(rot[2, 2]),
-                     mjcf.GEOM_CYLINDER: size[1] * abs(rot[2, 2]) + size[0] * np.sqrt(max(0.0, 1 - rot[2, 2] ** 2)),
-                     mjcf.GEOM_BOX: float(np.abs(rot[2]) @ size)}[t]
+            if t == mjcf.GEOM_MESH:
+                hv = np.array(mesh_verts[int(size[0]):int(size[0]) + int(size[1])])
+                reach = -float(((hv - gb[G_PX:G_PX + 3]) @ kin["xmat"][b].T)[:, 2].min())
+            else:
+                reach = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1] * abs(rot[2, 2]),
+                         mjcf.GEOM_CYLINDER: size[1] * abs(rot[2, 2]) + size[0] * np.sqrt(max(0.0, 1 - rot[2, 2] ** 2)),
+                         mjcf.GEOM_BOX: float(np.abs(rot[2]) @ size)}[t]
             bottom = (kin["xpos"][b] + kin["xmat"][b] @ gb[G_PX:G_PX + 3])[2] - reach
             standing.append((c, bottom, cap))
         for i, gblk in enumerate(geoms):
             gt[(i * G_SIZE + np.arange(G_SIZE)) * NCHAIN + c] = gblk
-            chain_prune[c].append([gblk[G_LINK], gblk[G_PX], gblk[G_PY], gblk[G_PZ], gblk[G_RBOUND]])
+            chain_prune[c].append([gblk[G_LINK], gblk[G_PX], gblk[G_PY], gblk[G_PZ], gblk[G_RBOUND], gblk[G_TYPE]])
         # the geoms of one link form a group with a bounding sphere: a link far above the floor costs one test per pass
         i = 0
         while i < len(geoms):
@@ -672,7 +701,12 @@ def lower(m, task):
                 self_collision_pairs=_count_self_pairs(m))
     h[H_NGPAIR] = len(gpt) // GPAIR_SIZE
     h[H_OFF_GPT] = HEADER_SIZE + CM_SIZE + GT_SIZE + (MT_SIZE if mt is not None else 0)
-    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt]), info
+    meshv = np.zeros((len(mesh_verts), 4))
+    if mesh_verts:
+        meshv[:, :3] = mesh_verts
+    h[H_NMESHV], h[H_OFF_MESHV] = len(mesh_verts), h[H_OFF_GPT] + len(gpt)
+    info["mesh_vertices"] = len(mesh_verts)
+    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel()]), info
 
 
 def _self_collision_tables(m, root, chains, kin):

@@ -362,7 +362,7 @@ def _geom_inertia(g, tris):
     return m, g["pos"].copy(), r @ np.diag(m * diag) @ r.T
 
 
-def _mesh_bounds(root, comp, base_dir):
+def _mesh_bounds(root, comp, base_dir, hulls=None):
     """{mesh name: bounding capsule (centre, axis, radius, half length)} in the mesh's own frame, from binary STL files."""
     out = {}
     if base_dir is None:
@@ -381,7 +381,18 @@ def _mesh_bounds(root, comp, base_dir):
             continue                      # ASCII STL: not read
         tri = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", 9), ("a", "<u2")]), count=ntri)
         v = tri["v"].reshape(-1, 3).astype(np.float64) * _floats(el.get("scale", "1 1 1"), 3)
-        out[el.get("name", os.path.splitext(os.path.basename(f))[0])] = _bounding_capsule(v)
+        name = el.get("name", os.path.splitext(os.path.basename(f))[0])
+        out[name] = _bounding_capsule(v)
+        if hulls is not None:
+            # vertices of the convex hull, in the order of their first appearance in the file (the support search of the
+            # plane-mesh collider breaks ties by that order): the engine collides the hull of a mesh, not the mesh
+            pts, first = np.unique(v, axis=0, return_index=True)
+            try:
+                from scipy.spatial import ConvexHull
+                keep = np.sort(first[ConvexHull(pts).vertices])
+                hulls[name] = v[keep]
+            except Exception:             # degenerate (flat) mesh or no scipy: every distinct vertex
+                hulls[name] = v[np.sort(first)]
     return out
 
 
@@ -598,12 +609,16 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.n_dropped_mesh_geoms = sum(1 for g in geoms if g["type"] == GEOM_MESH)
     if m.n_dropped_mesh_geoms and not drop_mesh_geoms:
         raise NotImplementedError("collidable mesh geoms need the convex-hull path (not built yet)")
-    bounds = _mesh_bounds(root, comp, handle.base_dir) if m.n_dropped_mesh_geoms else {}
+    hulls = {}
+    bounds = _mesh_bounds(root, comp, handle.base_dir, hulls) if m.n_dropped_mesh_geoms else {}
     kept = []
+    hull_of = {}                      # index in `kept` -> hull vertices in the frame of the geom's body
     for g in geoms:
         if g["type"] == GEOM_MESH:
             if g["mesh"] not in bounds:
                 continue
+            if g["mesh"] in hulls:
+                hull_of[len(kept)] = g["pos"] + hulls[g["mesh"]] @ quat_to_mat(g["quat"]).T
             centre, axis, radius, half = bounds[g["mesh"]]
             g = dict(g, pos=g["pos"] + quat_to_mat(g["quat"]) @ centre, quat=quat_mul(g["quat"], z_to_quat(axis)),
                      size=np.array([radius, half, 0.0]))
@@ -626,6 +641,16 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.geom_solimp = np.array([g["solimp"] for g in geoms]).reshape(-1, 5)
     m.geom_margin = np.array([g["margin"] for g in geoms])
     m.geom_gap = np.array([g["gap"] for g in geoms])
+    # convex hulls of the mesh geoms (plane-mesh collider: one contact at the hull's support vertex): vertices of geom g are
+    # hull_vert[geom_hull_adr[g] : + geom_hull_num[g]], in the frame of the geom's body; -1 / 0 for the other geoms
+    m.geom_hull_adr = -np.ones(m.ngeom, dtype=np.int32)
+    m.geom_hull_num = np.zeros(m.ngeom, dtype=np.int32)
+    chunks, n = [], 0
+    for gi in sorted(hull_of):
+        m.geom_hull_adr[gi], m.geom_hull_num[gi] = n, len(hull_of[gi])
+        chunks.append(hull_of[gi])
+        n += len(hull_of[gi])
+    m.hull_vert = (np.concatenate(chunks) if chunks else np.zeros((0, 3))).astype(np.float32)
 
     # ---------------- sites
     m.nsite = len(sites)

@@ -13,7 +13,7 @@ HEADER_SIZE = 32
 def pack_model(m):
     h = np.zeros(HEADER_SIZE)
     h[0] = LM_BLOB_MAGIC
-    h[1] = 3
+    h[1] = 4
     h[2:9] = [m.nbody, m.nv, m.ngeom, m.nu, m.cone, m.integrator, m.iterations]
     h[9:12] = [m.timestep, m.impratio, m.tolerance]
     h[12:15] = m.gravity
@@ -24,6 +24,8 @@ def pack_model(m):
     wrap = np.array([renum[int(i)] for i in getattr(m, "wrap_site", [])], dtype=np.float64)
     nt = int(getattr(m, "ntendon", 0))
     h[16:20] = [len(used), nt, len(wrap), int(getattr(m, "na", 0))]
+    hull_vert = np.asarray(getattr(m, "hull_vert", np.zeros((0, 3))), dtype=np.float64)
+    h[20] = len(hull_vert)
     zeros = lambda *shape: np.zeros(shape)
     nu = m.nu
     parts = [h,
@@ -42,5 +44,6 @@ def pack_model(m):
              getattr(m, "act_kind", zeros(nu)), getattr(m, "act_tendon", -np.ones(nu)), getattr(m, "act_dynprm", zeros(nu, 3)),
              getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2)),
              getattr(m, "act_biasprm", zeros(nu, 3)), getattr(m, "act_forcerange", zeros(nu, 2)),
-             getattr(m, "act_forcelimited", zeros(nu))]
+             getattr(m, "act_forcelimited", zeros(nu)),
+             getattr(m, "geom_hull_adr", -np.ones(m.ngeom)), getattr(m, "geom_hull_num", zeros(m.ngeom)), hull_vert]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

@@ -141,8 +141,17 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   TAKE(wrap_site, m->nwrap);
   TAKE(act_kind, nu); TAKE(act_tendon, nu); TAKE(act_dynprm, 3*nu); TAKE(act_gainprm, 9*nu); TAKE(act_lengthrange, 2*nu);
   TAKE(act_biasprm, 3*nu); TAKE(act_forcerange, 2*nu); TAKE(act_forcelimited, nu);
+  const int nhull = (int)m->blob[LMH_NHULLVERT];
+  const double *hull_adr, *hull_num, *hull_vert;
+  hull_adr = p; p += ng; hull_num = p; p += ng; hull_vert = p; p += 3 * nhull;
 #undef TAKE
   if (p - m->blob != n) { free(m->blob); free(m); return NULL; }
+  /* convex hulls that come with the model (mesh geoms): the same as lmo_set_mesh per geom */
+  for (int g = 0; g < ng; g++) if (IDX(hull_num, g) > 0 && IDX(hull_adr, g) >= 0) {
+    m->mesh_nvert[g] = IDX(hull_num, g);
+    m->mesh_vert[g] = (double*)malloc(sizeof(double) * 3 * m->mesh_nvert[g]);
+    memcpy(m->mesh_vert[g], hull_vert + 3 * IDX(hull_adr, g), sizeof(double) * 3 * m->mesh_nvert[g]);
+  }
 
   for (int b = 1; b < nb; b++) {
     int a = b;

@@ -149,6 +149,9 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   std::vector<float> gpt((size_t)H[LM_H_NGPAIR] * LM_GPAIR_SIZE + 1);
   for (size_t i = 0; i + 1 < gpt.size(); i++) gpt[i] = (float)H[(size_t)H[LM_H_OFF_GPT] + i];
   P.gpt = gpt.data();
+  std::vector<float> meshv(4 * (size_t)H[LM_H_NMESHV] + 4);
+  for (size_t i = 0; i + 4 < meshv.size(); i++) meshv[i] = (float)H[(size_t)H[LM_H_OFF_MESHV] + i];
+  P.meshv = meshv.data();
   int cnt_tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int t) {
     const int c = t & 3;

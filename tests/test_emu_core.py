@@ -33,7 +33,7 @@ def actions(n):
 def test_lowering_structure(setup):
     env, cmod, info, o = setup
     assert info["n_chains"] == 4 and info["max_links"] == 3
-    assert len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.GPAIR_SIZE * int(cmod[lowering.H_NGPAIR])
+    assert len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.GPAIR_SIZE * int(cmod[lowering.H_NGPAIR]) + 4 * int(cmod[lowering.H_NMESHV])
     assert sorted(int(x) for x in info["dof_to_lane"][6:]) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
 
 
@@ -268,7 +268,7 @@ def test_core_muscles():
     env = LocoEnv.make("HumanoidMuscle.walk", debug=True)
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
-    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE
+    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE + 4 * int(cmod[lowering.H_NMESHV])
     o = Oracle(pack_model(m))
     g = GOLD["HumanoidMuscle.walk.real"]
     qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]
@@ -366,3 +366,31 @@ def test_core_self_contacts(rep):
         assert np.abs(qe[0] - qo).max() < 1e-4 and np.abs(ve[0] - vo).max() < 1e-2, (i, np.abs(qe[0] - qo).max(), np.abs(ve[0] - vo).max())
         seen_multi += d["npairs"][i] > 1
     assert seen_multi >= 2
+
+
+@pytest.mark.parametrize("rep", [1, 4])
+def test_core_plane_mesh_unitree_h1(rep):
+    """Plane vs convex hull on the device code (one contact at the hull's support vertex; the vertices come from the mesh-vertex
+    table, in the replicated layout every replica searches a quarter of the hull): UnitreeH1's golden rows whose only contacts
+    are its mesh feet on the floor (walk rows 15-20: heel strike to double support), one control step against the golden
+    successor and the oracle."""
+    from test_oracle_golden import _h1_kat_inputs
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeH1.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["mesh_vertices"] > 5000 and info["max_links"] == 5
+    o = Oracle(pack_model(m))
+    g, qidx, rows = _h1_kat_inputs(env, "walk")
+    for k in ((15, 17, 19, 20) if rep == 1 else (16, 19)):
+        qpos, qvel, a = rows[k]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        f = o.forward(qpos, qvel, ctrl)
+        assert f["ncon"] >= 1 and all(m.geom_type[c["geom2"]] == 5 for c in f["contacts"])        # mesh feet only
+        _, _, _, cnt, dbg = pyemu.run(cmod, qpos, qvel, a, nsub=1, debug_env=0, ls_points=4, rep=rep)
+        assert cnt["ncon"] == f["ncon"] and cnt["overflow"] == 0, (k, cnt, f["ncon"])
+        assert np.abs(dbg["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max())
+        q10, v10, _, c10, _ = pyemu.run(cmod, qpos, qvel, a, nsub=10, ls_points=4, rep=rep)
+        assert c10["overflow"] == 0
+        assert np.abs(q10[0][qidx[2:]] - g[k + 1, :15]).max() < 1e-5 and np.abs(v10[0][qidx] - g[k + 1, 15:32]).max() < 2e-3, (k, np.abs(v10[0][qidx] - g[k + 1, 15:32]).max())

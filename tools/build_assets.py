@@ -24,11 +24,13 @@ from loco_mujoco_amd import mjcf                      # noqa: E402
 from loco_mujoco_amd.environments.unitree_a1 import UnitreeA1   # noqa: E402
 from loco_mujoco_amd.environments.atlas import Atlas, _ARM, _BACK   # noqa: E402
 from loco_mujoco_amd.environments.talos import Talos   # noqa: E402
+from loco_mujoco_amd.environments.unitree_h1 import UnitreeH1   # noqa: E402
 from loco_mujoco_amd.environments.humanoids import (HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque,   # noqa: E402
                                                     HumanoidTorque4Ages)
 
 GOLDEN_TASKS = ["UnitreeA1.simple.real", "UnitreeA1.hard.real", "HumanoidTorque.run.real", "HumanoidTorque.walk.real",
-                "Atlas.walk.real", "Atlas.carry.real", "Talos.walk.real", "Talos.carry.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real"] + [
+                "Atlas.walk.real", "Atlas.carry.real", "Talos.walk.real", "Talos.carry.real", "HumanoidMuscle.run.real", "HumanoidMuscle.walk.real",
+                "UnitreeH1.walk.real", "UnitreeH1.run.real", "UnitreeH1.carry.real", "UnitreeG1.walk.real", "UnitreeG1.run.real"] + [
                 "Humanoid%s4Ages.%s.%s.real" % (a, t, k) for a in ("Torque", "Muscle") for t in ("run", "walk") for k in (1, 2, 3, 4, "all")]
 
 
@@ -82,6 +84,21 @@ def main():
         m = Talos._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "talos" / "talos.xml"), 0.001, j, mo)
         m.save(ROOT / "loco_mujoco_amd" / "assets" / ("Talos.%s.model.npz" % variant))
         print("Talos (%s): nbody %d nv %d ngeom %d nu %d integrator %d cone %d" % (variant, m.nbody, m.nv, m.ngeom, m.nu, m.integrator, m.cone))
+
+    # UnitreeH1: collision meshes kept with their convex hulls (plane-mesh collider)
+    for variant, no_back in (("default", False), ("noback", True)):
+        t = UnitreeH1.__new__(UnitreeH1)
+        t._disable_arms, t._disable_back_joint = True, no_back
+        j, mo, _ = t._get_xml_modifications()
+        m = UnitreeH1._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "unitree_h1" / "h1.xml"), 0.001, j, mo)
+        m.save(ROOT / "loco_mujoco_amd" / "assets" / ("UnitreeH1.%s.model.npz" % variant))
+        print("UnitreeH1 (%s): nbody %d nv %d ngeom %d nu %d integrator %d cone %d hull vertices %d" % (variant, m.nbody, m.nv, m.ngeom, m.nu, m.integrator, m.cone, len(m.hull_vert)))
+    for w in UnitreeH1._valid_weights:
+        t = UnitreeH1.__new__(UnitreeH1)
+        t._disable_arms, t._disable_back_joint = True, False
+        j, mo, _ = t._get_xml_modifications()
+        m = UnitreeH1._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "unitree_h1" / "h1.xml"), 0.001, j, mo, w)
+        m.save(ROOT / "loco_mujoco_amd" / "assets" / ("UnitreeH1.carry.default.w%g.model.npz" % w))
 
     h = mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "humanoid" / "humanoid_torque.xml")
     ht = HumanoidTorque.__new__(HumanoidTorque)
@@ -147,6 +164,8 @@ def main():
     for rel in ["datasets/quadrupeds/real/mini_datasets/walk_straight.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_ATLAS.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_TALOS.npz",
+                "datasets/humanoids/real/mini_datasets/02-constspeed_UnitreeH1.npz",
+                "datasets/humanoids/real/mini_datasets/05-run_UnitreeH1.npz",
                 "datasets/humanoids/real/mini_datasets/02-constspeed_reduced_humanoid.npz",
                 "datasets/humanoids/real/mini_datasets/05-run_reduced_humanoid.npz"] + [
                 "datasets/humanoids/real/mini_datasets/%s_reduced_humanoid_POMDP_%s.npz" % (t, k)
