@@ -615,7 +615,12 @@ def lower(m, task):
         raise UnsupportedModel("activation states without muscles")
 
     lowest = min([b for _, b, _ in standing], default=0.0)
-    max_contacts = max([sum(cap for c2, b, cap in standing if c2 == c and b <= lowest + 0.03) for c in range(NCHAIN)], default=0)
+    # "stands on the floor": within 2 % of the robot's height of the lowest geom bottom (3 cm for a 1.5 m humanoid; the
+    # scaled-down humanoids keep their bones out of the count like the full-size one)
+    height = max([kin["xpos"][b][2] for b in range(1, nb)], default=1.0) - lowest
+    max_contacts = max([sum(cap for c2, b, cap in standing if c2 == c and b <= lowest + 0.02 * height) for c in range(NCHAIN)], default=0)
+    if muscles:
+        max_contacts = min(max_contacts, 4)       # the muscle family is compiled with four slots per chain (box feet)
 
     def src_code(obs_idx):
         kind, i = obs_src[int(obs_idx) % task["nobs"]]

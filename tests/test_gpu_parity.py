@@ -1343,7 +1343,8 @@ def test_unitree_h1_one_control_step_kats(task):
     eq = np.abs(obs[:, :15] - g[[k + 1 for k in ks], :15]).max(axis=1)
     ev = np.abs(obs[:, 15:32] - g[[k + 1 for k in ks], 15:32]).max(axis=1)
     print("UnitreeH1.%s KAT errors vs golden (%d rows): qpos max %.2e median %.2e | qvel max %.2e median %.2e" % (task, len(ks), eq.max(), np.median(eq), ev.max(), np.median(ev)))
-    assert eq.max() < QTOL and ev.max() < VTOL and not done.any() and (b.flags() == 0).all()
+    assert eq.max() < QTOL and ev.max() < VTOL and (b.flags() == 0).all()
+    assert list(done) == [k == len(g) - 2 for k in ks]            # only the last golden row is terminal
     # the environment itself: reset = golden row 0; the running gait starts in a flight phase (8 rows without any hull contact)
     np.random.seed(0)
     e1 = LocoEnv.make("UnitreeH1." + task, debug=True)
