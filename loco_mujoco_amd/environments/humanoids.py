@@ -402,13 +402,18 @@ class BaseHumanoid4Ages(BaseHumanoid):
                  clip_trajectory_to_joint_ranges=False, **kwargs):
         """``base_humanoid_4_ages.py:362-459``: dataset ``<path>_<mode>.npz``, reward ``multi_target_velocity`` with the
         target speed scaled by the humanoid's size."""
-        if dataset_type == "perfect":
-            raise NotImplementedError("perfect datasets (with actions) are not built yet (SURVEY.md §8f rank 1)")
         scaling = {"all": None, "1": 0.4, "2": 0.6, "3": 0.8, "4": 1.0}[mode]
         reward_type = kwargs.pop("reward_type", "multi_target_velocity")
         reward_params = kwargs.pop("reward_params", dict(target_velocity=1.25 if task == "walk" else 2.5))
         mdp = env(scaling=scaling, reward_type=reward_type, reward_params=reward_params, **kwargs)
         path = "%s_%s.npz" % (path, mode)
+        if dataset_type == "perfect":
+            # a recorded 100 Hz dataset (states, actions, last, ...: a download of the reference project), no mini fall-back
+            # (``base_humanoid_4_ages.py:410-412,449-454``)
+            traj_files = mdp.load_dataset_and_get_traj_files(path, 100)
+            mdp.load_trajectory(dict(traj_files=traj_files, traj_dt=1.0 / 100, control_dt=mdp.dt,
+                                     clip_trajectory_to_joint_ranges=clip_trajectory_to_joint_ranges), warn=False)
+            return mdp
         root = Path(os.environ.get("LOCO_MUJOCO_AMD_DATA", _PKG))
         use_mini = not (root / path).exists()
         if debug or use_mini:
@@ -442,13 +447,15 @@ class HumanoidTorque4Ages(BaseHumanoid4Ages):
                                          *HumanoidTorque4Ages.valid_task_confs.get_all())
         path = {"walk": "datasets/humanoids/real/02-constspeed_reduced_humanoid_POMDP",
                 "run": "datasets/humanoids/real/05-run_reduced_humanoid_POMDP"}[task]
+        if dataset_type == "perfect":                                     # ``humanoids.py:883-890``
+            path = "datasets/humanoids/perfect/humanoid4ages_torque_%s/HumanoidTorque4Ages_%s_stochastic_dataset" % (task, task)
         return BaseHumanoid4Ages.generate(HumanoidTorque4Ages, path, task, mode, dataset_type, **kwargs)
 
 
 class HumanoidMuscle4Ages(BaseHumanoid4Ages):
     """Reference ``humanoids.py:895-999``."""
 
-    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], modes=["all", "1", "2", "3", "4"], data_types=["real", "perfect"])
+    valid_task_confs = ValidTaskConf(tasks=["walk", "run"], modes=["all", "1", "2", "3", "4"], data_types=["real"])
 
     def __init__(self, **kwargs):
         if "use_muscles" in kwargs:

@@ -424,3 +424,93 @@ def test_humanoid_4_ages_surface():
     assert LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)._blocks        # batches: one block per size
     with pytest.raises(TypeError):
         e.reset(obs=np.zeros(38))
+
+
+def test_custom_reward_callback_sees_reference_shapes():
+    """a ``reward_type="custom"`` callback written for the reference gets what mushroom-rl's MuJoCo.step gives it:
+    ONE environment's 1-D state and the UN-normalised action of ``_preprocess_action`` (``base.py:606-621``), also in a batch
+    (environment by environment). The physics behind the step is the oracle stand-in here (no GPU)."""
+    from oracle_backend import attach
+    seen = []
+
+    def callback(state, action, next_state):
+        seen.append((np.shape(state), np.array(action, dtype=float), np.shape(next_state)))
+        return float(state[16]) + 0.0 * float(next_state[16])             # v_x: indexes like the reference's users do
+
+    for n in (1, 3):
+        np.random.seed(0)
+        env = attach(LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=n, reward_type="custom", reward_params=dict(reward_callback=callback)))
+        prev = np.atleast_2d(env.reset())
+        a = np.random.RandomState(1).uniform(-0.5, 0.5, (n, 12))
+        seen.clear()
+        obs, r, done, info = env.step(a if n > 1 else a[0])
+        calls = seen[-n:]                       # (the oracle stand-in of the backend evaluates the functor too, before LocoEnv.step does)
+        assert len(seen) >= n and all(s[0] == (37,) and s[2] == (37,) for s in calls)
+        for e in range(n):
+            assert np.allclose(calls[e][1], env._preprocess_action(a[e]))    # torques in N m (gear 33.5...), not [-1, 1]
+            assert np.isclose(np.atleast_1d(r)[e], prev[e, 16])
+        assert info == {}
+
+
+def test_foot_force_layout_and_reward_quirk():
+    """with ``use_foot_forces`` the goal entries sit BEFORE the twelve foot-force entries; the reference's
+    velocity-vector reward then reads foot forces through its negative indices (``unitreeA1.py:491-497``) — reproduced by
+    evaluating the functor on the host (no device form), while the device's observation map puts the goal where the
+    observation has it."""
+    from loco_mujoco_amd import lowering
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, use_foot_forces=True)
+    assert env.info.observation_space.shape == (49,)
+    assert env._reward_device_spec() is None and env._reward_function.device_spec() is not None
+    task = env._device_task()
+    assert task["reward_type"] == 0 and task["nobs"] == 49 and len(task["grf_groups"]) == 4
+    cmod, info = lowering.lower(env._model, task)                                # a positive goal index no longer raises
+    plain = LocoEnv.make("UnitreeA1.simple", debug=True)
+    assert plain._reward_device_spec() is not None and plain._device_task()["reward_type"] == 2
+
+
+def test_recorded_dataset_tasks_unitree_a1_and_4_ages(tmp_path, monkeypatch):
+    """dataset_type="perfect" for the quadruped (``unitreeA1.py:354-418,694-706``: the arrow's rotation matrix is rebuilt
+    from the (cos, sin) columns, ``goal_speed`` is the file's mean planar trunk speed) and for the four-sizes torque humanoid
+    (``base_humanoid_4_ages.py:410-412,449-454``, file ``<name>_<mode>.npz``). Synthetic files cut from the bundled mocap
+    samples; the muscle variant of the four sizes only has mocap data in the reference (``humanoids.py:945-947``)."""
+    from loco_mujoco_amd.utils.math import mat2angle_xy
+    np.random.seed(0)
+    src = LocoEnv.make("UnitreeA1.simple", debug=True).create_dataset()
+    n = 60
+    last = np.zeros(n, dtype=np.int64)
+    last[[19, 39, 59]] = 1
+    rec = dict(states=src["states"][:n], actions=np.random.uniform(-1, 1, (n, 12)), rewards=np.ones(n), next_states=src["next_states"][:n],
+               absorbing=np.zeros(n, dtype=np.int64), last=last)
+    d = tmp_path / "datasets" / "quadrupeds" / "perfect" / "unitreea1_simple"
+    d.mkdir(parents=True)
+    np.savez(d / "perfect_expert_dataset_det.npz", **rec)
+    monkeypatch.setenv("LOCO_MUJOCO_AMD_DATA", str(tmp_path))
+    env = LocoEnv.make("UnitreeA1.simple.perfect")
+    t = env.trajectories
+    assert t.number_of_trajectories == 3 and list(t.split_points) == [0, 20, 40, 60]
+    ds = env.create_dataset()
+    assert np.array_equal(ds["actions"], rec["actions"]) and np.array_equal(ds["last"], last)
+    files = env.load_dataset_and_get_traj_files(d / "perfect_expert_dataset_det.npz", 100)
+    s = rec["states"]
+    assert np.allclose([mat2angle_xy(np.reshape(m, (3, 3))) for m in files["dir_arrow"][:5]], np.arctan2(s[:5, 35], s[:5, 34]))
+    speed = np.linalg.norm(s[:, 16:18], axis=1)
+    assert np.allclose(files["goal_speed"], speed.mean()) and files["q_trunk_tx"][20] == 0 and files["q_trunk_tx"][40] == 0
+    assert np.allclose(files["q_trunk_tx"][1:20], np.cumsum(s[:19, 16]) / 100)
+    obs = env.reset()
+    assert obs.shape == (37,) and np.isfinite(obs).all() and abs(obs[36] - speed.mean()) < 1e-12
+    with pytest.raises(AssertionError):
+        LocoEnv.make("UnitreeA1.simple.perfect", use_foot_forces=True)
+    # the four-sizes torque humanoid
+    src4 = LocoEnv.make("HumanoidTorque4Ages.walk.2", debug=True).create_dataset()
+    rec4 = dict(states=src4["states"][:n], actions=np.random.uniform(-1, 1, (n, 13)), rewards=np.ones(n), next_states=src4["next_states"][:n],
+                absorbing=np.zeros(n, dtype=np.int64), last=last)
+    d4 = tmp_path / "datasets" / "humanoids" / "perfect" / "humanoid4ages_torque_walk"
+    d4.mkdir(parents=True)
+    np.savez(d4 / "HumanoidTorque4Ages_walk_stochastic_dataset_2.npz", **rec4)
+    e4 = LocoEnv.make("HumanoidTorque4Ages.walk.2.perfect")
+    assert e4.trajectories.number_of_trajectories == 3 and np.array_equal(e4.create_dataset()["actions"], rec4["actions"])
+    o4 = e4.reset()
+    assert o4.shape == (38,) and list(o4[-2:]) == [0.0, 1.0]
+    with pytest.raises(Exception):
+        LocoEnv.make("HumanoidMuscle4Ages.walk.2.perfect")
