@@ -13,7 +13,7 @@
  *   lm_set_state        <- LocoEnv.set_sim_state: data.joint(name).qpos/qvel = value (base.py:478-497)
  *                          after mj_resetData (base.py:180): also clears the solver warm start
  *   lm_get_state        <- data.qpos / data.qvel reads (ObservationHelper._build_obs, base.py:202)
- *   lm_set_dof_params / lm_set_dof_randomization <- DomainRandomizationHandler.get_randomized_model
+ *   lm_set_dof_params / lm_set_dof_randomization / lm_set_model_variants <- DomainRandomizationHandler.get_randomized_model
  *                          (utils/domain_randomization.py:219-227): joint damping/stiffness/frictionloss per environment
  *   lm_set/get_activation <- data.act (muscle activation state, humanoids.py:320 HumanoidMuscle; integrated by mj_step)
  *   lm_set_goal         <- per-episode goal written into the observation
@@ -111,6 +111,16 @@ int lm_get_dof_params(lm_batch* b, float* damping, float* stiffness, float* fric
 /* redraw rule used when the device restarts an episode (lm_set_auto_reset): spec[3][nv][3] = (kind, a, b) per parameter
    (damping, stiffness, frictionloss) and dof; kind 0 keep, 1 max(N(a,b),0), 2 U(a,b), 3 N(a,b). NULL disables. */
 int lm_set_dof_randomization(lm_batch* b, const float* spec);
+/* model variants: what the reference's domain randomisation changes by re-compiling the model with other inertial / armature /
+   geom-friction numbers (utils/domain_randomization.py:386-514 set_geom_conf / set_inertial_conf, base.py:183-185). The host
+   lowers n_variants randomised models (lowering.variant_tables) and hands over, per variant, the inertial record
+   [LM_IR_SIZE][4], the geom table [LM_GT_SIZE] and the geom-pair table [pair_floats] (NULL when the model has none). Every
+   environment holds the index of its variant (0 after this call); a device-side restart redraws it uniformly. Switches the
+   batch to the kernel variant with per-environment parameters, like lm_set_dof_params. n_variants = 0 removes the pool. */
+int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_tables, const float* pair_tables,
+                          int pair_floats, int n_variants);
+int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask);
+int lm_get_variant_index(lm_batch* b, int32_t* index);
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
 int lm_get_activation(lm_batch* b, float* act);
 

@@ -38,7 +38,7 @@ EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_dest
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
-           "lm_get_flags"]
+           "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index"]
 
 _lib = None
 
@@ -83,6 +83,9 @@ def load_library():
     lib.lm_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
     lib.lm_sync.argtypes = [C.c_void_p]
     lib.lm_get_flags.argtypes = [C.c_void_p, _U8]
+    lib.lm_set_model_variants.argtypes = [C.c_void_p, _F, _F, _F, C.c_int, C.c_int]
+    lib.lm_set_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _U8]
+    lib.lm_get_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -193,6 +196,30 @@ class HipBatch:
             return
         s = _f32(spec, (3, self.nv, 3))
         _check(self._lib.lm_set_dof_randomization(self._h, _fp(s)))
+
+    def set_model_variants(self, tables):
+        """``tables``: list of (record, geom table, geom-pair table) from ``lowering.variant_tables`` — the pool of randomised
+        models of this batch (None / empty removes it). Every environment starts on variant 0; a device-side restart redraws."""
+        if not tables:
+            _check(self._lib.lm_set_model_variants(self._h, None, None, None, 0, 0))
+            self.n_variants = 0
+            return
+        rec = np.ascontiguousarray(np.stack([t[0] for t in tables]), dtype=np.float32)
+        gt = np.ascontiguousarray(np.stack([t[1] for t in tables]), dtype=np.float32)
+        npair = len(tables[0][2])
+        gpt = np.ascontiguousarray(np.stack([t[2] for t in tables]), dtype=np.float32) if npair else None
+        _check(self._lib.lm_set_model_variants(self._h, _fp(rec), _fp(gt), _fp(gpt) if gpt is not None else None, npair, len(tables)))
+        self.n_variants = len(tables)
+
+    def set_variant_index(self, index, mask=None):
+        idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int32), (self.n,)))
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_set_variant_index(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), mp))
+
+    def get_variant_index(self):
+        idx = np.zeros(self.n, dtype=np.int32)
+        _check(self._lib.lm_get_variant_index(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return idx
 
     def set_activation(self, act, mask=None):
         """Muscle activations [n, na] (set_state zeroes them like mj_resetData; this is for checkpoints and tests)."""

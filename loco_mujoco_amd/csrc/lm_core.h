@@ -196,7 +196,14 @@ enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, 
 // contact's SECOND geom (the normal points from geom 1 to geom 2). Then the unit normal and the first tangent, world axes.
 enum { SL_PART = SL_SIZE, SL_NX, SL_NY, SL_NZ, SL_T1X, SL_T1Y, SL_T1Z, SL_SIZE_PAIRS };
 // per-environment joint parameters (domain randomisation): replaces the table's damping / stiffness / frictionloss
-template <int MC> struct DofPrm { float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC]; };
+// per-environment parameters of the kernels compiled with DR: joint damping / stiffness / frictionloss in registers, and the
+// environment's MODEL VARIANT (lowering.variant_tables): `inr` = its inertial record [LM_IR_SIZE][LM_NCHAIN] in global memory
+// (null: the batch has no variants), `gt` / `gpt` = its geom table and geom-pair table
+template <int MC> struct DofPrm {
+  float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC];
+  const float* inr; const float* gt; const float* gpt;
+  float rfl_r[6], rfl_c[MC];       // friction-loss regularisers of the variant (read inside the line search: kept in registers)
+};
 
 // lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM][link bounding-sphere centres MCx3 (PAIRS)]
 template <int MC, int NS, int NM = 0, bool PAIRS = false> struct LaneMem {
@@ -688,7 +695,18 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
 #define LK(k, f) CH(LM_C_LINKS + (k) * LM_LINK_SIZE + (f))
 #define LX(k, f) LK(k, LM_D_SIZE + (f))
-#define GE(g, f) P.gt[((g) * LM_G_SIZE + (f)) * LM_NCHAIN + c]
+  // model variants (DR kernels only): inertial numbers, armature, invweights and the termination scale come from the
+  // environment's record in global memory, the geom tables from its variant
+  const bool inr_on = DR && dp->inr != nullptr;
+  const float* gtp = inr_on ? dp->gt : P.gt;
+  const float* gptp = inr_on ? dp->gpt : P.gpt;
+#define INR(i) dp->inr[(i) * LM_NCHAIN + c]
+#define LXI(k, j) (inr_on ? INR((k) * LM_IR_LINK + (j)) : LX(k, LM_L_MASS + (j)))        /* j: mass, com xyz, inertia xx yy zz xy xz yz */
+#define LKV(k, j, f) (inr_on ? INR((k) * LM_IR_LINK + 10 + (j)) : LK(k, f))               /* j: 0 armature, 1 invweight (2 = friction-loss R: dp->rfl_*) */
+#define RBI(j) (inr_on ? INR(LM_IR_ROOT + (j)) : rb[LM_R_MASS + (j)])
+#define RDV(i, j, f) (inr_on ? INR(LM_IR_ROOT_DOF + 3 * (i) + (j)) : RD(i, f))
+  const float nscale = inr_on ? INR(LM_IR_SCALE) : P.scale;
+#define GE(g, f) gtp[((g) * LM_G_SIZE + (f)) * LM_NCHAIN + c]
 #define GP(g, f) cm[oz + P.off_prune + ((g) * LM_P_SIZE + (f)) * LM_NCHAIN + c]
 #define CU(i, f) cm[oz + P.off_cunsup + ((i) * LM_U_SIZE + (f)) * LM_NCHAIN + c]
 #define SL(s, f) lmem[((s) * LMm::kSlot + (f)) * ls]
@@ -728,9 +746,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // root body inertia about O
   SpI Iroot;
   {
-    float Iw[6], Il[6] = {rb[LM_R_IXX], rb[LM_R_IXX + 1], rb[LM_R_IXX + 2], rb[LM_R_IXX + 3], rb[LM_R_IXX + 4], rb[LM_R_IXX + 5]};
+    float Iw[6], Il[6] = {RBI(4), RBI(5), RBI(6), RBI(7), RBI(8), RBI(9)};
     rotate_inertia(R, Il, Iw);
-    Iroot = make_spi(rb[LM_R_MASS], mul(R, v3(rb[LM_R_CX], rb[LM_R_CY], rb[LM_R_CZ])), Iw);
+    Iroot = make_spi(RBI(0), mul(R, v3(RBI(1), RBI(2), RBI(3))), Iw);
   }
   // root velocity / acceleration recursion (replicated), base acceleration = -gravity
   Sp Vroot = sp0(), Aroot; Aroot.w = v3(0, 0, 0); Aroot.v = v3(-P.g.x, -P.g.y, -P.g.z);
@@ -793,9 +811,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           Vc[k] = V; Ac[k] = A;
           float Il[6], Iw[6];
 #pragma unroll
-          for (int i = 0; i < 6; i++) Il[i] = LX(k, LM_L_IXX + i);
+          for (int i = 0; i < 6; i++) Il[i] = LXI(k, 4 + i);
           rotate_inertia(Rk, Il, Iw);
-          Ic[k] = make_spi(LX(k, LM_L_MASS), pk + mul(Rk, v3(LX(k, LM_L_CX), LX(k, LM_L_CY), LX(k, LM_L_CZ))) - O, Iw);
+          Ic[k] = make_spi(LXI(k, 0), pk + mul(Rk, v3(LXI(k, 1), LXI(k, 2), LXI(k, 3))) - O, Iw);
           LMEM(LMm::kFrame + k * 18 + 0) = pk.x; LMEM(LMm::kFrame + k * 18 + 1) = pk.y; LMEM(LMm::kFrame + k * 18 + 2) = pk.z;
 #pragma unroll
           for (int i = 0; i < 9; i++) LMEM(LMm::kFrame + k * 18 + 3 + i) = Rk.a[i];
@@ -1089,7 +1107,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         // looked at in the first pass of a control step only.
         float hit = 0.0f;
         for (int j = Q::rep(); j < npairs; j += Q::kRep) {
-          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
+          const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
           const bool counted_only = rec[LM_GP_KIND] != 0.0f;
           if (counted_only && !first_detect) continue;
           const PairGeom G = pair_geom(rec);
@@ -1104,7 +1122,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         // ---- phase 2, every replica: record the contacts (rare)
         for (int hm = (int)hit, j = 0; hm != 0; hm >>= 1, j++) {
           if (!(hm & 1)) continue;
-          const float* rec = P.gpt + (first + j) * LM_GPAIR_SIZE;
+          const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
           const PairGeom G = pair_geom(rec);
           const float pmargin = rec[LM_GP_MARGIN], dist = G.dist;
           if (rec[LM_GP_KIND] != 0.0f) {                            // no collider for this pair of geom types: counted (once)
@@ -1173,7 +1191,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       for (int j = 0; j <= k; j++) Mcc[tri(k, j)] = spdot(Sc[j], L);
 #pragma unroll
       for (int r = 0; r < 6; r++) Mcr[k][r] = spdot(Sr[r], L);
-      Mcc[tri(k, k)] += (k < nl) ? LK(k, LM_D_ARM) : 1.0f;
+      Mcc[tri(k, k)] += (k < nl) ? LKV(k, 0, LM_D_ARM) : 1.0f;
     }
     // whole-robot composite and force: root body + sum over the 4 chains
     SpI tot = Iroot;
@@ -1192,7 +1210,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       Sp L = apply(tot, Sr[i]);
 #pragma unroll
       for (int j = 0; j <= i; j++) Mrr[tri(i, j)] = spdot(Sr[j], L);
-      Mrr[tri(i, i)] += RD(i, LM_D_ARM);
+      Mrr[tri(i, i)] += RDV(i, 0, LM_D_ARM);
       bias_r[i] = spdot(Sr[i], F);
     }
     LM_TICK(1);
@@ -1377,7 +1395,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         if (sgn != 0.0f) {
           float dist = (sgn > 0) ? dlo : dhi;
           float imp = impedance(&LK(k, LM_D_LIM_S0), LM_NCHAIN, dist, 0.0f);
-          float Rl = fmaxf(kMinVal, (1.0f - imp) * LK(k, LM_D_INVW) / imp);
+          float Rl = fmaxf(kMinVal, (1.0f - imp) * LKV(k, 1, LM_D_INVW) / imp);
           lim_s_c[k] = sgn; lim_D_c[k] = 1.0f / Rl;
           lim_aref_c[k] = -LK(k, LM_D_LIM_B) * (sgn * vc[k]) - LK(k, LM_D_LIM_K) * imp * dist;
         }
@@ -1469,11 +1487,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     float cost = 0, cr = 0;
     if (Q::rep() == 0) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), RD(i, LM_D_FLOSS_R));
+      for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), (inr_on ? dp->rfl_r[i] : RD(i, LM_D_FLOSS_R)));
       cost = w0 * cr;
 #pragma unroll
       for (int k = 0; k < MC; k++) if (k < nl) {
-        cost += friction_cost(xc[k] - fl_aref_c[k], FLOSS_C(k), LK(k, LM_D_FLOSS_R));
+        cost += friction_cost(xc[k] - fl_aref_c[k], FLOSS_C(k), (inr_on ? dp->rfl_c[k] : LK(k, LM_D_FLOSS_R)));
         float x = lim_s_c[k] * xc[k] - lim_aref_c[k];
         if (lim_s_c[k] != 0.0f && x < 0.0f) cost += 0.5f * lim_D_c[k] * x * x;
       }
@@ -1562,7 +1580,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        ff_r[i] = FLOSS_R(i); const float Rr = RD(i, LM_D_FLOSS_R);
+        ff_r[i] = FLOSS_R(i); const float Rr = (inr_on ? dp->rfl_r[i] : RD(i, LM_D_FLOSS_R));
         iR_r[i] = (ff_r[i] > 0.0f) ? 1.0f / Rr : 0.0f;
         const float x = ar[i] - fl_aref_r[i];
         jfr_r[i] = x;
@@ -1571,7 +1589,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       }
 #pragma unroll
       for (int k = 0; k < MC; k++) {
-        ff_c[k] = (k < nl) ? FLOSS_C(k) : 0.0f; const float Rr = (k < nl) ? LK(k, LM_D_FLOSS_R) : 1.0f;
+        ff_c[k] = (k < nl) ? FLOSS_C(k) : 0.0f; const float Rr = (k < nl) ? (inr_on ? dp->rfl_c[k] : LK(k, LM_D_FLOSS_R)) : 1.0f;
         iR_c[k] = (ff_c[k] > 0.0f) ? 1.0f / Rr : 0.0f;
         jfr_c[k] = ac[k] - fl_aref_c[k];
         jlim_c[k] = lim_s_c[k] * ac[k] - lim_aref_c[k];
@@ -1682,7 +1700,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
       for (int i = 0; i < 6; i++) gnorm2 = fmaf(gr_[i], gr_[i], gnorm2);
       LM_TICK(4);
-      if (P.scale * sqrtf(gnorm2) < P.tolerance || it == P.iterations) done = true;
+      if (nscale * sqrtf(gnorm2) < P.tolerance || it == P.iterations) done = true;
       else {
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
         float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21], Hrep[21];
@@ -1892,9 +1910,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int i = 0; i < 6; i++) q1r = fmaf(sr[i], gr_[i], q1r);
         const float dec = -Q::sum(q1 + w0 * q1r);
 #ifdef LM_LS_TRACE
-        if (c == 0) printf(" newton it %d scaled decrement %.4g (tol %.3g) nslot %d\n", iters, P.scale * dec, P.tolerance, nslot);
+        if (c == 0) printf(" newton it %d scaled decrement %.4g (tol %.3g) nslot %d\n", iters, nscale * dec, P.tolerance, nslot);
 #endif
-        if (!(P.scale * dec >= P.tolerance)) done = true;        // converged (also catches NaN)
+        if (!(nscale * dec >= P.tolerance)) done = true;        // converged (also catches NaN)
         else {
           iters++;
           // ---- exact line search along (sr, sc)

@@ -23,6 +23,7 @@ struct lm_model {
   float* d_gt;               // geom table: full records of the geoms with a collider
   float* d_mt;               // muscle table (models with muscles)
   float* d_gpt;              // geom-pair table of the self-collision path
+  int n_gpt_floats;          // its size (0: the model has no self-collision pairs)
   float* d_meshv;            // hull vertices of the mesh colliders
   std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
@@ -48,6 +49,8 @@ struct lm_batch {
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
   hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
+  float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats;   // model variants (lm_set_model_variants)
+  float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 5 slots, Euler, elliptic>; the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked
@@ -195,6 +198,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     HIPCHK(hipMalloc(&m->d_gpt, sizeof(float) * gpt.size()));
     HIPCHK(hipMemcpy(m->d_gpt, gpt.data(), sizeof(float) * gpt.size(), hipMemcpyHostToDevice));
     P.gpt = m->d_gpt;
+    m->n_gpt_floats = (int)(ngp * LM_GPAIR_SIZE);
   }
   {
     const size_t nmv = (size_t)cmod[LM_H_NMESHV], off = (size_t)cmod[LM_H_OFF_MESHV];
@@ -282,7 +286,8 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers};
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx,
+                  b->vrec, b->vgt, b->vgpt, b->var};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -291,15 +296,65 @@ void lm_batch_destroy(lm_batch* b) {
   delete b;
 }
 
+// masked uploads move only the masked environments: compact rows + their indices go up, a small kernel scatters them into
+// the [dim][N] arrays (reference counterpart: the per-environment reset of LocoEnv.reset, environments/base.py:344-373)
+__global__ void scatter_rows(float* __restrict__ dst, const float* __restrict__ rows, const int* __restrict__ idx,
+                             int n, int dim, int N) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * dim) return;
+  const int k = t / dim, d = t - k * dim;
+  dst[(size_t)d * N + idx[k]] = rows ? rows[t] : 0.0f;
+}
+__global__ void zero_ints(int* __restrict__ dst, const int* __restrict__ idx, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[idx[t]] = 0;
+}
+
+// indices of the masked environments, uploaded once per call into b->scr_idx; staging sized for `dim` floats per row
+static int mask_indices(lm_batch* b, const uint8_t* mask, int dim, std::vector<int>& idx) {
+  idx.clear();
+  for (int e = 0; e < b->N; e++) if (mask[e]) idx.push_back(e);
+  const size_t need = (size_t)std::max<size_t>(idx.size(), 1) * (size_t)std::max(dim, 1);
+  if (need > b->scr_cap) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->scr) HIPCHK(hipFree(b->scr));
+    b->scr = nullptr; b->scr_cap = 0;
+    HIPCHK(hipMalloc(&b->scr, sizeof(float) * need));
+    b->scr_cap = need;
+  }
+  if (!b->scr_idx) HIPCHK(hipMalloc(&b->scr_idx, sizeof(int) * b->N));
+  if (!idx.empty()) HIPCHK(hipMemcpyAsync(b->scr_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+// rows == nullptr: zero the masked rows
+static int scatter_masked(lm_batch* b, float* dev, const float* host_aos, int dim, const std::vector<int>& idx) {
+  const int n = (int)idx.size();
+  if (n == 0 || dim == 0) return 0;
+  if (host_aos) {
+    std::vector<float> rows((size_t)n * dim);
+    for (int k = 0; k < n; k++) memcpy(&rows[(size_t)k * dim], host_aos + (size_t)idx[k] * dim, sizeof(float) * dim);
+    HIPCHK(hipMemcpyAsync(b->scr, rows.data(), sizeof(float) * n * dim, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));     // `rows` is pageable host memory that dies with this frame
+  }
+  const int threads = 256, blocks = (n * dim + threads - 1) / threads;
+  hipLaunchKernelGGL(scatter_rows, dim3(blocks), dim3(threads), 0, b->stream, dev, host_aos ? b->scr : nullptr, b->scr_idx, n, dim, b->N);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
 static int upload_soa(lm_batch* b, float* dev, const float* host_aos, int dim, const uint8_t* mask) {
   const int N = b->N;
-  std::vector<float> soa((size_t)dim * N);
-  if (mask) HIPCHK(hipMemcpyAsync(soa.data(), dev, sizeof(float) * dim * N, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
-  for (int e = 0; e < N; e++) {
-    if (mask && !mask[e]) continue;
-    for (int d = 0; d < dim; d++) soa[(size_t)d * N + e] = host_aos[(size_t)e * dim + d];
+  if (mask) {
+    std::vector<int> idx;
+    if (mask_indices(b, mask, dim, idx)) return 1;
+    return scatter_masked(b, dev, host_aos, dim, idx);
   }
+  std::vector<float> soa((size_t)dim * N);
+  for (int e = 0; e < N; e++)
+    for (int d = 0; d < dim; d++) soa[(size_t)d * N + e] = host_aos[(size_t)e * dim + d];
   HIPCHK(hipMemcpyAsync(dev, soa.data(), sizeof(float) * dim * N, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
@@ -307,32 +362,29 @@ static int upload_soa(lm_batch* b, float* dev, const float* host_aos, int dim, c
 
 int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->m->device));
-  const int N = b->N, nv = b->m->T.nv;
-  if (upload_soa(b, b->qpos, qpos, nv, mask)) return 1;
-  if (upload_soa(b, b->qvel, qvel, nv, mask)) return 1;
-  std::vector<float> z((size_t)nv * N, 0.0f);
-  std::vector<int> zs(N, 0);
+  const int N = b->N, nv = b->m->T.nv, na = b->m->T.na;
   if (mask) {
-    // clear warm start / step counter only for the masked environments
-    std::vector<float> w((size_t)nv * N);
-    std::vector<int> st(N);
-    HIPCHK(hipMemcpy(w.data(), b->warm, sizeof(float) * nv * N, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(st.data(), b->ep_step, sizeof(int) * N, hipMemcpyDeviceToHost));
-    for (int e = 0; e < N; e++) if (mask[e]) { st[e] = 0; for (int d = 0; d < nv; d++) w[(size_t)d * N + e] = 0.0f; }
-    HIPCHK(hipMemcpy(b->warm, w.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->ep_step, st.data(), sizeof(int) * N, hipMemcpyHostToDevice));
-    if (b->act) {
-      const int na = b->m->T.na;
-      std::vector<float> av((size_t)na * N);
-      HIPCHK(hipMemcpy(av.data(), b->act, sizeof(float) * na * N, hipMemcpyDeviceToHost));
-      for (int e = 0; e < N; e++) if (mask[e]) for (int d = 0; d < na; d++) av[(size_t)d * N + e] = 0.0f;
-      HIPCHK(hipMemcpy(b->act, av.data(), sizeof(float) * na * N, hipMemcpyHostToDevice));
+    // positions, velocities, and the cleared warm start / activations / step counter of the masked environments only
+    std::vector<int> idx;
+    if (mask_indices(b, mask, nv, idx)) return 1;
+    if (scatter_masked(b, b->qpos, qpos, nv, idx)) return 1;
+    if (scatter_masked(b, b->qvel, qvel, nv, idx)) return 1;
+    if (scatter_masked(b, b->warm, nullptr, nv, idx)) return 1;
+    if (b->act && scatter_masked(b, b->act, nullptr, na, idx)) return 1;
+    if (!idx.empty()) {
+      const int n = (int)idx.size();
+      hipLaunchKernelGGL(zero_ints, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->ep_step, b->scr_idx, n);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(b->stream));
     }
-  } else {
-    if (b->act) HIPCHK(hipMemset(b->act, 0, sizeof(float) * b->m->T.na * N));
-    HIPCHK(hipMemcpy(b->warm, z.data(), sizeof(float) * nv * N, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->ep_step, zs.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    return 0;
   }
+  if (upload_soa(b, b->qpos, qpos, nv, nullptr)) return 1;
+  if (upload_soa(b, b->qvel, qvel, nv, nullptr)) return 1;
+  if (b->act) HIPCHK(hipMemsetAsync(b->act, 0, sizeof(float) * na * N, b->stream));
+  HIPCHK(hipMemsetAsync(b->warm, 0, sizeof(float) * nv * N, b->stream));
+  HIPCHK(hipMemsetAsync(b->ep_step, 0, sizeof(int) * N, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
 
@@ -393,6 +445,50 @@ int lm_set_dof_randomization(lm_batch* b, const float* spec) {
   return 0;
 }
 
+int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_tables, const float* pair_tables,
+                          int pair_floats, int n_variants) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (float** p : {&b->vrec, &b->vgt, &b->vgpt}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  b->nvar = 0; b->gpt_floats = 0;
+  if (n_variants <= 0) return 0;
+  if (!records || !geom_tables) return fail("model variants need inertial records and geom tables");
+  if ((pair_tables != nullptr) != (b->m->n_gpt_floats > 0) || (pair_tables && pair_floats != b->m->n_gpt_floats))
+    return fail("geom-pair tables of the variants do not match the model's");
+  if (!b->dofprm && lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;   // the kernels with per-environment parameters
+  const size_t nr = (size_t)n_variants * LM_IR_SIZE * LM_NCHAIN, ng = (size_t)n_variants * LM_GT_SIZE, np_ = (size_t)n_variants * pair_floats;
+  HIPCHK(hipMalloc(&b->vrec, sizeof(float) * nr)); HIPCHK(hipMemcpy(b->vrec, records, sizeof(float) * nr, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->vgt, sizeof(float) * ng)); HIPCHK(hipMemcpy(b->vgt, geom_tables, sizeof(float) * ng, hipMemcpyHostToDevice));
+  if (pair_tables) { HIPCHK(hipMalloc(&b->vgpt, sizeof(float) * np_)); HIPCHK(hipMemcpy(b->vgpt, pair_tables, sizeof(float) * np_, hipMemcpyHostToDevice)); }
+  if (!b->var) HIPCHK(hipMalloc(&b->var, sizeof(int) * b->N));
+  HIPCHK(hipMemset(b->var, 0, sizeof(int) * b->N));
+  b->nvar = n_variants; b->gpt_floats = pair_floats;
+  return 0;
+}
+
+int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (b->nvar <= 0) return fail("the batch has no model variants");
+  std::vector<int> cur(b->N);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(cur.data(), b->var, sizeof(int) * b->N, hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->N; e++) {
+    if (mask && !mask[e]) continue;
+    if (index[e] < 0 || index[e] >= b->nvar) return fail("variant index out of range");
+    cur[e] = index[e];
+  }
+  HIPCHK(hipMemcpy(b->var, cur.data(), sizeof(int) * b->N, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int lm_get_variant_index(lm_batch* b, int32_t* index) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->nvar <= 0) { for (int e = 0; e < b->N; e++) index[e] = 0; return 0; }
+  HIPCHK(hipMemcpy(index, b->var, sizeof(int) * b->N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->m->device));
   if (!b->act) return fail("model has no activation states");
@@ -419,7 +515,8 @@ int lm_set_goal(lm_batch* b, const float* goal, const uint8_t* mask) {
 static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
-  a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
+  a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
   a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;

@@ -93,6 +93,9 @@ struct KArgs {
   float* act;               // muscle activations, SoA [na][N], or null
   float* dofprm;            // per-environment joint damping | stiffness | frictionloss, SoA [3][nv][N], or null
   const float* drspec;      // their redraw rule at an episode restart [3][nv][3] = (kind, a, b), or null
+  // model variants (lm_set_model_variants): inertial records [nvar][LM_IR_SIZE][4], geom tables [nvar][LM_GT_SIZE], geom-pair
+  // tables [nvar][gpt_floats] (or null), and the variant of every environment [N] (redrawn at a device-side restart)
+  const float* vrec; const float* vgt; const float* vgpt; int* var; int nvar, gpt_floats;
   float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
@@ -184,6 +187,18 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     for (int k = 0; k < MC; k++) {
       dofp.damp_c[k] = (k < nl) ? a.dofprm[dc[k] * N + e] : 0.0f; dofp.stiff_c[k] = (k < nl) ? a.dofprm[pn + dc[k] * N + e] : 0.0f;
       dofp.floss_c[k] = (k < nl) ? a.dofprm[2 * pn + dc[k] * N + e] : 0.0f;
+    }
+    // the environment's model variant (inertial record, geom tables); redrawn below when the episode restarts
+    dofp.inr = nullptr; dofp.gt = a.P.gt; dofp.gpt = a.P.gpt;
+    if (a.vrec) {
+      const int var = a.var[e];
+      dofp.inr = a.vrec + (long long)var * (LM_IR_SIZE * LM_NCHAIN);
+      dofp.gt = a.vgt + (long long)var * LM_GT_SIZE;
+      dofp.gpt = a.vgpt ? a.vgpt + (long long)var * a.gpt_floats : a.P.gpt;
+#pragma unroll
+      for (int i = 0; i < 6; i++) dofp.rfl_r[i] = dofp.inr[(LM_IR_ROOT_DOF + 3 * i + 2) * LM_NCHAIN + c];
+#pragma unroll
+      for (int k = 0; k < MC; k++) dofp.rfl_c[k] = dofp.inr[(k * LM_IR_LINK + 12) * LM_NCHAIN + c];
     }
   }
 
@@ -316,6 +331,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       }
       step_no = 0;
       zero_act = true;
+      if (DR && a.vrec && a.nvar > 1 && c == 0 && valid) {
+        // new episode, new model variant (reference base.py:183-185: a freshly randomised model per reset)
+        const unsigned long long rv = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ 0xA24BAED4963EE407ull);
+        a.var[e] = (int)(rv % (unsigned long long)a.nvar);
+      }
       if (DR && a.drspec && valid) {
         // new episode, new joint parameters (reference base.py:183-185): counter-based draws keyed like the state draw
         auto redraw = [&](int dof, int p) {

@@ -48,8 +48,12 @@ class LocoEnv:
                  n_substeps=10, reward_type=None, reward_params=None, traj_params=None, random_start=True,
                  init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
                  use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
-                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, **viewer_params):
+                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=32, **viewer_params):
         self._model = model
+        # models compiled per batch for the randomisation rules that change compile-time constants (inertial, armature, geom
+        # friction): a pool the environments draw from per episode, see utils/domain_randomization.py
+        self._n_model_variants = int(n_model_variants)
+        self._variant_models = {}          # model index -> [CompiledModel] (kept for inspection and the parity tests)
         # joint-parameter randomisation per episode (reference base.py:103-107,183-185). The reference draws in worker
         # processes, i.e. outside the main np.random stream — so does this (own RandomState, reseeded by seed()).
         self._domain_rand = None
@@ -147,9 +151,24 @@ class LocoEnv:
         """The device batch (``HipBatch``). Created lazily; raises if the HIP library/GPU is missing."""
         if self._backend is None:
             from ..backend import HipBatch, HipModel
-            self._hip_model = HipModel(self._chain_model(), self._device)
+            nominal = self._chain_model()
+            self._hip_model = HipModel(nominal, self._device)
             self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if self._blocks else self.n_envs)
+            if self._domain_rand is not None and self._domain_rand.has_model_rules:
+                self._backend.set_model_variants(self._build_model_variants(nominal))
         return self._backend
+
+    def _build_model_variants(self, nominal):
+        """The pool of randomised models of the current model's batch: drawn with the randomisation's own generator, compiled
+        (``mjcf.model_variant``), lowered, reduced to what differs from the nominal tables (``lowering.variant_tables``)."""
+        from ..lowering import variant_tables
+        state = np.random.get_state()
+        np.random.set_state(self._domain_rand_rs.get_state())
+        models = [self._domain_rand.sample_model_variant(self._model) for _ in range(self._n_model_variants)]
+        self._domain_rand_rs.set_state(np.random.get_state())
+        np.random.set_state(state)
+        self._variant_models[self._current_model_idx] = models
+        return [variant_tables(nominal, self._chain_model(v)) for v in models]
 
     def _init_models(self, models):
         """Several models in one environment (the reference's ``MultiMuJoCo``: sizes of the humanoid, carried weights).
@@ -294,10 +313,13 @@ class LocoEnv:
             rows.append(self._create_observation(self.obs_helper._build_obs(self._host[e])))
         self._pending_state = True
         self._pending_dof_params = None
+        self._pending_variants = None
         if self._domain_rand is not None and self._domain_rand.active:
             state = np.random.get_state()
             np.random.set_state(self._domain_rand_rs.get_state())
             self._pending_dof_params = self._domain_rand.sample(self.n_envs)
+            if self._domain_rand.has_model_rules:
+                self._pending_variants = np.random.randint(0, self._n_model_variants, self.n_envs)
             self._domain_rand_rs.set_state(np.random.get_state())
             np.random.set_state(state)
         self._obs = np.stack(rows)
@@ -436,10 +458,13 @@ class LocoEnv:
             b.set_state(qpos[envs], qvel[envs])
             if prm is not None:
                 b.set_dof_params(damping=prm[0][envs], stiffness=prm[1][envs], frictionloss=prm[2][envs])
+            if getattr(self, "_pending_variants", None) is not None:
+                b.set_variant_index(self._pending_variants[envs])
             goal = self._goal_rows()
             if goal is not None:
                 b.set_goal(goal[:len(envs)])
         self._pending_dof_params = None
+        self._pending_variants = None
         self._pending_state = False
 
     def _goal_rows(self):
@@ -609,9 +634,9 @@ class LocoEnv:
             return None
         return spec
 
-    def _chain_model(self):
+    def _chain_model(self, model=None):
         from ..lowering import lower
-        return lower(self._model, self._device_task())[0]
+        return lower(self._model if model is None else model, self._device_task())[0]
 
     # ------------------------------------------------------------------ misc surface
     def _out(self, obs):

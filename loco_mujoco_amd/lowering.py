@@ -714,6 +714,57 @@ def lower(m, task):
     return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel()]), info
 
 
+# ---- model variants (inertial / armature / geom-friction randomisation): what differs between two lowerings of the same robot
+# with other inertial numbers. Constant-table entries: per link mass, centre of mass, inertia tensor, armature, dof_invweight0 and
+# the friction-loss regulariser (IR_LINK floats), the same for the root body and its 6 dofs, and the solver's termination scale
+# 1 / (meaninertia * nv). Everything else that changes lives in the global tables (geom table, geom-pair table), which a variant
+# brings whole. Layout of a record: [IR_SIZE][NCHAIN] (field-major, the chain's lane reads its own column).
+IR_LINK = 13
+IR_ROOT = MAXC * IR_LINK
+IR_ROOT_DOF = IR_ROOT + 10
+IR_SCALE = IR_ROOT_DOF + NROOT * 3
+IR_SIZE = IR_SCALE + 1
+_IR_LINK_FIELDS = [D_SIZE + L_MASS + i for i in range(10)] + [D_ARM, D_INVW, D_FLOSS_R]
+_IR_DOF_FIELDS = [D_ARM, D_INVW, D_FLOSS_R]
+
+
+def variant_tables(nominal, variant):
+    """
+    ``(record [IR_SIZE * NCHAIN], geom table, geom-pair table)`` of ``variant`` (a chain model from :func:`lower` of
+    ``mjcf.model_variant(...)``) relative to ``nominal`` — the per-variant data of ``lm_set_model_variants``. Raises if the
+    two lowerings differ anywhere else (topology, geometry, solver options): those cannot vary inside one batch.
+    """
+    if len(nominal) != len(variant):
+        raise UnsupportedModel("variant and nominal model have different tables")
+    cmn, cmv = nominal[HEADER_SIZE:HEADER_SIZE + CM_SIZE], variant[HEADER_SIZE:HEADER_SIZE + CM_SIZE]
+    rec = np.zeros((IR_SIZE, NCHAIN))
+    covered = []
+    for c in range(NCHAIN):
+        for k in range(MAXC):
+            for j, f in enumerate(_IR_LINK_FIELDS):
+                i = CM_CHAINS + (C_LINKS + k * LINK_SIZE + f) * NCHAIN + c
+                rec[k * IR_LINK + j, c] = cmv[i]
+                covered.append(i)
+        for j in range(10):
+            rec[IR_ROOT + j, c] = cmv[CM_ROOT + R_MASS + j]
+        for d in range(NROOT):
+            for j, f in enumerate(_IR_DOF_FIELDS):
+                rec[IR_ROOT_DOF + 3 * d + j, c] = cmv[CM_ROOT + R_DOFS + d * D_SIZE + f]
+        rec[IR_SCALE, c] = 1.0 / (variant[H_MEANINERTIA] * variant[H_NV])
+    covered += [CM_ROOT + R_MASS + j for j in range(10)]
+    covered += [CM_ROOT + R_DOFS + d * D_SIZE + f for d in range(NROOT) for f in _IR_DOF_FIELDS]
+    other = np.setdiff1d(np.nonzero(cmn != cmv)[0], covered)
+    hdiff = [i for i in np.nonzero(nominal[:HEADER_SIZE] != variant[:HEADER_SIZE])[0] if i != H_MEANINERTIA]
+    if len(other) or hdiff:
+        raise UnsupportedModel("model variant differs from the nominal model outside the inertial record "
+                               "(constant-table entries %s, header entries %s)" % (other[:8], hdiff))
+    g0 = HEADER_SIZE + CM_SIZE
+    o_gpt, n_gpt, o_mv = int(nominal[H_OFF_GPT]), int(nominal[H_NGPAIR]) * GPAIR_SIZE, int(nominal[H_OFF_MESHV])
+    if not (np.array_equal(nominal[g0 + GT_SIZE:o_gpt], variant[g0 + GT_SIZE:o_gpt]) and np.array_equal(nominal[o_mv:], variant[o_mv:])):
+        raise UnsupportedModel("model variant changes the muscle table or the mesh vertices")
+    return rec.ravel(), variant[g0:g0 + GT_SIZE].copy(), variant[o_gpt:o_gpt + n_gpt].copy()
+
+
 def _self_collision_tables(m, root, chains, kin):
     """
     Tables of the self-collision path (kernels compiled with PAIRS; elliptic cones): candidate geom pairs after the engine's

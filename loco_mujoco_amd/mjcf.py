@@ -244,20 +244,26 @@ class _Defaults:
         return attrs
 
 
-def _inertia_from_inertial(attrs):
-    """Returns (mass, ipos, 3x3 inertia tensor expressed in the BODY frame, about the COM)."""
-    mass = float(attrs["mass"])
-    ipos = _floats(attrs.get("pos", "0 0 0"), 3)
-    if "fullinertia" in attrs:
-        f = _floats(attrs["fullinertia"], 6)
+def inertia_from_spec(mass, kind, vals, quat, bounds):
+    """(mass, 3x3 inertia tensor in the BODY frame about the COM) of an ``<inertial>`` element: ``kind`` 2 = fullinertia
+    (xx yy zz xy xz yz), 1 = diaginertia + quat; then the compiler bounds ``(boundmass, boundinertia, balanceinertia)``,
+    which act on the principal moments."""
+    boundmass, boundinertia, balanceinertia = bounds
+    if kind == 2:
+        f = vals
         inertia = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
     else:
-        d = _floats(attrs["diaginertia"], 3)
-        q = _floats(attrs.get("quat", "1 0 0 0"), 4)
-        q = q / np.linalg.norm(q)
-        r = quat_to_mat(q)
-        inertia = r @ np.diag(d) @ r.T
-    return mass, ipos, inertia
+        r = quat_to_mat(quat)
+        inertia = r @ np.diag(vals[:3]) @ r.T
+    ev, evec = np.linalg.eigh(inertia)
+    if boundinertia > 0:
+        ev = np.maximum(ev, boundinertia)          # lower bound first ...
+    if balanceinertia and (ev[0] + ev[1] < ev[2]):
+        ev[:] = ev.mean()                          # ... then the triangle-inequality repair
+    inertia = evec @ np.diag(ev) @ evec.T
+    if boundmass > 0:
+        mass = max(mass, boundmass)
+    return mass, inertia
 
 
 def _bounding_capsule(v):
@@ -449,17 +455,20 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
             bid = len(bodies) - 1
             inertial = el.find("inertial")
             b["explicit_inertial"] = inertial is not None
+            b["inertial_kind"], b["inertial_vals"], b["inertial_quat"] = 0, np.zeros(6), np.array([1.0, 0, 0, 0])
             if inertial is not None:
-                b["mass"], b["ipos"], b["inertia"] = _inertia_from_inertial(inertial.attrib)
-                # compiler bounds act on the principal moments (MuJoCo: boundmass / boundinertia / balanceinertia)
-                ev, evec = np.linalg.eigh(b["inertia"])
-                if boundinertia > 0:
-                    ev = np.maximum(ev, boundinertia)          # lower bound first ...
-                if balanceinertia and (ev[0] + ev[1] < ev[2]):
-                    ev[:] = ev.mean()                          # ... then the triangle-inequality repair
-                b["inertia"] = evec @ np.diag(ev) @ evec.T
-                if boundmass > 0:
-                    b["mass"] = max(b["mass"], boundmass)
+                ia = inertial.attrib
+                # the XML-level numbers are kept: domain randomisation acts on THEM (reference
+                # utils/domain_randomization.py:460-514: mass, diaginertia, singular values of the fullinertia triangle)
+                if "fullinertia" in ia:
+                    b["inertial_kind"], b["inertial_vals"] = 2, _floats(ia["fullinertia"], 6)
+                else:
+                    q = _floats(ia.get("quat", "1 0 0 0"), 4)
+                    b["inertial_kind"], b["inertial_quat"] = 1, q / np.linalg.norm(q)
+                    b["inertial_vals"] = np.concatenate([_floats(ia["diaginertia"], 3), np.zeros(3)])
+                b["ipos"] = _floats(ia.get("pos", "0 0 0"), 3)
+                b["mass"], b["inertia"] = inertia_from_spec(float(ia["mass"]), b["inertial_kind"], b["inertial_vals"],
+                                                            b["inertial_quat"], (boundmass, boundinertia, balanceinertia))
             for j in el.findall("joint"):
                 a = defaults.resolve("joint", j, childclass)
                 jt = a.get("type", "hinge")
@@ -565,6 +574,12 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.body_mass = np.array([b["mass"] for b in bodies])
     m.body_ipos = np.array([b["ipos"] for b in bodies])
     m.body_inertia = np.array([b["inertia"] for b in bodies])          # (nbody,3,3) body frame, about COM
+    # XML-level <inertial> numbers (0 = none / from geoms, 1 = diaginertia + quat, 2 = fullinertia) and the compiler bounds
+    m.body_inertial_kind = np.array([b.get("inertial_kind", 0) for b in bodies], dtype=np.int32)
+    m.body_inertial_vals = np.array([b.get("inertial_vals", np.zeros(6)) for b in bodies], dtype=np.float64)
+    m.body_inertial_quat = np.array([b.get("inertial_quat", np.array([1.0, 0, 0, 0])) for b in bodies], dtype=np.float64)
+    m.body_xml_mass = np.array([b["mass"] if b.get("inertial_kind", 0) else 0.0 for b in bodies], dtype=np.float64)
+    m.compiler_bounds = np.array([boundmass, boundinertia, 1.0 if balanceinertia else 0.0])
     m.body_jntadr = np.array([b["jntadr"] for b in bodies], dtype=np.int32)
     m.body_jntnum = np.array([b["jntnum"] for b in bodies], dtype=np.int32)
     # weld id: the nearest ancestor-or-self that has joints (0 = welded to the world)
@@ -882,3 +897,35 @@ def _set_const(m):
         biw[b, 1] = (a[3, 3] + a[4, 4] + a[5, 5]) / 3.0
     m.body_invweight0 = biw
     m.meaninertia = float(np.trace(mm) / m.nv)
+
+
+def model_variant(m, body_mass=None, body_inertial=None, dof_armature=None, geom_friction=None):
+    """
+    A copy of ``m`` with other inertial / armature / friction numbers — what recompiling the XML after
+    ``apply_domain_randomization`` (reference utils/domain_randomization.py:228-294) gives: ``body_mass`` {body: mass},
+    ``body_inertial`` {body: 6 XML-level numbers of its kind}, ``dof_armature`` {dof: value}, ``geom_friction`` {geom: 3
+    numbers}. The derived constants (``dof_invweight0``, ``body_invweight0``, ``meaninertia``) are recomputed.
+    """
+    import copy
+    v = copy.copy(m)
+    for k, a in m.__dict__.items():
+        if isinstance(a, np.ndarray):
+            setattr(v, k, a.copy())
+    bounds = (float(m.compiler_bounds[0]), float(m.compiler_bounds[1]), bool(m.compiler_bounds[2]))
+    touched = set(body_mass or {}) | set(body_inertial or {})
+    for b in touched:
+        kind = int(m.body_inertial_kind[b])
+        if kind == 0:
+            raise ValueError("body %s has no <inertial> element" % m.body_names[b])
+        if body_inertial and b in body_inertial:
+            v.body_inertial_vals[b] = np.asarray(body_inertial[b], dtype=np.float64)
+        if body_mass and b in body_mass:
+            v.body_xml_mass[b] = float(body_mass[b])
+        v.body_mass[b], v.body_inertia[b] = inertia_from_spec(float(v.body_xml_mass[b]), kind, v.body_inertial_vals[b],
+                                                               v.body_inertial_quat[b], bounds)
+    for d, a in (dof_armature or {}).items():
+        v.dof_armature[d] = float(a)
+    for g, fr in (geom_friction or {}).items():
+        v.geom_friction[g] = np.asarray(fr, dtype=np.float64)
+    _set_const(v)
+    return v

@@ -113,6 +113,8 @@ constexpr bool kEmuDR = true;
 constexpr bool kEmuDR = false;
 #endif
 const double* g_dofprm = nullptr;
+// one model variant for every environment (lowering.variant_tables): inertial record, geom table, geom-pair table (or null)
+const float* g_vrec = nullptr; const float* g_vgt = nullptr; const float* g_vgpt = nullptr;
 }  // namespace
 
 // EMU_PYRAMID_ONLY compiles the humanoid families like the library does (condim-3 pyramids only, elliptic code out)
@@ -197,6 +199,11 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
           dofp.damp_c[k] = prm(0, dc[k], blk[LM_D_DAMP * LM_NCHAIN]); dofp.stiff_c[k] = prm(1, dc[k], blk[LM_D_STIFF * LM_NCHAIN]);
           dofp.floss_c[k] = prm(2, dc[k], blk[LM_D_FLOSS * LM_NCHAIN]);
         }
+        dofp.inr = g_vrec; dofp.gt = g_vrec ? g_vgt : P.gt; dofp.gpt = (g_vrec && g_vgpt) ? g_vgpt : P.gpt;
+        if (g_vrec) {
+          for (int i = 0; i < 6; i++) dofp.rfl_r[i] = g_vrec[(LM_IR_ROOT_DOF + 3 * i + 2) * LM_NCHAIN + c];
+          for (int k = 0; k < MC; k++) dofp.rfl_c[k] = g_vrec[(k * LM_IR_LINK + 12) * LM_NCHAIN + c];
+        }
       }
       lm::Counters cnt = {};
       using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
@@ -265,6 +272,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
 }
 
 extern "C" void emu_set_dof_params(const double* p) { g_dofprm = p; }
+extern "C" void emu_set_model_variant(const float* rec, const float* gt, const float* gpt) { g_vrec = rec; g_vgt = gt; g_vgpt = gpt; }
 
 extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                        int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,

@@ -39,10 +39,12 @@ def build(ls_points=1, dr=False, rep=1):
     return _lib_path(ls_points, dr, rep)
 
 
-def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False, rep=1):
-    """dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
+def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False, rep=1,
+        variant=None):
+    """variant: (record, geom table, geom-pair table) of ``lowering.variant_tables`` — one model variant for all environments
+    (implies dr). dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
     per-environment code path on the table's nominal values."""
-    dr = dr or dof_params is not None
+    dr = dr or dof_params is not None or variant is not None
     if rep > 1:
         ls_points = 4            # the replicated layout always evaluates four step lengths per round
     lib = C.CDLL(build(ls_points, dr, rep))
@@ -65,6 +67,12 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     if dr:
         prm = None if dof_params is None else np.ascontiguousarray(dof_params, dtype=np.float64).reshape(3, n, nv)
         lib.emu_set_dof_params(dp(prm) if prm is not None else None)
+        vt = None
+        if variant is not None:
+            vt = [np.ascontiguousarray(t, dtype=np.float32) for t in variant]
+            lib.emu_set_model_variant(dp(vt[0]), dp(vt[1]), dp(vt[2]) if len(vt[2]) else None)
+        else:
+            lib.emu_set_model_variant(None, None, None)
     rc = lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
                      dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
                      dp(actv) if actv is not None else None)

@@ -4,6 +4,7 @@ The device code (loco_mujoco_amd/csrc/lm_core.h) executed on the CPU by the 4-th
 a container without a GPU. Test tooling only — the product never runs this path.
 """
 
+import os
 import numpy as np
 import pytest
 
@@ -394,3 +395,42 @@ def test_core_plane_mesh_unitree_h1(rep):
         q10, v10, _, c10, _ = pyemu.run(cmod, qpos, qvel, a, nsub=10, ls_points=4, rep=rep)
         assert c10["overflow"] == 0
         assert np.abs(q10[0][qidx[2:]] - g[k + 1, :15]).max() < 1e-5 and np.abs(v10[0][qidx] - g[k + 1, 15:32]).max() < 2e-3, (k, np.abs(v10[0][qidx] - g[k + 1, 15:32]).max())
+
+
+def test_core_model_variants_vs_oracle_compiled_with_the_same_numbers():
+    """Inertial / armature / geom-friction randomisation (reference utils/domain_randomization.py:386-514): the kernel reads the
+    environment's inertial record and geom table from its model VARIANT; checked against the oracle built from the variant's
+    compiled model. Kernel <5,4,Euler,pyramid,DR,4 replicas>, on the CPU."""
+    from loco_mujoco_amd.utils.domain_randomization import JointRandomization
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    m = env._model
+    nominal = env._chain_model()
+    jr = JointRandomization(m, os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml"))
+    np.random.seed(1)
+    variant = jr.sample_model_variant()
+    tables = lowering.variant_tables(nominal, env._chain_model(variant))
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    n = 4
+    rows = tab[rs.randint(0, len(tab), n)]
+    qpos, qvel = rows[:, :m.nv], rows[:, m.nv:2 * m.nv]
+    acts = rs.uniform(-0.3, 0.3, (n, 12))
+
+    def oracle_step(model):
+        o = Oracle(pack_model(model))
+        out = []
+        for i in range(n):
+            ctrl = np.zeros(model.nu)
+            ctrl[env._action_indices] = env._preprocess_action(acts[i])
+            q1, v1, _, _ = o.step(qpos[i], qvel[i], ctrl, 10)
+            out.append(np.concatenate([q1, v1]))
+        return np.array(out)
+
+    ref_nom, ref_var = oracle_step(m), oracle_step(variant)
+    qn, vn, _, _, _ = pyemu.run(nominal, qpos, qvel, acts, nsub=10, rep=4, dr=True)
+    qv, vv, _, _, _ = pyemu.run(nominal, qpos, qvel, acts, nsub=10, rep=4, variant=tables)
+    assert np.abs(qn - ref_nom[:, :m.nv]).max() < 1e-4 and np.abs(vn - ref_nom[:, m.nv:]).max() < 1e-2
+    assert np.abs(qv - ref_var[:, :m.nv]).max() < 1e-4 and np.abs(vv - ref_var[:, m.nv:]).max() < 1e-2
+    # the variant is a different robot: the two oracles disagree by far more than the tolerance
+    assert np.abs(ref_var[:, m.nv:] - ref_nom[:, m.nv:]).max() > 0.1

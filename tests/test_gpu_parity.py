@@ -1354,3 +1354,161 @@ def test_unitree_h1_one_control_step_kats(task):
         for k in range(8):
             ob, r, absorbing, info = e1.step(np.random.randn(11) * 0.1)
             assert np.abs(ob[:15] - g[k + 1, :15]).max() < 1e-4 and np.abs(ob[15:] - g[k + 1, 15:]).max() < 1e-2 and not absorbing
+
+
+def test_masked_state_upload_touches_only_the_masked_environments(setup):
+    """``set_state(mask=...)`` (the per-environment reset of LocoEnv.reset, reference environments/base.py:344-373) moves
+    the masked rows only: the others keep their state AND their warm start — the continued rollout of the unmasked
+    environments is bitwise the rollout without the upload; the masked ones behave like freshly set environments."""
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+    n = 37                                                  # ragged: not a multiple of the 4 environments per workgroup
+    rows = tab[(np.arange(n) * 11) % len(tab)]
+    mask = np.zeros(n, dtype=bool)
+    mask[[0, 5, 6, 35, 36]] = True
+    fresh = tab[(np.arange(n) * 29 + 3) % len(tab)]
+
+    def start():
+        b = HipBatch(hm, n)
+        b.set_state(rows[:, :18], rows[:, 18:36])
+        b.set_goal(rows[:, 36:39])
+        b.rollout(3, action_mode=1, seed=5)
+        return b
+
+    ref = start()
+    q_mid, v_mid = ref.get_state()
+    ref.rollout(2, action_mode=0)
+    q_ref, v_ref = ref.get_state()
+
+    b = start()
+    b.set_state(fresh[:, :18], fresh[:, 18:36], mask=mask)
+    q1, v1 = b.get_state()
+    assert np.array_equal(q1[~mask], q_mid[~mask]) and np.array_equal(v1[~mask], v_mid[~mask])
+    assert np.array_equal(q1[mask], fresh[mask, :18].astype(np.float32))
+    assert np.array_equal(v1[mask], fresh[mask, 18:36].astype(np.float32))
+    b.rollout(2, action_mode=0)
+    q2, v2 = b.get_state()
+    assert np.array_equal(q2[~mask], q_ref[~mask]) and np.array_equal(v2[~mask], v_ref[~mask])
+
+    # the masked environments: same as a batch that was SET to those states (cold warm start, step counter 0)
+    c = HipBatch(hm, n)
+    c.set_state(fresh[:, :18], fresh[:, 18:36])
+    c.set_goal(rows[:, 36:39])
+    c.rollout(2, action_mode=0)
+    q3, v3 = c.get_state()
+    assert np.array_equal(q2[mask], q3[mask]) and np.array_equal(v2[mask], v3[mask])
+    # goals: masked upload leaves the other rows alone as well
+    g = np.tile(np.array([[0.5, 0.1, -0.2]]), (n, 1))
+    b.set_goal(g, mask=mask)
+    b.step(np.zeros((n, 12)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Model variants (SURVEY.md §8f rank 4): randomisation of armature, inertial numbers and geom friction
+# ---------------------------------------------------------------------------------------------------------------
+
+def _talos_variant_env(n, k):
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    return LocoEnv.make("Talos.walk", debug=True, n_envs=n, domain_randomization_config=cfg, n_model_variants=k)
+
+
+def test_model_variants_one_control_step_vs_oracle():
+    """Every environment runs the model variant it drew at reset (armature of back_bkz, mass / diaginertia of two leg bodies,
+    friction of the right foot's geoms) with its own joint damping: one control step vs the oracle built from the VARIANT's
+    compiled model with that damping (reference: a re-compiled MjModel per reset, base.py:183-185)."""
+    n, k = 16, 5
+    env = _talos_variant_env(n, k)
+    m = env._model
+    env.reset()
+    variants, prm = env._pending_variants.copy(), env._pending_dof_params.copy()
+    assert len(set(variants)) >= 3
+    q0 = np.stack([h.qpos for h in env._host]).astype(np.float32).astype(np.float64)
+    v0 = np.stack([h.qvel for h in env._host]).astype(np.float32).astype(np.float64)
+    rs = np.random.RandomState(2)
+    acts = rs.uniform(-0.3, 0.3, (n, 12))
+    env.step(acts)
+    assert np.array_equal(env.backend.get_variant_index(), variants) and env.backend.n_variants == k
+    q, v = env.backend.get_state()
+    eq, ev, enom = [], [], []
+    for i in range(n):
+        mv = env._variant_models[0][variants[i]]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        d, s, f = (prm[p][i].astype(np.float32) for p in range(3))
+        qo, vo = Oracle(pack_model(_with_dof_params(mv, d, s, f))).step(q0[i], v0[i], ctrl, nsub=10)[:2]
+        qn, vn = Oracle(pack_model(_with_dof_params(m, d, s, f))).step(q0[i], v0[i], ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max()); enom.append(np.abs(v[i] - vn).max())
+    print("Talos model variants vs oracle: qpos max %.2e qvel max %.2e (vs the NOMINAL model's oracle: qvel max %.2e)" % (max(eq), max(ev), max(enom)))
+    assert max(eq) < QTOL and max(ev) < VTOL
+    assert max(enom) > 10 * VTOL                         # the variants are different robots
+
+
+def test_model_variants_redrawn_at_device_side_restarts():
+    n, k = 256, 6
+    env = _talos_variant_env(n, k)
+    env.reset()
+    drawn = env._pending_variants.copy()
+    env.enable_auto_reset(seed=3, horizon=4)
+    env.step(np.zeros((n, 12)))
+    b = env.backend
+    first = b.get_variant_index().copy()
+    assert np.array_equal(first, drawn)                  # the host's draw of the first episodes was uploaded
+    seen = [first]
+    for _ in range(3):
+        st = b.rollout(4, action_mode=1, seed=11)
+        seen.append(b.get_variant_index().copy())
+    idx = np.stack(seen)
+    assert idx.min() >= 0 and idx.max() < k
+    assert (idx[1:] != idx[:-1]).mean() > 0.6            # restarts every 4 steps: a fresh uniform draw differs with p = 5/6
+    assert len(set(idx[-1])) == k and abs(np.bincount(idx[1:].ravel(), minlength=k) / idx[1:].size - 1.0 / k).max() < 0.05
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and st["nan_resets"] == 0
+    # keyed by (seed, global environment id, episode count): independent of how the environments are split over batches
+    from loco_mujoco_amd.backend import HipBatch
+
+    def run(nenv, offset):
+        bb = HipBatch(env._hip_model, nenv)
+        bb.set_model_variants(env._build_model_variants(env._chain_model()))
+        tab = env._reset_table()
+        rows = tab[(np.arange(offset, offset + nenv) * 7) % len(tab)]
+        bb.set_state(rows[:, :env._model.nv], rows[:, env._model.nv:2 * env._model.nv])
+        bb.set_reset_table(tab, seed=9, global_env_offset=offset)
+        bb.set_auto_reset(True, horizon=3)
+        bb.rollout(10, action_mode=1, seed=4)
+        return bb.get_variant_index(), bb.get_state()
+
+    env.seed(0); (ia, (qa, va)) = run(48, 0)
+    env.seed(0); (ib0, (qb0, vb0)) = run(24, 0)
+    env.seed(0); (ib1, (qb1, vb1)) = run(24, 24)
+    assert np.array_equal(ia, np.concatenate([ib0, ib1])) and np.array_equal(qa, np.concatenate([qb0, qb1]))
+
+
+def test_model_variants_with_self_collision_pairs_vs_oracle(tmp_path):
+    """UnitreeA1: the variant brings its own geom-pair table (body_invweight0 of both bodies enters a self-contact's
+    regulariser). Trunk mass + fullinertia (the reference's singular-value rule) + foot friction."""
+    y = tmp_path / "dr.yaml"
+    y.write_text("Inertial:\n  trunk:\n    mass: {sigma: 1.0}\n    fullinertia:\n      uniform_range_delta: 0.002\n"
+                 "Geoms:\n  FR_calf:\n    friction:\n      uniform_range_delta: [0.3, 0.004, 0.00005]\n")
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=12, domain_randomization_config=str(y), n_model_variants=3)
+    m = env._model
+    st = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_self_contact_states.npz"))
+    env.reset()
+    variants = env._pending_variants.copy()
+    pick = np.argsort(-st["nself"])[:12]
+    q0 = st["q"][pick].astype(np.float32).astype(np.float64)
+    v0 = st["v"][pick].astype(np.float32).astype(np.float64)
+    b = env.backend
+    env._upload_state()
+    b.set_state(q0, v0)
+    b.step(np.zeros((12, 12)))
+    q, v = b.get_state()
+    ncon = b.stats()["self_contacts"]
+    eq, ev = [], []
+    for i in range(12):
+        o = Oracle(pack_model(env._variant_models[0][variants[i]]))
+        qo, vo = o.step(q0[i], v0[i], np.zeros(m.nu), nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
+    print("A1 model variants on self-contact states vs oracle: qpos max %.2e qvel max %.2e (%d self-contact substeps)" % (max(eq), max(ev), ncon))
+    assert ncon > 0 and max(eq) < QTOL and max(ev) < VTOL
