@@ -206,8 +206,11 @@ template <int MC> struct DofPrm {
 };
 
 // lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM][link bounding-sphere centres MCx3 (PAIRS)]
-template <int MC, int NS, int NM = 0, bool PAIRS = false> struct LaneMem {
-  static constexpr int kSlot = PAIRS ? (int)SL_SIZE_PAIRS : (int)SL_SIZE;
+// compact slot record of the kernels compiled for condim-3 pyramids only (CONE == 0): one D, four edge rows — 21 floats
+// instead of 37, which is what lets the 8-slot humanoid family keep four workgroups per CU (LDS: 160 KB / 4)
+enum { SLC_D = SL_D, SLC_AREF = SLC_D + 1, SLC_JAR = SLC_AREF + 4, SLC_JV = SLC_JAR + 4, SLC_ZONE = SLC_JV + 4, SLC_GRF, SLC_SIZE };
+template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> struct LaneMem {
+  static constexpr int kSlot = COMPACT ? (int)SLC_SIZE : (PAIRS ? (int)SL_SIZE_PAIRS : (int)SL_SIZE);
   static constexpr int kSlots = 0;
   static constexpr int kMcc = NS * kSlot;
   static constexpr int kMcr = kMcc + MC * (MC + 1) / 2;
@@ -226,6 +229,8 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false> struct LaneMem {
   static constexpr int kPadded = kSize + ((5 - kSize % 4) % 4);
   static constexpr int kGroup = kPadded * 16;
 };
+// the lane memory of a kernel compiled for cone CONE (-1 run-time, 0 pyramids of condim 3 only, 1 elliptic)
+template <int MC, int NS, int NM, bool PAIRS, int CONE> using LaneMemFor = LaneMem<MC, NS, NM, PAIRS, (CONE == 0) && !PAIRS>;
 
 // Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
 // because their D is 0). Dj = D of row j, fr = friction coefficients of rows 1..5, mu = regularised cone mu.
@@ -771,7 +776,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots.
   // Everything that must survive into the solver (M, twists) is parked in lane memory so that the Newton loop
   // keeps only small vectors in registers.
-  using LMm = LaneMem<MC, NS, NM, PAIRS>;
+  using LMm = LaneMemFor<MC, NS, NM, PAIRS, CONE>;
+  // slot field offsets of THIS kernel's record layout (shadow the namespace-scope enumerators of the full layout)
+  constexpr bool kCompactSlots = (CONE == 0) && !PAIRS;
+  constexpr int SL_D = kCompactSlots ? (int)SLC_D : (int)lm::SL_D, SL_FR = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_FR;
+  constexpr int SL_AREF = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_AREF, SL_JAR = kCompactSlots ? (int)SLC_JAR : (int)lm::SL_JAR;
+  constexpr int SL_JV = kCompactSlots ? (int)SLC_JV : (int)lm::SL_JV, SL_ZONE = kCompactSlots ? (int)SLC_ZONE : (int)lm::SL_ZONE;
+  constexpr int SL_GRF = kCompactSlots ? (int)SLC_GRF : (int)lm::SL_GRF;
+  (void)SL_FR;
 #define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
   float a0r[6], a0c[MC];

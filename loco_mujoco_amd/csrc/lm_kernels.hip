@@ -254,7 +254,7 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
   HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
-  HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * 16)); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * 16));
+  HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (16 + 16 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (16 + 16 * (size_t)b->nblocks)));
   HIPCHK(hipStreamCreate(&b->stream));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); HIPCHK(hipEventCreateWithFlags(&b->ev_ext, hipEventDisableTiming));
   return 0;
@@ -688,6 +688,16 @@ int lm_debug_timers(lm_batch* b, unsigned long long* out16) {
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(out16, b->timers, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * 16));
+  return 0;
+}
+
+/* profiling builds: per workgroup of the LAST launch [nblocks][16] = cycles, then per environment (4) solver iterations,
+   contact slots (summed over passes), line-search evaluations */
+int lm_debug_wg_records(lm_batch* b, unsigned long long* out, int nblocks) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (nblocks != b->nblocks) return fail("nblocks mismatch");
+  HIPCHK(hipMemcpy(out, b->timers + 16, sizeof(unsigned long long) * 16 * (size_t)nblocks, hipMemcpyDeviceToHost));
   return 0;
 }
 

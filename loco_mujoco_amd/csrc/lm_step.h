@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {};
-  using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
+  using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, CONE>;
   const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
   LM_LMEM_T* lmem = lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
   constexpr int ls = 16;
@@ -421,6 +421,15 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     }
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+    {
+      unsigned long long* rec = a.timers + 16 + 16 * (long long)wg;       // wg: the workgroup after the XCD mapping (environments 4 wg .. 4 wg + 3)
+      const float ncon_env = QuadDpp::sum((float)cnt.ncon);
+      if (threadIdx.x == 0) { long long tot = 0; for (int i = 0; i < 12; i++) tot += cnt.t[i]; rec[0] = (unsigned long long)tot; }
+      if (c == 0 && QuadDpp::rep() == 0 && e_local < 4) {
+        rec[1 + e_local] = (unsigned long long)cnt.solver_iters; rec[5 + e_local] = (unsigned long long)ncon_env;
+        rec[9 + e_local] = (unsigned long long)cnt.ls_evals; rec[13 + (e_local & 1)] = (unsigned long long)(absorbing ? 1 : 0);
+      }
+    }
 #endif
   }
   }  // fused control steps
@@ -455,10 +464,12 @@ static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, cons
 template <int MC, int NS, bool RK4, int CONE, int NM, int PART, bool PAIRS = false>
 static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const dim3 grid((L.N + L.epb - 1) / L.epb);
-  using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
+  using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, CONE>;
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
   if constexpr (PART == 0) {
-    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    // the forward-only (debug) kernel reads the cone at run time: full slot records
+    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb),
+                                    (size_t)lm::LaneMemFor<MC, NS, NM, PAIRS, -1>::kGroup * ((4 * L.epb + 15) / 16), L, a);
     else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
     else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
     else return false;

@@ -206,7 +206,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         }
       }
       lm::Counters cnt = {};
-      using LMm = lm::LaneMem<MC, NS, NM, PAIRS>;
+      using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, kEmuCone<MC>>;
       float lmem[LMm::kSize];
       // rep = 1: lane memory starts uninitialised (MemorySanitizer sees reads of never-written words); replicated: every
       // private copy and the snapshot start as the same quiet NaN, so such a read poisons the result instead
