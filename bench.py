@@ -279,12 +279,15 @@ def main():
     import hashlib
     from loco_mujoco_amd import backend as _backend
     lib_sha = hashlib.sha256(open(_backend.LIB_PATH, "rb").read()).hexdigest()[:16]
-    prof = os.path.join(ROOT, "profiles", "r2_pmc.json")
+    # profiles/<tag>_pmc.json: "r2" for the bench line, "r2_<task>[.dr][<envs>]" for the other configurations
+    tag = "r2" if (default_task and n == 4096) else "r2_%s%s%s" % (args.task, ".dr" if args.dr else "", "" if n == 4096 else str(n))
+    prof = os.path.join(ROOT, "profiles", tag + "_pmc.json")
+    prof_name = "profiles/%s_pmc.json" % tag
     prof_note = "no committed profile for this workload"
-    if os.path.exists(prof) and n == 4096 and default_task and json.load(open(prof)).get("lib_sha16") != lib_sha:
-        prof_note = "profiles/r2_pmc.json was taken on another build of liblocohip.so (%s, this one is %s): counters not quoted" % (json.load(open(prof)).get("lib_sha16"), lib_sha)
-    elif os.path.exists(prof) and n == 4096 and default_task:
-        prof_note = "profiles/r2_pmc.json, taken on this build (liblocohip.so sha256[:16] = %s)" % lib_sha
+    if os.path.exists(prof) and json.load(open(prof)).get("lib_sha16") != lib_sha:
+        prof_note = "%s was taken on another build of liblocohip.so (%s, this one is %s): counters not quoted" % (prof_name, json.load(open(prof)).get("lib_sha16"), lib_sha)
+    elif os.path.exists(prof):
+        prof_note = "%s, taken on this build (liblocohip.so sha256[:16] = %s)" % (prof_name, lib_sha)
         try:
             pmc = json.load(open(prof))["pmc"]
             # separate --pmc passes (tools/probes/prof_run.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)
@@ -296,8 +299,8 @@ def main():
                         valu_busy_frac_of_wave_time=pmc["SQ_INSTS_VALU"]["per_dispatch"] / pmc["SQ_WAVE_CYCLES"]["per_dispatch"],
                         mean_wave_time_over_launch_time=4.0 * pmc["SQ_WAVE_CYCLES"]["per_dispatch"] / pmc["SQ_WAVES"]["per_dispatch"]
                         / (prof_ns * 2.4),
-                        note="profiles/r2_pmc.json; 2.4 GHz assumed; one wave per SIMD at 4096 environments, so the SIMD's "
-                             "VALU issue rate is the product of the two fractions")
+                        note=prof_name + "; 2.4 GHz assumed; with one wave per SIMD (4096 environments) the SIMD's VALU issue rate "
+                             "is the product of the two fractions")
         except Exception:
             traffic = None
     out = {

@@ -200,7 +200,9 @@ enum { SL_PART = SL_SIZE, SL_NX, SL_NY, SL_NZ, SL_T1X, SL_T1Y, SL_T1Z, SL_SIZE_P
 // environment's MODEL VARIANT (lowering.variant_tables): `inr` = its inertial record [LM_IR_SIZE][LM_NCHAIN] in global memory
 // (null: the batch has no variants), `gt` / `gpt` = its geom table and geom-pair table
 template <int MC> struct DofPrm {
-  float damp_r[6], stiff_r[6], floss_r[6], damp_c[MC], stiff_c[MC], floss_c[MC];
+  float floss_r[6], floss_c[MC];                 // read inside the line search: registers
+  const float* damp; const float* stiff; long long stride;   // damping / stiffness of dof d at [d * stride]: read where they are used
+                                                             // (twice per forward pass) — 22 registers fewer to carry through the solver
   const float* inr; const float* gt; const float* gpt;
   float rfl_r[6], rfl_c[MC];       // friction-loss regularisers of the variant (read inside the line search: kept in registers)
 };
@@ -682,7 +684,7 @@ LM_DEV void segment_closest(V3 p1, V3 d1, float h1, V3 p2, V3 d2, float h2, floa
 // NM > 0: the chain's muscles (table `mt`, lm_layout.h MT_*/MU_*) act on the chain dofs; their activations and
 // controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
 // DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
-template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, bool DR = false, bool PAIRS = false>
+template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, int DR = 0, bool PAIRS = false>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
@@ -700,9 +702,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define CH(f) cm[oz + LM_CM_CHAINS + (f) * LM_NCHAIN + c]
 #define LK(k, f) CH(LM_C_LINKS + (k) * LM_LINK_SIZE + (f))
 #define LX(k, f) LK(k, LM_D_SIZE + (f))
-  // model variants (DR kernels only): inertial numbers, armature, invweights and the termination scale come from the
-  // environment's record in global memory, the geom tables from its variant
-  const bool inr_on = DR && dp->inr != nullptr;
+  // DR: 0 = the table's joint parameters, 1 = per-environment damping / stiffness / frictionloss, 2 = + the environment's MODEL
+  // VARIANT: inertial numbers, armature, invweights and the termination scale come from its record in global memory, the
+  // geom tables from its variant (a compile-time level: the run-time choice cost every DR kernel 700 B of scratch)
+  constexpr bool inr_on = DR == 2;
   const float* gtp = inr_on ? dp->gt : P.gt;
   const float* gptp = inr_on ? dp->gpt : P.gpt;
 #define INR(i) dp->inr[(i) * LM_NCHAIN + c]
@@ -716,11 +719,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define CU(i, f) cm[oz + P.off_cunsup + ((i) * LM_U_SIZE + (f)) * LM_NCHAIN + c]
 #define SL(s, f) lmem[((s) * LMm::kSlot + (f)) * ls]
 #define PEER(dl, i) Q::peer(lmem, ls, (i), (dl))
-#define DAMP_R(i) (DR ? dp->damp_r[i] : RD(i, LM_D_DAMP))
-#define STIFF_R(i) (DR ? dp->stiff_r[i] : RD(i, LM_D_STIFF))
+#define DAMP_R(i) (DR ? dp->damp[(long long)(int)RD(i, LM_D_DOF) * dp->stride] : RD(i, LM_D_DAMP))
+#define STIFF_R(i) (DR ? dp->stiff[(long long)(int)RD(i, LM_D_DOF) * dp->stride] : RD(i, LM_D_STIFF))
 #define FLOSS_R(i) (DR ? dp->floss_r[i] : RD(i, LM_D_FLOSS))
-#define DAMP_C(k) (DR ? dp->damp_c[k] : LK(k, LM_D_DAMP))
-#define STIFF_C(k) (DR ? dp->stiff_c[k] : LK(k, LM_D_STIFF))
+#define DAMP_C(k) (DR ? dp->damp[(long long)(int)LK(k, LM_D_DOF) * dp->stride] : LK(k, LM_D_DAMP))
+#define STIFF_C(k) (DR ? dp->stiff[(long long)(int)LK(k, LM_D_DOF) * dp->stride] : LK(k, LM_D_STIFF))
 #define FLOSS_C(k) (DR ? dp->floss_c[k] : LK(k, LM_D_FLOSS))
   const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
   const int nl = (int)CH(LM_C_NLINKS);
@@ -2236,7 +2239,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, bool DR = false, bool PAIRS = false>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, int DR = 0, bool PAIRS = false>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,

@@ -75,10 +75,11 @@ static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;                  // A/B switch
-  static const lmk::family_fn table[lmk::LMK_NFAMILY][2] = {
-      {lmk::launch_f0p0, lmk::launch_f0p1}, {lmk::launch_f1p0, lmk::launch_f1p1}, {lmk::launch_f2p0, lmk::launch_f2p1},
-      {lmk::launch_f3p0, lmk::launch_f3p1}, {lmk::launch_f4p0, lmk::launch_f4p1}, {lmk::launch_f5p0, lmk::launch_f5p1},
-      {lmk::launch_f6p0, lmk::launch_f6p1}};
+  static const lmk::family_fn table[lmk::LMK_NFAMILY][3] = {
+      {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {lmk::launch_f1p0, lmk::launch_f1p1, lmk::launch_f1p2},
+      {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {lmk::launch_f3p0, lmk::launch_f3p1, lmk::launch_f3p2},
+      {lmk::launch_f4p0, lmk::launch_f4p1, lmk::launch_f4p2}, {lmk::launch_f5p0, lmk::launch_f5p1, lmk::launch_f5p2},
+      {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}};
   const int fam = family_of(b);
   const LaunchCtx L = {b->stream, b->N, b->epb};
   if (fam == 6) {
@@ -92,10 +93,11 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   int kind;
   const bool rep = b->epb <= 4 && !no_replicas;
   if (FWD) kind = lmk::LMK_FWD;
-  else if (a.nfused > 1) kind = b->dofprm ? lmk::LMK_FUSED_DR : lmk::LMK_FUSED;
+  else if (a.nfused > 1) kind = b->nvar > 0 ? lmk::LMK_FUSED_DRV : (b->dofprm ? lmk::LMK_FUSED_DR : lmk::LMK_FUSED);
+  else if (b->nvar > 0) kind = rep ? lmk::LMK_DRV_REP4 : lmk::LMK_DRV_REP1;
   else if (b->dofprm) kind = rep ? lmk::LMK_DR_REP4 : lmk::LMK_DR_REP1;
   else kind = rep ? lmk::LMK_REP4 : lmk::LMK_REP1;
-  if (!table[fam][0](L, a, kind) && !table[fam][1](L, a, kind)) g_launch_err = "no kernel of this kind in the family";
+  if (!table[fam][0](L, a, kind) && !table[fam][1](L, a, kind) && !table[fam][2](L, a, kind)) g_launch_err = "no kernel of this kind in the family";
 }
 
 extern "C" {

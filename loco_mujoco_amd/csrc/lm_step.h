@@ -125,7 +125,7 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, bool DR = false, int REP = 1, bool FUSED = false, bool PAIRS = false>
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, int DR = 0, int REP = 1, bool FUSED = false, bool PAIRS = false>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
@@ -182,15 +182,13 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   if (DR) {
     const long long pn = (long long)nv * N;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { dofp.damp_r[i] = a.dofprm[dr[i] * N + e]; dofp.stiff_r[i] = a.dofprm[pn + dr[i] * N + e]; dofp.floss_r[i] = a.dofprm[2 * pn + dr[i] * N + e]; }
+    for (int i = 0; i < 6; i++) dofp.floss_r[i] = a.dofprm[2 * pn + dr[i] * N + e];
 #pragma unroll
-    for (int k = 0; k < MC; k++) {
-      dofp.damp_c[k] = (k < nl) ? a.dofprm[dc[k] * N + e] : 0.0f; dofp.stiff_c[k] = (k < nl) ? a.dofprm[pn + dc[k] * N + e] : 0.0f;
-      dofp.floss_c[k] = (k < nl) ? a.dofprm[2 * pn + dc[k] * N + e] : 0.0f;
-    }
+    for (int k = 0; k < MC; k++) dofp.floss_c[k] = (k < nl) ? a.dofprm[2 * pn + dc[k] * N + e] : 0.0f;
+    dofp.damp = a.dofprm + e; dofp.stiff = a.dofprm + pn + e; dofp.stride = N;
     // the environment's model variant (inertial record, geom tables); redrawn below when the episode restarts
     dofp.inr = nullptr; dofp.gt = a.P.gt; dofp.gpt = a.P.gpt;
-    if (a.vrec) {
+    if (DR == 2) {
       const int var = a.var[e];
       dofp.inr = a.vrec + (long long)var * (LM_IR_SIZE * LM_NCHAIN);
       dofp.gt = a.vgt + (long long)var * LM_GT_SIZE;
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       }
       step_no = 0;
       zero_act = true;
-      if (DR && a.vrec && a.nvar > 1 && c == 0 && valid) {
+      if (DR == 2 && a.nvar > 1 && c == 0 && valid) {
         // new episode, new model variant (reference base.py:183-185: a freshly randomised model per reset)
         const unsigned long long rv = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ 0xA24BAED4963EE407ull);
         a.var[e] = (int)(rv % (unsigned long long)a.nvar);
@@ -448,7 +446,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 struct LaunchCtx { hipStream_t stream; int N, epb; };
 
 // kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
-enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_NKINDS };
+enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV, LMK_NKINDS };
 constexpr int LMK_NFAMILY = 7;      // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic
 
 template <class K>
@@ -468,16 +466,22 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
   if constexpr (PART == 0) {
     // the forward-only (debug) kernel reads the cone at run time: full slot records
-    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb),
+    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, 0, 1, false, PAIRS>, grid, dim3(4 * L.epb),
                                     (size_t)lm::LaneMemFor<MC, NS, NM, PAIRS, -1>::kGroup * ((4 * L.epb + 15) / 16), L, a);
-    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else return false;
+  } else if constexpr (PART == 1) {
+    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
     else return false;
   } else {
-    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
-    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, false, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, true, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    // per-environment joint parameters AND model variants (lm_set_model_variants)
+    if (kind == LMK_DRV_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DRV_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED_DRV) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
     else return false;
   }
   return true;
@@ -485,12 +489,12 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
 
 // defined in the lm_family.hip objects; false = this family/part has no kernel of that kind
 typedef bool (*family_fn)(const LaunchCtx&, const KArgs&, int kind);
-bool launch_f0p0(const LaunchCtx&, const KArgs&, int); bool launch_f0p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f1p0(const LaunchCtx&, const KArgs&, int); bool launch_f1p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f2p0(const LaunchCtx&, const KArgs&, int); bool launch_f2p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f3p0(const LaunchCtx&, const KArgs&, int); bool launch_f3p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int);
-bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int);
+bool launch_f0p0(const LaunchCtx&, const KArgs&, int); bool launch_f0p1(const LaunchCtx&, const KArgs&, int); bool launch_f0p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f1p0(const LaunchCtx&, const KArgs&, int); bool launch_f1p1(const LaunchCtx&, const KArgs&, int); bool launch_f1p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f2p0(const LaunchCtx&, const KArgs&, int); bool launch_f2p1(const LaunchCtx&, const KArgs&, int); bool launch_f2p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f3p0(const LaunchCtx&, const KArgs&, int); bool launch_f3p1(const LaunchCtx&, const KArgs&, int); bool launch_f3p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const LaunchCtx&, const KArgs&, int); bool launch_f4p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int); bool launch_f5p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int); bool launch_f6p2(const LaunchCtx&, const KArgs&, int);
 
 }  // namespace lmk

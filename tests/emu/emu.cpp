@@ -108,9 +108,9 @@ using QuadThreads = QuadThreadsT<EMU_LS_POINTS, EMU_REP>;
 // EMU_DR compiles the per-environment joint-parameter path (DR = true); the parameters come from emu_set_dof_params
 // ([3][n][nv]: damping, stiffness, frictionloss) or, when none are set, from the constant table (must change nothing)
 #ifdef EMU_DR
-constexpr bool kEmuDR = true;
+constexpr int kEmuDR = EMU_DR;         // 1: per-environment joint parameters, 2: + a model variant (emu_set_model_variant)
 #else
-constexpr bool kEmuDR = false;
+constexpr int kEmuDR = 0;
 #endif
 const double* g_dofprm = nullptr;
 // one model variant for every environment (lowering.variant_tables): inertial record, geom table, geom-pair table (or null)
@@ -186,19 +186,24 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         }
       }
       lm::DofPrm<MC> dofp = {};
+      std::vector<float> dof_ds;
       if (kEmuDR) {
         auto prm = [&](int which, int dof, float nominal) -> float {
           return g_dofprm ? (float)g_dofprm[((size_t)which * n + e) * nv + dof] : nominal;
         };
+        // damping | stiffness of this environment by dof index (the kernel reads them where they are used)
+        std::vector<float>& ds = dof_ds;
+        ds.assign(2 * (size_t)nv, 0.0f);
         for (int i = 0; i < 6; i++) {
           const float* blk = rb + LM_R_DOFS + i * LM_D_SIZE;
-          dofp.damp_r[i] = prm(0, dr[i], blk[LM_D_DAMP]); dofp.stiff_r[i] = prm(1, dr[i], blk[LM_D_STIFF]); dofp.floss_r[i] = prm(2, dr[i], blk[LM_D_FLOSS]);
+          ds[dr[i]] = prm(0, dr[i], blk[LM_D_DAMP]); ds[nv + dr[i]] = prm(1, dr[i], blk[LM_D_STIFF]); dofp.floss_r[i] = prm(2, dr[i], blk[LM_D_FLOSS]);
         }
         for (int k = 0; k < MC; k++) if (k < nl) {
           const float* blk = cm.data() + LM_CM_CHAINS + (LM_C_LINKS + k * LM_LINK_SIZE) * LM_NCHAIN + c;
-          dofp.damp_c[k] = prm(0, dc[k], blk[LM_D_DAMP * LM_NCHAIN]); dofp.stiff_c[k] = prm(1, dc[k], blk[LM_D_STIFF * LM_NCHAIN]);
+          ds[dc[k]] = prm(0, dc[k], blk[LM_D_DAMP * LM_NCHAIN]); ds[nv + dc[k]] = prm(1, dc[k], blk[LM_D_STIFF * LM_NCHAIN]);
           dofp.floss_c[k] = prm(2, dc[k], blk[LM_D_FLOSS * LM_NCHAIN]);
         }
+        dofp.damp = ds.data(); dofp.stiff = ds.data() + nv; dofp.stride = 1;
         dofp.inr = g_vrec; dofp.gt = g_vrec ? g_vgt : P.gt; dofp.gpt = (g_vrec && g_vgpt) ? g_vgpt : P.gpt;
         if (g_vrec) {
           for (int i = 0; i < 6; i++) dofp.rfl_r[i] = g_vrec[(LM_IR_ROOT_DOF + 3 * i + 2) * LM_NCHAIN + c];

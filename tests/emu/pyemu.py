@@ -6,23 +6,25 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_VARIANTS = [(1, False, 1), (4, False, 1), (4, True, 1), (4, False, 4), (4, True, 4)]          # what the tests use: built together, in parallel (g++ needs ~1 min each)
+_VARIANTS = [(1, 0, 1), (4, 0, 1), (4, 1, 1), (4, 0, 4), (4, 1, 4), (4, 2, 4)]          # what the tests use: built together, in parallel (g++ needs ~1 min each)
 
 
 def _lib_path(ls_points, dr, rep=1):
-    name = ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", "_dr.so" if dr else ".so")
+    name = ("libemu.so" if ls_points == 1 else "libemu%d.so" % ls_points).replace(".so", {0: ".so", 1: "_dr.so", 2: "_drv.so"}[int(dr)])
     return os.path.join(_HERE, name.replace(".so", "_rep%d.so" % rep if rep > 1 else ".so"))
 
 
 def build(ls_points=1, dr=False, rep=1):
     """ls_points = 1: the one-point-at-a-time line search of full waves; 4: the four-points-per-round line search of the
-    replicated small-batch layout (evaluated by one lane here); dr: the per-environment joint-parameter code path."""
+    replicated small-batch layout (evaluated by one lane here); dr: 1 = the per-environment joint-parameter code path, 2 = with
+    model variants (the kernels' DR template level)."""
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../loco_mujoco_amd/csrc/lm_core.h"),
             os.path.join(_HERE, "../../include/lm_layout.h")]
 
     def stale(lib):
         return not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
 
+    dr = int(dr)
     want = [(ls_points, dr, rep)] + [v for v in _VARIANTS if v != (ls_points, dr, rep)]
     procs = []
     for lp, d, rp in want:
@@ -30,7 +32,7 @@ def build(ls_points=1, dr=False, rep=1):
         if stale(lib):
             tmp = lib + ".tmp%d" % os.getpid()
             procs.append((subprocess.Popen(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                                            "-DEMU_LS_POINTS=%d" % lp, "-DEMU_REP=%d" % rp, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR"] if d else [])
+                                            "-DEMU_LS_POINTS=%d" % lp, "-DEMU_REP=%d" % rp, "-DEMU_PYRAMID_ONLY"] + (["-DEMU_DR=%d" % d] if d else [])
                                            + ["-o", tmp, srcs[0]]), tmp, lib))
     for p, tmp, lib in procs:
         if p.wait() != 0:
@@ -44,7 +46,7 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     """variant: (record, geom table, geom-pair table) of ``lowering.variant_tables`` — one model variant for all environments
     (implies dr). dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
     per-environment code path on the table's nominal values."""
-    dr = dr or dof_params is not None or variant is not None
+    dr = 2 if variant is not None else int(bool(dr or dof_params is not None))
     if rep > 1:
         ls_points = 4            # the replicated layout always evaluates four step lengths per round
     lib = C.CDLL(build(ls_points, dr, rep))
