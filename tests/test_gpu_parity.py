@@ -1521,3 +1521,24 @@ def test_model_variants_with_self_collision_pairs_vs_oracle(tmp_path):
         eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
     print("A1 model variants on self-contact states vs oracle: qpos max %.2e qvel max %.2e (%d self-contact substeps)" % (max(eq), max(ev), ncon))
     assert ncon > 0 and max(eq) < QTOL and max(ev) < VTOL
+
+
+def test_parity_subset_with_the_O2_build():
+    """Guard against optimisation-level-dependent physics (profiles/r2_ab_probes.md §5): the same source built at
+    -O2 (`__graft_entry__.build()` leaves it in-tree as liblocohip_O2.so) has to pass the known-answer, per-environment-parameter,
+    model-variant, self-contact and fused-rollout tests of every kernel family. Run in a subprocess so that this process keeps
+    the shipped library."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(loco_mujoco_amd.__file__), "csrc", "liblocohip_O2.so")
+    if not os.path.exists(lib):
+        pytest.skip("liblocohip_O2.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, LOCOHIP_LIB=lib)
+    sel = "kats or per_environment_joint or model_variants or self_contacts or fused_rollout or cylinder_states or foot_force"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "--tb=line", "-p", "no:cacheprovider",
+                        "-k", sel, "--deselect", os.path.abspath(__file__) + "::test_native_library_is_loaded"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
+    print("-O2 build:", tail)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in tail and "failed" not in tail
