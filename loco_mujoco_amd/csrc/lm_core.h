@@ -151,7 +151,7 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
   float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
-  long long t[12];
+  long long t[16];
 #endif
 };
 #ifdef LM_TIMERS
@@ -845,6 +845,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
         } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
       }
+      LM_TICK(11);     // kinematics, twists, link inertias
   // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link. The replicas of a
   // small-batch environment take every kRep-th geom; in each pass they exchange how many contacts they found, so that
   // the slot records land in lane memory in the same order (geom, then candidate point) as without replicas.
@@ -985,6 +986,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         nslot += total;
       }
+      LM_TICK(12);     // broad phase + primitive colliders of the group
       // ---- convex meshes of the group (plane vs hull: ONE contact, at the support vertex — pinned by the UnitreeH1 golden
       // rows): every replica takes the same geom and a quarter of its hull vertices (mesh-vertex table, global
       // memory, link frame); the lowest vertex wins, ties go to the first in the table like a sequential search
@@ -1035,6 +1037,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         const float sz = LMEM(fb + 2) + LMEM(fb + 9) * CU(i, 1) + LMEM(fb + 10) * CU(i, 2) + LMEM(fb + 11) * CU(i, 3);
         if (sz - CU(i, 4) < CU(i, 5)) n_unhandled++;
       }
+      LM_TICK(13);     // hull colliders (and the group loop's tail)
       if (Q::kRep > 1) { n_overflow = (int)Q::rep_sum((float)n_overflow); n_unhandled = (int)Q::rep_sum((float)n_unhandled); }
       cnt.overflow += n_overflow; cnt.unhandled += n_unhandled;
     }

@@ -418,11 +418,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (PAIRS && cnt.selfcon) atomicAdd(&blk_stats[11], (float)cnt.selfcon);
     }
 #ifdef LM_TIMERS
-    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+    if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
     {
       unsigned long long* rec = a.timers + 16 + 16 * (long long)wg;       // wg: the workgroup after the XCD mapping (environments 4 wg .. 4 wg + 3)
       const float ncon_env = QuadDpp::sum((float)cnt.ncon);
-      if (threadIdx.x == 0) { long long tot = 0; for (int i = 0; i < 12; i++) tot += cnt.t[i]; rec[0] = (unsigned long long)tot; }
+      if (threadIdx.x == 0) { long long tot = 0; for (int i = 0; i < 16; i++) tot += cnt.t[i]; rec[0] = (unsigned long long)tot; }
       if (c == 0 && QuadDpp::rep() == 0 && e_local < 4) {
         rec[1 + e_local] = (unsigned long long)cnt.solver_iters; rec[5 + e_local] = (unsigned long long)ncon_env;
         rec[9 + e_local] = (unsigned long long)cnt.ls_evals; rec[13 + (e_local & 1)] = (unsigned long long)(absorbing ? 1 : 0);
