@@ -58,9 +58,10 @@ struct lm_batch {
 // run time, plain layout only.
 static int family_of(const lm_batch* b) {
   const Task& T = b->m->T;
-  const bool big = T.max_links > 3, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
+  const bool big = T.max_links > 3, six = T.max_links > 5, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
   static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
   const bool pyr3 = T.all_pyr3 && !generic;
+  if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return 0;
   if (big && rk4 && T.na == 0 && few && pyr3) return 1;
   if (big && rk4 && T.na == 0 && pyr3) return 2;
@@ -79,8 +80,9 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
       {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {lmk::launch_f1p0, lmk::launch_f1p1, lmk::launch_f1p2},
       {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {lmk::launch_f3p0, lmk::launch_f3p1, lmk::launch_f3p2},
       {lmk::launch_f4p0, lmk::launch_f4p1, lmk::launch_f4p2}, {lmk::launch_f5p0, lmk::launch_f5p1, lmk::launch_f5p2},
-      {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}};
+      {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}, {lmk::launch_f7p0, lmk::launch_f7p1, lmk::launch_f7p2}};
   const int fam = family_of(b);
+  if (fam < 0) { g_launch_err = "chains of six links are compiled for Euler, condim-3 pyramids, no muscles only"; return; }
   const LaunchCtx L = {b->stream, b->N, b->epb};
   if (fam == 6) {
     if (b->m->T.na > 0) { g_launch_err = "muscle models need the <5 links, <=4 contacts per chain, Euler> family"; return; }
@@ -116,7 +118,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   if (!cmod || n < LM_HEADER_SIZE + LM_CM_SIZE + LM_GT_SIZE) return fail("chain model too short");
   if ((unsigned)cmod[LM_H_MAGIC] != (unsigned)LM_LMC_MAGIC) return fail("bad chain-model magic");
   if ((int)cmod[LM_H_CM_SIZE] != LM_CM_SIZE || (int)cmod[LM_H_GT_SIZE] != LM_GT_SIZE) return fail("chain-model table size mismatch (regenerate include/lm_layout.h)");
-  if ((int)cmod[LM_H_MAXLINKS] > 5) return fail("chains longer than 5 links are not supported");
+  if ((int)cmod[LM_H_MAXLINKS] > LM_MAXC) return fail("chains longer than 6 links are not supported");
   if ((int)cmod[LM_HEADER_SIZE + LM_R_NDOF] != 6) return fail("root body must have 6 dofs");
   const int n_muscle = (int)cmod[LM_H_NMUSCLE];
   if (n_muscle < 0 || n_muscle > LM_MT_MAXMUS) return fail("bad muscle count");

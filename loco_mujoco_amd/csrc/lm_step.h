@@ -447,7 +447,7 @@ struct LaunchCtx { hipStream_t stream; int N, epb; };
 
 // kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
 enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV, LMK_NKINDS };
-constexpr int LMK_NFAMILY = 7;      // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic
+constexpr int LMK_NFAMILY = 8;      // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots)
 
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
@@ -496,5 +496,6 @@ bool launch_f3p0(const LaunchCtx&, const KArgs&, int); bool launch_f3p1(const La
 bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const LaunchCtx&, const KArgs&, int); bool launch_f4p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int); bool launch_f5p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int); bool launch_f6p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f7p0(const LaunchCtx&, const KArgs&, int); bool launch_f7p1(const LaunchCtx&, const KArgs&, int); bool launch_f7p2(const LaunchCtx&, const KArgs&, int);
 
 }  // namespace lmk

@@ -146,16 +146,107 @@ class UnitreeH1(BaseRobotHumanoid):
         return [j + "_actuator" for j in _BACK + _ARM + [j + "_r" for j in _LEG] + [j + "_l" for j in _LEG]]
 
 
+_G1_PELVIS = ["pelvis_tx", "pelvis_tz", "pelvis_ty", "pelvis_tilt", "pelvis_list", "pelvis_rotation"]
+_G1_LEG = ["hip_pitch_joint", "hip_roll_joint", "hip_yaw_joint", "knee_joint", "ankle_pitch_joint", "ankle_roll_joint"]
+_G1_ARM = ["shoulder_pitch_joint", "shoulder_roll_joint", "shoulder_yaw_joint", "elbow_pitch_joint", "elbow_roll_joint"]
+_G1_BACK = ["torso_joint"]
+
+
 class UnitreeG1(BaseRobotHumanoid):
-    """``loco_mujoco/environments/humanoids/unitreeG1.py``: not built. Its legs have SIX joints each (hip pitch / roll / yaw, knee,
-    ankle pitch / roll); the device kernels are compiled for chains of up to five links (``lowering.MAXC``)."""
+    """
+    Unitree G1 — host-side mirror of ``loco_mujoco/environments/humanoids/unitreeG1.py``. The reference's default keeps the
+    torso joint and the arms: 29 dofs (6 pelvis + 2 x 6 leg + torso + 2 x 5 arm), 23 torque motors, 56-dim observation; joints
+    with damping 0.5, armature 0.01, frictionloss 0.1; Euler; pyramidal cones; four 1 mm spheres per foot, a cylinder per shin,
+    collision meshes everywhere else (convex hulls against the floor, hull against hull counted, like UnitreeH1).
+
+    Host side (model compiler, reset / observation pipeline, datasets, termination, oracle): every configuration.
+    **Device**: the kernels simulate a root body with up to four serial chains. With ``disable_back_joint=True`` the robot is
+    exactly that (two 6-link legs, two 5-link arms on the welded torso: the ``<6 links, 8 slots, Euler, pyramids>`` family); with
+    the torso joint (the default) the arms hang off a link of a chain — a branch — and ``step()`` raises ``UnsupportedModel``.
+    The golden rollouts (default configuration) are pinned on the oracle (``tests/test_oracle_golden.py``).
+    """
 
     valid_task_confs = ValidTaskConf(tasks=["walk", "run"], data_types=["real"])
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("UnitreeG1 is not built: six-joint legs need a <6 links per chain> kernel family (SURVEY.md §8f rank 3)")
+    def __init__(self, disable_arms=False, disable_back_joint=False, xml_path=None, timestep=0.001, **kwargs):
+        self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, False
+        if kwargs.get("use_foot_forces", False):
+            raise NotImplementedError("UnitreeG1 foot forces (four force points per foot, unitreeG1.py:292-311) are not built: "
+                                      "the device reports two force groups per chain")
+        joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
+        drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
+        observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
+        action_spec = [a for a in self._get_action_specification() if a not in motors_to_remove]
+        variant = self._variant_name(disable_arms, disable_back_joint)
+        if xml_path is not None:
+            model = self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, joints_to_remove, motors_to_remove, disable_arms)
+        else:
+            name = "UnitreeG1.%s.model.npz" % variant
+            if not (_PKG / "assets" / name).exists():
+                raise NotImplementedError("no compiled model %s in the package; pass xml_path=... to compile another one" % name)
+            model = mjcf.CompiledModel.load(_PKG / "assets" / name)
+            assert abs(model.timestep - timestep) < 1e-12
+        collision_groups = [("floor", ["floor"])] + [("%s_foot_%d" % (s, i), ["%s_foot_%d_col" % (s, i)])
+                                                     for s in ("right", "left") for i in (1, 2, 3, 4)]
+        super().__init__(model, action_spec, observation_spec, collision_groups, timestep=timestep, **kwargs)
+        self._init_weight_models([model], [None])
 
     @staticmethod
-    def generate(task="walk", dataset_type="real", **kwargs):
+    def _variant_name(disable_arms, disable_back_joint):
+        return {(False, False): "default", (False, True): "noback", (True, False): "noarms", (True, True): "legs"}[(bool(disable_arms), bool(disable_back_joint))]
+
+    @classmethod
+    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, reorient):
+        Atlas._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, [])
+        if reorient:
+            cls._reorient_arms(handle)
+        return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)       # meshes kept with their convex hulls
+
+    @staticmethod
+    def _reorient_arms(xml_handle):
+        """Elbows turned so that the fixed arms clear the hips (``unitreeG1.py:425-446``)."""
+        for body, quat in (("left_shoulder_pitch_link", "1.0 0.25 0.1 0.0"), ("right_elbow_pitch_link", "1.0 0.0 0.25 0.0"),
+                           ("right_shoulder_pitch_link", "1.0 -0.25 0.1 0.0"), ("left_elbow_pitch_link", "1.0 0.0 0.25 0.0")):
+            xml_handle.find("body", body).set("quat", quat)
+        return xml_handle
+
+    def _get_xml_modifications(self):
+        """``unitreeG1.py:322-353``: the motors carry their joints' names."""
+        joints = []
+        if self._disable_arms:
+            joints += [s + "_" + j for s in ("right", "left") for j in _G1_ARM]
+        if self._disable_back_joint:
+            joints += _G1_BACK
+        return joints, list(joints), []
+
+    # ------------------------------------------------------------------ termination (same bands as UnitreeH1)
+    _bounds = UnitreeH1._bounds
+    _has_fallen = UnitreeH1._has_fallen
+    _termination_spec = UnitreeH1._termination_spec
+
+    def _get_grf_size(self):
+        return 24
+
+    # ------------------------------------------------------------------ task factory
+    @staticmethod
+    def generate(task="walk", dataset_type="real", debug=False, **kwargs):
+        """``LocoEnv.make("UnitreeG1.walk.real")`` (``unitreeG1.py:395-423``)."""
         check_validity_task_mode_dataset(UnitreeG1.__name__, task, None, dataset_type, *UnitreeG1.valid_task_confs.get_all())
-        return UnitreeG1()
+        path = "datasets/humanoids/real/05-run_UnitreeG1.npz" if task == "run" else "datasets/humanoids/real/02-constspeed_UnitreeG1.npz"
+        return BaseRobotHumanoid.generate(UnitreeG1, path, task, dataset_type, debug=debug, clip_trajectory_to_joint_ranges=True, **kwargs)
+
+    # ------------------------------------------------------------------ specs (XML order: ``unitreeG1.py:448-481``)
+    @staticmethod
+    def _joint_names():
+        return (_G1_PELVIS + ["left_" + j for j in _G1_LEG] + ["right_" + j for j in _G1_LEG] + _G1_BACK
+                + ["left_" + j for j in _G1_ARM] + ["right_" + j for j in _G1_ARM])
+
+    @staticmethod
+    def _get_observation_specification():
+        joints = UnitreeG1._joint_names()
+        return ([("q_" + j, j, ObservationType.JOINT_POS) for j in joints]
+                + [("dq_" + j, j, ObservationType.JOINT_VEL) for j in joints])
+
+    @staticmethod
+    def _get_action_specification():
+        return UnitreeG1._joint_names()[6:]

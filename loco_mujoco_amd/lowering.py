@@ -26,7 +26,7 @@ import numpy as np
 
 from . import mjcf
 
-MAXC = 5          # links per chain the table has room for
+MAXC = 6          # links per chain the table has room for (5 for every robot but UnitreeG1's legs)
 NCHAIN = 4
 NROOT = 6
 MAXG = 40         # floor-collidable geoms per chain (with / without a device collider, each)

@@ -119,7 +119,7 @@ const float* g_vrec = nullptr; const float* g_vgt = nullptr; const float* g_vgpt
 
 // EMU_PYRAMID_ONLY compiles the humanoid families like the library does (condim-3 pyramids only, elliptic code out)
 #ifdef EMU_PYRAMID_ONLY
-template <int MC> constexpr int kEmuCone = (MC == 5) ? 0 : -1;
+template <int MC> constexpr int kEmuCone = (MC >= 5) ? 0 : -1;
 #else
 template <int MC> constexpr int kEmuCone = -1;
 #endif
@@ -285,6 +285,8 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   // same family selection as the library's launch_variant()
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
+  if ((int)chain_model[LM_H_MAXLINKS] > 5)
+    return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters) : -1;
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
     return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
   if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, 6, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);

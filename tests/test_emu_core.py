@@ -434,3 +434,26 @@ def test_core_model_variants_vs_oracle_compiled_with_the_same_numbers():
     assert np.abs(qv - ref_var[:, :m.nv]).max() < 1e-4 and np.abs(vv - ref_var[:, m.nv:]).max() < 1e-2
     # the variant is a different robot: the two oracles disagree by far more than the tolerance
     assert np.abs(ref_var[:, m.nv:] - ref_nom[:, m.nv:]).max() > 0.1
+
+
+def test_core_six_link_chains_unitree_g1():
+    """Kernel family <6 links, 8 slots, Euler, pyramids> on the CPU: UnitreeG1 with its torso joint welded (legs of 6 joints,
+    arms of 5; four 1 mm spheres per foot), replicated layout, one control step vs the oracle."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True, disable_back_joint=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert sorted(len(c) for c in info["chains"]) == [5, 5, 6, 6]
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    n = 2
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-0.3, 0.3, (n, m.nu))
+    o = Oracle(pack_model(m))
+    q, v, _, cnt, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], acts, nsub=10, rep=4)
+    assert cnt["ncon"] > 0 and cnt["overflow"] == 0
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo, _, _ = o.step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)
+        assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3

@@ -1542,3 +1542,54 @@ def test_parity_subset_with_the_O2_build():
     print("-O2 build:", tail)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in tail and "failed" not in tail
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# UnitreeG1 with its torso joint welded (kernel family <6 links, 8 slots, Euler, pyramids>). The golden rollouts of the robot
+# are of its default configuration (torso joint free: the arms branch off a chain) and are pinned on the oracle.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_unitree_g1_welded_torso_vs_oracle_and_rollout():
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True, disable_back_joint=True)
+    m = env._model
+    assert m.nv == 28 and len(env._action_indices) == 22
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    rs = np.random.RandomState(3)
+    n = 256
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-1, 1, (n, 22))
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    b.step(acts)
+    q, v = b.get_state()
+    flags = b.flags()
+    oracle = Oracle(pack_model(m))
+    eq, ev = [], []
+    for i in range(0, n, 2):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i].astype(np.float32))
+        qo, vo = oracle.step(rows[i, :m.nv].astype(np.float32).astype(np.float64), rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64), ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
+    print("UnitreeG1 (torso welded), 128 dataset states, random actions, one control step vs oracle: qpos max %.2e median %.2e | qvel max %.2e median %.2e; "
+          "dropped contacts in %d environments" % (max(eq), np.median(eq), max(ev), np.median(ev), int((flags & 1).sum())))
+    assert max(eq) < QTOL and max(ev) < VTOL and (flags & 1).sum() == 0
+    # batch rollout with device-side restarts: finite, episodes end and restart, nothing dropped while the robot is on its feet
+    b = HipBatch(hm, 2048)
+    rows = tab[rs.randint(0, len(tab), 2048)]
+    b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    b.set_reset_table(tab, seed=1)
+    b.set_auto_reset(True, horizon=100)
+    st = b.rollout(40, action_mode=1, seed=2)
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and st["nan_resets"] == 0 and st["episodes"] > 100
+    print("UnitreeG1 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, newton its/substep %.2f"
+          % (st["kernel_ms"] / 40, 2048 * 40 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["solver_iters"] / st["env_steps"] / 10))
+    # the reference's default configuration cannot be lowered: the error names the reason, nothing falls back
+    from loco_mujoco_amd.lowering import UnsupportedModel
+    with pytest.raises(UnsupportedModel, match="branching"):
+        full = LocoEnv.make("UnitreeG1.walk", debug=True)
+        full.reset()
+        full.step(np.zeros(23))

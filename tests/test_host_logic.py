@@ -579,3 +579,35 @@ def test_recorded_dataset_tasks_unitree_a1_and_4_ages(tmp_path, monkeypatch):
     assert o4.shape == (38,) and list(o4[-2:]) == [0.0, 1.0]
     with pytest.raises(Exception):
         LocoEnv.make("HumanoidMuscle4Ages.walk.2.perfect")
+
+
+def test_unitree_g1_surface():
+    """UnitreeG1 (reference humanoids/unitreeG1.py): default = torso joint + arms (host side and oracle only: the arms branch off
+    a chain link); ``disable_back_joint=True`` is the device configuration (root + chains of 6, 6, 5, 5 links)."""
+    from loco_mujoco_amd import lowering
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True)
+    m = env._model
+    assert (m.nv, m.nu) == (29, 23) and env.info.observation_space.shape == (56,) and env.info.action_space.shape == (23,)
+    assert [k for k, _, _ in env.obs_helper.observation_spec][:8] == ["q_pelvis_tx", "q_pelvis_tz", "q_pelvis_ty", "q_pelvis_tilt", "q_pelvis_list",
+                                                                     "q_pelvis_rotation", "q_left_hip_pitch_joint", "q_left_hip_roll_joint"]
+    assert np.allclose(m.dof_frictionloss, 0.1) and np.allclose(m.dof_damping[6:], 0.5) and np.allclose(m.dof_armature[6:], 0.01)
+    obs = env.reset()
+    assert obs.shape == (56,) and not env._has_fallen(obs)
+    low = obs.copy(); low[0] = -0.31
+    assert env._has_fallen(low) and env._has_fallen(low, return_err_msg=True)[1].startswith("pelvis_y_condition")
+    with pytest.raises(lowering.UnsupportedModel, match="branching"):
+        env._chain_model()
+    with pytest.raises(NotImplementedError):
+        LocoEnv.make("UnitreeG1.walk", debug=True, use_foot_forces=True)
+    with pytest.raises(ValueError):
+        LocoEnv.make("UnitreeG1.carry")
+    for kw, nv, nu, chains in ((dict(disable_back_joint=True), 28, 22, [5, 5, 6, 6]), (dict(disable_arms=True), 19, 13, [1, 6, 6]),
+                               (dict(disable_arms=True, disable_back_joint=True), 18, 12, [6, 6])):
+        e = LocoEnv.make("UnitreeG1.run", debug=True, **kw)
+        assert (e._model.nv, e._model.nu) == (nv, nu) and e.info.observation_space.shape == (2 * nv - 2,)
+        cm, info = lowering.lower(e._model, e._device_task())
+        assert sorted(len(c) for c in info["chains"]) == chains and int(cm[lowering.H_MAXLINKS]) == 6
+        assert e.reset().shape == (2 * nv - 2,)
+    ds = LocoEnv.make("UnitreeG1.run", debug=True, disable_back_joint=True).create_dataset()
+    assert ds["states"].shape[1] == 54 and len(ds["states"]) > 50

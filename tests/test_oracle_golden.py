@@ -583,3 +583,47 @@ def test_h1_environment_rows_with_the_packaged_hulls(task):
         if np.abs(v[qidx] - g[k + 1, 15:32]).max() < 1e-6 and np.abs(q[qidx[2:]] - g[k + 1, :15]).max() < 1e-8:
             exact.append(k)
     assert exact == H1_EXACT[task]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# UnitreeG1: the reference's default configuration — 29 dofs, torso joint, free arms — on the oracle.
+# ---------------------------------------------------------------------------------------------------------------
+
+G1_ROWS = {"walk": 25, "run": 26}          # golden rows k -> k + 1 reproduced; walk's last two rows carry a hull-against-hull contact
+
+
+@pytest.mark.parametrize("task", ["walk", "run"])
+def test_unitree_g1_golden_rollout_on_the_oracle(task):
+    """``tests/test_datasets/UnitreeG1.{walk,run}.real.npy`` (generator ``tests/test_environments.py:15-38``): reset reproduces
+    row 0, the reference's test loop through ``LocoEnv`` follows the golden rollout row by row (1e-12) — to the end for `run`,
+    until the first convex-convex contact for `walk` — and every such row is a one-control-step known-answer test."""
+    np.random.seed(0)
+    env = attach(LocoEnv.make("UnitreeG1." + task, debug=True))
+    m = env._model
+    g = GOLD["UnitreeG1.%s.real" % task]
+    assert m.nv == 29 and env.info.action_space.shape == (23,) and env.info.observation_space.shape == (56,)
+    assert np.abs(env.reset() - g[0]).max() < 1e-12
+    n_ok = 0
+    for k in range(1, len(g)):
+        obs, r, absorbing, _ = env.step(np.random.randn(23) * 0.1)
+        if np.abs(obs - g[k]).max() > 1e-11:
+            break
+        n_ok = k
+        assert absorbing == (k == len(g) - 1)            # the reference's rollout ends with the first absorbing state
+    assert n_ok == G1_ROWS[task]
+    # the same rows as one-step KATs from the golden states (full state is observed: x, y are dynamically irrelevant)
+    qidx = [m.jnt_id(n) for k_, n, t in env.obs_helper.observation_spec if k_.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    o = env._backend.oracle
+    exact = 0
+    for k in range(len(g) - 1):
+        a = np.random.randn(23) * 0.1
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :27]
+        qvel[qidx] = g[k, 27:56]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+        exact += int(np.abs(v[qidx] - g[k + 1, 27:56]).max() < 1e-9 and np.abs(q[qidx[2:]] - g[k + 1, :27]).max() < 1e-11)
+    assert exact == G1_ROWS[task]
