@@ -174,8 +174,6 @@ def main():
         if args.dr:
             import loco_mujoco_amd
             kw = dict(disable_back_joint=False)
-        if args.task.startswith("UnitreeG1"):
-            kw = dict(disable_back_joint=True)
         env = LocoEnv.make(args.task, debug=True, **kw)
         r = cpu_baseline(env, env._reset_table(), args.task, args.cpu_random_policy, args.cpu_budget, seed=args.cpu_seed)
         print("RATE %.3f" % r["value"])
@@ -205,8 +203,6 @@ def main():
         import loco_mujoco_amd
         make_kw = dict(disable_back_joint=False, domain_randomization_config=os.path.join(
             os.path.dirname(loco_mujoco_amd.__file__), "environments", "data", "atlas", "domain_randomization_atlas.yaml"))
-    if args.task.startswith("UnitreeG1"):
-        make_kw = dict(disable_back_joint=True)       # the device configuration of this robot (torso joint welded)
     env = LocoEnv.make(args.task, debug=True, **make_kw)
     table = env._reset_table()
     hm = HipModel(env._chain_model(), device=local_rank)
@@ -314,8 +310,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, %d envs/GPU, %s rollout, device-side auto-reset "
                                "(horizon 1000), 10 physics substeps per env-step"
-                               % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else "")
-                                  + (" (torso joint welded)" if args.task.startswith("UnitreeG1") else ""), n,
+                               % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else ""), n,
                                   "zero-action" if default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

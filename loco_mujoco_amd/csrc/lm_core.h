@@ -445,6 +445,31 @@ LM_DEV void arrow_solve(const float* Lcc, const float (*W)[6], const float* Lrr,
   }
 }
 
+// ---- two chains that share their first link (a torso joint with an arm chain on either side: lowering.py, C_DUPROLE) ----------
+// Both lanes carry the link — the owner (role +1) with its mass, joint parameters and geoms, the other (role -1) a massless copy —
+// so that every lane's chain stays serial and the matrices keep their arrow structure. The two copies x_a, x_b of the shared
+// dof are ONE coordinate: every solve H x = r becomes the equality-constrained one (c = e_a - e_b):
+//     H x + c lambda = r,  c.x = 0   =>   x = H^-1 r - lambda H^-1 c,  lambda = (c . H^-1 r) / (c . H^-1 c)
+// i.e. a second triangular solve with the same factors. In the independent coordinates that is exactly (P^T H P)^-1 P^T r.
+template <class Q, int MC>
+LM_DEV void tie_shared_dof(const float* Lcc, const float (*W)[6], const float* Lrr, float* xc, float* xr, int role) {
+  float zc[MC], zr[6];
+#pragma unroll
+  for (int k = 0; k < MC; k++) zc[k] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) zr[i] = 0.0f;
+  zc[0] = (float)role;
+  arrow_solve<Q, MC>(Lcc, W, Lrr, zc, zr);
+  const float cx = Q::sum((float)role * xc[0]), cz = Q::sum((float)role * zc[0]);
+  const float lam = cx / cz;
+#pragma unroll
+  for (int k = 0; k < MC; k++) xc[k] = fmaf(-lam, zc[k], xc[k]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) xr[i] = fmaf(-lam, zr[i], xr[i]);
+  const float xa = Q::sum(role > 0 ? xc[0] : 0.0f);      // bit-identical copies from here on
+  if (role < 0) xc[0] = xa;
+}
+
 // ---- arrow factorisation with ONE cross block per lane (self-collisions between two chains) --------------------------
 // A contact between links of chains a < b couples their blocks: H_ab = X (MC x MC, kept by lane a). Elimination order
 // a, b, (other chains), root:  Y = L_a^-1 X;  H_bb -= Y^T Y;  H_br -= Y^T W_a;  then b factors what is left. `role`: 0 = no
@@ -722,11 +747,15 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define DAMP_R(i) (DR ? dp->damp[(long long)(int)RD(i, LM_D_DOF) * dp->stride] : RD(i, LM_D_DAMP))
 #define STIFF_R(i) (DR ? dp->stiff[(long long)(int)RD(i, LM_D_DOF) * dp->stride] : RD(i, LM_D_STIFF))
 #define FLOSS_R(i) (DR ? dp->floss_r[i] : RD(i, LM_D_FLOSS))
-#define DAMP_C(k) (DR ? dp->damp[(long long)(int)LK(k, LM_D_DOF) * dp->stride] : LK(k, LM_D_DAMP))
-#define STIFF_C(k) (DR ? dp->stiff[(long long)(int)LK(k, LM_D_DOF) * dp->stride] : LK(k, LM_D_STIFF))
-#define FLOSS_C(k) (DR ? dp->floss_c[k] : LK(k, LM_D_FLOSS))
+#define DUPK(k) (MC == 6 && duprole < 0 && (k) == 0)       /* the copy of a shared link carries no joint parameters */
+#define DAMP_C(k) (DR ? (DUPK(k) ? 0.0f : dp->damp[(long long)(int)LK(k, LM_D_DOF) * dp->stride]) : LK(k, LM_D_DAMP))
+#define STIFF_C(k) (DR ? (DUPK(k) ? 0.0f : dp->stiff[(long long)(int)LK(k, LM_D_DOF) * dp->stride]) : LK(k, LM_D_STIFF))
+#define FLOSS_C(k) (DR ? (DUPK(k) ? 0.0f : dp->floss_c[k]) : LK(k, LM_D_FLOSS))
   const float w0 = (c == 0) ? 1.0f : 0.0f;    // root rows are replicated in all lanes, counted once
   const int nl = (int)CH(LM_C_NLINKS);
+  // chains that share their first link (compiled for the six-link family only): +1 owner, -1 massless copy, see tie_shared_dof
+  const int duprole = (MC == 6) ? (int)CH(LM_C_DUPROLE) : 0;
+  const bool anydup = (MC == 6) && Q::sum(fabsf((float)duprole)) > 0.0f;
   LM_TICK_INIT();
 
   // ================= position stage: kinematics, twists, inertias, contacts =================
@@ -1371,6 +1400,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
       for (int k = 0; k < MC; k++) a0c[k] = sm_c[k];
       arrow_solve<Q, MC>(Mcc, Mcr, Lrr, a0c, a0r);
+      if (anydup) tie_shared_dof<Q, MC>(Mcc, Mcr, Lrr, a0c, a0r, duprole);
     }
   }
   // cross-chain contacts: who is coupled with whom (quad-uniform). The factorisation handles a MATCHING (every chain coupled
@@ -1916,6 +1946,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           if (!coupled) {
             arrow_factor<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr);
             arrow_solve<Q, MC>(Hcc, Hcr, Lr, sc, sr);
+            if (anydup) tie_shared_dof<Q, MC>(Hcc, Hcr, Lr, sc, sr, duprole);
           }
         }
 
@@ -2215,6 +2246,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
     for (int k = 0; k < MC; k++) xc[k] = sm_c[k] + qf_c[k];
     arrow_solve<Q, MC>(Hcc, Hcr, Lr, xc, xr);
+    if (anydup) tie_shared_dof<Q, MC>(Hcc, Hcr, Lr, xc, xr, duprole);
 #pragma unroll
     for (int i = 0; i < 6; i++) { vr[i] = fmaf(P.h, xr[i], vr[i]); qr[i] = fmaf(P.h, vr[i], qr[i]); }
 #pragma unroll
@@ -2226,6 +2258,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #undef STIFF_R
 #undef FLOSS_R
 #undef DAMP_C
+#undef DUPK
 #undef STIFF_C
 #undef FLOSS_C
 #undef RD

@@ -50,7 +50,9 @@ LINK_SIZE = D_SIZE + L_SIZE
 # G_GRF: ground-reaction-force group of this geom within its chain (0/1), -1 = not reported
 # G_TRAN: elliptic: tran (R_normal = (1-imp)/imp * tran); pyramidal: 2 mu^2 (1+mu^2) tran (shared R of all edges)
 # ---- chain block (LDS, interleaved [field][chain]) = [nlinks, ngeoms, unsupported geoms (count), force-group slots, links...]
-C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_LINKS = 0, 1, 2, 3, 4, 5, 6, 7
+C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_DUPROLE, C_LINKS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+# C_DUPROLE: +1 = this chain's first link is SHARED with another chain and this lane owns its dof, -1 = this lane carries the
+# massless copy of that link (a torso with two arms: two chains [torso, arm], one dof for the torso), 0 = neither
 # C_NLPAIR: link-pair entries of the self-collision broad phase that involve this chain
 # C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
 CHAIN_SIZE = C_LINKS + MAXC * LINK_SIZE
@@ -251,16 +253,25 @@ def lower(m, task):
         return m.body_weldid[m.body_parent[b]]
     children = {b: [c for c in jointed if c != b and jointed_parent(c) == b] for b in jointed}
     chains = []
+    shared_first = {}                  # chain index of a copy -> chain index of the owner of its (shared) first link
     for start in children[root]:
-        chain, b = [], start
-        while True:
-            chain.append(b)
-            if len(children[b]) == 0:
-                break
-            if len(children[b]) > 1:
-                raise UnsupportedModel("branching below the root is not supported")
-            b = children[b][0]
-        chains.append(chain)
+        heads = [[start]]
+        if len(children[start]) == 2 and m.body_jntnum[start] == 1:
+            # ONE branch, right behind a one-dof first link (a torso joint with two arms): two chains that share that link.
+            # The first owns the dof, the link's mass and geoms; the second carries a massless copy of it; the kernel ties the two
+            # copies of the dof together in every solve (csrc/lm_core.h, arrow_solve_shared)
+            heads = [[start, children[start][0]], [start, children[start][1]]]
+            shared_first[len(chains) + 1] = len(chains)
+        for chain in heads:
+            b = chain[-1]
+            while True:
+                if len(children[b]) == 0:
+                    break
+                if len(children[b]) > 1:
+                    raise UnsupportedModel("branching below the root is not supported (except one branch right behind a one-dof first link)")
+                b = children[b][0]
+                chain.append(b)
+            chains.append(chain)
     if len(chains) > NCHAIN:
         raise UnsupportedModel("more than %d chains" % NCHAIN)
 
@@ -433,7 +444,7 @@ def lower(m, task):
             sup.append(blk)
         return sup, unsup
 
-    info = dict(root=root, chains=chains)
+    info = dict(root=root, chains=chains, shared_first=shared_first)
     mesh_verts = []                    # hull vertices of the mesh colliders, link frame (device table, global memory)
 
     # ---- root block
@@ -474,10 +485,21 @@ def lower(m, task):
         max_links = max(max_links, len(links))
         blk[C_NLINKS] = len(links)
         geoms, unsup = [], []
+        blk[C_DUPROLE] = -1 if c in shared_first else (1 if c in shared_first.values() else 0)
         for li, (b, d, first, last) in enumerate(links):
             lb = blk[C_LINKS + li * LINK_SIZE:C_LINKS + (li + 1) * LINK_SIZE]
+            copy = c in shared_first and li == 0
             fill_dof(lb[:D_SIZE], d, qobs, vobs)
-            dof_to_lane[d] = c
+            if copy:
+                # the massless copy of the shared link: same joint and dof index (both lanes load the same q, v), but everything
+                # that acts ON the dof — damping, stiffness, armature, friction loss, limit, motor, observation, termination —
+                # belongs to the owner's record
+                for f in (D_DAMP, D_ARM, D_STIFF, D_FLOSS, D_LIMITED, D_GEAR):      # (the friction-loss regulariser stays: a row with
+                    lb[f] = 0.0                                                     # frictionloss 0 is inactive, its R must not be 0)
+                lb[D_ACT], lb[D_QOBS], lb[D_VOBS] = -1, -1, -1
+                lb[D_TERM_QLO], lb[D_TERM_QHI], lb[D_TERM_VLO], lb[D_TERM_VHI] = -3e38, 3e38, -3e38, 3e38
+            else:
+                dof_to_lane[d] = c
             ex = lb[D_SIZE:]
             if first:
                 # pose of body b relative to its jointed parent's frame (through welded ancestors), at qpos0
@@ -488,7 +510,7 @@ def lower(m, task):
                 ex[L_R0:L_R0 + 9] = (rp.T @ kin["xmat"][b]).reshape(9)
             else:
                 ex[L_R0:L_R0 + 9] = np.eye(3).reshape(9)
-            if last:
+            if last and not copy:
                 mass, com, inertia = merged_inertial(b)
                 ex[L_MASS], ex[L_CX:L_CX + 3] = mass, com
                 ex[L_IXX:L_IXX + 6] = [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1], inertia[0, 2],

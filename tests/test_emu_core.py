@@ -457,3 +457,23 @@ def test_core_six_link_chains_unitree_g1():
         ctrl[env._action_indices] = env._preprocess_action(acts[i])
         qo, vo, _, _ = o.step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)
         assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3
+
+
+def test_core_shared_first_link_unitree_g1_default():
+    """The default UnitreeG1: the two arm chains share the torso link (owner lane + massless copy, tied together in every
+    solve — tie_shared_dof). Two golden rows as one-control-step known-answer tests of the device code on the CPU."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["shared_first"] == {3: 2}
+    g = GOLD["UnitreeG1.walk.real"]
+    qidx = [m.jnt_id(n) for k_, n, t in env.obs_helper.observation_spec if k_.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = np.array([np.random.randn(23) * 0.1 for _ in range(3)])
+    qpos, qvel = np.zeros((3, m.nv)), np.zeros((3, m.nv))
+    qpos[:, qidx[2:]] = g[:3, :27]
+    qvel[:, qidx] = g[:3, 27:56]
+    q, v, _, cnt, _ = pyemu.run(cmod, qpos[1:], qvel[1:], acts[1:], nsub=10, rep=4)
+    assert np.abs(q[:, qidx[2:]] - g[2:4, :27]).max() < 1e-5 and np.abs(v[:, qidx] - g[2:4, 27:56]).max() < 1e-3

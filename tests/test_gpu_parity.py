@@ -1545,9 +1545,56 @@ def test_parity_subset_with_the_O2_build():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# UnitreeG1 with its torso joint welded (kernel family <6 links, 8 slots, Euler, pyramids>). The golden rollouts of the robot
-# are of its default configuration (torso joint free: the arms branch off a chain) and are pinned on the oracle.
+# UnitreeG1 (kernel family <6 links, 8 slots, Euler, pyramids>). In the reference's default configuration the two arms hang off
+# the torso link: the two arm chains SHARE that link (owner lane + massless copy, tied together in every solve, csrc/lm_core.h
+# tie_shared_dof); with the torso joint welded the robot is a plain root + chains model.
 # ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("task,rows", [("walk", 25), ("run", 26)])
+def test_unitree_g1_one_control_step_kats_and_env_rollout(task, rows):
+    """The reference's golden rollouts of the DEFAULT UnitreeG1 (29 dofs, torso joint, free arms): every row the oracle
+    reproduces (all of `run`; `walk` up to its first hull-against-hull contact) as a one-control-step known-answer test on
+    the device, and the reference's test loop through ``LocoEnv`` on the device."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1." + task, debug=True)
+    m = env._model
+    g = GOLD["UnitreeG1.%s.real" % task]
+    assert m.nv == 29 and g.shape[1] == 56
+    qidx = [m.jnt_id(nm) for k, nm, t in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    n = len(g) - 1
+    acts = np.array([np.random.randn(23) * 0.1 for _ in range(n)])
+    qpos, qvel = np.zeros((n, m.nv)), np.zeros((n, m.nv))
+    qpos[:, qidx[2:]] = g[:n, :27]
+    qvel[:, qidx] = g[:n, 27:56]
+    b = HipBatch(HipModel(env._chain_model()), n)
+    b.set_state(qpos, qvel)
+    obs, rew, done = b.step(acts)
+    eq, ev = np.abs(obs[:rows, :27] - g[1:rows + 1, :27]).max(axis=1), np.abs(obs[:rows, 27:56] - g[1:rows + 1, 27:56]).max(axis=1)
+    print("UnitreeG1.%s KAT errors vs golden (%d of %d rows pinned): qpos max %.2e median %.2e | qvel max %.2e median %.2e"
+          % (task, rows, n, eq.max(), np.median(eq), ev.max(), np.median(ev)))
+    assert eq.max() < QTOL and ev.max() < VTOL
+    assert b.stats()["overflow_contacts"] == 0
+    if rows == n:
+        assert list(done) == [False] * (n - 1) + [True]
+    # the reference's own test loop (tests/test_environments.py:15-38) through LocoEnv on the device
+    np.random.seed(0)
+    o = env.reset()
+    assert np.abs(o - g[0]).max() < 1e-12
+    out, absorbing = [o], False
+    for _ in range(100):
+        if absorbing:
+            break
+        o, r, absorbing, info = env.step(np.random.randn(23) * 0.1)
+        out.append(o)
+    out = np.array(out)
+    k = min(len(out), rows + 1)
+    assert np.abs(out[:k, :27] - g[:k, :27]).max() < 5e-3
+    if rows == n:
+        assert out.shape == g.shape, "episode must terminate at the same step as the reference"
+
 
 def test_unitree_g1_welded_torso_vs_oracle_and_rollout():
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -1587,9 +1634,4 @@ def test_unitree_g1_welded_torso_vs_oracle_and_rollout():
     assert np.isfinite(q).all() and np.isfinite(v).all() and st["nan_resets"] == 0 and st["episodes"] > 100
     print("UnitreeG1 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, newton its/substep %.2f"
           % (st["kernel_ms"] / 40, 2048 * 40 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["solver_iters"] / st["env_steps"] / 10))
-    # the reference's default configuration cannot be lowered: the error names the reason, nothing falls back
-    from loco_mujoco_amd.lowering import UnsupportedModel
-    with pytest.raises(UnsupportedModel, match="branching"):
-        full = LocoEnv.make("UnitreeG1.walk", debug=True)
-        full.reset()
-        full.step(np.zeros(23))
+

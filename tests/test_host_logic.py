@@ -582,8 +582,8 @@ def test_recorded_dataset_tasks_unitree_a1_and_4_ages(tmp_path, monkeypatch):
 
 
 def test_unitree_g1_surface():
-    """UnitreeG1 (reference humanoids/unitreeG1.py): default = torso joint + arms (host side and oracle only: the arms branch off
-    a chain link); ``disable_back_joint=True`` is the device configuration (root + chains of 6, 6, 5, 5 links)."""
+    """UnitreeG1 (reference humanoids/unitreeG1.py): default = torso joint + arms, lowered to four six-link chains of which the two
+    arm chains share the torso link; the reduced configurations are plain root + chains models."""
     from loco_mujoco_amd import lowering
     np.random.seed(0)
     env = LocoEnv.make("UnitreeG1.walk", debug=True)
@@ -596,8 +596,17 @@ def test_unitree_g1_surface():
     assert obs.shape == (56,) and not env._has_fallen(obs)
     low = obs.copy(); low[0] = -0.31
     assert env._has_fallen(low) and env._has_fallen(low, return_err_msg=True)[1].startswith("pelvis_y_condition")
-    with pytest.raises(lowering.UnsupportedModel, match="branching"):
-        env._chain_model()
+    # the arms hang off the torso link: two chains share it as their first link (owner lane 2, massless copy in lane 3)
+    cm, info = lowering.lower(m, env._device_task())
+    assert [len(c) for c in info["chains"]] == [6, 6, 6, 6] and info["shared_first"] == {3: 2}
+    assert info["chains"][2][0] == info["chains"][3][0] == m.body_id("torso_link")
+    role = [int(cm[lowering.HEADER_SIZE + lowering.CM_CHAINS + lowering.C_DUPROLE * lowering.NCHAIN + c]) for c in range(4)]
+    assert role == [0, 0, 1, -1]
+    link0 = lambda c, f: cm[lowering.HEADER_SIZE + lowering.CM_CHAINS + (lowering.C_LINKS + f) * lowering.NCHAIN + c]
+    t = m.jnt_id("torso_joint")
+    assert link0(2, lowering.D_DOF) == link0(3, lowering.D_DOF) == t and link0(2, lowering.D_DAMP) == 0.5 and link0(3, lowering.D_DAMP) == 0
+    assert link0(2, lowering.D_SIZE + lowering.L_MASS) > 5 and link0(3, lowering.D_SIZE + lowering.L_MASS) == 0
+    assert link0(2, lowering.D_LIMITED) == 1 and link0(3, lowering.D_LIMITED) == 0 and link0(3, lowering.D_QOBS) == -1
     with pytest.raises(NotImplementedError):
         LocoEnv.make("UnitreeG1.walk", debug=True, use_foot_forces=True)
     with pytest.raises(ValueError):
