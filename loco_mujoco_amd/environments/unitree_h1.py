@@ -159,11 +159,11 @@ class UnitreeG1(BaseRobotHumanoid):
     with damping 0.5, armature 0.01, frictionloss 0.1; Euler; pyramidal cones; four 1 mm spheres per foot, a cylinder per shin,
     collision meshes everywhere else (convex hulls against the floor, hull against hull counted, like UnitreeH1).
 
-    Host side (model compiler, reset / observation pipeline, datasets, termination, oracle): every configuration.
-    **Device**: the kernels simulate a root body with up to four serial chains. With ``disable_back_joint=True`` the robot is
-    exactly that (two 6-link legs, two 5-link arms on the welded torso: the ``<6 links, 8 slots, Euler, pyramids>`` family); with
-    the torso joint (the default) the arms hang off a link of a chain — a branch — and ``step()`` raises ``UnsupportedModel``.
-    The golden rollouts (default configuration) are pinned on the oracle (``tests/test_oracle_golden.py``).
+    Device: the kernels simulate a root body with up to four serial chains. The arms hang off the torso link — a branch: the two
+    arm chains SHARE that link as their first (owner lane + massless copy, the two copies of the torso dof tied together in every
+    solve; ``lowering.py`` ``shared_first``, ``csrc/lm_core.h`` ``tie_shared_dof``), kernel family ``<6 links, 8 slots, Euler,
+    pyramids>``. The golden rollouts of this configuration are reproduced by the oracle (1e-14) and on the device (2.6e-6 / 2e-4).
+    ``disable_back_joint`` / ``disable_arms`` give plain root + chains models.
     """
 
     valid_task_confs = ValidTaskConf(tasks=["walk", "run"], data_types=["real"])
