@@ -312,7 +312,9 @@ def main():
                                "(horizon 1000), 10 physics substeps per env-step"
                                % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else ""), n,
                                   "zero-action" if default_task else "random-policy"),
-                   "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
+                   "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
+                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 12 doubles at report time",
+                                  "tcp": "socket reduction of 12 doubles at report time (RCCL not used)"}[coll.backend]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,

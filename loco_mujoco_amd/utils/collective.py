@@ -99,21 +99,44 @@ class Collective:
                     time.sleep(0.05)
             self._peers = [s]
         if self.backend == "rccl":
-            self._init_rccl(int(os.environ.get("LOCAL_RANK", 0)) if device is None else int(device))
+            # RCCL over xGMI. Should the communicator not come up on some rank (driver / IPC configuration of the node), every
+            # rank falls back to the reduction over the rendezvous sockets that already exist — agreed on over those sockets,
+            # so that no rank waits inside a collective the others never enter. The bench line reports which one was used.
+            dev = int(os.environ.get("LOCAL_RANK", 0)) if device is None else int(device)
+            self.backend = "tcp"
+            err = None
+            uid = (C.c_byte * 128)()
+            try:                                         # phase A, local: libraries, device, (rank 0) the unique id
+                self._hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+                self._nccl = C.CDLL("librccl.so")
+                self._check_hip(self._hip.hipSetDevice(dev), "hipSetDevice")
+                if self.rank == 0:
+                    self._check(self._nccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            except Exception as e:                       # noqa: BLE001 - any failure of the optional fast path
+                err = e
+            if self.rank == 0:                           # the id always travels (zeros after a failure): nobody waits for it
+                for p in self._peers:
+                    p.sendall(bytes(uid))
+            else:
+                C.memmove(uid, _recv_exact(self._peers[0], 128), 128)
+            agreed = self.all_reduce(np.array([0.0 if err is None else 1.0]), MAX)[0] == 0.0
+            if agreed:
+                try:                                     # phase B, collective: the communicator
+                    self._init_rccl(uid)
+                except Exception as e:                   # noqa: BLE001
+                    err = e
+                agreed = self.all_reduce(np.array([0.0 if err is None else 1.0]), MAX)[0] == 0.0
+            if agreed:
+                self.backend = "rccl"
+            else:
+                if self.rank == 0:
+                    import sys
+                    print("collective: RCCL communicator not available (%s): metric reduction over TCP sockets instead"
+                          % (err or "failure on another rank"), file=sys.stderr)
+                self._comm = None
 
     # ------------------------------------------------------------------ RCCL (ctypes)
-    def _init_rccl(self, device):
-        self._hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
-        self._nccl = C.CDLL("librccl.so")
-        uid = (C.c_byte * 128)()
-        if self.rank == 0:
-            self._check(self._nccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-            for p in self._peers:
-                p.sendall(bytes(uid))
-        else:
-            C.memmove(uid, _recv_exact(self._peers[0], 128), 128)
-        self._check_hip(self._hip.hipSetDevice(device), "hipSetDevice")
-
+    def _init_rccl(self, uid):
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_byte * 128)]
         u = UniqueId()

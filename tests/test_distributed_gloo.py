@@ -5,6 +5,8 @@ all-reduce bench.py performs at report time. Environments are independent, so th
 
 import os
 import socket
+
+import pytest
 import subprocess
 import sys
 import textwrap
@@ -66,7 +68,7 @@ WORKER2 = textwrap.dedent("""
     import numpy as np
     sys.path.insert(0, %r)
     from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
-    coll = Collective(backend="tcp")
+    coll = Collective(backend=os.environ.get("LM_TEST_COLLECTIVE", "tcp"))
     rank, world = coll.rank, coll.world
     vals = np.array([1.0 + rank, 800.0, 3.0 + rank, 0.25 * (rank + 1)])
     tmax = coll.all_reduce(vals, MAX)
@@ -74,11 +76,14 @@ WORKER2 = textwrap.dedent("""
     coll.barrier()
     coll.close()
     if rank == 0:
-        print(json.dumps(dict(world=world, tmax=tmax.tolist(), tsum=tsum.tolist())))
+        print(json.dumps(dict(world=world, tmax=tmax.tolist(), tsum=tsum.tolist(), backend=coll.backend)))
 """) % ROOT
 
 
-def test_product_collective_world2_through_the_launcher(tmp_path):
+@pytest.mark.parametrize("backend", ["tcp", "rccl"])
+def test_product_collective_world2_through_the_launcher(tmp_path, backend):
+    """"rccl" on a box without GPUs: the communicator cannot come up, both ranks agree (over the rendezvous sockets) to reduce
+    over those sockets instead — the fallback of the driver's multi-GPU run should RCCL not initialise on its node."""
     script = tmp_path / "worker2.py"
     script.write_text(WORKER2)
     with socket.socket() as s:
@@ -86,9 +91,9 @@ def test_product_collective_world2_through_the_launcher(tmp_path):
         port = s.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         capture_output=True, text=True, timeout=300)
+                         capture_output=True, text=True, timeout=300, env=dict(os.environ, LM_TEST_COLLECTIVE=backend))
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert res["world"] == 2
+    assert res["world"] == 2 and res["backend"] == "tcp"
     assert res["tmax"] == [2.0, 800.0, 4.0, 0.5] and res["tsum"] == [3.0, 1600.0, 7.0, 0.75]
