@@ -6,7 +6,7 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $GRAFT_REPO_ROOT
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
-for t in HumanoidTorque.run Atlas.walk HumanoidMuscle.run Talos.walk UnitreeH1.walk; do
+for t in HumanoidTorque.run Atlas.walk HumanoidMuscle.run Talos.walk UnitreeH1.walk UnitreeG1.walk; do
   timeout 240 python bench.py --task $t --steps 300 --warmup 30 > $OUT/bench_$t.json 2> $OUT/bench_$t.err
 done
 timeout 240 python bench.py --task Atlas.walk --dr --envs-per-gpu 2048 --steps 300 --warmup 30 > $OUT/bench_Atlas.walk.dr2048.json 2> /dev/null
