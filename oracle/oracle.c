@@ -493,6 +493,126 @@ static void bounding_capsule(int type, const double* size, const double* pos, co
   }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* distance between two convex geoms (GJK), used ONLY to decide whether a pair WITHOUT a restated   */
+/* collider is within its contact margin — i.e. whether the engine would have produced a contact   */
+/* here that this restatement lacks (`unhandled_pairs`). No contact is generated from it.          */
+/* Core shapes: sphere = point, capsule = segment, box = 8 corners, cylinder = two discs, mesh =     */
+/* its hull vertices (body frame); spheres and capsules add their radius afterwards.                */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int type; const double* pos; const double* R; const double* size; const double* verts; int nverts;
+                 const double* bpos; const double* bmat; } cvx;
+
+static double cvx_radius(const cvx* g) { return (g->type == LM_GEOM_SPHERE || g->type == LM_GEOM_CAPSULE) ? g->size[0] : 0.0; }
+
+static void cvx_support(const cvx* g, const double* dir, double* out) {
+  if (g->type == LM_GEOM_MESH) {
+    /* vertices in the BODY frame: direction into that frame, best vertex, back to the world */
+    double dl[3] = { g->bmat[0]*dir[0] + g->bmat[3]*dir[1] + g->bmat[6]*dir[2], g->bmat[1]*dir[0] + g->bmat[4]*dir[1] + g->bmat[7]*dir[2],
+                     g->bmat[2]*dir[0] + g->bmat[5]*dir[1] + g->bmat[8]*dir[2] };
+    int best = 0; double db = -1e300;
+    for (int i = 0; i < g->nverts; i++) { double d = dot3(g->verts + 3*i, dl); if (d > db) { db = d; best = i; } }
+    mulmat3(out, g->bmat, g->verts + 3*best); add3(out, out, g->bpos);
+    return;
+  }
+  double ax[3] = { g->R[2], g->R[5], g->R[8] };
+  copy3(out, g->pos);
+  switch (g->type) {
+    case LM_GEOM_SPHERE: break;
+    case LM_GEOM_CAPSULE: addscl3(out, ax, dot3(ax, dir) >= 0 ? g->size[1] : -g->size[1]); break;
+    case LM_GEOM_BOX:
+      for (int k = 0; k < 3; k++) { double e[3] = { g->R[k], g->R[3 + k], g->R[6 + k] }; addscl3(out, e, dot3(e, dir) >= 0 ? g->size[k] : -g->size[k]); }
+      break;
+    case LM_GEOM_CYLINDER: {
+      double da = dot3(ax, dir), perp[3] = { dir[0] - da*ax[0], dir[1] - da*ax[1], dir[2] - da*ax[2] };
+      double np_ = norm3(perp);
+      addscl3(out, ax, da >= 0 ? g->size[1] : -g->size[1]);
+      if (np_ > 1e-14) addscl3(out, perp, g->size[0] / np_);
+      break;
+    }
+    default: break;
+  }
+}
+
+/* closest point to the origin on the simplex (1..4 points); reduces the simplex to the supporting face; returns 1 if the
+   origin lies inside a tetrahedron (the shapes overlap) */
+static int simplex_closest(double (*S)[3], int* n, double* v) {
+  if (*n == 1) { copy3(v, S[0]); return 0; }
+  double best = 1e300, bv[3] = {0, 0, 0}; int bidx[4], bn = 0;
+  /* points */
+  for (int i = 0; i < *n; i++) { double d = dot3(S[i], S[i]); if (d < best) { best = d; copy3(bv, S[i]); bidx[0] = i; bn = 1; } }
+  /* edges */
+  for (int i = 0; i < *n; i++) for (int j = i + 1; j < *n; j++) {
+    double e[3]; sub3(e, S[j], S[i]);
+    double ee = dot3(e, e); if (ee < 1e-300) continue;
+    double t = -dot3(S[i], e) / ee; if (t <= 0 || t >= 1) continue;
+    double q[3]; copy3(q, S[i]); addscl3(q, e, t);
+    double d = dot3(q, q); if (d < best) { best = d; copy3(bv, q); bidx[0] = i; bidx[1] = j; bn = 2; }
+  }
+  /* triangles */
+  for (int i = 0; i < *n; i++) for (int j = i + 1; j < *n; j++) for (int k = j + 1; k < *n; k++) {
+    double e1[3], e2[3], nn[3]; sub3(e1, S[j], S[i]); sub3(e2, S[k], S[i]); cross3(nn, e1, e2);
+    double n2 = dot3(nn, nn); if (n2 < 1e-300) continue;
+    double t = dot3(S[i], nn) / n2, q[3] = { t*nn[0], t*nn[1], t*nn[2] };      /* projection of the origin on the plane */
+    /* inside test by barycentric coordinates */
+    double r[3]; sub3(r, q, S[i]);
+    double d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), r1 = dot3(r, e1), r2 = dot3(r, e2), det = d11*d22 - d12*d12;
+    if (fabs(det) < 1e-300) continue;
+    double a = (d22*r1 - d12*r2) / det, b = (d11*r2 - d12*r1) / det;
+    if (a <= 0 || b <= 0 || a + b >= 1) continue;
+    double d = dot3(q, q); if (d < best) { best = d; copy3(bv, q); bidx[0] = i; bidx[1] = j; bidx[2] = k; bn = 3; }
+  }
+  if (*n == 4) {
+    /* origin inside the tetrahedron? same side of every face as the opposite vertex */
+    int inside = 1;
+    for (int f = 0; f < 4 && inside; f++) {
+      int a = (f + 1) & 3, b = (f + 2) & 3, c = (f + 3) & 3;
+      double e1[3], e2[3], nn[3]; sub3(e1, S[b], S[a]); sub3(e2, S[c], S[a]); cross3(nn, e1, e2);
+      double so = -dot3(S[a], nn), sd; double df[3]; sub3(df, S[f], S[a]); sd = dot3(df, nn);
+      if (fabs(sd) < 1e-300) { inside = 0; break; }
+      if ((so > 0) != (sd > 0) && so != 0) inside = 0;
+    }
+    if (inside) { v[0] = v[1] = v[2] = 0; return 1; }
+  }
+  double T[4][3];
+  for (int i = 0; i < bn; i++) copy3(T[i], S[bidx[i]]);
+  for (int i = 0; i < bn; i++) copy3(S[i], T[i]);
+  *n = bn; copy3(v, bv);
+  return 0;
+}
+
+/* distance between the two geoms' surfaces (negative or zero: they overlap), to about 1e-9 relative */
+static double convex_distance(const cvx* A, const cvx* B) {
+  double S[4][3], v[3], dir[3], a[3], b[3];
+  int n = 0;
+  sub3(dir, B->pos, A->pos); if (dot3(dir, dir) < 1e-24) { dir[0] = 1; dir[1] = dir[2] = 0; }
+  cvx_support(A, dir, a); double nd[3] = { -dir[0], -dir[1], -dir[2] }; cvx_support(B, nd, b);
+  sub3(S[0], a, b); n = 1; copy3(v, S[0]);
+  for (int it = 0; it < 64; it++) {
+    double vv = dot3(v, v);
+    if (vv < 1e-24) return -(cvx_radius(A) + cvx_radius(B));                     /* cores touch */
+    double mv[3] = { -v[0], -v[1], -v[2] }, wpt[3];
+    cvx_support(A, mv, a); cvx_support(B, v, b); sub3(wpt, a, b);
+    if (vv - dot3(v, wpt) <= 1e-12 * vv) break;                                   /* no progress possible: v is the closest point */
+    int dup = 0;
+    for (int i = 0; i < n; i++) { double df[3]; sub3(df, S[i], wpt); if (dot3(df, df) < 1e-28) dup = 1; }
+    if (dup) break;
+    copy3(S[n], wpt); n++;
+    if (simplex_closest(S, &n, v)) return -(cvx_radius(A) + cvx_radius(B));      /* origin enclosed: the cores overlap */
+  }
+  return sqrt(dot3(v, v)) - cvx_radius(A) - cvx_radius(B);
+}
+
+/* test hook (tests/test_oracle_golden.py): GJK distance of two vertex clouds' hulls, world frame */
+double lmo_test_hull_distance(const double* va, int na, const double* vb, int nb) {
+  static const double zero[3] = {0, 0, 0}, eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sz[3] = {0, 0, 0};
+  double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+  for (int i = 0; i < na; i++) for (int k = 0; k < 3; k++) ca[k] += va[3*i + k] / na;
+  for (int i = 0; i < nb; i++) for (int k = 0; k < 3; k++) cb[k] += vb[3*i + k] / nb;
+  cvx A = { LM_GEOM_MESH, ca, eye, sz, va, na, zero, eye }, B = { LM_GEOM_MESH, cb, eye, sz, vb, nb, zero, eye };
+  return convex_distance(&A, &B);
+}
+
 static void collide(const lmo_model* m, work* w) {
   w->ncon = 0; w->unhandled_pairs = 0;
   for (int pi = 0; pi < m->npair; pi++) {
@@ -636,13 +756,18 @@ static void collide(const lmo_model* m, work* w) {
       segment_closest(p1, a1, s1[1], p2, a2, s2[1], &s, &t);
       double c1[3], c2[3]; copy3(c1, p1); addscl3(c1, a1, s); copy3(c2, p2); addscl3(c2, a2, t);
       sphere_sphere(w, &tm, c1, s1[0], c2, s2[0]);
-    } else if (t1 == LM_GEOM_MESH && t2 == LM_GEOM_MESH) {
-      /* mesh-mesh (libccd in the reference's engine): not restated; count bounding capsules within reach */
-      double a1[3] = { R1[2], R1[5], R1[8] }, a2[3] = { R2[2], R2[5], R2[8] }, sa, ta;
-      segment_closest(p1, a1, s1[1], p2, a2, s2[1], &sa, &ta);
-      double c1[3], c2[3], dd[3]; copy3(c1, p1); addscl3(c1, a1, sa); copy3(c2, p2); addscl3(c2, a2, ta);
-      sub3(dd, c2, c1);
-      if (norm3(dd) - s1[0] - s2[0] < margin) w->unhandled_pairs++;
+    } else if (t1 == LM_GEOM_MESH || t2 == LM_GEOM_MESH
+               || ((t1 == LM_GEOM_CYLINDER || t2 == LM_GEOM_CYLINDER || t1 == LM_GEOM_BOX || t2 == LM_GEOM_BOX) && !(t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX))) {
+      /* a pair the engine collides through libccd or a native box collider, not restated: COUNTED when the exact distance of
+         the two convex shapes (hull vertices for meshes; GJK) is below the contact margin — the engine would have a contact
+         here. A mesh without hull vertices falls back to its bounding capsule. */
+      const int b1 = IDX(m->geom_body, g1), b2 = IDX(m->geom_body, g2);
+      double c1s[3] = { s1[0], s1[1], s1[2] }, c2s[3] = { s2[0], s2[1], s2[2] };
+      cvx A = { t1, p1, R1, c1s, m->mesh_vert[g1], m->mesh_nvert[g1], w->xpos[b1], w->xmat[b1] };
+      cvx B = { t2, p2, R2, c2s, m->mesh_vert[g2], m->mesh_nvert[g2], w->xpos[b2], w->xmat[b2] };
+      if (t1 == LM_GEOM_MESH && m->mesh_nvert[g1] == 0) A.type = LM_GEOM_CAPSULE;      /* bounding capsule (r, h) in size[0], size[1] */
+      if (t2 == LM_GEOM_MESH && m->mesh_nvert[g2] == 0) B.type = LM_GEOM_CAPSULE;
+      if (convex_distance(&A, &B) < margin + 1e-9) w->unhandled_pairs++;
     } else if (t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX) {
       /* box-box contacts are not restated; the pair is only COUNTED, and only when no separating axis
          (3 + 3 face normals, 9 edge cross products) keeps the boxes more than `margin` apart */

@@ -627,3 +627,42 @@ def test_unitree_g1_golden_rollout_on_the_oracle(task):
         q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
         exact += int(np.abs(v[qidx] - g[k + 1, 27:56]).max() < 1e-9 and np.abs(q[qidx[2:]] - g[k + 1, :27]).max() < 1e-11)
     assert exact == G1_ROWS[task]
+
+
+def test_hull_distance_gjk_of_the_pair_counter():
+    """`unhandled_pairs` counts a pair without a restated collider (convex hull against anything, box / cylinder against a
+    non-plane geom) exactly when the two convex shapes are closer than the contact margin: GJK distance in float64. Known
+    answers + random hull pairs against a convex QP (scipy SLSQP)."""
+    import ctypes as C
+    from scipy.optimize import minimize
+    from oracle import pyoracle
+    lib = pyoracle.lib()
+    lib.lmo_test_hull_distance.restype = C.c_double
+    lib.lmo_test_hull_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+
+    def gjk(a, b):
+        a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+        return lib.lmo_test_hull_distance(a.ctypes.data, len(a), b.ctypes.data, len(b))
+
+    cube = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64)
+    assert abs(gjk(cube, cube + [3.5, 0, 0]) - 1.5) < 1e-12                       # face to face
+    assert abs(gjk(cube, cube + [3, 3, 0]) - np.sqrt(2)) < 1e-12                  # edge to edge
+    assert abs(gjk(cube, cube + [3, 3, 3]) - np.sqrt(3)) < 1e-12                  # corner to corner
+    assert gjk(cube, cube + [1.5, 0.3, -0.2]) <= 0 and gjk(cube, 0.1 * cube) <= 0  # overlapping, nested
+    rs = np.random.RandomState(0)
+    rot = np.linalg.qr(rs.randn(3, 3))[0]
+    assert abs(gjk(cube @ rot.T, (cube + [0, 0, 2.25]) @ rot.T) - 0.25) < 1e-12   # frame independent
+
+    def qp_distance(a, b):
+        na = len(a)
+        f = lambda x: float((x[:na] @ a - x[na:] @ b) @ (x[:na] @ a - x[na:] @ b))
+        g = lambda x: np.concatenate([2 * a @ (x[:na] @ a - x[na:] @ b), -2 * b @ (x[:na] @ a - x[na:] @ b)])
+        cons = [dict(type="eq", fun=lambda x: x[:na].sum() - 1), dict(type="eq", fun=lambda x: x[na:].sum() - 1)]
+        x0 = np.concatenate([np.full(na, 1.0 / na), np.full(len(b), 1.0 / len(b))])
+        r = minimize(f, x0, jac=g, bounds=[(0, 1)] * len(x0), constraints=cons, method="SLSQP", options=dict(maxiter=500, ftol=1e-16))
+        return np.sqrt(max(r.fun, 0.0))
+
+    for _ in range(25):
+        a = rs.randn(rs.randint(4, 20), 3) * rs.uniform(0.2, 1.0, 3)
+        b = rs.randn(rs.randint(4, 20), 3) * rs.uniform(0.2, 1.0, 3) + rs.randn(3) * rs.uniform(0, 3)
+        assert abs(max(gjk(a, b), 0.0) - qp_distance(a, b)) < 1e-6
