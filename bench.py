@@ -120,6 +120,9 @@ def cpu_baseline(env, table, task, random_policy, budget_s=12.0, seed=0):
     from oracle.pyoracle import Oracle
     m = env._model
     oracle = Oracle(pack_model(m))
+    # timing: the same physics as the device simulates. The oracle's bookkeeping of geom pairs WITHOUT a collider (exact GJK
+    # distances of convex hulls, test instrumentation that no simulator needs) stays out of the timed loop
+    oracle.set_option("skip_pair_counter", 1)
     rs = np.random.RandomState(seed)
     nv, na = m.nv, getattr(m, "na", 0)
     qi = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec[2:] if k.startswith("q_")]

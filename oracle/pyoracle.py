@@ -95,7 +95,7 @@ class Oracle:
         assert rc == 0
 
     def set_option(self, what, value):
-        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2}[what], float(value))
+        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3}[what], float(value))
 
     def step(self, qpos, qvel, ctrl, nsub=1, warmstart=None):
         """Returns new (qpos, qvel, warmstart, stats-dict). Inputs are not modified."""

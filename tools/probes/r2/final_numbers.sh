@@ -20,6 +20,7 @@ d = json.loads(open('$f').read().strip().splitlines()[-1])
 print('%-40s %.3f ms  %.0f env-steps/s  fused %s  cpu %s' % ('$f'.split('/')[-1], d['ms_per_step'], d['value'], (d.get('rollout_fused') or {}).get('ms_per_step'), (d.get('cpu_baseline') or {}).get('value')))
 "; done
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+[ -n "$SKIP_PROF" ] && exit 0          # SKIP_PROF=1: bench lines only
 bash tools/probes/prof_run.sh r2 200 > $OUT/prof_a1.log 2>&1
 bash tools/probes/prof_run.sh r2_HumanoidTorque.run 100 "--task HumanoidTorque.run" > $OUT/prof_ht.log 2>&1
 bash tools/probes/prof_run.sh r2_Atlas.walk.dr2048 100 "--task Atlas.walk --dr --envs-per-gpu 2048" > $OUT/prof_atlas.log 2>&1
