@@ -1228,7 +1228,9 @@ def _worker_oracle_steps(args):
 
 @pytest.mark.parametrize("task,kw,policy,nroll,min_ok", [("UnitreeA1.simple", {}, "zero", 12, 0.97), ("UnitreeA1.simple", {}, "random", 12, 0.97),
                                                          ("HumanoidTorque.run", {}, "random", 12, 0.35), ("HumanoidTorque.run", {}, "random", 3, 0.6),
-                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.85)])
+                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.85),
+                                                         ("Talos.walk", {}, "random", 12, 0.9), ("UnitreeH1.walk", {}, "random", 3, 0.4),
+                                                         ("UnitreeG1.walk", {}, "random", 3, 0.4)])
 def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok):
     """the error distribution over 4096 REACHABLE states per configuration. The states come from a device
     rollout (dataset states, then `nroll` control steps under the configuration's policy, no restarts: walking, stumbling and
