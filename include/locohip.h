@@ -121,6 +121,10 @@ int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_t
                           int pair_floats, int n_variants);
 int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask);
 int lm_get_variant_index(lm_batch* b, int32_t* index);
+/* several MODELS of one environment as variants (the reference's MultiMuJoCo draws a model per episode, base.py:186-190): the
+   reset table holds n_variants blocks of rows_per_variant rows (each block with its model's constants in the goal columns);
+   a device-side restart from row i then puts the environment on variant i / rows_per_variant. 0 = independent uniform redraw. */
+int lm_set_variant_rows(lm_batch* b, int rows_per_variant);
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
 int lm_get_activation(lm_batch* b, float* act);
 

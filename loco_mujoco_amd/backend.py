@@ -38,7 +38,7 @@ EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_dest
            "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
-           "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index"]
+           "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows"]
 
 _lib = None
 
@@ -86,6 +86,7 @@ def load_library():
     lib.lm_set_model_variants.argtypes = [C.c_void_p, _F, _F, _F, C.c_int, C.c_int]
     lib.lm_set_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _U8]
     lib.lm_get_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.lm_set_variant_rows.argtypes = [C.c_void_p, C.c_int]
     _lib = lib
     return lib
 
@@ -215,6 +216,11 @@ class HipBatch:
         idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int32), (self.n,)))
         keep, mp = _mask(mask, self.n)
         _check(self._lib.lm_set_variant_index(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), mp))
+
+    def set_variant_rows(self, rows_per_variant):
+        """The reset table is n_variants blocks of ``rows_per_variant`` rows: a device-side restart from row i puts the environment
+        on variant i // rows_per_variant (0: variants are redrawn independently of the row)."""
+        _check(self._lib.lm_set_variant_rows(self._h, int(rows_per_variant)))
 
     def get_variant_index(self):
         idx = np.zeros(self.n, dtype=np.int32)

@@ -49,7 +49,7 @@ struct lm_batch {
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
   hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
-  float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats;   // model variants (lm_set_model_variants)
+  float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats, var_rows;   // model variants (lm_set_model_variants, lm_set_variant_rows)
   float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
@@ -485,6 +485,14 @@ int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask)
   return 0;
 }
 
+int lm_set_variant_rows(lm_batch* b, int rows_per_variant) {
+  if (rows_per_variant < 0) return fail("rows_per_variant must be >= 0");
+  if (rows_per_variant > 0 && (b->nvar <= 0 || b->table_rows != b->nvar * rows_per_variant))
+    return fail("the reset table must hold n_variants blocks of rows_per_variant rows (set the variants and the table first)");
+  b->var_rows = rows_per_variant;
+  return 0;
+}
+
 int lm_get_variant_index(lm_batch* b, int32_t* index) {
   HIPCHK(hipSetDevice(b->m->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -520,7 +528,7 @@ static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
-  a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
   a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
@@ -602,6 +610,7 @@ int lm_set_reset_table(lm_batch* b, const float* rows, int n_rows, uint64_t seed
   HIPCHK(hipMalloc(&b->table, sizeof(float) * w * n_rows));
   HIPCHK(hipMemcpy(b->table, rows, sizeof(float) * w * n_rows, hipMemcpyHostToDevice));
   b->table_rows = n_rows; b->seed = seed; b->env_offset = global_env_offset;
+  b->var_rows = 0;                 // a new table: the variant no longer follows the row until lm_set_variant_rows says so
   return 0;
 }
 

@@ -96,6 +96,7 @@ struct KArgs {
   // model variants (lm_set_model_variants): inertial records [nvar][LM_IR_SIZE][4], geom tables [nvar][LM_GT_SIZE], geom-pair
   // tables [nvar][gpt_floats] (or null), and the variant of every environment [N] (redrawn at a device-side restart)
   const float* vrec; const float* vgt; const float* vgpt; int* var; int nvar, gpt_floats;
+  int var_rows;             // > 0: the reset table is nvar blocks of var_rows rows, the variant follows the row (lm_set_variant_rows)
   float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (DR == 2 && a.nvar > 1 && c == 0 && valid) {
         // new episode, new model variant (reference base.py:183-185: a freshly randomised model per reset)
         const unsigned long long rv = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ 0xA24BAED4963EE407ull);
-        a.var[e] = (int)(rv % (unsigned long long)a.nvar);
+        a.var[e] = (a.var_rows > 0) ? (int)((r % (unsigned long long)a.table_rows) / (unsigned long long)a.var_rows)      // the model of the row drawn above
+                                    : (int)(rv % (unsigned long long)a.nvar);
       }
       if (DR && a.drspec && valid) {
         // new episode, new joint parameters (reference base.py:183-185): counter-based draws keyed like the state draw

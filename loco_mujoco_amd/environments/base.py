@@ -108,6 +108,7 @@ class LocoEnv:
         self._n_models = 1
         self._current_model_idx = 0
         self._blocks = False             # several models in one BATCH: contiguous blocks of environments, one per model
+        self._pooled = False             # ... or ONE batch whose environments draw their model per episode (model variants)
         self._random_env_reset = True
 
     # ------------------------------------------------------------------ registry / factory
@@ -151,10 +152,15 @@ class LocoEnv:
         """The device batch (``HipBatch``). Created lazily; raises if the HIP library/GPU is missing."""
         if self._backend is None:
             from ..backend import HipBatch, HipModel
-            nominal = self._chain_model()
+            nominal = self._chain_model(self._models[0] if self._pooled else None)
             self._hip_model = HipModel(nominal, self._device)
             self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if self._blocks else self.n_envs)
-            if self._domain_rand is not None and self._domain_rand.has_model_rules:
+            if self._pooled:
+                if self._domain_rand is not None and self._domain_rand.has_model_rules:
+                    raise NotImplementedError("several models in one batch AND randomised compile-time constants: both use the model variants")
+                from ..lowering import variant_tables
+                self._backend.set_model_variants([variant_tables(nominal, self._chain_model(m)) for m in self._models])
+            elif self._domain_rand is not None and self._domain_rand.has_model_rules:
                 self._backend.set_model_variants(self._build_model_variants(nominal))
         return self._backend
 
@@ -177,16 +183,23 @@ class LocoEnv:
         self._n_models = len(self._models)
         self._current_model_idx = 0
         self._model_backends = [None] * self._n_models
-        # A device batch has ONE model table. With n_envs > 1 the environments are therefore split into contiguous blocks,
-        # one block (= one device batch) per model: environment e keeps model e * n_models // n_envs for its whole life
-        # instead of drawing one per episode — the same mixture over the batch, no per-environment model table.
-        self._blocks = self.n_envs > 1 and self._n_models > 1
+        # A device batch has ONE constant table. Models that differ only in what a model VARIANT carries (inertial numbers,
+        # invweights, geom tables: the carried weights) share one batch, and every environment draws its model per episode
+        # like the reference (base.py:186-190) — `_pooled`. Models that differ in geometry (the humanoid's four sizes) get
+        # contiguous blocks of environments, one block (= one device batch) per model: environment e keeps model
+        # e * n_models // n_envs for its whole life — the same mixture over the batch — `_blocks`.
+        self._pooled = self.n_envs > 1 and self._n_models > 1 and self._models_differ_like_variants()
+        self._blocks = self.n_envs > 1 and self._n_models > 1 and not self._pooled
         if self._blocks and self.n_envs < self._n_models:
             raise ValueError("n_envs=%d cannot hold %d models" % (self.n_envs, self._n_models))
         self._env_model = np.zeros(self.n_envs, dtype=np.int64)
         if self._blocks:
             for i in range(self._n_models):
                 self._env_model[self._model_envs(i)] = i
+
+    def _models_differ_like_variants(self):
+        """True if the models of this environment can live in one batch as model variants (``lowering.variant_tables``)."""
+        return False
 
     def _model_envs(self, idx):
         """Environment indices of model ``idx``'s block."""
@@ -200,6 +213,10 @@ class LocoEnv:
     def _select_model(self, idx):
         """Make model ``idx`` (drawn per episode, ``base.py:186-190``) current."""
         if self._n_models <= 1:
+            return
+        if self._pooled:                   # one shared batch: only the host-side model changes
+            self._current_model_idx = idx
+            self._model = self._models[idx]
             return
         self._model_backends[self._current_model_idx] = self._backend
         self._current_model_idx = idx
@@ -322,6 +339,8 @@ class LocoEnv:
                 self._pending_variants = np.random.randint(0, self._n_model_variants, self.n_envs)
             self._domain_rand_rs.set_state(np.random.get_state())
             np.random.set_state(state)
+        if self._pooled:
+            self._pending_variants = self._env_model.copy()          # the model every environment drew for this episode
         self._obs = np.stack(rows)
         return self._out(self._obs)
 
@@ -335,6 +354,8 @@ class LocoEnv:
             self._select_model(np.random.randint(0, self._n_models))
         elif self._n_models > 1:
             self._select_model((self._current_model_idx + 1) % self._n_models)
+        if self._pooled:
+            self._env_model[e] = self._current_model_idx
         self._cur_env = e
         self.setup(obs)
 
@@ -484,7 +505,17 @@ class LocoEnv:
                 self._select_model(idx)
             b = self.backend
             first = int(self._model_envs(idx)[0]) if self._blocks else 0
-            b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset + first)
+            if self._pooled:
+                # one block of reset rows per model (the rows carry the model's constants, e.g. the weight): a device-side
+                # restart from row i puts the environment on model i // rows_per_model
+                tabs = []
+                for i in range(self._n_models):
+                    self._select_model(i)
+                    tabs.append(self._reset_table())
+                b.set_reset_table(np.concatenate(tabs), seed=seed, global_env_offset=global_env_offset)
+                b.set_variant_rows(len(tabs[0]))
+            else:
+                b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset + first)
             if self._domain_rand is not None and self._domain_rand.active:
                 b.set_dof_randomization(self._domain_rand.spec)
             b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)

@@ -39,6 +39,10 @@ class BaseRobotHumanoid(LocoEnv):
         if len(models) > 1:
             self._init_models(models)
 
+    def _models_differ_like_variants(self):
+        """The carried-weight models differ in the torso link's inertial numbers only: one batch, a weight per episode."""
+        return bool(self._hold_weight)
+
     def _weight_obs(self):
         """Mass of the current model's ``weight`` body (``base_robot_humanoid.py:118-122``)."""
         return np.array([self._model.body_mass[self._model.body_names.index("weight")]])
@@ -83,7 +87,12 @@ class BaseRobotHumanoid(LocoEnv):
         return 1 if self._hold_weight else 0
 
     def _goal_rows(self):
-        return np.tile(self._weight_obs(), (self.n_envs, 1)) if self._hold_weight else None
+        if not self._hold_weight:
+            return None
+        if self._pooled:
+            w = np.array([m.body_mass[m.body_names.index("weight")] for m in self._models])
+            return w[self._env_model][:, None]
+        return np.tile(self._weight_obs(), (self.n_envs, 1))
 
     def _reset_table(self):
         rows = super()._reset_table()

@@ -530,35 +530,53 @@ def test_error_distribution_three_control_steps_vs_oracle(task, nu):
 # ---------------------------------------------------------------------------------------------------------------
 
 def test_several_models_in_one_batch_on_the_device():
+    """MultiMuJoCo in a batch (reference base.py:186-190: a model per episode). The four carried weights differ like model
+    variants: ONE batch, every environment draws its weight per episode on the host and at device-side restarts. The humanoid's
+    four sizes differ in geometry: contiguous blocks of environments, one batch per size."""
     np.random.seed(0)
-    env = LocoEnv.make("Talos.carry", debug=True, n_envs=22)
+    env = LocoEnv.make("Talos.carry", debug=True, n_envs=64)
     obs = env.reset()
-    assert env._blocks and obs.shape == (22, 35)
+    assert env._pooled and not env._blocks and obs.shape == (64, 35)
     weights = obs[:, -1].copy()
-    assert sorted(set(weights)) == [0.1, 1.0, 5.0, 10.0]
+    table = np.array([0.1, 1.0, 5.0, 10.0])
+    assert sorted(set(weights)) == list(table) and np.array_equal(weights, table[env._env_model])
     rs = np.random.RandomState(3)
-    a = rs.uniform(-0.3, 0.3, (22, 12))
+    a = rs.uniform(-0.3, 0.3, (64, 12))
+    q0 = np.stack([h.qpos for h in env._host]).astype(np.float32).astype(np.float64)
+    v0 = np.stack([h.qvel for h in env._host]).astype(np.float32).astype(np.float64)
     o1, r1, d1, _ = env.step(a)
     assert np.allclose(o1[:, -1], weights) and np.isfinite(o1).all()
-    # every block equals the single-weight environment on the same states and actions (same kernels, same inputs: bitwise)
-    for idx in range(4):
-        envs = env._model_envs(idx)
-        one = LocoEnv.make("Talos.carry", debug=True, n_envs=len(envs), weight_mass=float(weights[envs[0]]))
-        one.reset()
-        for k, e in enumerate(envs):
-            one._host[k].qpos[:], one._host[k].qvel[:] = env._host[e].qpos, env._host[e].qvel
-        one._pending_state = True
-        o2, r2, d2, _ = one.step(a[envs])
-        assert np.array_equal(o2, o1[envs]) and np.array_equal(r2, r1[envs]) and np.array_equal(d2, d1[envs])
-    # the heavier the box, the more the same action sequence pitches the robot forward: the blocks really differ
-    assert np.abs(o1[env._model_envs(0)][:, :-1].mean(0) - o1[env._model_envs(3)][:, :-1].mean(0)).max() > 1e-4
-    # device-side restarts per block keep every environment on its model
+    assert np.array_equal(env.backend.get_variant_index(), env._env_model)
+    # every environment against the oracle compiled from the model of ITS weight
+    q, v = env.backend.get_state()
+    oracles = [Oracle(pack_model(m)) for m in env._models]
+    eq, ev, spread = [], [], []
+    for e in range(64):
+        m = env._models[env._env_model[e]]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a[e])
+        qo, vo = oracles[env._env_model[e]].step(q0[e], v0[e], ctrl, nsub=10)[:2]
+        qn, vn = oracles[(env._env_model[e] + 2) % 4].step(q0[e], v0[e], ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[e] - qo).max()); ev.append(np.abs(v[e] - vo).max()); spread.append(np.abs(vo - vn).max())
+    print("Talos.carry, 64 environments with a weight per episode, vs the oracle of each weight: qpos max %.2e qvel max %.2e "
+          "(another weight's oracle differs by %.2e)" % (max(eq), max(ev), np.median(spread)))
+    assert max(eq) < QTOL and max(ev) < VTOL and np.median(spread) > 10 * max(ev)
+    # device-side restarts draw a new weight with the new episode: the weight in the observation is the variant's
     env.enable_auto_reset(seed=5, horizon=7)
-    for _ in range(12):
-        o, r, d, _ = env.step(rs.uniform(-1, 1, (22, 12)))
-        assert np.allclose(o[:, -1], weights) and np.isfinite(o).all()
+    seen = set()
+    for _ in range(16):
+        o, r, d, _ = env.step(rs.uniform(-1, 1, (64, 12)))
+        idx = env.backend.get_variant_index()
+        assert np.allclose(o[:, -1], table[idx]) and np.isfinite(o).all()
+        seen.update(idx.tolist())
+    assert seen == {0, 1, 2, 3} and (idx != env._env_model).any()
+    # a fixed weight is a single model again
+    one = LocoEnv.make("Talos.carry", debug=True, n_envs=4, weight_mass=5.0)
+    assert not one._pooled and not one._blocks and np.allclose(one.reset()[:, -1], 5.0)
+    # the four sizes: blocks
     h = LocoEnv.make("HumanoidMuscle4Ages.run.all", debug=True, n_envs=12)
     oh = h.reset()
+    assert h._blocks and not h._pooled
     bits = oh[:, -2:].copy()
     h.enable_auto_reset(seed=1, horizon=5)
     for _ in range(8):

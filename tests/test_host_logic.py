@@ -178,30 +178,44 @@ def test_recorded_dataset_task(tmp_path, monkeypatch):
 
 
 def test_several_models_in_one_batch():
-    """n_envs > 1 with several models: contiguous blocks of environments, one model (= one device batch) each."""
+    """n_envs > 1 with several models (the reference's MultiMuJoCo draws one per episode, base.py:186-190). Carried weights differ
+    like model variants: one batch, a weight per environment and episode (``_pooled``). The humanoid's four sizes differ in
+    geometry: contiguous blocks of environments, one model (= one device batch) each (``_blocks``)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle_backend import attach
+    from loco_mujoco_amd import lowering
     np.random.seed(0)
-    env = attach(LocoEnv.make("Atlas.carry", debug=True, n_envs=10))
-    assert env._blocks and [list(env._model_envs(i)) for i in range(4)] == [[0, 1, 2], [3, 4], [5, 6, 7], [8, 9]]
+    env = LocoEnv.make("Atlas.carry", debug=True, n_envs=10)
+    assert env._pooled and not env._blocks and env._n_models == 4
     obs = env.reset()
-    assert obs.shape == (10, 31) and obs[:, -1].tolist() == [0.1] * 3 + [1.0] * 2 + [5.0] * 3 + [10.0] * 2
-    a = np.random.uniform(-0.2, 0.2, (10, 10))
+    w = np.array([0.1, 1.0, 5.0, 10.0])
+    assert obs.shape == (10, 31) and np.array_equal(obs[:, -1], w[env._env_model]) and len(set(env._env_model)) > 1
+    assert np.array_equal(env._pending_variants, env._env_model) and np.array_equal(env._goal_rows()[:, 0], w[env._env_model])
+    first = env._env_model.copy()
+    env.reset()
+    assert (env._env_model != first).any()                       # a new draw per episode
+    nominal = env._chain_model(env._models[0])
+    tabs = [lowering.variant_tables(nominal, env._chain_model(m)) for m in env._models]      # what the backend uploads
+    assert len(tabs) == 4 and all((tabs[0][0] != t[0]).any() for t in tabs[1:])
+    assert not LocoEnv.make("Atlas.carry", debug=True, n_envs=4, weight_mass=5.0)._pooled
+    # blocks: every block is the single-model environment of that size on the same states and actions
+    np.random.seed(0)
+    env = attach(LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=6))
+    assert env._blocks and [list(env._model_envs(i)) for i in range(4)] == [[0, 1], [2], [3, 4], [5]]
+    obs = env.reset()
+    a = np.random.uniform(-0.2, 0.2, (6, 13))
     o1, r, d, _ = env.step(a)
-    assert o1.shape == (10, 31) and np.array_equal(o1[:, -1], obs[:, -1]) and r.shape == (10,) and d.shape == (10,)
-    # every block is the single-model environment of that weight on the same states and actions
-    for idx, w in enumerate([0.1, 1.0, 5.0, 10.0]):
+    assert o1.shape == (6, 38) and np.array_equal(o1[:, -2:], obs[:, -2:]) and r.shape == (6,) and d.shape == (6,)
+    for idx in range(4):
         envs = env._model_envs(idx)
         np.random.seed(1)
-        one = attach(LocoEnv.make("Atlas.carry", debug=True, n_envs=len(envs), weight_mass=w))
+        one = attach(LocoEnv.make("HumanoidTorque4Ages.walk.%d" % (idx + 1), debug=True, n_envs=len(envs)))
         one.reset()
         for k, e in enumerate(envs):
             one._host[k].qpos[:], one._host[k].qvel[:] = obs_state(env, e)
         one._pending_state = True
         o2, _, _, _ = one.step(a[envs])
         assert np.abs(o2 - o1[envs]).max() < 1e-12
-    o2, _, _, _ = env.step(a)                      # a second step continues every block from its own state
-    assert not np.array_equal(o2[:, :-1], o1[:, :-1]) and np.array_equal(o2[:, -1], obs[:, -1])
     # the humanoid's four sizes: every block restarts from its own size's trajectories and shows its size bits
     np.random.seed(0)
     h = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)
