@@ -53,9 +53,9 @@ struct lm_batch {
   float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
-// <3 links, 5 slots, Euler, elliptic>; the humanoid families are compiled for condim-3 pyramids only (T.all_pyr3, checked
-// when the model is created): the elliptic code compiles out, no scratch. Everything else: generic kernels, cone read at
-// run time, plain layout only.
+// <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
+// condim-3 pyramids only (T.all_pyr3, checked when the model is created): the elliptic code compiles out and the contact
+// slots are compact. Everything else: generic kernels, cone read at run time, plain layout only.
 static int family_of(const lm_batch* b) {
   const Task& T = b->m->T;
   const bool big = T.max_links > 3, six = T.max_links > 5, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;

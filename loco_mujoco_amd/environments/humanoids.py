@@ -6,11 +6,12 @@ configuration of BASELINE config 3: box feet (``base_humanoid.py:435-470``), arm
 19 dofs (6 pelvis + 2 x 5 leg + 3 lumbar), 36-dim observation, RK4 integrator, pyramidal friction cones
 (``data/humanoid/humanoid_torque.xml:8-19``).
 
-The skeleton's bones are collidable MESH geoms in the reference model. No convex-hull collider is built here
-(SURVEY.md §8f): they are kept as proximity-only bounding spheres, and every substep in which one of them comes
-within reach of the floor is counted in the ``unhandled_geoms`` statistic instead of producing a contact. The box
-feet — the only geoms that touch the floor while the model is upright — are simulated. The reference's golden
-rollouts of this environment (tests/test_datasets/HumanoidTorque.*.npy) are reproduced to 1e-13 this way.
+The skeleton's bones are collidable MESH geoms in the reference model. Their convex hulls collide with the floor on the device
+(plane vs hull: one contact at the support vertex, the rule pinned by the UnitreeH1 golden rows); bone against
+bone is the engine's convex-convex path (libccd), which is not restated: such pairs are counted by the oracle when their hulls
+come within the contact margin (``unhandled_pairs``). The box feet — the only geoms that touch the floor while the model is
+upright — are simulated; the reference's golden rollouts of this environment (tests/test_datasets/HumanoidTorque.*.npy) are
+reproduced to 1e-13 up to the first bone-against-bone contact.
 """
 
 import os

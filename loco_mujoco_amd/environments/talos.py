@@ -69,7 +69,7 @@ class Talos(BaseRobotHumanoid):
             cls._add_weight(handle, weight)
         else:
             cls._reorient_arms(handle)
-        # the upper body's collision meshes (floor-only like every robot geom) are kept as proximity-only bounding capsules
+        # the collision meshes are kept with their convex hulls (plane vs hull on the device; hull pairs are counted by the oracle)
         return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)
 
     @staticmethod
