@@ -11,14 +11,19 @@
 //   * M and the Newton Hessian H = M + J^T W J share the arrow sparsity {chain block, chain-root coupling,
 //     root block}: every lane eliminates its own chain block, the 6x6 root Schur complement is a 21-float
 //     quad sum, its Cholesky is replicated.
+//   * two departures from the arrow, each handled as a correction around it: a self-contact between two chains adds a
+//     cross block between two lanes (arrow_factor_x: the pair is eliminated together); two chains that share their first
+//     link (a torso with an arm on either side) tie the two copies of its dof in every solve (tie_shared_dof).
 // Semantics restated: MuJoCo 2.3.7 mj_step (third party; the reference reaches it through mushroom-rl's
 // MuJoCo.step): soft constraints with solref/solimp impedance, friction-loss,
-// joint-limit and elliptic-cone contact rows, Newton on the convex primal problem with exact line search,
-// semi-implicit Euler with implicit joint damping.
+// joint-limit, pyramidal and elliptic-cone contact rows (floor: sphere, capsule, cylinder, box, convex hull; sphere /
+// capsule pairs between links), Newton on the convex primal problem with exact line search, semi-implicit Euler with
+// implicit joint damping or RK4, spatial tendons and muscles.
 //
 // This header has no HIP dependency: the includer defines LM_DEV (function qualifier) and supplies the quad
-// policy Q {sum(float), any(bool), kRep, kPoints, rep(), rep_bcast(x, r), rep_sum(x), fence()}.
-// csrc/lm_kernels.hip instantiates it with DPP / ds_bpermute intrinsics, tests/emu/emu.cpp with OS threads.
+// policy Q {sum(float), any(bool), kRep, kPoints, rep(), rep_bcast(x, r), rep_sum(x), fence(), peer(lmem, ls, i, dl),
+// quad_read(x, lane), quad_sync()}. csrc/lm_step.h instantiates it with DPP / ds_bpermute intrinsics (the step kernel),
+// tests/emu/emu.cpp with OS threads.
 #pragma once
 #include <math.h>
 #include <type_traits>
