@@ -703,6 +703,56 @@ class LocoEnv:
         return np.array(out)
 
 
+    def play_trajectory_from_velocity(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
+        """Replay of the loaded trajectory from its joint VELOCITIES (reference ``base.py:388-476``): the positions of the
+        first sample, then ``qpos += dt * qvel`` with the trajectory's velocities; the goal / site entries of every sample
+        are taken as they are. Returns the observation of every replayed step; no dynamics, no rendering."""
+        assert self.trajectories is not None
+        self._cur_env = 0
+        self.reset()
+        sample = self.trajectories.get_current_sample()
+        self.set_sim_state(sample)
+        len_qpos, len_qvel = self._len_qpos_qvel()
+        curr_qpos = np.array([np.asarray(x, dtype=np.float64).reshape(-1)[0] for x in sample[0:len_qpos]])
+        n_episodes = 1 if n_episodes is None else n_episodes
+        out = []
+        for _ in range(n_episodes):
+            steps = 0
+            while n_steps_per_episode is None or steps < n_steps_per_episode:
+                qvel = sample[len_qpos:len_qpos + len_qvel]
+                sample = list(sample)
+                sample[:len_qpos] = [qp + self.dt * np.asarray(qv, dtype=np.float64).reshape(-1)[0] for qp, qv in zip(curr_qpos, qvel)]
+                self.set_sim_state(sample)
+                curr_qpos = self._get_joint_pos()
+                out.append(self._create_observation(self.obs_helper._build_obs(self._host[0])))
+                steps += 1
+                sample = self.trajectories.get_next_sample()
+                if sample is None:                      # end of the trajectory: the episode ends here
+                    break
+            self.reset()
+            sample = self.trajectories.get_current_sample()
+            curr_qpos = np.array([np.asarray(x, dtype=np.float64).reshape(-1)[0] for x in sample[0:len_qpos]])
+        return np.array(out)
+
+    def _get_joint_pos(self):
+        """Positions of the observed joints, in observation-specification order (reference ``base.py:709-718``)."""
+        h = self._host[self._cur_env]
+        return np.array([h.qpos[self._model.jnt_id(name)] for key, name, ot in self.obs_helper.observation_spec
+                         if ot == ObservationType.JOINT_POS])
+
+    def _get_joint_vel(self):
+        """Velocities of the observed joints, in observation-specification order (reference ``base.py:720-729``)."""
+        h = self._host[self._cur_env]
+        return np.array([h.qvel[self._model.jnt_id(name)] for key, name, ot in self.obs_helper.observation_spec
+                         if ot == ObservationType.JOINT_VEL])
+
+    @staticmethod
+    def _delete_from_xml_handle(xml_handle, joints_to_remove, motors_to_remove, equ_constraints):
+        """Remove joints, motors and equality constraints from an MJCF handle (reference ``base.py:899-922``)."""
+        from .atlas import Atlas
+        return Atlas._delete_from_xml_handle(xml_handle, joints_to_remove, motors_to_remove, equ_constraints)
+
+
 class ValidTaskConf:
     """Valid (task, mode, dataset type) combinations of an environment (reference ``base.py:972-1041``)."""
 

@@ -634,3 +634,24 @@ def test_unitree_g1_surface():
         assert e.reset().shape == (2 * nv - 2,)
     ds = LocoEnv.make("UnitreeG1.run", debug=True, disable_back_joint=True).create_dataset()
     assert ds["states"].shape[1] == 54 and len(ds["states"]) > 50
+
+
+def test_play_trajectory_from_velocity_integrates_the_dataset_velocities():
+    """Reference ``base.py:388-476``: positions of the first sample, then qpos += dt * qvel with the trajectory's velocities."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    obs = env.play_trajectory_from_velocity(n_episodes=1, n_steps_per_episode=12)
+    assert obs.shape == (12, 37) and np.isfinite(obs).all()
+    nq = 16                                              # observed joint positions (trunk x, y dropped)
+    np.random.seed(0)
+    env2 = LocoEnv.make("UnitreeA1.simple", debug=True)
+    env2.reset()
+    sample = env2.trajectories.get_current_sample()
+    q = np.array([np.asarray(x).reshape(-1)[0] for x in sample[:18]])
+    for k in range(12):
+        v = np.array([np.asarray(x).reshape(-1)[0] for x in sample[18:36]])
+        q = q + env2.dt * v
+        assert np.abs(obs[k, :nq] - q[2:]).max() < 1e-12 and np.abs(obs[k, nq:nq + 18] - v).max() < 1e-12
+        sample = env2.trajectories.get_next_sample()
+    assert env._get_joint_pos().shape == (18,) and env._get_joint_vel().shape == (18,)
+    assert hasattr(LocoEnv, "_delete_from_xml_handle")
