@@ -66,6 +66,17 @@ class GymnasiumWrapper(_Env):
     def play_trajectory(self, **kwargs):
         return self._env.play_trajectory(**kwargs)
 
+    def play_trajectory_from_velocity(self, **kwargs):
+        return self._env.play_trajectory_from_velocity(**kwargs)
+
+    def _set_observation_space(self):
+        self.observation_space = self._convert_space(self._env.info.observation_space)
+        return self.observation_space
+
+    def _set_action_space(self):
+        self.action_space = self._convert_space(self._env.info.action_space)
+        return self.action_space
+
     @property
     def unwrapped(self):
         return self._env

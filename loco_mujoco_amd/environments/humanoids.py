@@ -249,6 +249,29 @@ class BaseHumanoid4Ages(BaseHumanoid):
     into four contiguous blocks, one size each, for their whole life (``LocoEnv._init_models``)."""
 
     _default_scalings = [0.4, 0.6, 0.8, 1.0]
+    _hidable_obs = ("positions", "velocities", "foot_forces", "env_type")
+
+    def get_mask(self, obs_to_hide):
+        """Boolean mask over the observation that hides groups of entries (``base_humanoid_4_ages.py:187-241``): "positions",
+        "velocities", "foot_forces" (only with foot forces on), "env_type" (the size bits; only with more than one size)."""
+        if type(obs_to_hide) == str:
+            obs_to_hide = (obs_to_hide,)
+        assert all(x in self._hidable_obs for x in obs_to_hide), "Some of the observations you want to hide are not" \
+                                                                 "supported. Valid observations to hide are %s." \
+                                                                 % (self._hidable_obs,)
+        pos_dim, vel_dim = self._len_qpos_qvel()
+        mask = [np.full(pos_dim - 2, "positions" not in obs_to_hide), np.full(vel_dim, "velocities" not in obs_to_hide)]
+        if self._use_foot_forces:
+            mask.append(np.full(self._get_grf_size(), "foot_forces" not in obs_to_hide))
+        else:
+            assert "foot_forces" not in obs_to_hide, "Creating a mask to hide foot forces without activating " \
+                                                     "the latter is not allowed."
+        if self.more_than_one_env:
+            mask.append(np.full(len(self._get_env_id_map(0, self.n_all_models)), "env_type" not in obs_to_hide))
+        else:
+            assert "env_type" not in obs_to_hide, "Creating a mask to hide the env type without having more than " \
+                                                  "one env is not allowed."
+        return np.concatenate(mask).ravel()
 
     def __init__(self, scaling=None, scaling_trajectory_map=None, use_muscles=False, use_box_feet=True,
                  disable_arms=True, alpha_box_feet=0.5, xml_path=None, timestep=0.001, **kwargs):

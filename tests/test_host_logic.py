@@ -655,3 +655,24 @@ def test_play_trajectory_from_velocity_integrates_the_dataset_velocities():
         sample = env2.trajectories.get_next_sample()
     assert env._get_joint_pos().shape == (18,) and env._get_joint_vel().shape == (18,)
     assert hasattr(LocoEnv, "_delete_from_xml_handle")
+
+
+def test_get_mask_of_the_four_sizes_and_wrapper_surface():
+    """``base_humanoid_4_ages.py:187-241`` (the size bits are only part of the mask when the environment holds more than one
+    size — the reference's behaviour, although the observation always carries them) and the rest of the Gymnasium wrapper's
+    surface (``gymnasium.py:112-165``)."""
+    from loco_mujoco_amd.environments.gymnasium import GymnasiumWrapper
+    np.random.seed(0)
+    e = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True)
+    m = e.get_mask(("velocities", "env_type"))
+    assert m.shape == (38,) and m.sum() == 17 and m[:17].all() and not m[17:].any()
+    assert e.get_mask("positions").sum() == 21
+    one = LocoEnv.make("HumanoidTorque4Ages.walk.1", debug=True)
+    assert one.get_mask("positions").shape == (36,) and one.info.observation_space.shape == (38,)
+    with pytest.raises(AssertionError):
+        one.get_mask("env_type")
+    with pytest.raises(AssertionError):
+        e.get_mask("foot_forces")
+    g = GymnasiumWrapper("UnitreeA1.simple", debug=True)
+    assert g._set_action_space().shape == (12,) and g._set_observation_space().shape == (37,)
+    assert g.play_trajectory_from_velocity(n_steps_per_episode=3).shape == (3, 37)
