@@ -9,7 +9,7 @@ loco_mujoco_amd — MI355X-native batched drop-in for the ``LocoEnv.step()`` hot
 __version__ = "0.1.0"
 
 from .environments import (Atlas, GymnasiumWrapper, HumanoidMuscle, HumanoidMuscle4Ages, HumanoidTorque,
-                           HumanoidTorque4Ages, LocoEnv, Talos, UnitreeA1)
+                           HumanoidTorque4Ages, LocoEnv, Talos, UnitreeA1, UnitreeG1, UnitreeH1)
 
 
 def get_all_task_names():
