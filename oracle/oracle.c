@@ -105,6 +105,10 @@ struct lmo_model {
   int skip_pair_counter;       /* 1: pairs without a restated collider are not examined (no `unhandled_pairs`): timing runs */
   /* convex hulls attached to mesh geoms (lmo_set_mesh): hull vertices in the frame of the geom's BODY */
   int mesh_nvert[LMO_MAXGEOM]; double* mesh_vert[LMO_MAXGEOM];
+  /* OPTIONAL (off unless lmo_set_mesh_graph is called; experiment of profiles/r2_ab_probes.md §9): hull-graph neighbours of
+     every hull vertex (CSR, nearest first) and the distance below which a further plane-hull contact is too close to one
+     already found */
+  int* mesh_nbr_adr[LMO_MAXGEOM]; int* mesh_nbr[LMO_MAXGEOM]; double mesh_tol[LMO_MAXGEOM];
 };
 
 #define IDX(a, i) ((int)((a)[i]))
@@ -185,7 +189,7 @@ lmo_model* lmo_model_create(const double* blob, long n) {
 
 void lmo_model_destroy(lmo_model* m) {
   if (!m) return;
-  for (int g = 0; g < LMO_MAXGEOM; g++) free(m->mesh_vert[g]);
+  for (int g = 0; g < LMO_MAXGEOM; g++) { free(m->mesh_vert[g]); free(m->mesh_nbr_adr[g]); free(m->mesh_nbr[g]); }
   free(m->blob); free(m);
 }
 void lmo_set_option(lmo_model* m, int what, double value) {
@@ -197,6 +201,18 @@ void lmo_set_option(lmo_model* m, int what, double value) {
 
 /* attach the convex hull of mesh geom g (nv hull vertices [nv][3] in the frame of the geom's body): the geom then collides
    with planes (one contact at the support vertex); without a hull a mesh geom is proximity-only */
+/* experiment: further plane-hull contacts at the hull-graph neighbours of the support vertex (adr[nv + 1], nbr[adr[nv]]) that
+   penetrate and lie at least `tol` away from every contact already found, at most 3 of them. Not part of the pinned model. */
+int lmo_set_mesh_graph(lmo_model* m, int g, const int* adr, const int* nbr, double tol) {
+  if (g < 0 || g >= m->ngeom || m->mesh_nvert[g] <= 0) return 1;
+  int nv = m->mesh_nvert[g];
+  free(m->mesh_nbr_adr[g]); free(m->mesh_nbr[g]);
+  m->mesh_nbr_adr[g] = (int*)malloc(sizeof(int) * (nv + 1)); memcpy(m->mesh_nbr_adr[g], adr, sizeof(int) * (nv + 1));
+  m->mesh_nbr[g] = (int*)malloc(sizeof(int) * (adr[nv] + 1)); memcpy(m->mesh_nbr[g], nbr, sizeof(int) * adr[nv]);
+  m->mesh_tol[g] = tol;
+  return 0;
+}
+
 int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert) {
   if (g < 0 || g >= m->ngeom || nv <= 0) return 1;
   free(m->mesh_vert[g]);
@@ -731,6 +747,20 @@ static void collide(const lmo_model* m, work* w) {
           mulmat3(wv, w->xmat[b2], V + 3*best); add3(wv, wv, w->xpos[b2]);
           copy3(pos, wv); addscl3(pos, n, -0.5 * dbest);
           add_contact(w, &tm, dbest, pos, n, NULL);
+          if (m->mesh_nbr_adr[g2]) {                       /* experiment, see lmo_set_mesh_graph */
+            double cp[4][3]; int nc = 1; copy3(cp[0], pos);
+            for (int e = m->mesh_nbr_adr[g2][best]; e < m->mesh_nbr_adr[g2][best + 1] && nc < 4; e++) {
+              const int j = m->mesh_nbr[g2][e];
+              double wj[3], rj[3]; mulmat3(wj, w->xmat[b2], V + 3*j); add3(wj, wj, w->xpos[b2]); sub3(rj, wj, p1);
+              const double dj = dot3(rj, n);
+              if (dj > margin) continue;
+              double pj[3]; copy3(pj, wj); addscl3(pj, n, -0.5 * dj);
+              int close = 0;
+              for (int q = 0; q < nc; q++) { double df[3]; sub3(df, pj, cp[q]); if (norm3(df) < m->mesh_tol[g2]) close = 1; }
+              if (close) continue;
+              add_contact(w, &tm, dj, pj, n, NULL); copy3(cp[nc], pj); nc++;
+            }
+          }
         }
       } else if (t2 == LM_GEOM_MESH) {
         /* no convex-hull collider (not restated): count the bounding capsule coming within reach */

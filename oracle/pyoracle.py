@@ -94,6 +94,23 @@ class Oracle:
         rc = lib().lmo_set_mesh(self._h, int(geom), len(v), v.ctypes.data_as(C.c_void_p))
         assert rc == 0
 
+    def set_mesh_graph(self, geom, hull_vertices, tol):
+        """EXPERIMENT (profiles/r2_ab_probes.md §9; off unless called): further plane-hull contacts at the hull-graph neighbours of the
+        support vertex — scipy's qhull graph of the hull vertices, neighbours nearest first — that penetrate and lie at least
+        ``tol`` metres from every contact already found (at most 3)."""
+        from scipy.spatial import ConvexHull
+        v = np.ascontiguousarray(hull_vertices, dtype=np.float64)
+        nb = [set() for _ in range(len(v))]
+        for tri in ConvexHull(v).simplices:
+            for a in tri:
+                nb[a].update(int(b) for b in tri if b != a)
+        order = [sorted(x, key=lambda j, i=i: np.linalg.norm(v[j] - v[i])) for i, x in enumerate(nb)]
+        adr = np.zeros(len(v) + 1, dtype=np.int32)
+        adr[1:] = np.cumsum([len(x) for x in order])
+        nbr = np.array([j for x in order for j in x] + [0], dtype=np.int32)
+        lib().lmo_set_mesh_graph.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        assert lib().lmo_set_mesh_graph(self._h, int(geom), adr.ctypes.data, nbr.ctypes.data, float(tol)) == 0
+
     def set_option(self, what, value):
         lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3}[what], float(value))
 

@@ -666,3 +666,36 @@ def test_hull_distance_gjk_of_the_pair_counter():
         a = rs.randn(rs.randint(4, 20), 3) * rs.uniform(0.2, 1.0, 3)
         b = rs.randn(rs.randint(4, 20), 3) * rs.uniform(0.2, 1.0, 3) + rs.randn(3) * rs.uniform(0, 3)
         assert abs(max(gjk(a, b), 0.0) - qp_distance(a, b)) < 1e-6
+
+
+def test_h1_lead_further_plane_hull_contacts_at_graph_neighbours():
+    """A LEAD, not part of the pinned model (profiles/r2_ab_probes.md §9): UnitreeH1's missed golden rows lack FLOOR force. With
+    further contacts at the hull-graph neighbours of the support vertex (penetrating, at least 4.5 cm from the contacts already
+    found) every reproduced row stays reproduced, two more are (run 29, walk 21), and the other missed rows move towards the
+    golden numbers. Kept as a test so that the next step starts from evidence."""
+    gained = {"run": [29], "walk": [21]}
+    closer = {"run": [13, 14, 15, 16, 27, 28], "walk": [0, 22, 23, 24]}
+    for task in ("run", "walk"):
+        errs = {}
+        for mode in ("pinned", "lead"):
+            np.random.seed(0)
+            env = attach(LocoEnv.make("UnitreeH1." + task, debug=True))
+            m = env._model
+            o = env._backend.oracle
+            if mode == "lead":
+                for g in range(m.ngeom):
+                    n = int(m.geom_hull_num[g])
+                    if n > 0:
+                        o.set_mesh_graph(g, m.hull_vert[m.geom_hull_adr[g]:m.geom_hull_adr[g] + n], 0.045)
+            g_, qidx, rows = _h1_kat_inputs(env, task)
+            e = []
+            for k, (qpos, qvel, a) in enumerate(rows):
+                ctrl = np.zeros(m.nu)
+                ctrl[env._action_indices] = env._preprocess_action(a)
+                q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+                e.append(np.abs(v[qidx] - g_[k + 1, 15:32]).max())
+            errs[mode] = np.array(e)
+        exact0 = [k for k in range(len(errs["pinned"])) if errs["pinned"][k] < 1e-6]
+        exact1 = [k for k in range(len(errs["lead"])) if errs["lead"][k] < 1e-6]
+        assert exact0 == H1_EXACT[task] and exact1 == sorted(H1_EXACT[task] + gained[task])
+        assert all(errs["lead"][k] < 0.35 * errs["pinned"][k] for k in closer[task])
