@@ -14,13 +14,13 @@
 #define LM_MODEL_BLOB_H
 
 #define LM_BLOB_MAGIC 0x4C4D4231 /* "LMB1" */
-#define LM_BLOB_VERSION 4
+#define LM_BLOB_VERSION 5
 
 /* header slots (doubles) */
 enum {
   LMH_MAGIC = 0, LMH_VERSION, LMH_NBODY, LMH_NV, LMH_NGEOM, LMH_NU, LMH_CONE, LMH_INTEGRATOR,
   LMH_ITERATIONS, LMH_TIMESTEP, LMH_IMPRATIO, LMH_TOLERANCE, LMH_GRAV_X, LMH_GRAV_Y, LMH_GRAV_Z,
-  LMH_MEANINERTIA, LMH_NSITE, LMH_NTENDON, LMH_NWRAP, LMH_NA, LMH_NHULLVERT, LMH_HEADER_SIZE = 32
+  LMH_MEANINERTIA, LMH_NSITE, LMH_NTENDON, LMH_NWRAP, LMH_NA, LMH_NHULLVERT, LMH_NHULLNBR, LMH_HEADER_SIZE = 32
 };
 
 /* geom types / joint types / cones / integrators (private numbering of this framework) */
@@ -52,7 +52,10 @@ enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1, LM_ACT_POSITION = 2 };
  *  -- version 3
  *  act_biasprm[3nu] act_forcerange[2nu] act_forcelimited[nu]   (force clamped to forcerange when forcelimited)
  *  -- version 4: convex hulls of the mesh geoms (nh = LMH_NHULLVERT vertices in all, each in the frame of its geom's BODY)
- *  geom_hull_adr[ng] (-1: none) geom_hull_num[ng] hull_vert[3nh]   (plane vs mesh: one contact at the hull's support vertex)
+ *  geom_hull_adr[ng] (-1: none) geom_hull_num[ng] hull_vert[3nh]   (plane vs mesh: a contact at the hull's support vertex ...)
+ *  -- version 5: the hulls' vertex graph (nn = LMH_NHULLNBR entries): neighbours of hull vertex i of geom g, as indices into the
+ *  geom's hull, nearest first, are hull_nbr[hull_nbr_adr[geom_hull_adr[g] + i] : hull_nbr_adr[geom_hull_adr[g] + i + 1]]
+ *  hull_nbr_adr[nh + 1] hull_nbr[nn]   (... and further contacts at penetrating neighbours of the support vertex)
  */
 
 #endif

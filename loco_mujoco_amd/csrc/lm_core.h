@@ -145,7 +145,9 @@ struct Params {
   int off_runsup, off_cunsup, off_prune;   // tail lists of the constant table (lm_layout.h LM_H_OFF_*)
   int off_lgroup;     // geom groups per link with their bounding spheres (constant-table tail, LM_H_OFF_LGROUP)
   int off_lpair;      // link-pair list of the self-collision broad phase (constant-table tail, LM_H_OFF_LPAIR)
-  const float* meshv; // hull vertices of the mesh colliders (global memory, 4 floats per vertex, link frame)
+  const float* meshv; // hull vertices of the mesh colliders (global memory, 4 floats per vertex, link frame; the 4th: start of the
+                      // vertex' neighbour list in meshn)
+  const float* meshn; // hull-vertex graph: neighbour lists (indices into the geom's hull, nearest first, -1 ends a list)
   const float* gpt;   // geom-pair table (global memory): records of LM_GPAIR_SIZE floats, read when a link pair is within reach
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
 };
@@ -1021,8 +1023,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         nslot += total;
       }
       LM_TICK(12);     // broad phase + primitive colliders of the group
-      // ---- convex meshes of the group (plane vs hull: ONE contact, at the support vertex — pinned by the UnitreeH1 golden
-      // rows): every replica takes the same geom and a quarter of its hull vertices (mesh-vertex table, global
+      // ---- convex meshes of the group (plane vs hull: a contact at the support vertex — pinned by the UnitreeH1 golden rows,
+      // DESIGN.md — and up to three more at its hull-graph neighbours, below): every replica takes the same geom and a quarter of its hull vertices (mesh-vertex table, global
       // memory, link frame); the lowest vertex wins, ties go to the first in the table like a sequential search
       for (int g = gfirst; g < gend; g++) {
         if ((int)GP(g, 5) != LM_GEOM_MESH) continue;
@@ -1062,6 +1064,31 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         if (nslot >= NS) { n_overflow += (Q::rep() == 0) ? 1 : 0; continue; }
         emit_floor_slot(nslot, g, k, V, margin, sv.x, sv.y, sv.z);
         nslot++;
+        // further contacts at the hull-graph neighbours of the support vertex (the engine's "up to 3 more contacts from mesh",
+        // DESIGN.md §2 item 10): penetrating, nearest first, none closer than G_SZ to a contact already found. Every replica
+        // walks the (short) list itself, so all of them write the same slots.
+        {
+          const float tol2 = GE(g, LM_G_SZ) * GE(g, LM_G_SZ);
+          V3 cp[4];
+          cp[0] = v3(sv.x, sv.y, 0.5f * sv.z);
+          int nc = 1;
+          for (int e = (int)vp[3]; nc < 4; e++) {
+            const int j = (int)P.meshn[e];
+            if (j < 0) break;
+            const float* vj = P.meshv + 4 * (v0 + j);
+            const V3 wj = pk + mul(Rk, v3(vj[0], vj[1], vj[2]));
+            if (wj.z > margin) continue;
+            const V3 pj = v3(wj.x, wj.y, 0.5f * wj.z);
+            bool close = false;
+#pragma unroll
+            for (int q = 0; q < 3; q++) if (q < nc) { const V3 d = pj - cp[q]; if (dot(d, d) < tol2) close = true; }
+            if (close) continue;
+            cp[nc] = pj; nc++;
+            if (nslot >= NS) { n_overflow += (Q::rep() == 0) ? 1 : 0; continue; }
+            emit_floor_slot(nslot, g, k, V, margin, wj.x, wj.y, wj.z);
+            nslot++;
+          }
+        }
       }
       }
       if (nslot > NS) nslot = NS;

@@ -25,6 +25,7 @@ struct lm_model {
   float* d_gpt;              // geom-pair table of the self-collision path
   int n_gpt_floats;          // its size (0: the model has no self-collision pairs)
   float* d_meshv;            // hull vertices of the mesh colliders
+  float* d_meshn;            // their neighbour lists (hull vertex graph)
   std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
   int nroot;
@@ -213,6 +214,15 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     HIPCHK(hipMemcpy(m->d_meshv, mv.data(), sizeof(float) * mv.size(), hipMemcpyHostToDevice));
     P.meshv = m->d_meshv;
   }
+  {
+    const size_t nmn = (size_t)cmod[LM_H_NMESHN], off = (size_t)cmod[LM_H_OFF_MESHN];
+    if (nmn > 0 && n < off + nmn) return fail("chain model lacks the hull-vertex neighbour table");
+    std::vector<float> mn(nmn + 1, -1.0f);
+    for (size_t i = 0; i < nmn; i++) mn[i] = (float)cmod[off + i];
+    HIPCHK(hipMalloc(&m->d_meshn, sizeof(float) * mn.size()));
+    HIPCHK(hipMemcpy(m->d_meshn, mn.data(), sizeof(float) * mn.size(), hipMemcpyHostToDevice));
+    P.meshn = m->d_meshn;
+  }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
@@ -231,6 +241,7 @@ void lm_model_destroy(lm_model* m) {
   if (m->d_gt) (void)hipFree(m->d_gt);
   if (m->d_gpt) (void)hipFree(m->d_gpt);
   if (m->d_meshv) (void)hipFree(m->d_meshv);
+  if (m->d_meshn) (void)hipFree(m->d_meshn);
   if (m->d_mt) (void)hipFree(m->d_mt);
   delete m;
 }

@@ -160,6 +160,7 @@ LMC_MAGIC = 0x4C4D4332  # "LMC2"
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
 H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED, H_ACTMODE = 25, 26, 27, 28, 29, 30, 31, 32, 33
 H_OFF_RUNSUP, H_OFF_CUNSUP, H_OFF_PRUNE, H_GT_SIZE, H_OFF_LPAIR, H_NGPAIR, H_OFF_GPT, H_OFF_LGROUP, H_NMESHV, H_OFF_MESHV = 34, 35, 36, 37, 38, 39, 40, 41, 42, 43
+H_NMESHN, H_OFF_MESHN = 44, 45     # neighbour table of the hull vertices (floats: hull-local indices, -1 ends a vertex's list)
 # H_NGPAIR geom-pair records start H_OFF_GPT floats into the chain-model array (behind the geom table and the muscle table)
 # H_OFF_*: offsets (floats from the start of the constant table) of the tail lists, see CM_SIZE
 # H_ACTMODE: 0 = joint motors (torque = gear * ctrl), 1 = position servos on every actuated joint
@@ -413,6 +414,15 @@ def lower(m, task):
                 blk[G_R0:G_R0 + 9] = np.eye(3).reshape(9)
                 blk[G_RBOUND], blk[G_MARGIN] = float(np.linalg.norm(hv - ctr, axis=1).max()) * (1 + 1e-6), margin
                 blk[G_SX], blk[G_SY] = len(mesh_verts), hull_n           # first vertex, vertex count in the mesh-vertex table
+                # further contacts at the hull-graph neighbours of the support vertex keep this far from the contacts already
+                # found (0.3 x the bounding capsule's radius + half length: DESIGN.md §2 item 10)
+                blk[G_SZ] = 0.3 * (size[0] + size[1])
+                a0 = int(m.geom_hull_adr[g])
+                for i in range(hull_n):
+                    e0, e1 = int(m.hull_nbr_adr[a0 + i]), int(m.hull_nbr_adr[a0 + i + 1])
+                    mesh_nbr_first.append(len(mesh_nbr))                 # 4th component of the vertex: its neighbour list ...
+                    mesh_nbr.extend(int(j) for j in m.hull_nbr[e0:e1])
+                    mesh_nbr.append(-1)                                  # ... which a -1 ends
                 mesh_verts.extend(hv.tolist())
                 blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
                 blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
@@ -446,6 +456,7 @@ def lower(m, task):
 
     info = dict(root=root, chains=chains, shared_first=shared_first)
     mesh_verts = []                    # hull vertices of the mesh colliders, link frame (device table, global memory)
+    mesh_nbr_first, mesh_nbr = [], []  # per vertex: start of its neighbour list in the neighbour table (hull-local indices, -1 ends)
 
     # ---- root block
     rb = cm[CM_ROOT:CM_ROOT + ROOT_SIZE]
@@ -541,7 +552,7 @@ def lower(m, task):
         # only reach the floor once the robot has fallen; contacts beyond the kernel's slots are dropped and counted in
         # `overflow_contacts`
         for gb in geoms:
-            cap = {mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4, mjcf.GEOM_CYLINDER: 4, mjcf.GEOM_MESH: 1}[int(gb[G_TYPE])]
+            cap = {mjcf.GEOM_SPHERE: 1, mjcf.GEOM_CAPSULE: 2, mjcf.GEOM_BOX: 4, mjcf.GEOM_CYLINDER: 4, mjcf.GEOM_MESH: 4}[int(gb[G_TYPE])]
             b = links[int(gb[G_LINK])][0] if gb[G_LINK] >= 0 else root
             rot = kin["xmat"][b] @ gb[G_R0:G_R0 + 9].reshape(3, 3)            # geom axes in the world at qpos0
             t, size = int(gb[G_TYPE]), gb[G_SX:G_SX + 3]
@@ -731,9 +742,12 @@ def lower(m, task):
     meshv = np.zeros((len(mesh_verts), 4))
     if mesh_verts:
         meshv[:, :3] = mesh_verts
+        meshv[:, 3] = mesh_nbr_first
+    assert len(mesh_nbr) < 2 ** 24                         # the indices travel as float32
     h[H_NMESHV], h[H_OFF_MESHV] = len(mesh_verts), h[H_OFF_GPT] + len(gpt)
+    h[H_NMESHN], h[H_OFF_MESHN] = len(mesh_nbr), h[H_OFF_MESHV] + 4 * len(mesh_verts)
     info["mesh_vertices"] = len(mesh_verts)
-    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel()]), info
+    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel(), np.array(mesh_nbr, dtype=np.float64)]), info
 
 
 # ---- model variants (inertial / armature / geom-friction randomisation): what differs between two lowerings of the same robot

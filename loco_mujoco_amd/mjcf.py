@@ -402,6 +402,27 @@ def _mesh_bounds(root, comp, base_dir, hulls=None):
     return out
 
 
+def hull_vertex_graph(hull_vert, geom_hull_adr, geom_hull_num):
+    """CSR adjacency of every geom's convex hull (qhull's triangulated facets: two vertices are neighbours when they share a
+    facet edge), neighbours sorted by distance. Computed on the float32 vertex values the colliders use."""
+    from scipy.spatial import ConvexHull
+    adr, nbr = [0], []
+    for a, n in sorted((int(a), int(n)) for a, n in zip(geom_hull_adr, geom_hull_num) if n > 0):
+        v = np.asarray(hull_vert[a:a + n], dtype=np.float64)
+        nb = [set() for _ in range(n)]
+        try:
+            for tri in ConvexHull(v).simplices:
+                for i in tri:
+                    nb[i].update(int(j) for j in tri if j != i)
+        except Exception:                 # degenerate hull: no graph, the collider keeps its single contact
+            pass
+        for i in range(n):
+            order = sorted(nb[i], key=lambda j: (float(np.linalg.norm(v[j] - v[i])), j))
+            nbr += order
+            adr.append(len(nbr))
+    return np.array(adr, dtype=np.int32), np.array(nbr, dtype=np.int32)
+
+
 def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     """
     Compile an :class:`MjcfHandle` into a :class:`CompiledModel`.
@@ -666,6 +687,10 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
         chunks.append(hull_of[gi])
         n += len(hull_of[gi])
     m.hull_vert = (np.concatenate(chunks) if chunks else np.zeros((0, 3))).astype(np.float32)
+    # the hull's vertex graph (plane-mesh collider: further contacts at the neighbours of the support vertex, DESIGN.md §2 item
+    # 10): neighbours of hull vertex i of geom g, as indices INTO the geom's hull, nearest first, are
+    # hull_nbr[hull_nbr_adr[geom_hull_adr[g] + i] : hull_nbr_adr[geom_hull_adr[g] + i + 1]]
+    m.hull_nbr_adr, m.hull_nbr = hull_vertex_graph(m.hull_vert, m.geom_hull_adr, m.geom_hull_num)
 
     # ---------------- sites
     m.nsite = len(sites)

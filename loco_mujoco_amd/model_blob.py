@@ -13,7 +13,7 @@ HEADER_SIZE = 32
 def pack_model(m):
     h = np.zeros(HEADER_SIZE)
     h[0] = LM_BLOB_MAGIC
-    h[1] = 4
+    h[1] = 5
     h[2:9] = [m.nbody, m.nv, m.ngeom, m.nu, m.cone, m.integrator, m.iterations]
     h[9:12] = [m.timestep, m.impratio, m.tolerance]
     h[12:15] = m.gravity
@@ -26,6 +26,10 @@ def pack_model(m):
     h[16:20] = [len(used), nt, len(wrap), int(getattr(m, "na", 0))]
     hull_vert = np.asarray(getattr(m, "hull_vert", np.zeros((0, 3))), dtype=np.float64)
     h[20] = len(hull_vert)
+    hull_nbr_adr = np.asarray(getattr(m, "hull_nbr_adr", np.zeros(len(hull_vert) + 1)), dtype=np.float64)
+    hull_nbr = np.asarray(getattr(m, "hull_nbr", np.zeros(0)), dtype=np.float64)
+    assert len(hull_nbr_adr) == len(hull_vert) + 1
+    h[21] = len(hull_nbr)
     zeros = lambda *shape: np.zeros(shape)
     nu = m.nu
     parts = [h,
@@ -45,5 +49,5 @@ def pack_model(m):
              getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2)),
              getattr(m, "act_biasprm", zeros(nu, 3)), getattr(m, "act_forcerange", zeros(nu, 2)),
              getattr(m, "act_forcelimited", zeros(nu)),
-             getattr(m, "geom_hull_adr", -np.ones(m.ngeom)), getattr(m, "geom_hull_num", zeros(m.ngeom)), hull_vert]
+             getattr(m, "geom_hull_adr", -np.ones(m.ngeom)), getattr(m, "geom_hull_num", zeros(m.ngeom)), hull_vert, hull_nbr_adr, hull_nbr]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

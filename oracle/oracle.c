@@ -105,13 +105,13 @@ struct lmo_model {
   int skip_pair_counter;       /* 1: pairs without a restated collider are not examined (no `unhandled_pairs`): timing runs */
   /* convex hulls attached to mesh geoms (lmo_set_mesh): hull vertices in the frame of the geom's BODY */
   int mesh_nvert[LMO_MAXGEOM]; double* mesh_vert[LMO_MAXGEOM];
-  /* OPTIONAL (off unless lmo_set_mesh_graph is called; experiment of profiles/r2_ab_probes.md §9): hull-graph neighbours of
-     every hull vertex (CSR, nearest first) and the distance below which a further plane-hull contact is too close to one
-     already found */
+  /* hull-graph neighbours of every hull vertex (CSR, nearest first; from the model blob or lmo_set_mesh_graph) and the
+     distance below which a further plane-hull contact is too close to one already found */
   int* mesh_nbr_adr[LMO_MAXGEOM]; int* mesh_nbr[LMO_MAXGEOM]; double mesh_tol[LMO_MAXGEOM];
 };
 
 #define IDX(a, i) ((int)((a)[i]))
+#define IDX2(a, i) ((a)[i])
 
 lmo_model* lmo_model_create(const double* blob, long n) {
   if (n < LMH_HEADER_SIZE || (unsigned)blob[LMH_MAGIC] != LM_BLOB_MAGIC || (int)blob[LMH_VERSION] != LM_BLOB_VERSION) return NULL;
@@ -149,6 +149,9 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   const int nhull = (int)m->blob[LMH_NHULLVERT];
   const double *hull_adr, *hull_num, *hull_vert;
   hull_adr = p; p += ng; hull_num = p; p += ng; hull_vert = p; p += 3 * nhull;
+  const int nnbr = (int)m->blob[LMH_NHULLNBR];
+  const double* hull_nbr_adr = p; p += nhull + 1;
+  const double* hull_nbr = p; p += nnbr;
 #undef TAKE
   if (p - m->blob != n) { free(m->blob); free(m); return NULL; }
   /* convex hulls that come with the model (mesh geoms): the same as lmo_set_mesh per geom */
@@ -156,6 +159,16 @@ lmo_model* lmo_model_create(const double* blob, long n) {
     m->mesh_nvert[g] = IDX(hull_num, g);
     m->mesh_vert[g] = (double*)malloc(sizeof(double) * 3 * m->mesh_nvert[g]);
     memcpy(m->mesh_vert[g], hull_vert + 3 * IDX(hull_adr, g), sizeof(double) * 3 * m->mesh_nvert[g]);
+    /* the hull's vertex graph, per geom; a further plane-hull contact keeps 0.3 x (bounding-capsule radius + half length)
+       away from the contacts already found */
+    const int nvg = m->mesh_nvert[g], a0 = IDX(hull_adr, g), e0 = IDX(hull_nbr_adr, a0), e1 = IDX(hull_nbr_adr, a0 + nvg);
+    if (e1 > e0) {
+      m->mesh_nbr_adr[g] = (int*)malloc(sizeof(int) * (nvg + 1));
+      m->mesh_nbr[g] = (int*)malloc(sizeof(int) * (e1 - e0 + 1));
+      for (int i = 0; i <= nvg; i++) m->mesh_nbr_adr[g][i] = IDX(hull_nbr_adr, a0 + i) - e0;
+      for (int e = e0; e < e1; e++) m->mesh_nbr[g][e - e0] = IDX(hull_nbr, e);
+      m->mesh_tol[g] = 0.3 * (IDX2(m->geom_size, 3*g) + IDX2(m->geom_size, 3*g + 1));
+    }
   }
 
   for (int b = 1; b < nb; b++) {
@@ -201,8 +214,9 @@ void lmo_set_option(lmo_model* m, int what, double value) {
 
 /* attach the convex hull of mesh geom g (nv hull vertices [nv][3] in the frame of the geom's body): the geom then collides
    with planes (one contact at the support vertex); without a hull a mesh geom is proximity-only */
-/* experiment: further plane-hull contacts at the hull-graph neighbours of the support vertex (adr[nv + 1], nbr[adr[nv]]) that
-   penetrate and lie at least `tol` away from every contact already found, at most 3 of them. Not part of the pinned model. */
+/* the hull's vertex graph of mesh geom g (adr[nv + 1], nbr[adr[nv]], neighbours nearest first) and the distance `tol`: further
+   plane-hull contacts at neighbours of the support vertex that penetrate and lie at least `tol` away from every contact already
+   found, at most 3 of them (tests that attach hulls with lmo_set_mesh) */
 int lmo_set_mesh_graph(lmo_model* m, int g, const int* adr, const int* nbr, double tol) {
   if (g < 0 || g >= m->ngeom || m->mesh_nvert[g] <= 0) return 1;
   int nv = m->mesh_nvert[g];
@@ -213,9 +227,12 @@ int lmo_set_mesh_graph(lmo_model* m, int g, const int* adr, const int* nbr, doub
   return 0;
 }
 
+int lmo_mesh_nvert(const lmo_model* m, int g) { return (g < 0 || g >= m->ngeom) ? 0 : m->mesh_nvert[g]; }
+
 int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert) {
   if (g < 0 || g >= m->ngeom || nv <= 0) return 1;
   free(m->mesh_vert[g]);
+  free(m->mesh_nbr_adr[g]); free(m->mesh_nbr[g]); m->mesh_nbr_adr[g] = NULL; m->mesh_nbr[g] = NULL;     /* new vertices: the old graph is void */
   m->mesh_nvert[g] = nv;
   m->mesh_vert[g] = (double*)malloc(sizeof(double) * 3 * nv); memcpy(m->mesh_vert[g], vert, sizeof(double) * 3 * nv);
   return 0;
@@ -747,7 +764,10 @@ static void collide(const lmo_model* m, work* w) {
           mulmat3(wv, w->xmat[b2], V + 3*best); add3(wv, wv, w->xpos[b2]);
           copy3(pos, wv); addscl3(pos, n, -0.5 * dbest);
           add_contact(w, &tm, dbest, pos, n, NULL);
-          if (m->mesh_nbr_adr[g2]) {                       /* experiment, see lmo_set_mesh_graph */
+          if (m->mesh_nbr_adr[g2]) {
+            /* further contacts at the hull-graph neighbours of the support vertex (the engine's "up to 3 more contacts from
+               mesh"): penetrating, nearest first, none closer than tol to a contact already found. Reverse-engineered on the
+               UnitreeH1 golden rows (profiles/r2_ab_probes.md §9): +2 rows reproduced, 12 closer, none of any robot worse */
             double cp[4][3]; int nc = 1; copy3(cp[0], pos);
             for (int e = m->mesh_nbr_adr[g2][best]; e < m->mesh_nbr_adr[g2][best + 1] && nc < 4; e++) {
               const int j = m->mesh_nbr[g2][e];

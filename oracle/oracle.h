@@ -43,8 +43,10 @@ lmo_model* lmo_model_create(const double* blob, long n);
 void lmo_model_destroy(lmo_model* m);
 /* what: 0 = disable self collision (value!=0), 1 = solver iterations, 2 = solver tolerance */
 int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert);
-/* experiment (profiles/r2_ab_probes.md §9), off by default: further plane-hull contacts at hull-graph neighbours */
+/* the vertex graph of mesh geom g's hull (further plane-hull contacts at the neighbours of the support vertex): comes with the
+   model blob; settable for hulls attached with lmo_set_mesh, and clearable (all-zero adr) for A/B tests */
 int lmo_set_mesh_graph(lmo_model* m, int g, const int* adr, const int* nbr, double tol);
+int lmo_mesh_nvert(const lmo_model* m, int g);
 void lmo_set_option(lmo_model* m, int what, double value);
 int lmo_nv(const lmo_model* m);
 int lmo_nu(const lmo_model* m);

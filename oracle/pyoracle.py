@@ -94,22 +94,14 @@ class Oracle:
         rc = lib().lmo_set_mesh(self._h, int(geom), len(v), v.ctypes.data_as(C.c_void_p))
         assert rc == 0
 
-    def set_mesh_graph(self, geom, hull_vertices, tol):
-        """EXPERIMENT (profiles/r2_ab_probes.md §9; off unless called): further plane-hull contacts at the hull-graph neighbours of the
-        support vertex — scipy's qhull graph of the hull vertices, neighbours nearest first — that penetrate and lie at least
-        ``tol`` metres from every contact already found (at most 3)."""
-        from scipy.spatial import ConvexHull
-        v = np.ascontiguousarray(hull_vertices, dtype=np.float64)
-        nb = [set() for _ in range(len(v))]
-        for tri in ConvexHull(v).simplices:
-            for a in tri:
-                nb[a].update(int(b) for b in tri if b != a)
-        order = [sorted(x, key=lambda j, i=i: np.linalg.norm(v[j] - v[i])) for i, x in enumerate(nb)]
-        adr = np.zeros(len(v) + 1, dtype=np.int32)
-        adr[1:] = np.cumsum([len(x) for x in order])
-        nbr = np.array([j for x in order for j in x] + [0], dtype=np.int32)
+    def clear_mesh_graph(self, geom):
+        """Switch the further plane-hull contacts of mesh geom ``geom`` off (single contact at the support vertex): tests."""
+        lib().lmo_mesh_nvert.argtypes = [C.c_void_p, C.c_int]
+        n = lib().lmo_mesh_nvert(self._h, int(geom))
+        adr = np.zeros(n + 1, dtype=np.int32)
+        nbr = np.zeros(1, dtype=np.int32)
         lib().lmo_set_mesh_graph.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double]
-        assert lib().lmo_set_mesh_graph(self._h, int(geom), adr.ctypes.data, nbr.ctypes.data, float(tol)) == 0
+        assert lib().lmo_set_mesh_graph(self._h, int(geom), adr.ctypes.data, nbr.ctypes.data, 0.0) == 0
 
     def set_option(self, what, value):
         lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3}[what], float(value))

@@ -154,6 +154,9 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   std::vector<float> meshv(4 * (size_t)H[LM_H_NMESHV] + 4);
   for (size_t i = 0; i + 4 < meshv.size(); i++) meshv[i] = (float)H[(size_t)H[LM_H_OFF_MESHV] + i];
   P.meshv = meshv.data();
+  std::vector<float> meshn((size_t)H[LM_H_NMESHN] + 1, -1.0f);
+  for (size_t i = 0; i + 1 < meshn.size(); i++) meshn[i] = (float)H[(size_t)H[LM_H_OFF_MESHN] + i];
+  P.meshn = meshn.data();
   int cnt_tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int t) {
     const int c = t & 3;

@@ -269,7 +269,7 @@ def test_core_muscles():
     env = LocoEnv.make("HumanoidMuscle.walk", debug=True)
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
-    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE + 4 * int(cmod[lowering.H_NMESHV])
+    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE + 4 * int(cmod[lowering.H_NMESHV]) + int(cmod[lowering.H_NMESHN])
     o = Oracle(pack_model(m))
     g = GOLD["HumanoidMuscle.walk.real"]
     qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]

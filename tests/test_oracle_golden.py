@@ -142,6 +142,8 @@ def test_h1_rows_pin_smooth_dynamics_and_plane_mesh_contact():
                 exact[task].append(k)
             else:
                 assert hip > 0.2 or g[k, 7] < 0 or g[k, 12] < 0, (task, k, err)      # explained by the thigh / hip-yaw contact
+    # (the feet's hulls are attached with set_mesh here, without a vertex graph: ONE contact per foot; with the graph that comes
+    # with the packaged model two more rows are reproduced, test_h1_further_plane_hull_contacts_at_graph_neighbours)
     assert exact["run"] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 24, 25, 26]                  # the flight phases
     assert exact["walk"] == [1, 2, 15, 16, 17, 18, 19, 20, 25, 26]                  # single- and double-support with feet only
 
@@ -560,7 +562,7 @@ def _h1_kat_inputs(env, task):
     return g, qidx, out
 
 
-H1_EXACT = {"run": [0, 1, 2, 3, 4, 5, 6, 7, 8, 24, 25, 26], "walk": [1, 2, 15, 16, 17, 18, 19, 20, 25, 26]}
+H1_EXACT = {"run": [0, 1, 2, 3, 4, 5, 6, 7, 8, 24, 25, 26, 29], "walk": [1, 2, 15, 16, 17, 18, 19, 20, 21, 25, 26]}
 
 
 @pytest.mark.parametrize("task", ["run", "walk"])
@@ -668,25 +670,26 @@ def test_hull_distance_gjk_of_the_pair_counter():
         assert abs(max(gjk(a, b), 0.0) - qp_distance(a, b)) < 1e-6
 
 
-def test_h1_lead_further_plane_hull_contacts_at_graph_neighbours():
-    """A LEAD, not part of the pinned model (profiles/r2_ab_probes.md §9): UnitreeH1's missed golden rows lack FLOOR force. With
-    further contacts at the hull-graph neighbours of the support vertex (penetrating, at least 4.5 cm from the contacts already
-    found) every reproduced row stays reproduced, two more are (run 29, walk 21), and the other missed rows move towards the
-    golden numbers. Kept as a test so that the next step starts from evidence."""
+def test_h1_further_plane_hull_contacts_at_graph_neighbours():
+    """Plane vs convex hull: after the contact at the support vertex, further contacts at the hull-graph
+    neighbours of that vertex that penetrate and keep 0.3 x rbound from the contacts already found — the engine's "up to 3 more
+    contacts from mesh", reverse-engineered on UnitreeH1's golden rows (profiles/r2_ab_probes.md §9). Against the single
+    contact (graph switched off here): every row reproduced before stays reproduced, two more are (run 29, walk 21), and the
+    other rows with a foot nearly flat on the floor move towards the golden numbers; no golden row of any robot gets worse."""
     gained = {"run": [29], "walk": [21]}
     closer = {"run": [13, 14, 15, 16, 27, 28], "walk": [0, 22, 23, 24]}
     for task in ("run", "walk"):
         errs = {}
-        for mode in ("pinned", "lead"):
+        for mode in ("single", "graph"):
             np.random.seed(0)
             env = attach(LocoEnv.make("UnitreeH1." + task, debug=True))
             m = env._model
             o = env._backend.oracle
-            if mode == "lead":
+            if mode == "single":
                 for g in range(m.ngeom):
                     n = int(m.geom_hull_num[g])
                     if n > 0:
-                        o.set_mesh_graph(g, m.hull_vert[m.geom_hull_adr[g]:m.geom_hull_adr[g] + n], 0.045)
+                        o.clear_mesh_graph(g)
             g_, qidx, rows = _h1_kat_inputs(env, task)
             e = []
             for k, (qpos, qvel, a) in enumerate(rows):
@@ -695,7 +698,8 @@ def test_h1_lead_further_plane_hull_contacts_at_graph_neighbours():
                 q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
                 e.append(np.abs(v[qidx] - g_[k + 1, 15:32]).max())
             errs[mode] = np.array(e)
-        exact0 = [k for k in range(len(errs["pinned"])) if errs["pinned"][k] < 1e-6]
-        exact1 = [k for k in range(len(errs["lead"])) if errs["lead"][k] < 1e-6]
-        assert exact0 == H1_EXACT[task] and exact1 == sorted(H1_EXACT[task] + gained[task])
-        assert all(errs["lead"][k] < 0.35 * errs["pinned"][k] for k in closer[task])
+        exact0 = [k for k in range(len(errs["single"])) if errs["single"][k] < 1e-6]
+        exact1 = [k for k in range(len(errs["graph"])) if errs["graph"][k] < 1e-6]
+        assert exact1 == H1_EXACT[task] and exact0 == [k for k in H1_EXACT[task] if k not in gained[task]]
+        assert all(errs["graph"][k] < 0.35 * errs["single"][k] for k in closer[task])
+        assert all(errs["graph"][k] <= 3 * errs["single"][k] or errs["graph"][k] < 1e-6 for k in range(len(e)))
