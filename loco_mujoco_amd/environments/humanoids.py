@@ -7,7 +7,8 @@ configuration of BASELINE config 3: box feet (``base_humanoid.py:435-470``), arm
 (``data/humanoid/humanoid_torque.xml:8-19``).
 
 The skeleton's bones are collidable MESH geoms in the reference model. Their convex hulls collide with the floor on the device
-(plane vs hull: one contact at the support vertex, the rule pinned by the UnitreeH1 golden rows); bone against
+(plane vs hull: a contact at the support vertex and up to three at its hull-graph neighbours, the rules found on the UnitreeH1 golden
+rows); bone against
 bone is the engine's convex-convex path (libccd), which is not restated: such pairs are counted by the oracle when their hulls
 come within the contact margin (``unhandled_pairs``). The box feet — the only geoms that touch the floor while the model is
 upright — are simulated; the reference's golden rollouts of this environment (tests/test_datasets/HumanoidTorque.*.npy) are

@@ -403,7 +403,7 @@ def lower(m, task):
                       mjcf.GEOM_CYLINDER: np.hypot(size[0], size[1]), mjcf.GEOM_BOX: np.linalg.norm(size)}[t]
             hull_n = int(getattr(m, "geom_hull_num", np.zeros(m.ngeom, int))[g])
             if t == mjcf.GEOM_MESH and hull_n > 0:
-                # plane vs convex hull: one contact at the support vertex. The hull's vertices go into the
+                # plane vs convex hull: a contact at the support vertex (+ its neighbours). The hull's vertices go into the
                 # mesh-vertex table in the frame of the LINK; the prune sphere is the hull's bounding sphere
                 hv = p + m.hull_vert[m.geom_hull_adr[g]:m.geom_hull_adr[g] + hull_n].astype(np.float64) @ r.T
                 ctr = 0.5 * (hv.min(0) + hv.max(0))
