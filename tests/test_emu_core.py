@@ -477,3 +477,30 @@ def test_core_shared_first_link_unitree_g1_default():
     qvel[:, qidx] = g[:3, 27:56]
     q, v, _, cnt, _ = pyemu.run(cmod, qpos[1:], qvel[1:], acts[1:], nsub=10, rep=4)
     assert np.abs(q[:, qidx[2:]] - g[2:4, :27]).max() < 1e-5 and np.abs(v[:, qidx] - g[2:4, 27:56]).max() < 1e-3
+
+
+def test_core_shared_first_link_with_per_environment_joint_parameters():
+    """UnitreeG1 (default) in the kernels with per-environment joint parameters: the massless COPY of the shared torso link must
+    not apply the torso joint's damping / frictionloss a second time (csrc/lm_core.h DUPK). vs the oracle compiled per environment."""
+    import copy
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True)
+    m = env._model
+    cmod = env._chain_model()
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    n = 2
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-0.3, 0.3, (n, 23))
+    damp = np.tile(m.dof_damping, (n, 1)) * rs.uniform(0.5, 2.0, (n, m.nv))
+    floss = np.tile(m.dof_frictionloss, (n, 1)) * rs.uniform(0.5, 1.5, (n, m.nv))
+    prm = np.stack([damp, np.tile(m.jnt_stiffness, (n, 1)), floss]).astype(np.float32)
+    q, v, _, _, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], acts, nsub=10, rep=4, dof_params=prm)
+    for i in range(n):
+        m2 = copy.copy(m)
+        m2.dof_damping, m2.jnt_stiffness, m2.dof_frictionloss = (prm[p][i].astype(np.float64) for p in range(3))
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo = Oracle(pack_model(m2)).step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)[:2]
+        qn, vn = Oracle(pack_model(m)).step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)[:2]
+        assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3 and np.abs(vo - vn).max() > 0.1
