@@ -14,7 +14,7 @@
 #define LM_MODEL_BLOB_H
 
 #define LM_BLOB_MAGIC 0x4C4D4231 /* "LMB1" */
-#define LM_BLOB_VERSION 5
+#define LM_BLOB_VERSION 6
 
 /* header slots (doubles) */
 enum {
@@ -56,6 +56,7 @@ enum { LM_ACT_MOTOR = 0, LM_ACT_MUSCLE = 1, LM_ACT_POSITION = 2 };
  *  -- version 5: the hulls' vertex graph (nn = LMH_NHULLNBR entries): neighbours of hull vertex i of geom g, as indices into the
  *  geom's hull, nearest first, are hull_nbr[hull_nbr_adr[geom_hull_adr[g] + i] : hull_nbr_adr[geom_hull_adr[g] + i + 1]]
  *  hull_nbr_adr[nh + 1] hull_nbr[nn]   (... and further contacts at penetrating neighbours of the support vertex)
+ *  -- version 6: geom_center[3ng], body frame: the centre the convex-convex collider starts from (geom frame origin; mesh: its centre of mass)
  */
 
 #endif

@@ -308,6 +308,20 @@ def _mesh_triangles(root, comp, base_dir):
     return out
 
 
+def _mesh_com(v):
+    """Centre of mass of a triangle soup (ntri, 3, 3) as the engine's compiler finds it (pyramids from the area-weighted mean
+    of the triangle centres, |volume| each): the origin of a mesh geom's frame, and the interior point the convex-convex
+    collider (MPR) starts from."""
+    a, b, c = v[:, 0], v[:, 1], v[:, 2]
+    nrm = np.cross(b - a, c - a)
+    area = 0.5 * np.linalg.norm(nrm, axis=1)
+    nrm = nrm / np.maximum(2.0 * area, 1e-300)[:, None]
+    cen = (a + b + c) / 3.0
+    facecen = (area[:, None] * cen).sum(0) / area.sum()
+    pv = np.abs(np.einsum("ij,ij->i", cen - facecen, nrm) * area / 3.0)
+    return (pv[:, None] * (0.75 * cen + 0.25 * facecen)).sum(0) / pv.sum()
+
+
 def _geom_inertia(g, tris):
     """(mass, centre, inertia about the centre) of one geom in the BODY frame; None if it carries no mass.
     Primitives: closed formulas; meshes: the engine's pyramid sums over the triangles (see below)."""
@@ -368,7 +382,7 @@ def _geom_inertia(g, tris):
     return m, g["pos"].copy(), r @ np.diag(m * diag) @ r.T
 
 
-def _mesh_bounds(root, comp, base_dir, hulls=None):
+def _mesh_bounds(root, comp, base_dir, hulls=None, graphs=None):
     """{mesh name: bounding capsule (centre, axis, radius, half length)} in the mesh's own frame, from binary STL files."""
     out = {}
     if base_dir is None:
@@ -391,36 +405,28 @@ def _mesh_bounds(root, comp, base_dir, hulls=None):
         out[name] = _bounding_capsule(v)
         if hulls is not None:
             # vertices of the convex hull, in the order of their first appearance in the file (the support search of the
-            # plane-mesh collider breaks ties by that order): the engine collides the hull of a mesh, not the mesh
+            # plane-mesh collider breaks ties by that order): the engine collides the hull of a mesh, not the mesh. The hull's
+            # vertex graph comes from the same qhull run over ALL distinct points of the file (triangulated facets; which
+            # diagonal a nearly planar quad gets depends on the run, and this is the variant that reproduces most UnitreeH1
+            # golden rows: profiles/r3_notes.md §2)
             pts, first = np.unique(v, axis=0, return_index=True)
+            u = v[np.sort(first)]
             try:
                 from scipy.spatial import ConvexHull
-                keep = np.sort(first[ConvexHull(pts).vertices])
-                hulls[name] = v[keep]
-            except Exception:             # degenerate (flat) mesh or no scipy: every distinct vertex
-                hulls[name] = v[np.sort(first)]
+                h = ConvexHull(u, qhull_options="Qt")
+                keep = np.sort(h.vertices)
+                hulls[name] = u[keep]
+                local = {int(k): i for i, k in enumerate(keep)}
+                nb = [set() for _ in keep]
+                for tri in h.simplices:
+                    for i in tri:
+                        nb[local[int(i)]].update(local[int(j)] for j in tri if j != i)
+                if graphs is not None:
+                    graphs[name] = [sorted(s_, key=lambda j, i=i: (float(np.linalg.norm(u[keep[j]] - u[keep[i]])), j))
+                                    for i, s_ in enumerate(nb)]
+            except Exception:             # degenerate (flat) mesh or no scipy: every distinct vertex, no graph
+                hulls[name] = u
     return out
-
-
-def hull_vertex_graph(hull_vert, geom_hull_adr, geom_hull_num):
-    """CSR adjacency of every geom's convex hull (qhull's triangulated facets: two vertices are neighbours when they share a
-    facet edge), neighbours sorted by distance. Computed on the float32 vertex values the colliders use."""
-    from scipy.spatial import ConvexHull
-    adr, nbr = [0], []
-    for a, n in sorted((int(a), int(n)) for a, n in zip(geom_hull_adr, geom_hull_num) if n > 0):
-        v = np.asarray(hull_vert[a:a + n], dtype=np.float64)
-        nb = [set() for _ in range(n)]
-        try:
-            for tri in ConvexHull(v).simplices:
-                for i in tri:
-                    nb[i].update(int(j) for j in tri if j != i)
-        except Exception:                 # degenerate hull: no graph, the collider keeps its single contact
-            pass
-        for i in range(n):
-            order = sorted(nb[i], key=lambda j: (float(np.linalg.norm(v[j] - v[i])), j))
-            nbr += order
-            adr.append(len(nbr))
-    return np.array(adr, dtype=np.int32), np.array(nbr, dtype=np.int32)
 
 
 def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
@@ -645,16 +651,22 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.n_dropped_mesh_geoms = sum(1 for g in geoms if g["type"] == GEOM_MESH)
     if m.n_dropped_mesh_geoms and not drop_mesh_geoms:
         raise NotImplementedError("collidable mesh geoms need the convex-hull path (not built yet)")
-    hulls = {}
-    bounds = _mesh_bounds(root, comp, handle.base_dir, hulls) if m.n_dropped_mesh_geoms else {}
+    hulls, graphs = {}, {}
+    bounds = _mesh_bounds(root, comp, handle.base_dir, hulls, graphs) if m.n_dropped_mesh_geoms else {}
     kept = []
     hull_of = {}                      # index in `kept` -> hull vertices in the frame of the geom's body
+    graph_of = {}                     # index in `kept` -> neighbour lists of the hull's vertices (indices into the hull)
+    mesh_tris = _mesh_triangles(root, comp, handle.base_dir) if m.n_dropped_mesh_geoms else {}
     for g in geoms:
+        g["center"] = np.array(g["pos"], dtype=np.float64)
         if g["type"] == GEOM_MESH:
             if g["mesh"] not in bounds:
                 continue
             if g["mesh"] in hulls:
                 hull_of[len(kept)] = g["pos"] + hulls[g["mesh"]] @ quat_to_mat(g["quat"]).T
+                graph_of[len(kept)] = graphs.get(g["mesh"])
+            if g["mesh"] in mesh_tris:
+                g["center"] = g["pos"] + quat_to_mat(g["quat"]) @ _mesh_com(mesh_tris[g["mesh"]])
             centre, axis, radius, half = bounds[g["mesh"]]
             g = dict(g, pos=g["pos"] + quat_to_mat(g["quat"]) @ centre, quat=quat_mul(g["quat"], z_to_quat(axis)),
                      size=np.array([radius, half, 0.0]))
@@ -665,6 +677,9 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     m.geom_type = np.array([g["type"] for g in geoms], dtype=np.int32)
     m.geom_body = np.array([g["body"] for g in geoms], dtype=np.int32)
     m.geom_pos = np.array([g["pos"] for g in geoms]).reshape(-1, 3)
+    # centre of every geom for the convex-convex collider, body frame: the geom frame origin — for a mesh geom that is the
+    # mesh's centre of mass (geom_pos of a mesh geom is the centre of its bounding capsule instead)
+    m.geom_center = np.array([g["center"] for g in geoms]).reshape(-1, 3)
     m.geom_quat = np.array([g["quat"] for g in geoms]).reshape(-1, 4)
     m.geom_size = np.array([g["size"] for g in geoms]).reshape(-1, 3)
     m.geom_contype = np.array([g["contype"] for g in geoms], dtype=np.int32)
@@ -690,7 +705,13 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     # the hull's vertex graph (plane-mesh collider: further contacts at the neighbours of the support vertex, DESIGN.md §2 item
     # 10): neighbours of hull vertex i of geom g, as indices INTO the geom's hull, nearest first, are
     # hull_nbr[hull_nbr_adr[geom_hull_adr[g] + i] : hull_nbr_adr[geom_hull_adr[g] + i + 1]]
-    m.hull_nbr_adr, m.hull_nbr = hull_vertex_graph(m.hull_vert, m.geom_hull_adr, m.geom_hull_num)
+    adr, nbr = [0], []
+    for gi in sorted(hull_of):
+        lists = graph_of.get(gi) or [[] for _ in range(len(hull_of[gi]))]
+        for lst in lists:
+            nbr += [int(j) for j in lst]
+            adr.append(len(nbr))
+    m.hull_nbr_adr, m.hull_nbr = np.array(adr, dtype=np.int32), np.array(nbr, dtype=np.int32)
 
     # ---------------- sites
     m.nsite = len(sites)

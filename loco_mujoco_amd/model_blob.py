@@ -13,7 +13,7 @@ HEADER_SIZE = 32
 def pack_model(m):
     h = np.zeros(HEADER_SIZE)
     h[0] = LM_BLOB_MAGIC
-    h[1] = 5
+    h[1] = 6
     h[2:9] = [m.nbody, m.nv, m.ngeom, m.nu, m.cone, m.integrator, m.iterations]
     h[9:12] = [m.timestep, m.impratio, m.tolerance]
     h[12:15] = m.gravity
@@ -49,5 +49,6 @@ def pack_model(m):
              getattr(m, "act_gainprm", zeros(nu, 9)), getattr(m, "act_lengthrange", zeros(nu, 2)),
              getattr(m, "act_biasprm", zeros(nu, 3)), getattr(m, "act_forcerange", zeros(nu, 2)),
              getattr(m, "act_forcelimited", zeros(nu)),
-             getattr(m, "geom_hull_adr", -np.ones(m.ngeom)), getattr(m, "geom_hull_num", zeros(m.ngeom)), hull_vert, hull_nbr_adr, hull_nbr]
+             getattr(m, "geom_hull_adr", -np.ones(m.ngeom)), getattr(m, "geom_hull_num", zeros(m.ngeom)), hull_vert, hull_nbr_adr, hull_nbr,
+             getattr(m, "geom_center", m.geom_pos)]
     return np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts]))

@@ -90,7 +90,7 @@ struct lmo_model {
       *dof_invweight0;
   const double *geom_type, *geom_body, *geom_pos, *geom_quat, *geom_size, *geom_contype, *geom_conaffinity,
       *geom_condim, *geom_priority, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin,
-      *geom_gap;
+      *geom_gap, *geom_center;
   const double *act_dof, *act_gear, *act_ctrlrange, *act_ctrllimited;
   int nsite, ntendon, nwrap, na;
   const double *site_body, *site_pos, *tendon_adr, *tendon_num, *wrap_site;
@@ -102,6 +102,7 @@ struct lmo_model {
   int pair_g1[LMO_MAXPAIR], pair_g2[LMO_MAXPAIR];
   /* run-time switches (test hooks) */
   int disable_self_collision;
+  int disable_ccd;             /* 1: no convex-convex (MPR) contacts; such pairs are counted instead (A/B tests) */
   int skip_pair_counter;       /* 1: pairs without a restated collider are not examined (no `unhandled_pairs`): timing runs */
   /* convex hulls attached to mesh geoms (lmo_set_mesh): hull vertices in the frame of the geom's BODY */
   int mesh_nvert[LMO_MAXGEOM]; double* mesh_vert[LMO_MAXGEOM];
@@ -152,6 +153,9 @@ lmo_model* lmo_model_create(const double* blob, long n) {
   const int nnbr = (int)m->blob[LMH_NHULLNBR];
   const double* hull_nbr_adr = p; p += nhull + 1;
   const double* hull_nbr = p; p += nnbr;
+  /* version 6: the point the convex-convex collider (MPR) takes as a geom's centre, in the frame of the geom's body: the geom
+     frame origin; for a mesh geom the mesh's centre of mass (where the engine's compiler puts the geom frame) */
+  m->geom_center = p; p += 3 * ng;
 #undef TAKE
   if (p - m->blob != n) { free(m->blob); free(m); return NULL; }
   /* convex hulls that come with the model (mesh geoms): the same as lmo_set_mesh per geom */
@@ -210,6 +214,7 @@ void lmo_set_option(lmo_model* m, int what, double value) {
   if (what == 1) m->iterations = (int)value;
   if (what == 2) m->tolerance = value;
   if (what == 3) m->skip_pair_counter = (int)value;
+  if (what == 4) m->disable_ccd = (int)value;
 }
 
 /* attach the convex hull of mesh geom g (nv hull vertices [nv][3] in the frame of the geom's body): the geom then collides
@@ -249,7 +254,7 @@ typedef struct {
   double xpos[LMO_MAXBODY][3], xquat[LMO_MAXBODY][4], xmat[LMO_MAXBODY][9], xipos[LMO_MAXBODY][3];
   double iw[LMO_MAXBODY][9];                       /* world-frame inertia about COM */
   double xanchor[LMO_MAXV][3], xaxis[LMO_MAXV][3];
-  double gpos[LMO_MAXGEOM][3], gmat[LMO_MAXGEOM][9];
+  double gpos[LMO_MAXGEOM][3], gmat[LMO_MAXGEOM][9], gcen[LMO_MAXGEOM][3];
   /* dynamics */
   double M[LMO_MAXV * LMO_MAXV], L[LMO_MAXV * LMO_MAXV];
   double bias[LMO_MAXV], passive[LMO_MAXV], actuator[LMO_MAXV], smooth[LMO_MAXV], qacc_smooth[LMO_MAXV];
@@ -326,6 +331,8 @@ static void kinematics(const lmo_model* m, const double* qpos, work* w) {
     add3(w->gpos[g], w->xpos[b], t);
     quat_mul(q, w->xquat[b], m->geom_quat + 4 * g);
     quat2mat(w->gmat[g], q);
+    mulmat3(t, w->xmat[b], m->geom_center + 3 * g);
+    add3(w->gcen[g], w->xpos[b], t);
   }
 }
 
@@ -648,6 +655,230 @@ double lmo_test_hull_distance(const double* va, int na, const double* vb, int nb
   return convex_distance(&A, &B);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* convex-convex narrow phase: the engine's mjc_Convex = libccd's ccdMPRPenetration (Minkowski     */
+/* Portal Refinement, G. Snethen; libccd src/mpr.c as vendored by MuJoCo 2.3.7) driven by          */
+/* MuJoCo's support / centre callbacks (engine_collision_convex.c: mjccd_support, mjccd_center).   */
+/* Restated from the published algorithm: the third-party sources are not under /root/reference.   */
+/* Pinned by the reference's golden rollouts with bone-mesh contacts (HumanoidTorque.walk rows     */
+/* 19-28, UnitreeH1.{walk,run}: tests/test_oracle_golden.py) — an iterative method, so to a stated */
+/* tolerance (the engine's mpr_tolerance 1e-6, mpr_iterations 50), not to the last bit.            */
+/*  - centre of a geom = its frame origin (mesh: the mesh's centre of mass, where the compiler     */
+/*    puts the geom frame); support of shape A - B in direction d = sup_A(d) - sup_B(-d);          */
+/*  - both shapes are inflated by margin/2 along the (unit) search direction, the contact distance */
+/*    is margin - depth, the normal points from geom 1 to geom 2, the position is the mean of the  */
+/*    two witness points (barycentric coordinates of the origin in the final portal).              */
+/* ------------------------------------------------------------------------------------------ */
+#define CCD_EPS 2.220446049250313e-16
+#define MPR_TOLERANCE 1e-6
+#define MPR_ITERATIONS 50
+typedef struct { double v[3], v1[3], v2[3]; } mpr_sup;
+typedef struct { const cvx* g; const double* center; double halfmargin; } mpr_obj;
+
+static int ccd_is_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a_, double b_) {
+  double ab = fabs(a_ - b_);
+  if (ab < CCD_EPS) return 1;
+  double a = fabs(a_), b = fabs(b_);
+  return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
+}
+static int ccd_vec_eq(const double* a, const double* b) { return ccd_eq(a[0], b[0]) && ccd_eq(a[1], b[1]) && ccd_eq(a[2], b[2]); }
+static void ccd_normalize(double* v) { double n = sqrt(dot3(v, v)); v[0] /= n; v[1] /= n; v[2] /= n; }   /* libccd: no zero guard */
+static double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
+
+/* mjccd_support: support point of ONE geom in world direction dir (unit), in its local frame first */
+static void mj_support(const mpr_obj* o, const double* dir, double* out) {
+  const cvx* g = o->g;
+  if (g->type == LM_GEOM_MESH) {
+    double dl[3] = { g->bmat[0]*dir[0] + g->bmat[3]*dir[1] + g->bmat[6]*dir[2], g->bmat[1]*dir[0] + g->bmat[4]*dir[1] + g->bmat[7]*dir[2],
+                     g->bmat[2]*dir[0] + g->bmat[5]*dir[1] + g->bmat[8]*dir[2] };
+    int best = 0; double db = -1e10;
+    for (int i = 0; i < g->nverts; i++) { double d = dot3(g->verts + 3*i, dl); if (d > db) { db = d; best = i; } }
+    mulmat3(out, g->bmat, g->verts + 3*best); add3(out, out, g->bpos);
+  } else {
+    const double* R = g->R; const double* sz = g->size;
+    double dl[3] = { R[0]*dir[0] + R[3]*dir[1] + R[6]*dir[2], R[1]*dir[0] + R[4]*dir[1] + R[7]*dir[2], R[2]*dir[0] + R[5]*dir[1] + R[8]*dir[2] };
+    double res[3] = {0, 0, 0};
+    switch (g->type) {
+      case LM_GEOM_SPHERE: for (int k = 0; k < 3; k++) res[k] = dl[k] * sz[0]; break;
+      case LM_GEOM_CAPSULE: for (int k = 0; k < 3; k++) res[k] = dl[k] * sz[0]; res[2] += sgn(dl[2]) * sz[1]; break;
+      case LM_GEOM_CYLINDER: {
+        double t = sqrt(dl[0]*dl[0] + dl[1]*dl[1]);
+        if (t > MINVAL) { res[0] = dl[0] / t * sz[0]; res[1] = dl[1] / t * sz[0]; }
+        res[2] = sgn(dl[2]) * sz[1];
+        break;
+      }
+      case LM_GEOM_BOX: for (int k = 0; k < 3; k++) res[k] = sgn(dl[k]) * sz[k]; break;
+      default: break;
+    }
+    mulmat3(out, R, res); add3(out, out, g->pos);
+  }
+  addscl3(out, dir, o->halfmargin);
+}
+static void mpr_support(const mpr_obj* A, const mpr_obj* B, const double* dir, mpr_sup* s) {
+  double nd[3] = { -dir[0], -dir[1], -dir[2] };
+  mj_support(A, dir, s->v1); mj_support(B, nd, s->v2); sub3(s->v, s->v1, s->v2);
+}
+static void mpr_portal_dir(const mpr_sup* P, double* dir) {
+  double a[3], b[3]; sub3(a, P[2].v, P[1].v); sub3(b, P[3].v, P[1].v); cross3(dir, a, b); ccd_normalize(dir);
+}
+static int mpr_reach_tolerance(const mpr_sup* P, const mpr_sup* v4, const double* dir) {
+  double dv1 = dot3(P[1].v, dir), dv2 = dot3(P[2].v, dir), dv3 = dot3(P[3].v, dir), dv4 = dot3(v4->v, dir);
+  double d = fmin(fmin(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+  return ccd_eq(d, MPR_TOLERANCE) || d < MPR_TOLERANCE;
+}
+static void mpr_expand_portal(mpr_sup* P, const mpr_sup* v4) {
+  double c[3]; cross3(c, v4->v, P[0].v);
+  if (dot3(P[1].v, c) > 0) { if (dot3(P[2].v, c) > 0) P[1] = *v4; else P[3] = *v4; }
+  else { if (dot3(P[3].v, c) > 0) P[2] = *v4; else P[1] = *v4; }
+}
+static double point_segment_dist2(const double* P, const double* x0, const double* b, double* witness) {
+  double d[3], a[3]; sub3(d, b, x0); sub3(a, x0, P);
+  double t = -dot3(a, d) / dot3(d, d), dist;
+  if (t < 0 || ccd_is_zero(t)) { dist = dot3(a, a); if (witness) copy3(witness, x0); }            /* |x0 - P|^2 */
+  else if (t > 1 || ccd_eq(t, 1)) { double e[3]; sub3(e, b, P); dist = dot3(e, e); if (witness) copy3(witness, b); }
+  else {
+    if (witness) { copy3(witness, d); for (int k = 0; k < 3; k++) witness[k] = witness[k] * t + x0[k]; double e[3]; sub3(e, witness, P); dist = dot3(e, e); }
+    else { double e[3] = { a[0] + t*d[0], a[1] + t*d[1], a[2] + t*d[2] }; dist = dot3(e, e); }
+  }
+  return dist;
+}
+static double point_tri_dist2(const double* P, const double* x0, const double* B, const double* Cc, double* witness) {
+  double d1[3], d2[3], a[3]; sub3(d1, B, x0); sub3(d2, Cc, x0); sub3(a, x0, P);
+  double v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+  double d = w * v - r * r, s, t, dist;
+  if (ccd_is_zero(d)) s = t = -1; else { s = (q * r - w * p) / d; t = (-s * r - q) / w; }
+  if ((ccd_is_zero(s) || s > 0) && (ccd_eq(s, 1) || s < 1) && (ccd_is_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + s, 1) || t + s < 1)) {
+    for (int k = 0; k < 3; k++) witness[k] = x0[k] + d1[k] * s + d2[k] * t;
+    double e[3]; sub3(e, witness, P); dist = dot3(e, e);
+  } else {
+    double w2[3], d2_;
+    dist = point_segment_dist2(P, x0, B, witness);
+    d2_ = point_segment_dist2(P, x0, Cc, w2); if (d2_ < dist) { dist = d2_; copy3(witness, w2); }
+    d2_ = point_segment_dist2(P, B, Cc, w2); if (d2_ < dist) { dist = d2_; copy3(witness, w2); }
+  }
+  return dist;
+}
+/* barycentric position of the origin in the portal tetrahedron -> mean of the witness points on the two shapes */
+static void mpr_find_pos(const mpr_sup* P, double* pos) {
+  double dir[3], vec[3], b[4], sum;
+  mpr_portal_dir(P, dir);
+  cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
+  cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
+  cross3(vec, P[0].v, P[1].v); b[2] = dot3(vec, P[3].v);
+  cross3(vec, P[2].v, P[1].v); b[3] = dot3(vec, P[0].v);
+  sum = b[0] + b[1] + b[2] + b[3];
+  if (ccd_is_zero(sum) || sum < 0) {
+    b[0] = 0;
+    cross3(vec, P[2].v, P[3].v); b[1] = dot3(vec, dir);
+    cross3(vec, P[3].v, P[1].v); b[2] = dot3(vec, dir);
+    cross3(vec, P[1].v, P[2].v); b[3] = dot3(vec, dir);
+    sum = b[1] + b[2] + b[3];
+  }
+  double inv = 1.0 / sum, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+  for (int i = 0; i < 4; i++) { addscl3(p1, P[i].v1, b[i]); addscl3(p2, P[i].v2, b[i]); }
+  for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p1[k] * inv + p2[k] * inv);
+}
+/* returns 0 and (depth, dir, pos) when the (inflated) shapes overlap, -1 otherwise */
+static int mpr_penetration(const mpr_obj* A, const mpr_obj* B, double* depth, double* pdir, double* pos) {
+  static const double origin[3] = {0, 0, 0};
+  mpr_sup P[4], v4; double dir[3], va[3], vb[3], dot; int res = 0;
+  /* ---- portal discovery */
+  copy3(P[0].v1, A->center); copy3(P[0].v2, B->center); sub3(P[0].v, P[0].v1, P[0].v2);
+  if (ccd_vec_eq(P[0].v, origin)) P[0].v[0] += CCD_EPS * 10.0;
+  for (int k = 0; k < 3; k++) dir[k] = -P[0].v[k];
+  ccd_normalize(dir);
+  mpr_support(A, B, dir, &P[1]);
+  dot = dot3(P[1].v, dir);
+  if (ccd_is_zero(dot) || dot < 0) return -1;
+  cross3(dir, P[0].v, P[1].v);
+  if (ccd_is_zero(dot3(dir, dir))) res = ccd_vec_eq(P[1].v, origin) ? 1 : 2;
+  else {
+    ccd_normalize(dir);
+    mpr_support(A, B, dir, &P[2]);
+    dot = dot3(P[2].v, dir);
+    if (ccd_is_zero(dot) || dot < 0) return -1;
+    sub3(va, P[1].v, P[0].v); sub3(vb, P[2].v, P[0].v); cross3(dir, va, vb); ccd_normalize(dir);
+    if (dot3(dir, P[0].v) > 0) { mpr_sup t = P[1]; P[1] = P[2]; P[2] = t; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
+    int size = 3;
+    while (size < 4) {
+      mpr_support(A, B, dir, &P[3]);
+      dot = dot3(P[3].v, dir);
+      if (ccd_is_zero(dot) || dot < 0) return -1;
+      int cont = 0;
+      cross3(va, P[1].v, P[3].v); dot = dot3(va, P[0].v);
+      if (dot < 0 && !ccd_is_zero(dot)) { P[2] = P[3]; cont = 1; }
+      if (!cont) {
+        cross3(va, P[3].v, P[2].v); dot = dot3(va, P[0].v);
+        if (dot < 0 && !ccd_is_zero(dot)) { P[1] = P[3]; cont = 1; }
+      }
+      if (cont) { sub3(va, P[1].v, P[0].v); sub3(vb, P[2].v, P[0].v); cross3(dir, va, vb); ccd_normalize(dir); }
+      else size = 4;
+    }
+  }
+  if (res == 1) {                                        /* touching contact on v1 */
+    *depth = 0; pdir[0] = pdir[1] = pdir[2] = 0;
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (P[1].v1[k] + P[1].v2[k]);
+    return 0;
+  }
+  if (res == 2) {                                        /* origin on the segment v0-v1: depth = |v1|, direction = v1 */
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (P[1].v1[k] + P[1].v2[k]);
+    copy3(pdir, P[1].v); *depth = sqrt(dot3(pdir, pdir)); ccd_normalize(pdir);
+    return 0;
+  }
+  /* ---- portal refinement: until the portal's outward side holds the origin */
+  for (;;) {
+    mpr_portal_dir(P, dir);
+    dot = dot3(dir, P[1].v);
+    if (ccd_is_zero(dot) || dot > 0) break;              /* the portal encapsulates the origin */
+    mpr_support(A, B, dir, &v4);
+    dot = dot3(v4.v, dir);
+    if (!(ccd_is_zero(dot) || dot > 0) || mpr_reach_tolerance(P, &v4, dir)) return -1;
+    mpr_expand_portal(P, &v4);
+  }
+  /* ---- penetration: push the portal to the surface of the Minkowski difference */
+  for (unsigned long it = 0;; it++) {
+    mpr_portal_dir(P, dir);
+    mpr_support(A, B, dir, &v4);
+    if (mpr_reach_tolerance(P, &v4, dir) || it > MPR_ITERATIONS) {
+      *depth = sqrt(point_tri_dist2(origin, P[1].v, P[2].v, P[3].v, pdir));
+      if (ccd_is_zero(pdir[0]) && ccd_is_zero(pdir[1]) && ccd_is_zero(pdir[2])) copy3(pdir, dir);
+      ccd_normalize(pdir);
+      mpr_find_pos(P, pos);
+      return 0;
+    }
+    mpr_expand_portal(P, &v4);
+  }
+}
+
+/* pairs the engine's collision table routes to mjc_Convex (types in the table's order: sphere < capsule < cylinder < box < mesh) */
+static int engine_uses_ccd(int t1, int t2) {
+  if (t2 == LM_GEOM_MESH) return t1 != LM_GEOM_PLANE;
+  if (t1 == LM_GEOM_CAPSULE && t2 == LM_GEOM_CYLINDER) return 1;
+  if (t1 == LM_GEOM_CYLINDER && (t2 == LM_GEOM_CYLINDER || t2 == LM_GEOM_BOX)) return 1;
+  return 0;
+}
+/* mjc_fixNormal: a sphere or a capsule in the pair replaces the MPR direction by the direction from its centre / axis to the
+   contact point (both round: the normalised difference of the two) */
+static void fix_normal(const cvx* A, const cvx* B, const double* pos, double* normal) {
+  double n[2][3]; int done[2] = {0, 0};
+  for (int i = 0; i < 2; i++) {
+    const cvx* g = i ? B : A;
+    if (g->type == LM_GEOM_SPHERE) { sub3(n[i], pos, g->pos); done[i] = 1; }
+    else if (g->type == LM_GEOM_CAPSULE) {
+      double ax[3] = { g->R[2], g->R[5], g->R[8] }, rel[3]; sub3(rel, pos, g->pos);
+      double t = dot3(rel, ax); if (t < -g->size[1]) t = -g->size[1]; else if (t > g->size[1]) t = g->size[1];
+      for (int k = 0; k < 3; k++) n[i][k] = rel[k] - t * ax[k];
+      done[i] = 1;
+    }
+    if (done[i]) normalize3(n[i]);
+  }
+  if (done[0] && done[1]) { sub3(normal, n[0], n[1]); normalize3(normal); }
+  else if (done[0]) copy3(normal, n[0]);
+  else if (done[1]) { for (int k = 0; k < 3; k++) normal[k] = -n[1][k]; }
+}
+
 static void collide(const lmo_model* m, work* w) {
   w->ncon = 0; w->unhandled_pairs = 0;
   for (int pi = 0; pi < m->npair; pi++) {
@@ -766,8 +997,11 @@ static void collide(const lmo_model* m, work* w) {
           add_contact(w, &tm, dbest, pos, n, NULL);
           if (m->mesh_nbr_adr[g2]) {
             /* further contacts at the hull-graph neighbours of the support vertex (the engine's "up to 3 more contacts from
-               mesh"): penetrating, nearest first, none closer than tol to a contact already found. Reverse-engineered on the
-               UnitreeH1 golden rows (profiles/r2_ab_probes.md §9): +2 rows reproduced, 12 closer, none of any robot worse */
+               mesh"): penetrating, nearest first, none closer than tol to the SUPPORT contact. Reverse-engineered on the
+               UnitreeH1 golden rows (profiles/r2_ab_probes.md §9, profiles/r3_notes.md §2): walk row 23 is reproduced to 1e-7 only
+               with the toe vertex + two heel vertices 11 mm apart from each other (170 mm from the toe) while toe-side
+               neighbours 23 mm away stay out - so the tolerance is measured against the first contact, not between the
+               extra ones. Against the round-2 rule (tolerance against every contact found): +2 rows reproduced, none lost */
             double cp[4][3]; int nc = 1; copy3(cp[0], pos);
             for (int e = m->mesh_nbr_adr[g2][best]; e < m->mesh_nbr_adr[g2][best + 1] && nc < 4; e++) {
               const int j = m->mesh_nbr[g2][e];
@@ -776,7 +1010,7 @@ static void collide(const lmo_model* m, work* w) {
               if (dj > margin) continue;
               double pj[3]; copy3(pj, wj); addscl3(pj, n, -0.5 * dj);
               int close = 0;
-              for (int q = 0; q < nc; q++) { double df[3]; sub3(df, pj, cp[q]); if (norm3(df) < m->mesh_tol[g2]) close = 1; }
+              { double df[3]; sub3(df, pj, cp[0]); if (norm3(df) < m->mesh_tol[g2]) close = 1; }
               if (close) continue;
               add_contact(w, &tm, dj, pj, n, NULL); copy3(cp[nc], pj); nc++;
             }
@@ -786,8 +1020,8 @@ static void collide(const lmo_model* m, work* w) {
         /* no convex-hull collider (not restated): count the bounding capsule coming within reach */
         double ax[3] = { R2[2], R2[5], R2[8] };
         sub3(rel, p2, p1);
-        if (dot3(rel, n) - s2[1] * fabs(dot3(ax, n)) - s2[0] < margin) w->unhandled_pairs++;
-      } else w->unhandled_pairs++;
+        if (dot3(rel, n) - s2[1] * fabs(dot3(ax, n)) - s2[0] < margin) { w->unhandled_pairs++; if (getenv("LMO_DEBUG")) fprintf(stderr, "plane-mesh-nohull %d\n", g2); }
+      } else { w->unhandled_pairs++; if (getenv("LMO_DEBUG")) fprintf(stderr, "plane-other %d type %d\n", g2, t2); }
       continue;
     }
     if (m->disable_self_collision) continue;
@@ -808,6 +1042,17 @@ static void collide(const lmo_model* m, work* w) {
       segment_closest(p1, a1, s1[1], p2, a2, s2[1], &s, &t);
       double c1[3], c2[3]; copy3(c1, p1); addscl3(c1, a1, s); copy3(c2, p2); addscl3(c2, a2, t);
       sphere_sphere(w, &tm, c1, s1[0], c2, s2[0]);
+    } else if (!m->disable_ccd && engine_uses_ccd(t1, t2) && (t1 != LM_GEOM_MESH || m->mesh_nvert[g1] > 0) && (t2 != LM_GEOM_MESH || m->mesh_nvert[g2] > 0)) {
+      /* mjc_Convex: one contact from MPR on the two shapes inflated by margin / 2 each */
+      const int b1 = IDX(m->geom_body, g1), b2 = IDX(m->geom_body, g2);
+      cvx A = { t1, p1, R1, s1, m->mesh_vert[g1], m->mesh_nvert[g1], w->xpos[b1], w->xmat[b1] };
+      cvx B = { t2, p2, R2, s2, m->mesh_vert[g2], m->mesh_nvert[g2], w->xpos[b2], w->xmat[b2] };
+      mpr_obj oa = { &A, w->gcen[g1], 0.5 * margin }, ob = { &B, w->gcen[g2], 0.5 * margin };
+      double depth, dir[3], pos[3];
+      if (mpr_penetration(&oa, &ob, &depth, dir, pos) == 0 && !(dir[0] == 0 && dir[1] == 0 && dir[2] == 0)) {
+        fix_normal(&A, &B, pos, dir);
+        add_contact(w, &tm, margin - depth, pos, dir, NULL);
+      }
     } else if (m->skip_pair_counter) {
       /* timing runs: the pair has no collider here, and whether the engine would have a contact is not asked */
     } else if (t1 == LM_GEOM_MESH || t2 == LM_GEOM_MESH
@@ -821,11 +1066,11 @@ static void collide(const lmo_model* m, work* w) {
       cvx B = { t2, p2, R2, c2s, m->mesh_vert[g2], m->mesh_nvert[g2], w->xpos[b2], w->xmat[b2] };
       if (t1 == LM_GEOM_MESH && m->mesh_nvert[g1] == 0) A.type = LM_GEOM_CAPSULE;      /* bounding capsule (r, h) in size[0], size[1] */
       if (t2 == LM_GEOM_MESH && m->mesh_nvert[g2] == 0) B.type = LM_GEOM_CAPSULE;
-      if (convex_distance(&A, &B) < margin + 1e-9) w->unhandled_pairs++;
+      if (convex_distance(&A, &B) < margin + 1e-9) { w->unhandled_pairs++; if (getenv("LMO_DEBUG")) fprintf(stderr, "cvx %d %d types %d %d\n", g1, g2, t1, t2); }
     } else if (t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX) {
       /* box-box contacts are not restated; the pair is only COUNTED, and only when no separating axis
          (3 + 3 face normals, 9 edge cross products) keeps the boxes more than `margin` apart */
-      if (box_box_gap(p1, R1, s1, p2, R2, s2) < margin) w->unhandled_pairs++;
+      if (box_box_gap(p1, R1, s1, p2, R2, s2) < margin) { w->unhandled_pairs++; if (getenv("LMO_DEBUG")) fprintf(stderr, "boxbox %d %d\n", g1, g2); }
     } else {
       /* box / cylinder vs other non-plane geoms (the engine: native capsule-box / sphere-box colliders, libccd for
          everything with a cylinder): not restated. The pair is COUNTED when the geoms' bounding capsules (cylinder (r, h) ->
@@ -838,7 +1083,7 @@ static void collide(const lmo_model* m, work* w) {
       segment_closest(ca, aa, ha, cb, ab, hb, &sa, &ta);
       double c1[3], c2[3], dd[3]; copy3(c1, ca); addscl3(c1, aa, sa); copy3(c2, cb); addscl3(c2, ab, ta);
       sub3(dd, c2, c1);
-      if (norm3(dd) - ra - rb < margin) w->unhandled_pairs++;
+      if (norm3(dd) - ra - rb < margin) { w->unhandled_pairs++; if (getenv("LMO_DEBUG")) fprintf(stderr, "capsule-bound %d %d types %d %d\n", g1, g2, t1, t2); }
     }
   }
 }

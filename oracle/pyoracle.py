@@ -104,7 +104,7 @@ class Oracle:
         assert lib().lmo_set_mesh_graph(self._h, int(geom), adr.ctypes.data, nbr.ctypes.data, 0.0) == 0
 
     def set_option(self, what, value):
-        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3}[what], float(value))
+        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3, "disable_ccd": 4}[what], float(value))
 
     def step(self, qpos, qvel, ctrl, nsub=1, warmstart=None):
         """Returns new (qpos, qvel, warmstart, stats-dict). Inputs are not modified."""
