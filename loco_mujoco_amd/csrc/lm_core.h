@@ -37,6 +37,7 @@
 namespace lm {
 
 struct V3 { float x, y, z; };
+struct alignas(16) F4 { float x, y, z, w; };      // one 128-bit load
 LM_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 LM_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 LM_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -142,13 +143,13 @@ struct Params {
   int integrator;     // LM_INT_EULER (0) | LM_INT_RK4 (1)
   int cone;           // 0 pyramidal | 1 elliptic
   int act_position;   // 1: the chain joints' actuators are position servos (torque = clamp(kp*ctrl - kp*q, force range))
-  int off_runsup, off_cunsup, off_prune;   // tail lists of the constant table (lm_layout.h LM_H_OFF_*)
-  int off_lgroup;     // geom groups per link with their bounding spheres (constant-table tail, LM_H_OFF_LGROUP)
-  int off_lpair;      // link-pair list of the self-collision broad phase (constant-table tail, LM_H_OFF_LPAIR)
+  int off_runsup;     // collider-less geoms of the root body (constant-table tail, LM_H_OFF_RUNSUP; the chains' lists start at LM_C_OFF_*)
   const float* meshv; // hull vertices of the mesh colliders (global memory, 4 floats per vertex, link frame; the 4th: start of the
                       // vertex' neighbour list in meshn)
   const float* meshn; // hull-vertex graph: neighbour lists (indices into the geom's hull, nearest first, -1 ends a list)
-  const float* gpt;   // geom-pair table (global memory): records of LM_GPAIR_SIZE floats, read when a link pair is within reach
+  const float* gpt;   // geom-pair table (global memory): records of LM_GPAIR_SIZE floats, read when a BODY pair is within reach
+  const float* meshadj; // adjacency blocks of the hull vertices (global memory, 4 floats per entry): hill climbing of the convex-pair collider
+  const float* bpt;   // body-pair table (global memory): records of LM_BP_SIZE floats, read when a link pair is within reach
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
 };
 
@@ -200,8 +201,8 @@ enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, 
        SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_GRF /* force group of the chain (0/1) or -1 */, SL_SIZE };
 // pair extension of a slot record (kernels with self-collisions, PAIRS): SL_PART = 0 for a floor contact, else
 // sign * (1 + partner lane * 8 + partner link), partner link 7 = the root body; sign = +1 when this lane's body carries the
-// contact's SECOND geom (the normal points from geom 1 to geom 2). Then the unit normal and the first tangent, world axes.
-enum { SL_PART = SL_SIZE, SL_NX, SL_NY, SL_NZ, SL_T1X, SL_T1Y, SL_T1Z, SL_SIZE_PAIRS };
+// contact's SECOND geom (the normal points from geom 1 to geom 2). Then the unit normal, world axes.
+enum { SL_PART = SL_SIZE, SL_NX, SL_NY, SL_NZ, SL_SIZE_PAIRS };       // (the tangents follow from the normal: make_frame)
 // per-environment joint parameters (domain randomisation): replaces the table's damping / stiffness / frictionloss
 // per-environment parameters of the kernels compiled with DR: joint damping / stiffness / frictionloss in registers, and the
 // environment's MODEL VARIANT (lowering.variant_tables): `inr` = its inertial record [LM_IR_SIZE][LM_NCHAIN] in global memory
@@ -217,9 +218,10 @@ template <int MC> struct DofPrm {
 // lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM][link bounding-sphere centres MCx3 (PAIRS)]
 // compact slot record of the kernels compiled for condim-3 pyramids only (CONE == 0): one D, four edge rows — 21 floats
 // instead of 37, which is what lets the 8-slot humanoid family keep four workgroups per CU (LDS: 160 KB / 4)
-enum { SLC_D = SL_D, SLC_AREF = SLC_D + 1, SLC_JAR = SLC_AREF + 4, SLC_JV = SLC_JAR + 4, SLC_ZONE = SLC_JV + 4, SLC_GRF, SLC_SIZE };
+enum { SLC_D = SL_D, SLC_AREF = SLC_D + 1, SLC_JAR = SLC_AREF + 4, SLC_JV = SLC_JAR + 4, SLC_ZONE = SLC_JV + 4, SLC_GRF, SLC_SIZE,
+       SLC_SIZE_PAIRS = SLC_SIZE + 4 };      // + the pair extension (SL_PART, normal) behind the compact record
 template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> struct LaneMem {
-  static constexpr int kSlot = COMPACT ? (int)SLC_SIZE : (PAIRS ? (int)SL_SIZE_PAIRS : (int)SL_SIZE);
+  static constexpr int kSlot = COMPACT ? (PAIRS ? (int)SLC_SIZE_PAIRS : (int)SLC_SIZE) : (PAIRS ? (int)SL_SIZE_PAIRS : (int)SL_SIZE);
   static constexpr int kSlots = 0;
   static constexpr int kMcc = NS * kSlot;
   static constexpr int kMcr = kMcc + MC * (MC + 1) / 2;
@@ -239,7 +241,7 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> 
   static constexpr int kGroup = kPadded * 16;
 };
 // the lane memory of a kernel compiled for cone CONE (-1 run-time, 0 pyramids of condim 3 only, 1 elliptic)
-template <int MC, int NS, int NM, bool PAIRS, int CONE> using LaneMemFor = LaneMem<MC, NS, NM, PAIRS, (CONE == 0) && !PAIRS>;
+template <int MC, int NS, int NM, bool PAIRS, int CONE> using LaneMemFor = LaneMem<MC, NS, NM, PAIRS, (CONE == 0)>;
 
 // Elliptic-cone contact: cost/force/Hessian in the contact frame at jar[0..5] (rows beyond dim are ignored
 // because their D is 0). Dj = D of row j, fr = friction coefficients of rows 1..5, mu = regularised cone mu.
@@ -666,6 +668,259 @@ LM_DEV void arrow_solve_x(const float* Lcc, const float (*W)[6], const float* Lr
   }
 }
 
+// ---- arrow factorisation with cross blocks between ANY chains of the quad (self-collisions) --------------------------------
+// A contact between links of chains a < b couples their blocks: H_ab = X (MC x MC), kept by the LOWER lane a in slot b - a - 1 of
+// its X array. The lanes are eliminated in order 0, 1, ...: lane a factors what is left of its block, Y_ab = L_a^-1 X_ab for
+// every lane b above it, and the lanes above take off Y_ab^T Y_ab (own block), Y_ab^T W_a (root coupling) and — when a is coupled
+// with two lanes b < d — the fill-in Y_ab^T Y_ad on X_bd. `adj` = the quad's coupling bits (bit 4 i + j: chains i and j are
+// coupled; quad-uniform, fill-in added here), so uncoupled pairs cost nothing. Afterwards every lane holds the Y blocks of ALL its
+// partners: the upper ones where their X was, a copy of the lower partner p's in slot NX - 1 - p, and the solve only exchanges
+// vectors. Exact for any coupling pattern (a folded-up humanoid couples all three of its chains); NX >= number of chains - 1.
+template <class Q, int MC, int NX>
+LM_DEV void arrow_factor_g(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, const float* Hrr_part, float* Lrr,
+                           float (*X)[MC][MC], int c, int& adj) {
+#pragma nounroll
+  for (int a = 0; a < NX + 1; a++) {
+    const int row = (adj >> (4 * a)) & 15;
+    if (c == a || (a == NX && c > NX)) {              // (a lane beyond the last one that can hold a cross block: plain factorisation)
+#pragma unroll
+      for (int j = 0; j < MC; j++) {
+        float sd = Hcc[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) sd = fmaf(-Hcc[tri(j, k)], Hcc[tri(j, k)], sd);
+        float d = sqrtf(fmaxf(sd, 1e-30f)), id = 1.0f / d;
+        Hcc[tri(j, j)] = d;
+#pragma unroll
+        for (int i = j + 1; i < MC; i++) {
+          float t = Hcc[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; k++) t = fmaf(-Hcc[tri(i, k)], Hcc[tri(j, k)], t);
+          Hcc[tri(i, j)] = t * id;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+        const float idg = 1.0f / Hcc[tri(i, i)];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          float t = Hcr[i][r];
+#pragma unroll
+          for (int k = 0; k < i; k++) t = fmaf(-Hcc[tri(i, k)], Hcr[k][r], t);
+          Hcr[i][r] = t * idg;
+        }
+#pragma unroll
+        for (int x = 0; x < NX; x++) if (x < NX - a && c == a) {      // my blocks with the lanes ABOVE me (the other slots hold copies from below)
+#pragma unroll
+          for (int j = 0; j < MC; j++) {
+            float t = X[x][i][j];
+#pragma unroll
+            for (int k = 0; k < i; k++) t = fmaf(-Hcc[tri(i, k)], X[x][k][j], t);
+            X[x][i][j] = t * idg;
+          }
+        }
+      }
+    }
+    if ((row >> (a + 1)) == 0) continue;              // lane a is coupled with no lane above it (quad-uniform)
+    float Wa[MC][6];
+#pragma unroll
+    for (int k = 0; k < MC; k++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) Wa[k][r] = Q::quad_read(Hcr[k][r], a);
+#pragma nounroll
+    for (int x1 = 0; x1 < NX; x1++) {
+      const int b = a + 1 + x1;
+      if (b > NX || !((row >> b) & 1)) continue;
+      float Y1[MC][MC];
+#pragma unroll
+      for (int k = 0; k < MC; k++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) Y1[k][j] = Q::quad_read(X[x1][k][j], a);
+      if (c == b) {
+#pragma unroll
+        for (int i = 0; i < MC; i++) {
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            float t = Hcc[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < MC; k++) t = fmaf(-Y1[k][i], Y1[k][j], t);
+            Hcc[tri(i, j)] = t;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            float t = Hcr[i][r];
+#pragma unroll
+            for (int k = 0; k < MC; k++) t = fmaf(-Y1[k][i], Wa[k][r], t);
+            Hcr[i][r] = t;
+          }
+        }
+        // keep a copy of the lower partner's Y for the solves
+#pragma unroll
+        for (int k = 0; k < MC; k++)
+#pragma unroll
+          for (int j = 0; j < MC; j++) X[NX - 1 - a][k][j] = Y1[k][j];
+      }
+#pragma nounroll
+      for (int x2 = x1 + 1; x2 < NX; x2++) {
+        const int d = a + 1 + x2;
+        if (d > NX || !((row >> d) & 1)) continue;
+        float Y2[MC][MC];
+#pragma unroll
+        for (int k = 0; k < MC; k++)
+#pragma unroll
+          for (int j = 0; j < MC; j++) Y2[k][j] = Q::quad_read(X[x2][k][j], a);
+        if (c == b) {                              // fill-in on X_bd (slot d - b - 1 of lane b)
+#pragma unroll
+          for (int i = 0; i < MC; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) {
+              float t = 0.0f;
+#pragma unroll
+              for (int k = 0; k < MC; k++) t = fmaf(Y1[k][i], Y2[k][j], t);
+#pragma unroll
+              for (int xs = 0; xs < NX; xs++) if (xs == d - b - 1) X[xs][i][j] -= t;
+            }
+        }
+        adj |= (1 << (4 * b + d)) | (1 << (4 * d + b));
+      }
+    }
+  }
+  float S[21];
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      float t = Hrr_part[tri(a, b)];
+#pragma unroll
+      for (int k = 0; k < MC; k++) t = fmaf(-Hcr[k][a], Hcr[k][b], t);
+      S[tri(a, b)] = Q::sum(t) + Hrr_rep[tri(a, b)];
+    }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float sd = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) sd = fmaf(-Lrr[tri(j, k)], Lrr[tri(j, k)], sd);
+    float d = sqrtf(fmaxf(sd, 1e-30f)), id = 1.0f / d;
+    Lrr[tri(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float t = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fmaf(-Lrr[tri(i, k)], Lrr[tri(j, k)], t);
+      Lrr[tri(i, j)] = t * id;
+    }
+  }
+}
+
+// solve with the factors of arrow_factor_g (`adj` as it left the coupling bits, fill-in included)
+template <class Q, int MC, int NX>
+LM_DEV void arrow_solve_g(const float* Lcc, const float (*W)[6], const float* Lrr, const float (*Y)[MC][MC], int c, int adj,
+                          float* xc, float* xr) {
+  // forward, lanes in order: y_a = L_a^-1 g_a, then every coupled lane b above takes Y_ab^T y_a off its right-hand side
+#pragma nounroll
+  for (int a = 0; a < NX + 1; a++) {
+    if (c == a) {
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+        float t = xc[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t = fmaf(-Lcc[tri(i, k)], xc[k], t);
+        xc[i] = t / Lcc[tri(i, i)];
+      }
+    }
+    const int row = (adj >> (4 * a)) & 15;
+    if ((row >> (a + 1)) == 0) continue;
+    float t[MC];
+#pragma unroll
+    for (int k = 0; k < MC; k++) t[k] = Q::quad_read(xc[k], a);
+    if (c > a && ((row >> c) & 1)) {
+#pragma unroll
+      for (int xs = 0; xs < NX; xs++) if (xs == NX - 1 - a) {
+#pragma unroll
+        for (int i = 0; i < MC; i++)
+#pragma unroll
+          for (int k = 0; k < MC; k++) xc[i] = fmaf(-Y[xs][k][i], t[k], xc[i]);
+      }
+    }
+  }
+  // lanes NX + 1 .. 3 (if any) hold no cross block: their forward solve
+  if (c > NX) {
+#pragma unroll
+    for (int i = 0; i < MC; i++) {
+      float t = xc[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t = fmaf(-Lcc[tri(i, k)], xc[k], t);
+      xc[i] = t / Lcc[tri(i, i)];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float t = 0;
+#pragma unroll
+    for (int k = 0; k < MC; k++) t = fmaf(W[k][r], xc[k], t);
+    xr[r] -= Q::sum(t);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t = fmaf(-Lrr[tri(i, k)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float t = xr[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t = fmaf(-Lrr[tri(k, i)], xr[k], t);
+    xr[i] = t / Lrr[tri(i, i)];
+  }
+  // backward, lanes in reverse order: x_a = L_a^-T (y_a - W_a x_r - sum over coupled lanes b above of Y_ab x_b)
+  if (c > NX) {
+#pragma unroll
+    for (int i = 0; i < MC; i++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) xc[i] = fmaf(-W[i][r], xr[r], xc[i]);
+#pragma unroll
+    for (int i = MC - 1; i >= 0; i--) {
+      float tt = xc[i];
+#pragma unroll
+      for (int k = i + 1; k < MC; k++) tt = fmaf(-Lcc[tri(k, i)], xc[k], tt);
+      xc[i] = tt / Lcc[tri(i, i)];
+    }
+  }
+#pragma nounroll
+  for (int a = NX; a >= 0; a--) {
+    if (c == a) {
+#pragma unroll
+      for (int i = 0; i < MC; i++) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) xc[i] = fmaf(-W[i][r], xr[r], xc[i]);
+      }
+#pragma unroll
+      for (int i = MC - 1; i >= 0; i--) {
+        float tt = xc[i];
+#pragma unroll
+        for (int k = i + 1; k < MC; k++) tt = fmaf(-Lcc[tri(k, i)], xc[k], tt);
+        xc[i] = tt / Lcc[tri(i, i)];
+      }
+    }
+    // lane a's solution goes to the coupled lanes BELOW it: they take Y_pa x_a off before their own back substitution
+    const int row = (adj >> (4 * a)) & 15;
+    if ((row & ((1 << a) - 1)) == 0) continue;
+    float t[MC];
+#pragma unroll
+    for (int k = 0; k < MC; k++) t[k] = Q::quad_read(xc[k], a);
+    if (c < a && ((row >> c) & 1)) {
+#pragma unroll
+      for (int xs = 0; xs < NX; xs++) if (xs == a - c - 1) {
+#pragma unroll
+        for (int i = 0; i < MC; i++)
+#pragma unroll
+          for (int j = 0; j < MC; j++) xc[i] = fmaf(-Y[xs][i][j], t[j], xc[i]);
+      }
+    }
+  }
+}
+
 // contact-frame components (n=+z, t1=+y, t2=-x; then the same for rotation) of motion S at r
 LM_DEV void contact_rows(Sp S, V3 r, float* out) {
   V3 u = S.v + cross(S.w, r);
@@ -747,8 +1002,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #define RDV(i, j, f) (inr_on ? INR(LM_IR_ROOT_DOF + 3 * (i) + (j)) : RD(i, f))
   const float nscale = inr_on ? INR(LM_IR_SCALE) : P.scale;
 #define GE(g, f) gtp[((g) * LM_G_SIZE + (f)) * LM_NCHAIN + c]
-#define GP(g, f) cm[oz + P.off_prune + ((g) * LM_P_SIZE + (f)) * LM_NCHAIN + c]
-#define CU(i, f) cm[oz + P.off_cunsup + ((i) * LM_U_SIZE + (f)) * LM_NCHAIN + c]
+  // the chain's tail lists (prune records, collider-less geoms, geom groups, link pairs): contiguous per chain, start in the chain block
+#define GP(g, f) cm[oz + (int)CH(LM_C_OFF_PRUNE) + (g) * LM_P_SIZE + (f)]
+#define CU(i, f) cm[oz + (int)CH(LM_C_OFF_CUNSUP) + (i) * LM_U_SIZE + (f)]
 #define SL(s, f) lmem[((s) * LMm::kSlot + (f)) * ls]
 #define PEER(dl, i) Q::peer(lmem, ls, (i), (dl))
 #define DAMP_R(i) (DR ? dp->damp[(long long)(int)RD(i, LM_D_DOF) * dp->stride] : RD(i, LM_D_DAMP))
@@ -817,11 +1073,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // keeps only small vectors in registers.
   using LMm = LaneMemFor<MC, NS, NM, PAIRS, CONE>;
   // slot field offsets of THIS kernel's record layout (shadow the namespace-scope enumerators of the full layout)
-  constexpr bool kCompactSlots = (CONE == 0) && !PAIRS;
+  constexpr bool kCompactSlots = (CONE == 0);
   constexpr int SL_D = kCompactSlots ? (int)SLC_D : (int)lm::SL_D, SL_FR = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_FR;
   constexpr int SL_AREF = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_AREF, SL_JAR = kCompactSlots ? (int)SLC_JAR : (int)lm::SL_JAR;
   constexpr int SL_JV = kCompactSlots ? (int)SLC_JV : (int)lm::SL_JV, SL_ZONE = kCompactSlots ? (int)SLC_ZONE : (int)lm::SL_ZONE;
   constexpr int SL_GRF = kCompactSlots ? (int)SLC_GRF : (int)lm::SL_GRF;
+  constexpr int SL_PART = kCompactSlots ? (int)SLC_SIZE : (int)lm::SL_PART;
+  constexpr int SL_NX = SL_PART + 1, SL_NY = SL_PART + 2, SL_NZ = SL_PART + 3;
   (void)SL_FR;
 #define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
@@ -915,9 +1173,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       };
       // two levels: the geoms of a link (or of the root body: link -1, this lane's share) form a group with a bounding sphere;
       // a link high above the floor costs one test per pass
-      const int ngroups = (int)CH(LM_C_NLGROUP);
+      const int ngroups = (int)CH(LM_C_NLGROUP), off_lgroup_c = (int)CH(LM_C_OFF_LGROUP);
       for (int gi = 0; gi < ngroups; gi++) {
-#define LG(f) cm[oz + P.off_lgroup + (gi * LM_LG_SIZE + (f)) * LM_NCHAIN + c]
+#define LG(f) cm[oz + off_lgroup_c + gi * LM_LG_SIZE + (f)]
         const int glink = (int)LG(0), gfirst = (int)LG(1), gend = gfirst + (int)LG(2);
         {
           const int fbg = LMm::kFrame + (glink < 0 ? 0 : glink) * 18;
@@ -1065,12 +1323,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         emit_floor_slot(nslot, g, k, V, margin, sv.x, sv.y, sv.z);
         nslot++;
         // further contacts at the hull-graph neighbours of the support vertex (the engine's "up to 3 more contacts from mesh",
-        // DESIGN.md §2 item 10): penetrating, nearest first, none closer than G_SZ to a contact already found. Every replica
+        // DESIGN.md §2 item 10): penetrating, nearest first, none closer than G_SZ to the SUPPORT contact. Every replica
         // walks the (short) list itself, so all of them write the same slots.
         {
           const float tol2 = GE(g, LM_G_SZ) * GE(g, LM_G_SZ);
-          V3 cp[4];
-          cp[0] = v3(sv.x, sv.y, 0.5f * sv.z);
+          const V3 cp0 = v3(sv.x, sv.y, 0.5f * sv.z);
           int nc = 1;
           for (int e = (int)vp[3]; nc < 4; e++) {
             const int j = (int)P.meshn[e];
@@ -1078,12 +1335,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const float* vj = P.meshv + 4 * (v0 + j);
             const V3 wj = pk + mul(Rk, v3(vj[0], vj[1], vj[2]));
             if (wj.z > margin) continue;
-            const V3 pj = v3(wj.x, wj.y, 0.5f * wj.z);
-            bool close = false;
-#pragma unroll
-            for (int q = 0; q < 3; q++) if (q < nc) { const V3 d = pj - cp[q]; if (dot(d, d) < tol2) close = true; }
-            if (close) continue;
-            cp[nc] = pj; nc++;
+            const V3 dj = v3(wj.x, wj.y, 0.5f * wj.z) - cp0;
+            if (dot(dj, dj) < tol2) continue;
+            nc++;
             if (nslot >= NS) { n_overflow += (Q::rep() == 0) ? 1 : 0; continue; }
             emit_floor_slot(nslot, g, k, V, margin, wj.x, wj.y, wj.z);
             nslot++;
@@ -1133,34 +1387,401 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (c == 0 && Q::rep() == 0) cnt.pair_passes++;
       Q::quad_sync();                // the peers' frames and sphere centres are read below
       const V3 rootc = O + mul(R, v3(rb[LM_R_BSX], rb[LM_R_BSY], rb[LM_R_BSZ]));
-      const int nlp = (int)CH(LM_C_NLPAIR);
+      const int nlp = (int)CH(LM_C_NLPAIR), off_lpair_c = (int)CH(LM_C_OFF_LPAIR);
       int n_over = 0;
+      // ---- convex pairs (geom-pair kind 2): the engine's general convex collider = libccd's Minkowski Portal Refinement driven
+      // by the engine's support / centre callbacks (oracle/oracle.c: mpr_penetration is the float64 restatement this follows
+      // step by step). One support call site: the phases of the algorithm are a small state machine around it. Both shapes are
+      // inflated by margin / 2 along the search direction; result: normal from geom 1 to geom 2, contact point (relative to O)
+      // midway between the two witness points, distance = margin - depth. The portal (4 points x (v, v1)) lives in the part of lane
+      // memory that holds the inertia matrix later in the pass (dead here); the support search of a hull climbs its vertex graph.
+      // Both lanes of a cross-chain pair run it on the same numbers: identical results, mirror slots.
+      // Work queue of the convex pairs: the passes over entries / body pairs / geom pairs only COLLECT the pairs whose bounding
+      // capsules are within the margin; MPR then runs for all lanes of the wave at the same time, one queued pair per replica (in a
+      // SIMT machine the collider called from inside the divergent loops would run once per lane, one after the other). Queue,
+      // results and portals sit in the part of lane memory that holds M, the twists and the link images later in the pass.
+      constexpr int kQueue = (MC >= 5) ? 24 : 8;                      // queued pairs per lane and pass (more: counted as dropped contacts)
+      constexpr int kQRes_n = (NS < 8) ? 4 : 8;                       // contacts the queue can hand back
+      constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue, kPortal = kQRes + 7 * kQRes_n;
+      static_assert(!PAIRS || kPortal + 18 * 4 <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
+      int nq = 0;
+      auto mpr_contact = [&](const float* rec, bool g1own, V3 po_, const M3& Ro_, V3 pp_, const M3& Rp_, float pmargin,
+                             V3& nrm, V3& cpo, float& dist_out) -> bool {
+        const V3 pw[2] = {(g1own ? po_ : pp_) - O, (g1own ? pp_ : po_) - O};
+        const M3* Rw[2] = {g1own ? &Ro_ : &Rp_, g1own ? &Rp_ : &Ro_};
+        const float hmg = 0.5f * pmargin, eps = 1.1920929e-7f;
+        auto sgn = [](float x) -> float { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); };
+        auto unit = [](V3 a) -> V3 { return (1.0f / sqrtf(fmaxf(dot(a, a), 1e-37f))) * a; };
+        int hint[2] = {-1, -1};            // where the hill climbing of either hull starts: its previous support vertex
+        auto support1 = [&](int which, V3 d) -> V3 {
+          const M3& Rl = *Rw[which];
+          const float* cap = rec + (which ? LM_GP_P2 : LM_GP_P1);        // bounding capsule: centre 3, axis 3, half length, radius
+          const float* x = rec + (which ? LM_GP_X2 : LM_GP_X1);
+          const V3 dl = v3(Rl.a[0] * d.x + Rl.a[3] * d.y + Rl.a[6] * d.z, Rl.a[1] * d.x + Rl.a[4] * d.y + Rl.a[7] * d.z,
+                           Rl.a[2] * d.x + Rl.a[5] * d.y + Rl.a[8] * d.z);
+          const int type = (int)x[LM_GX_TYPE];
+          V3 loc = v3(0, 0, 0);
+          if (type == LM_GEOM_MESH) {
+            // hill climbing on the hull's vertex graph from the vertex the previous search of this geom ended at (the engine's own
+            // support search for meshes with a graph): a handful of steps x ~6 neighbours instead of a scan over every vertex.
+            // P.meshadj: per vertex a block [x y z degree][neighbour x y z, neighbour's block]...: one step = one contiguous block,
+            // its header and first eight neighbours fetched together (one memory round trip per step)
+            const F4* A = reinterpret_cast<const F4*>(P.meshadj);
+            int cur = hint[which];
+            if (cur < 0) {                  // first search of this pair: from the hull's extreme vertex along the dominant axis of the direction
+              const float ax_ = fabsf(dl.x), ay_ = fabsf(dl.y), az_ = fabsf(dl.z);
+              const int k = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
+              const float comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
+              cur = (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0f) ? 1 : 0)];
+            }
+            float best = -3.0e38f;
+#pragma nounroll
+            for (int step = 0; step < 256; step++) {
+              const F4 h = A[cur];
+              F4 e[8];
+#pragma unroll
+              for (int j = 0; j < 8; j++) e[j] = A[cur + 1 + j];          // (beyond the block's end for a lower degree: ignored; the table is padded)
+              const int deg = (int)h.w;
+              if (step == 0) { best = dl.x * h.x + dl.y * h.y + dl.z * h.z; loc = v3(h.x, h.y, h.z); }
+              int nxt = cur;
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                const float dd = dl.x * e[j].x + dl.y * e[j].y + dl.z * e[j].z;
+                if (j < deg && dd > best) { best = dd; nxt = (int)e[j].w; loc = v3(e[j].x, e[j].y, e[j].z); }
+              }
+#pragma nounroll
+              for (int j = 8; j < deg; j++) {
+                const F4 ej = A[cur + 1 + j];
+                const float dd = dl.x * ej.x + dl.y * ej.y + dl.z * ej.z;
+                if (dd > best) { best = dd; nxt = (int)ej.w; loc = v3(ej.x, ej.y, ej.z); }
+              }
+              if (nxt == cur) break;
+              cur = nxt;
+            }
+            hint[which] = cur;
+          } else {
+            const V3 ctr = v3(cap[0], cap[1], cap[2]), ax = v3(cap[3], cap[4], cap[5]);
+            if (type == LM_GEOM_BOX) {
+              const V3 ex = v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
+              const V3 ez = cross(ex, ey);
+              loc = ctr + (sgn(dot(dl, ex)) * x[LM_GX_E0]) * ex + (sgn(dot(dl, ey)) * x[LM_GX_E0 + 1]) * ey + (sgn(dot(dl, ez)) * x[LM_GX_E0 + 2]) * ez;
+            } else if (type == LM_GEOM_CYLINDER) {
+              const float da = dot(dl, ax);
+              const V3 perp = dl + (-da) * ax;
+              const float t = sqrtf(dot(perp, perp));
+              loc = ctr + (sgn(da) * cap[6]) * ax;
+              if (t > 1e-15f) loc = loc + (cap[7] / t) * perp;
+            } else loc = ctr + cap[7] * dl + (sgn(dot(dl, ax)) * cap[6]) * ax;          // sphere (half length 0), capsule
+          }
+          return pw[which] + mul(Rl, loc) + hmg * d;
+        };
+        const int pb = kPortal + 18 * Q::rep() - 6;          // every replica works on a pair of its own: a portal each (points 1..3; point 0 stays in registers)
+        auto pv = [&](int q) -> V3 { return v3(LMEM(pb + 6 * q), LMEM(pb + 6 * q + 1), LMEM(pb + 6 * q + 2)); };
+        auto pv1 = [&](int q) -> V3 { return v3(LMEM(pb + 6 * q + 3), LMEM(pb + 6 * q + 4), LMEM(pb + 6 * q + 5)); };
+        auto put = [&](int q, V3 v, V3 v1) {
+          LMEM(pb + 6 * q) = v.x; LMEM(pb + 6 * q + 1) = v.y; LMEM(pb + 6 * q + 2) = v.z;
+          LMEM(pb + 6 * q + 3) = v1.x; LMEM(pb + 6 * q + 4) = v1.y; LMEM(pb + 6 * q + 5) = v1.z;
+        };
+        const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
+        const V3 c1 = pw[0] + mul(*Rw[0], v3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ]));
+        const V3 c2 = pw[1] + mul(*Rw[1], v3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ]));
+        V3 v0 = c1 - c2;
+        if (fabsf(v0.x) < eps && fabsf(v0.y) < eps && fabsf(v0.z) < eps) v0.x += 10.0f * eps;
+        auto portal_dir = [&]() -> V3 { const V3 a1 = pv(1); return unit(cross(pv(2) - a1, pv(3) - a1)); };
+        auto expand = [&](V3 v4, V3 v41) {
+          const V3 cr = cross(v4, v0);
+          int q;
+          if (dot(pv(1), cr) > 0.0f) q = (dot(pv(2), cr) > 0.0f) ? 1 : 3;
+          else q = (dot(pv(3), cr) > 0.0f) ? 2 : 1;
+          put(q, v4, v41);
+        };
+        {
+          // one-direction separation test first: along the line between the closest points of the two bounding capsules. Shapes
+          // (inflated by margin / 2 each) that are apart along ANY direction do not overlap - the portal search below would say so
+          // after five or six support searches, this says it after two, and most queued pairs end here
+          const V3 cA = pw[0] + mul(*Rw[0], v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2])), aA = mul(*Rw[0], v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
+          const V3 cB = pw[1] + mul(*Rw[1], v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2])), aB = mul(*Rw[1], v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
+          float sa, ta;
+          segment_closest(cA, aA, rec[LM_GP_H1], cB, aB, rec[LM_GP_H2], sa, ta);
+          const V3 dsep = (cB + ta * aB) - (cA + sa * aA);
+          if (dot(dsep, dsep) > 1e-12f) {
+            const V3 du = unit(dsep);
+            V3 sp[2];
+#pragma nounroll
+            for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : -1.0f * du);
+            if (dot(sp[0] - sp[1], du) < 0.0f) return false;
+          }
+        }
+        V3 dir = unit(-1.0f * v0);
+        int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
+        int nsupport = 0; (void)nsupport;
+#pragma nounroll
+        for (int guard = 0; guard < 128 && result == 0; guard++) {
+          nsupport++;
+          V3 sup[2];
+#pragma nounroll
+          for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : -1.0f * dir);
+          const V3 sv = sup[0] - sup[1];
+          const float dt = dot(sv, dir);
+          if (stage == 0) {
+            put(1, sv, sup[0]);
+            if (dt < eps) { result = -1; break; }
+            dir = cross(v0, sv);
+            if (dot(dir, dir) < eps * eps) { result = (dot(sv, sv) < eps * eps) ? -1 : 2; break; }     // touching at v1: no normal | origin on v0-v1
+            dir = unit(dir);
+            stage = 1;
+          } else if (stage == 1) {
+            if (dt < eps) { result = -1; break; }
+            put(2, sv, sup[0]);
+            dir = unit(cross(pv(1) - v0, sv - v0));
+            if (dot(dir, v0) > 0.0f) { const V3 a = pv(1), a1 = pv1(1); put(1, sv, sup[0]); put(2, a, a1); dir = -1.0f * dir; }
+            stage = 2;
+          } else if (stage == 2) {
+            if (dt < eps) { result = -1; break; }
+            put(3, sv, sup[0]);
+            bool cont = false;
+            if (dot(cross(pv(1), sv), v0) < -eps) { put(2, sv, sup[0]); cont = true; }
+            else if (dot(cross(sv, pv(2)), v0) < -eps) { put(1, sv, sup[0]); cont = true; }
+            if (cont) dir = unit(cross(pv(1) - v0, pv(2) - v0));
+            else {
+              dir = portal_dir();
+#ifdef LM_PAIR_TRACE
+              if (getenv("LM_MPR_TRACE")) { const V3 a_ = pv(1), b_ = pv(2), c_ = pv(3); printf(" d discovered: v0 %.6f %.6f %.6f | v1 %.6f %.6f %.6f | v2 %.6f %.6f %.6f | v3 %.6f %.6f %.6f\n", v0.x, v0.y, v0.z, a_.x, a_.y, a_.z, b_.x, b_.y, b_.z, c_.x, c_.y, c_.z); }
+#endif
+              stage = (dot(dir, pv(1)) >= -eps) ? 4 : 3;          // the portal already holds the origin: straight to the penetration phase
+            }
+          } else {
+            // reach of the new support point beyond the portal along dir
+            const float reach = fminf(fminf(dt - dot(pv(1), dir), dt - dot(pv(2), dir)), dt - dot(pv(3), dir));
+#ifdef LM_PAIR_TRACE
+            if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, dot(pv(1), dir), reach);
+#endif
+            if (stage == 3) {
+              if (dt < -eps || reach <= 1e-6f) { result = -1; break; }
+              expand(sv, sup[0]);
+              dir = portal_dir();
+              if (dot(dir, pv(1)) >= -eps) stage = 4;
+            } else {
+              if (reach <= 1e-6f || iter > 50) { result = 1; break; }
+              expand(sv, sup[0]);
+              dir = portal_dir();
+              iter++;
+            }
+          }
+        }
+#ifdef LM_PAIR_TRACE
+        printf("   mpr lane %d rep %d result %d stage %d iter %d supports %d types %d %d\n", c, Q::rep(), result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
+#endif
+        if (result <= 0) return false;
+        float depth; V3 pdir, pos;
+        if (result == 2) {
+          const V3 v1 = pv(1), s1 = pv1(1);
+          depth = sqrtf(dot(v1, v1)); pdir = unit(v1);
+          pos = 0.5f * (s1 + (s1 - v1));
+        } else {
+          // closest point of the portal triangle to the origin (libccd: ccdVec3PointTriDist2) -> depth and direction
+          const V3 a = pv(1), b = pv(2), cc = pv(3);
+          const V3 d1 = b - a, d2 = cc - a;
+          const float v = dot(d1, d1), w = dot(d2, d2), pq = dot(a, d1), qq = dot(a, d2), r = dot(d1, d2);
+          const float det = w * v - r * r;
+          float sb = -1.0f, tb = -1.0f;
+          if (fabsf(det) > 1e-30f) { sb = (qq * r - w * pq) / det; tb = (-sb * r - qq) / w; }
+          V3 wit;
+          if (sb >= -eps && sb <= 1.0f + eps && tb >= -eps && tb <= 1.0f + eps && sb + tb <= 1.0f + eps) wit = a + sb * d1 + tb * d2;
+          else {
+            auto seg = [&](V3 x0, V3 x1e, V3& wout) -> float {
+              const V3 dd = x1e - x0;
+              float t = -dot(x0, dd) / fmaxf(dot(dd, dd), 1e-37f);
+              t = fminf(fmaxf(t, 0.0f), 1.0f);
+              wout = x0 + t * dd;
+              return dot(wout, wout);
+            };
+            V3 w2;
+            float best = seg(a, b, wit);
+            float d = seg(a, cc, w2); if (d < best) { best = d; wit = w2; }
+            d = seg(b, cc, w2); if (d < best) { best = d; wit = w2; }
+          }
+          depth = sqrtf(dot(wit, wit));
+          pdir = (dot(wit, wit) < eps * eps) ? dir : unit(wit);
+          // barycentric coordinates of the origin in the portal tetrahedron -> witness points on the two shapes
+          const V3 p0 = v0;
+          float bc[4];
+          bc[0] = dot(cross(a, b), cc); bc[1] = dot(cross(cc, b), p0); bc[2] = dot(cross(p0, a), cc); bc[3] = dot(cross(b, a), p0);
+          float sum = (bc[0] + bc[1]) + (bc[2] + bc[3]);
+          if (!(sum > 1e-24f)) {
+            const V3 pd = portal_dir();
+            bc[0] = 0.0f; bc[1] = dot(cross(b, cc), pd); bc[2] = dot(cross(cc, a), pd); bc[3] = dot(cross(a, b), pd);
+            sum = bc[1] + bc[2] + bc[3];
+          }
+          const float inv = 1.0f / sum;
+          V3 q1 = bc[0] * c1, q2 = bc[0] * c2;
+#pragma unroll
+          for (int q = 1; q < 4; q++) { const V3 s1 = pv1(q), vv = pv(q); q1 = q1 + bc[q] * s1; q2 = q2 + bc[q] * (s1 - vv); }
+          pos = (0.5f * inv) * (q1 + q2);
+        }
+        // the engine's mjc_fixNormal: a sphere / capsule in the pair takes the direction from its centre line to the contact point
+        {
+          V3 nn[2]; bool have[2] = {false, false};
+#pragma unroll
+          for (int w = 0; w < 2; w++) {
+            const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
+            const int type = (int)x[LM_GX_TYPE];
+            if (type == LM_GEOM_SPHERE || type == LM_GEOM_CAPSULE) {
+              const float* cap = rec + (w ? LM_GP_P2 : LM_GP_P1);
+              const V3 ctr = pw[w] + mul(*Rw[w], v3(cap[0], cap[1], cap[2])), ax = mul(*Rw[w], v3(cap[3], cap[4], cap[5]));
+              const V3 rel = pos - ctr;
+              const float t = fminf(fmaxf(dot(rel, ax), -cap[6]), cap[6]);
+              nn[w] = unit(rel + (-t) * ax); have[w] = true;
+            }
+          }
+          if (have[0] && have[1]) pdir = unit(nn[0] - nn[1]);
+          else if (have[0]) pdir = nn[0];
+          else if (have[1]) pdir = -1.0f * nn[1];
+        }
+        nrm = pdir; cpo = pos; dist_out = pmargin - depth;
+        return true;
+      };
+      struct EntryCtx { int ka, kb, lb, own_q, dl; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
+      auto entry_ctx = [&](int i, EntryCtx& E) {
+        const int code = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 0];
+        E.ka = code & 7; E.kb = (code >> 3) & 7; E.lb = (code >> 6) & 3; E.own_q = (code >> 8) & 1; E.dl = E.lb - c;
+        E.same_lane = E.kb != 7 && E.lb == c;             // two links of my own chain: the entry (and its slots) live in this lane only
+      };
+      auto entry_frames = [&](EntryCtx& E) {               // own / partner link frame and velocity
+        E.pp = O; E.Rp = R; E.Vp = Vroot;
+        {
+          const int fb = LMm::kFrame + E.ka * 18;
+          E.po = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+#pragma unroll
+          for (int j = 0; j < 9; j++) E.Ro.a[j] = LMEM(fb + 3 + j);
+          E.Vo.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); E.Vo.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+        }
+        if (E.kb != 7) {
+          const int fb = LMm::kFrame + E.kb * 18, dl = E.dl;
+          E.pp = v3(PEER(dl, fb), PEER(dl, fb + 1), PEER(dl, fb + 2));
+#pragma unroll
+          for (int j = 0; j < 9; j++) E.Rp.a[j] = PEER(dl, fb + 3 + j);
+          E.Vp.w = v3(PEER(dl, fb + 12), PEER(dl, fb + 13), PEER(dl, fb + 14)); E.Vp.v = v3(PEER(dl, fb + 15), PEER(dl, fb + 16), PEER(dl, fb + 17));
+        }
+      };
+      // one self-contact -> slot record (every replica writes the same words)
+      auto emit_pair_slot = [&](const EntryCtx& E, const float* rec, bool g1own, V3 nrm, V3 cp, float dist) {
+        const float pmargin = rec[LM_GP_MARGIN];
+        if (nslot >= NS) { n_over++; return; }
+        V3 t1, t2;
+        make_frame(nrm, t1, t2);
+        const int slot = nslot++;
+        SL(slot, SL_LINK) = (float)E.ka; SL(slot, SL_GRF) = -1.0f;
+        SL(slot, SL_PART) = (g1own ? -1.0f : 1.0f) * (float)(1 + ((E.kb == 7) ? 0 : E.lb) * 8 + E.kb);
+        SL(slot, SL_NX) = nrm.x; SL(slot, SL_NY) = nrm.y; SL(slot, SL_NZ) = nrm.z;
+        SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
+        if (E.kb != 7 && !E.same_lane) pair_mask |= 1 << E.lb;
+        // relative velocity of body 2 against body 1 at the contact point, in the contact frame
+        Sp Vrel = g1own ? (E.Vp + (-1.0f) * E.Vo) : (E.Vo + (-1.0f) * E.Vp);
+        float vel[6];
+        frame_rows(Vrel, cp, nrm, t1, t2, vel);
+        const float imp = impedance(rec + LM_GP_S0, 1, dist, pmargin);
+        const float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * rec[LM_GP_TRAN]);
+        const float Bp = rec[LM_GP_B], Kr = rec[LM_GP_K] * imp * (dist - pmargin);
+        const int dim = (int)rec[LM_GP_DIM];
+        const float mu = rec[LM_GP_MU];
+        SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = mu; SL(slot, SL_D) = D0;
+        if (PYR3(dim)) {
+          // pyramid edges in the slot's own frame (a frictionless condim-1 pair arrives as mu = 0: four coinciding edges)
+          float xv[4];
+          pyr_rows(vel, mu, xv);
+#pragma unroll
+          for (int r = 0; r < 4; r++) SL(slot, SL_AREF + r) = -Bp * xv[r] - Kr;
+        } else {
+#pragma unroll
+          for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / rec[LM_GP_RR1 + j2 - 1] : 0.0f; SL(slot, SL_FR + j2 - 1) = rec[LM_GP_F0 + j2 - 1]; }
+#pragma unroll
+          for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -Bp * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
+        }
+        if (Q::rep() == 0 && (g1own || E.kb == 7 || E.same_lane)) cnt.selfcon++;
+      };
+      // work the queue off in rounds: replica r takes pair kRep * round + r. A pair first meets a one-direction separation test (the
+      // direction between the closest points of the two bounding capsules: when the hulls, inflated by the margin, are apart along
+      // it, the convex collider would find them apart too — two support searches instead of five or six), then MPR. Contacts go
+      // to the result area in queue order (the replicas agree on the positions by exchanging their found flags each round);
+      // afterwards every replica records them as slots.
+      auto flush_queue = [&]() {
+        Q::fence();
+        int nres = 0;
+        const int nrounds = (nq + Q::kRep - 1) / Q::kRep;
+#pragma nounroll
+        for (int round = 0; round < nrounds; round++) {
+          const int t = round * Q::kRep + Q::rep();
+          bool found = false;
+          V3 nrm = v3(0, 0, 0), cp = v3(0, 0, 0); float dist = 0.0f;
+          if (t < nq) {
+            const int item = (int)LMEM(kQItem + t);
+            EntryCtx E;
+            entry_ctx(item >> 16, E);
+            entry_frames(E);
+            const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
+            const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
+#ifndef LM_NO_MPR
+            found = mpr_contact(rec, g1own, E.po, E.Ro, E.pp, E.Rp, rec[LM_GP_MARGIN], nrm, cp, dist);
+#endif
+          }
+          // where do my results go: behind those of this round's lower replicas
+          int before = 0, total = found ? 1 : 0;
+          if (Q::kRep > 1) {
+            total = 0;
+#pragma unroll
+            for (int r = 0; r < Q::kRep; r++) { const int f_r = (int)Q::rep_bcast(found ? 1.0f : 0.0f, r); if (r < Q::rep()) before += f_r; total += f_r; }
+          }
+          if (found) {
+            const int k = nres + before;
+            if (k < kQRes_n) {
+              LMEM(kQRes + 7 * k) = dist;
+              LMEM(kQRes + 7 * k + 1) = nrm.x; LMEM(kQRes + 7 * k + 2) = nrm.y; LMEM(kQRes + 7 * k + 3) = nrm.z;
+              LMEM(kQRes + 7 * k + 4) = cp.x; LMEM(kQRes + 7 * k + 5) = cp.y; LMEM(kQRes + 7 * k + 6) = cp.z;
+              LMEM(kQItem + t) = -LMEM(kQItem + t) - 1.0f;       // mark: this item has a result (the marked items own the results in order)
+            }
+          }
+          nres += total;
+        }
+        if (nres > kQRes_n) { n_over += nres - kQRes_n; nres = kQRes_n; }
+        Q::fence();
+        // the marked items, in queue order, own the results 0, 1, ... in the same order
+        int k = 0;
+#pragma nounroll
+        for (int t = 0; t < nq && k < nres; t++) {
+          const float raw = LMEM(kQItem + t);
+          if (!(raw < 0.0f)) continue;
+          const int item = (int)(-raw - 1.0f);
+          EntryCtx E;
+          entry_ctx(item >> 16, E);
+          entry_frames(E);
+          const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
+          const float dist = LMEM(kQRes + 7 * k);
+          const V3 nrm = v3(LMEM(kQRes + 7 * k + 1), LMEM(kQRes + 7 * k + 2), LMEM(kQRes + 7 * k + 3));
+          const V3 cp = v3(LMEM(kQRes + 7 * k + 4), LMEM(kQRes + 7 * k + 5), LMEM(kQRes + 7 * k + 6));
+          k++;
+#ifdef LM_PAIR_TRACE
+          if (Q::rep() == 0) printf("   contact lane %d entry %d rec %d kind 2 dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, item >> 16, item & 65535, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
+#endif
+          emit_pair_slot(E, rec, ((int)rec[LM_GP_G1Q] == E.own_q), nrm, cp, dist);
+        }
+        nq = 0;
+        Q::fence();
+      };
       for (int i = 0; i < nlp; i++) {
-        const int code = (int)cm[oz + P.off_lpair + (i * LM_LP_SIZE + 0) * LM_NCHAIN + c];
-        const int ka = code & 7, kb = (code >> 3) & 7, lb = (code >> 6) & 3, own_q = (code >> 8) & 1, dl = lb - c;
+        EntryCtx E;
+        entry_ctx(i, E);
+        const int ka = E.ka, kb = E.kb, lb = E.lb, own_q = E.own_q, dl = E.dl;
         const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
         const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
         const V3 dc = cb - ca;
-        const float d2c = dot(dc, dc), thr2 = cm[oz + P.off_lpair + (i * LM_LP_SIZE + 2) * LM_NCHAIN + c];
+        const float d2c = dot(dc, dc), thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
         // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
         if (!(d2c < thr2)) { gap_min = fminf(gap_min, sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD); continue; }
-        // ---- narrow phase over the geom pairs of this link pair
-        const int rng = (int)cm[oz + P.off_lpair + (i * LM_LP_SIZE + 1) * LM_NCHAIN + c], first = rng & 4095, npairs = rng >> 12;
-        V3 po, pp = O; M3 Ro, Rp = R; Sp Vo, Vp = Vroot;       // own / partner link frame and velocity
-        {
-          const int fb = LMm::kFrame + ka * 18;
-          po = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
-#pragma unroll
-          for (int j = 0; j < 9; j++) Ro.a[j] = LMEM(fb + 3 + j);
-          Vo.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); Vo.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
-        }
-        if (kb != 7) {
-          const int fb = LMm::kFrame + kb * 18;
-          pp = v3(PEER(dl, fb), PEER(dl, fb + 1), PEER(dl, fb + 2));
-#pragma unroll
-          for (int j = 0; j < 9; j++) Rp.a[j] = PEER(dl, fb + 3 + j);
-          Vp.w = v3(PEER(dl, fb + 12), PEER(dl, fb + 13), PEER(dl, fb + 14)); Vp.v = v3(PEER(dl, fb + 15), PEER(dl, fb + 16), PEER(dl, fb + 17));
-        }
+        // ---- mid phase over the body pairs of this link pair, narrow phase over the geom pairs of those in reach
+        const int rng = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 1], bfirst = rng & 65535, nbp = rng >> 16;
+        entry_frames(E);
+        const V3 po = E.po, pp = E.pp; const M3& Ro = E.Ro; const M3& Rp = E.Rp;
         // geometry of geom pair j: closest points of the two capsule segments (same arithmetic in both lanes of a cross pair)
         struct PairGeom { V3 c1, c2, q1, dq; float r1, r2, dd, dist; bool g1own; };
         auto pair_geom = [&](const float* rec) -> PairGeom {
@@ -1180,68 +1801,81 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           G.dd = sqrtf(dot(G.dq, G.dq)); G.dist = G.dd - G.r1 - G.r2;
           return G;
         };
-        // ---- phase 1, dealt to the replicas (the records come from global memory: latency-bound): which geom pairs are within
-        // their margin? Bit j of `hit`. Only pairs WITH a collider hold the next detection back (gap_min): the bounding capsules
-        // of the counted-only pairs (trunk cylinders against the thighs ...) sit millimetres apart in every gait; those are
-        // looked at in the first pass of a control step only.
-        float hit = 0.0f;
-        for (int j = Q::rep(); j < npairs; j += Q::kRep) {
-          const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
-          const bool counted_only = rec[LM_GP_KIND] != 0.0f;
-          if (counted_only && !first_detect) continue;
-          const PairGeom G = pair_geom(rec);
-          const float pmargin = rec[LM_GP_MARGIN];
-#ifdef LM_PAIR_TRACE
-          if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f\n", c, i, first + j, rec[LM_GP_KIND], G.dist);
-#endif
-          if (!counted_only) gap_min = fminf(gap_min, G.dist - pmargin);
-          if (G.dist < pmargin) hit += (float)(1 << j);
+        // ---- body pairs (dealt to the replicas): one bounding capsule per body; only body pairs within the largest margin of their
+        // geom pairs go on. The others hold the next detection back by their clearance.
+        float bhit = 0.0f;
+        for (int jb = Q::rep(); jb < nbp; jb += Q::kRep) {
+          const float* br = P.bpt + (bfirst + jb) * LM_BP_SIZE;
+          const float* bo = br + (own_q ? LM_BP_P2 : LM_BP_P1); const float* bq = br + (own_q ? LM_BP_P1 : LM_BP_P2);
+          const V3 co = po + mul(Ro, v3(bo[0], bo[1], bo[2])), ao = mul(Ro, v3(bo[3], bo[4], bo[5]));
+          const V3 cq = pp + mul(Rp, v3(bq[0], bq[1], bq[2])), aq = mul(Rp, v3(bq[3], bq[4], bq[5]));
+          float sa, ta;
+          segment_closest(co, ao, bo[6], cq, aq, bq[6], sa, ta);
+          const V3 dq = cq + ta * aq - (co + sa * ao);
+          const float bgap = sqrtf(dot(dq, dq)) - bo[7] - bq[7] - br[LM_BP_MARGIN];
+          if (bgap < 0.0f) bhit += (float)(1 << jb);
+          else gap_min = fminf(gap_min, bgap);
         }
-        if (Q::kRep > 1) hit = Q::rep_sum(hit);                  // disjoint bits: the sum is the union (npairs <= 24: exact)
-        // ---- phase 2, every replica: record the contacts (rare)
-        for (int hm = (int)hit, j = 0; hm != 0; hm >>= 1, j++) {
-          if (!(hm & 1)) continue;
-          const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
-          const PairGeom G = pair_geom(rec);
-          const float pmargin = rec[LM_GP_MARGIN], dist = G.dist;
-          if (rec[LM_GP_KIND] != 0.0f) {                            // no collider for this pair of geom types: counted (once)
-            if ((G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
-            continue;
+        if (Q::kRep > 1) bhit = Q::rep_sum(bhit);
+        for (int bm = (int)bhit, jb = 0; bm != 0; bm >>= 1, jb++) {
+          if (!(bm & 1)) continue;
+          const float* brec = P.bpt + (bfirst + jb) * LM_BP_SIZE;
+          const int first = (int)brec[LM_BP_FIRST], npairs = (int)brec[LM_BP_N];
+          // ---- phase 1, dealt to the replicas (the records come from global memory: latency-bound): which geom pairs are within
+          // their margin? Bit j of `hit`. Only pairs WITH a collider hold the next detection back (gap_min): the bounding capsules
+          // of the counted-only pairs (trunk box against the thighs ...) sit millimetres apart in every gait; those are
+          // looked at in the first pass of a control step only.
+          float hit = 0.0f;
+          for (int j = Q::rep(); j < npairs; j += Q::kRep) {
+            const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
+            const bool counted_only = rec[LM_GP_KIND] == 1.0f;
+            if (counted_only && !first_detect) continue;
+            const PairGeom G = pair_geom(rec);
+            const float pmargin = rec[LM_GP_MARGIN];
+#ifdef LM_PAIR_TRACE
+            if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f\n", c, i, first + j, rec[LM_GP_KIND], G.dist);
+#endif
+            if (!counted_only) gap_min = fminf(gap_min, G.dist - pmargin);
+            if (G.dist < pmargin) hit += (float)(1 << j);
           }
-          // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
-          // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
-          {
-            const V3 cc = G.c2 - G.c1;
-            if (sqrtf(dot(cc, cc)) - (rec[LM_GP_H1] + G.r1) - (rec[LM_GP_H2] + G.r2) > 0.0f) continue;
+          if (Q::kRep > 1) hit = Q::rep_sum(hit);                  // disjoint bits: the sum is the union (npairs <= 24: exact)
+          // ---- phase 2, every replica: closed-form contacts are recorded, convex pairs queued (rare)
+          for (int hm = (int)hit, j = 0; hm != 0; hm >>= 1, j++) {
+            if (!(hm & 1)) continue;
+            const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
+            const PairGeom G = pair_geom(rec);
+            const int kind = (int)rec[LM_GP_KIND];
+            if (kind == 1) {                                          // no collider for this pair of geom types: counted (once)
+              if ((G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
+              continue;
+            }
+            // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
+            // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
+            {
+              const V3 cc = G.c2 - G.c1;
+              const float rb1 = (kind == 2) ? rec[LM_GP_X1 + LM_GX_RBOUND] : rec[LM_GP_H1] + G.r1;
+              const float rb2 = (kind == 2) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
+              if (sqrtf(dot(cc, cc)) - rb1 - rb2 > 0.0f) continue;
+            }
+            if (kind == 2) {
+              if (nq >= kQueue) { n_over++; continue; }                // more convex pairs of this lane in reach than the queue holds: dropped, counted
+              LMEM(kQItem + nq) = (float)(i * 65536 + first + j);
+              nq++;
+              continue;
+            }
+            const float dist = G.dist;
+            const V3 nrm = (G.dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / G.dd) * G.dq;
+            const V3 cp = G.q1 + (G.r1 + 0.5f * dist) * nrm - O;
+#ifdef LM_PAIR_TRACE
+            if (Q::rep() == 0) printf("   contact lane %d entry %d rec %d kind %d dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, i, first + j, kind, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
+#endif
+            emit_pair_slot(E, rec, G.g1own, nrm, cp, dist);
           }
-          if (nslot >= NS) { n_over++; continue; }
-          const V3 nrm = (G.dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / G.dd) * G.dq;
-          V3 t1, t2;
-          make_frame(nrm, t1, t2);
-          const V3 cp = G.q1 + (G.r1 + 0.5f * dist) * nrm - O;
-          const int slot = nslot++;
-          SL(slot, SL_LINK) = (float)ka; SL(slot, SL_GRF) = -1.0f;
-          SL(slot, SL_PART) = (G.g1own ? -1.0f : 1.0f) * (float)(1 + ((kb == 7) ? 0 : lb) * 8 + kb);
-          SL(slot, SL_NX) = nrm.x; SL(slot, SL_NY) = nrm.y; SL(slot, SL_NZ) = nrm.z;
-          SL(slot, SL_T1X) = t1.x; SL(slot, SL_T1Y) = t1.y; SL(slot, SL_T1Z) = t1.z;
-          SL(slot, SL_RX) = cp.x; SL(slot, SL_RY) = cp.y; SL(slot, SL_RZ) = cp.z;
-          if (kb != 7) pair_mask |= 1 << lb;
-          // relative velocity of body 2 against body 1 at the contact point, in the contact frame
-          Sp Vrel = G.g1own ? (Vp + (-1.0f) * Vo) : (Vo + (-1.0f) * Vp);
-          float vel[6];
-          frame_rows(Vrel, cp, nrm, t1, t2, vel);
-          const float imp = impedance(rec + LM_GP_S0, 1, dist, pmargin);
-          const float D0 = imp / fmaxf(kMinVal, (1.0f - imp) * rec[LM_GP_TRAN]);
-          const float Bp = rec[LM_GP_B], Kr = rec[LM_GP_K] * imp * (dist - pmargin);
-          const int dim = (int)rec[LM_GP_DIM];
-          SL(slot, SL_DIM) = (float)dim; SL(slot, SL_MU) = rec[LM_GP_MU]; SL(slot, SL_D) = D0;
-#pragma unroll
-          for (int j2 = 1; j2 < 6; j2++) { SL(slot, SL_D + j2) = (j2 < dim) ? D0 / rec[LM_GP_RR1 + j2 - 1] : 0.0f; SL(slot, SL_FR + j2 - 1) = rec[LM_GP_F0 + j2 - 1]; }
-#pragma unroll
-          for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -Bp * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
-          if (Q::rep() == 0 && (G.g1own || kb == 7)) cnt.selfcon++;
         }
       }
+      LM_TICK(14);              // self-collisions: broad / mid / narrow-phase tests
+      flush_queue();            // every lane of the wave arrives here together: the queued pairs of all of them run side by side
+      LM_TICK(15);              // self-collisions: convex pairs (MPR)
       if (Q::kRep > 1) gap_min = fminf(fminf(Q::rep_bcast(gap_min, 0), Q::rep_bcast(gap_min, 1)), fminf(Q::rep_bcast(gap_min, 2), Q::rep_bcast(gap_min, 3)));
       if (Q::rep() == 0) cnt.overflow += n_over;
       if (pair_slack) *pair_slack = gap_min;
@@ -1435,24 +2069,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (anydup) tie_shared_dof<Q, MC>(Mcc, Mcr, Lrr, a0c, a0r, duprole);
     }
   }
-  // cross-chain contacts: who is coupled with whom (quad-uniform). The factorisation handles a MATCHING (every chain coupled
-  // with at most one other chain); anything else falls back to a block-diagonal majorant of the cross terms (the Newton
-  // direction is then inexact, the solution is not: more iterations) and is counted with the dropped contacts.
+  // cross-chain contacts: who is coupled with whom (quad-uniform bits: 4 i + j = chains i and j share a contact). The
+  // factorisation eliminates the lanes in order and carries the cross blocks along (arrow_factor_g): exact for any pattern.
   bool any_pair = false;
-  int xrole = 0, xpartner = 0;       // 1: lower lane of a coupled pair (keeps the cross block), 2: upper lane
-  bool xmajor = false;
+  int adj0 = 0;
+  constexpr int NX = PAIRS ? ((MC <= 3) ? 3 : 2) : 1;         // cross blocks a lane may hold: chains above it (quadruped 4 chains, humanoids 3)
   if (PAIRS) {
-    const int all = (int)(Q::sum((float)(pair_mask_out << (4 * c))) + 0.5f);
-    any_pair = all != 0;
-    if (any_pair) {
-      bool matching = true;
+    adj0 = (int)(Q::sum((float)(pair_mask_out << (4 * c))) + 0.5f);
+    // symmetric closure (a lane that ran out of slots may lack its mirror of a contact its partner holds)
+    int sym = adj0;
 #pragma unroll
-      for (int l = 0; l < 4; l++) { const int row = (all >> (4 * l)) & 15; if (row & (row - 1)) matching = false; }
-      if (matching) {
-        const int row = (all >> (4 * c)) & 15;
-        if (row) { xpartner = (row & 1) ? 0 : ((row & 2) ? 1 : ((row & 4) ? 2 : 3)); xrole = (xpartner > c) ? 1 : 2; }
-      } else { xmajor = true; if (c == 0 && Q::rep() == 0) cnt.overflow++; }
-    }
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) if ((adj0 >> (4 * i + j)) & 1) sym |= 1 << (4 * j + i);
+    adj0 = sym;
+    any_pair = adj0 != 0;
+    if (MC > 3 && (adj0 >> 12) != 0) any_pair = false;         // (a fourth humanoid chain has no cross-block storage: never lowered with pairs)
   }
   auto ldS = [&](int base) -> Sp {       // twist from lane memory
     Sp S; S.w = v3(LMEM(base), LMEM(base + 1), LMEM(base + 2)); S.v = v3(LMEM(base + 3), LMEM(base + 4), LMEM(base + 5)); return S;
@@ -1526,7 +2158,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // ---- slots of self-contacts (PAIRS): the row space is the motion of body 2 against body 1, the frame is the slot's own
   auto slot_sign = [&](int s) -> float { return PAIRS ? SL(s, SL_PART) : 0.0f; };                 // 0: floor contact
   auto slot_frame = [&](int s, V3& n, V3& t1, V3& t2) {
-    n = v3(SL(s, SL_NX), SL(s, SL_NY), SL(s, SL_NZ)); t1 = v3(SL(s, SL_T1X), SL(s, SL_T1Y), SL(s, SL_T1Z)); t2 = cross(n, t1);
+    n = v3(SL(s, SL_NX), SL(s, SL_NY), SL(s, SL_NZ)); make_frame(n, t1, t2);
   };
   auto peer_twist = [&](int dl, int base) -> Sp {
     Sp S; S.w = v3(PEER(dl, base), PEER(dl, base + 1), PEER(dl, base + 2)); S.v = v3(PEER(dl, base + 3), PEER(dl, base + 4), PEER(dl, base + 5)); return S;
@@ -1551,7 +2183,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   auto slot_weight = [&](int s) -> float {
     if (!PAIRS) return 1.0f;
     const float part = slot_sign(s);
-    return (part != 0.0f && (((int)fabsf(part) - 1) & 7) != 7) ? 0.5f : 1.0f;
+    const int code = (int)fabsf(part) - 1;          // mirrored: the partner is a link of ANOTHER chain (not the root body, not my own chain)
+    return (part != 0.0f && (code & 7) != 7 && (code >> 3) != c) ? 0.5f : 1.0f;
   };
   auto friction_cost = [&](float x, float f, float Rr) -> float {
     if (f <= 0.0f) return 0.0f;
@@ -1585,11 +2218,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         else contact_rows(pick((int)SL(s, SL_LINK)), v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ)), jar);
         const int dim = (int)SL(s, SL_DIM);
         if (PYR3(dim)) {
-          float x[4], f3[3];
+          float x[4], f3[3], cs = 0.0f;
           pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
           for (int r = 0; r < 4; r++) x[r] -= SL(s, SL_AREF + r);
-          pyr_force(x, SL(s, SL_D), SL(s, SL_MU), f3, cost);
+          pyr_force(x, SL(s, SL_D), SL(s, SL_MU), f3, cs);
+          cost += (IP ? slot_weight(s) : 1.0f) * cs;
         } else {
 #pragma unroll
           for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
@@ -1727,9 +2361,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             if constexpr (IP) {
               V3 n, t1, t2;
               slot_frame(s, n, t1, t2);
-              const Sp Fw = ((slot_sign(s) > 0.0f) ? 1.0f : -1.0f) * frame_wrench(fc, rc, n, t1, t2);
+              const float part = slot_sign(s);
+              const Sp Fw = ((part > 0.0f) ? 1.0f : -1.0f) * frame_wrench(fc, rc, n, t1, t2);
+              const int pcode = (int)fabsf(part) - 1, plink = ((pcode >> 3) == c && (pcode & 7) != 7) ? (pcode & 7) : -1;   // partner link of my own chain
 #pragma unroll
-              for (int k = 0; k < MC; k++) if (link == k) Fp[k] = Fp[k] + Fw;
+              for (int k = 0; k < MC; k++) { if (link == k) Fp[k] = Fp[k] + Fw; if (plink == k) Fp[k] = Fp[k] + (-1.0f) * Fw; }
             } else {
               Sp Fw = contact_wrench(fc, rc);
               if (link < 0) Frt = Frt + Fw;
@@ -1784,11 +2420,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       else {
         // ---- Hessian H = M + J^T W J (arrow blocks), factor, Newton direction
         float Hcc[MC * (MC + 1) / 2], Hcr[MC][6], Hpart[21], Hrep[21];
-        float Xc[PAIRS ? MC : 1][PAIRS ? MC : 1];      // cross block H_ab of a pair of coupled chains (kept by the lower lane a)
+        float Xc[NX][PAIRS ? MC : 1][PAIRS ? MC : 1];  // cross blocks H_ab of this chain a with the chains b above it (slot b - a - 1)
 #pragma unroll
-        for (int i = 0; i < (PAIRS ? MC : 1); i++)
+        for (int x = 0; x < NX; x++)
 #pragma unroll
-          for (int j = 0; j < (PAIRS ? MC : 1); j++) Xc[i][j] = 0.0f;
+          for (int i = 0; i < (PAIRS ? MC : 1); i++)
+#pragma unroll
+            for (int j = 0; j < (PAIRS ? MC : 1); j++) Xc[x][i][j] = 0.0f;
         // when the slots are split over the replicas, only replica 0 starts from M (+ unit-row terms); the butterfly
         // sum below then gives every replica M + all contact blocks
         const float own = (split && Q::rep() != 0) ? 0.0f : 1.0f;
@@ -1827,6 +2465,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           float Jc[6 + MC][6];
           float Jp[PAIRS ? MC : 1][6];      // the PARTNER chain's columns of a cross-chain contact (lower lane of the pair only)
           bool cross = false;
+          int xslot = 0;                   // slot of the cross block this contact feeds (partner lane - my lane - 1)
           if constexpr (IP) {
             const float part = slot_sign(s);
             // self-contact: the row space is the motion of body 2 against body 1 -> the root columns vanish, my chain's
@@ -1839,19 +2478,18 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             for (int r = 0; r < 6; r++)
 #pragma unroll
               for (int j = 0; j < 6; j++) Jc[r][j] = 0;
+            const bool own_pair = pl != 7 && pc == c;          // both bodies in my chain: the joints up to the nearer one cancel
 #pragma unroll
             for (int k = 0; k < MC; k++) {
-              if (k <= link) frame_rows(sg * ldS(LMm::kSc + k * 6), rc, n, t1, t2, Jc[6 + k]);
+              const float coef = ((k <= link) ? 1.0f : 0.0f) - ((own_pair && k <= pl) ? 1.0f : 0.0f);
+              if (coef != 0.0f) frame_rows((sg * coef) * ldS(LMm::kSc + k * 6), rc, n, t1, t2, Jc[6 + k]);
               else {
 #pragma unroll
                 for (int j = 0; j < 6; j++) Jc[6 + k][j] = 0;
               }
             }
-            if (pl != 7 && xmajor) {              // no exact cross block: twice my own block majorises the pair's Hessian
-#pragma unroll
-              for (int i = 0; i < 21; i++) Hc[i] *= 2.0f;
-            }
-            cross = pl != 7 && xrole == 1 && pc == xpartner;
+            cross = pl != 7 && !own_pair && pc > c && any_pair;   // the lower lane of the pair keeps the cross block
+            xslot = pc - c - 1;
             if (cross) {
 #pragma unroll
               for (int k = 0; k < MC; k++) {
@@ -1900,7 +2538,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   float d = 0;
 #pragma unroll
                   for (int j = 0; j < 6; j++) d = fmaf(t[j], Jp[b][j], d);
-                  Xc[a - 6][b] += d;
+#pragma unroll
+                  for (int xs = 0; xs < NX; xs++) if (xs == xslot) Xc[xs][a - 6][b] += d;
                 }
               }
             }
@@ -1930,7 +2569,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   float d = 0;
 #pragma unroll
                   for (int j = 0; j < 3; j++) d = fmaf(t[j], Jp[b][j], d);
-                  Xc[a - 6][b] += d;
+#pragma unroll
+                  for (int xs = 0; xs < NX; xs++) if (xs == xslot) Xc[xs][a - 6][b] += d;
                 }
               }
             }
@@ -1946,9 +2586,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         if (split) {
           if (PAIRS && any_pair) {
 #pragma unroll
-            for (int i = 0; i < MC; i++)
+            for (int x = 0; x < NX; x++)
 #pragma unroll
-              for (int j = 0; j < MC; j++) Xc[i][j] = Q::rep_sum(Xc[i][j]);
+              for (int i = 0; i < MC; i++)
+#pragma unroll
+                for (int j = 0; j < MC; j++) Xc[x][i][j] = Q::rep_sum(Xc[x][i][j]);
           }
 #pragma unroll
           for (int i = 0; i < MC * (MC + 1) / 2; i++) Hcc[i] = Q::rep_sum(Hcc[i]);
@@ -1968,11 +2610,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int k = 0; k < MC; k++) sc[k] = -gc[k];
         if (!(P.ablate & 4)) {
           bool coupled = false;
-          if constexpr (PAIRS) coupled = any_pair && !xmajor;
           if constexpr (PAIRS) {
+            coupled = any_pair;
             if (coupled) {
-              arrow_factor_x<Q, MC>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, xrole, xpartner, true);
-              arrow_solve_x<Q, MC>(Hcc, Hcr, Lr, Xc, xrole, xpartner, true, sc, sr);
+              int adj = adj0;
+              arrow_factor_g<Q, MC, NX>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, c, adj);
+              arrow_solve_g<Q, MC, NX>(Hcc, Hcr, Lr, Xc, c, adj, sc, sr);
             }
           }
           if (!coupled) {

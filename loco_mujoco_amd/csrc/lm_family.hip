@@ -1,5 +1,5 @@
 // lm_family.hip — one kernel family (LM_FAMILY) and part (LM_PART) of the step kernels; see lm_step.h.
-// The library links 20 of these objects (parts 0..2 of the families 0..5 and 7, parts 0..1 of the generic family 6) so that `make -j`
+// The library links one object per family and part (parts 0..2 of the families 0..5 and 7..10, parts 0..1 of the generic family 6) so that `make -j`
 // builds them in parallel.
 #include "lm_step.h"
 
@@ -28,6 +28,12 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
   return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART>(L, a, kind);
 #elif LM_FAMILY == 7    // UnitreeG1 with the torso joint welded: two 6-link legs (four 1 mm spheres per foot), two 5-link arms
   return launch_family<6, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 8    // HumanoidTorque with its bone hulls colliding (RK4): floor + self-contacts in eight slots
+  return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART, true>(L, a, kind);
+#elif LM_FAMILY == 9    // UnitreeH1: hip-yaw cylinders and link meshes colliding (Euler)
+  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART, true>(L, a, kind);
+#elif LM_FAMILY == 10   // HumanoidMuscle with its bone hulls colliding
+  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART, true>(L, a, kind);
 #elif LM_PART == 2
   return false;          // the generic family has no kernels with per-environment parameters
 #else

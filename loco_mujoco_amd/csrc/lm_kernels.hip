@@ -26,6 +26,8 @@ struct lm_model {
   int n_gpt_floats;          // its size (0: the model has no self-collision pairs)
   float* d_meshv;            // hull vertices of the mesh colliders
   float* d_meshn;            // their neighbour lists (hull vertex graph)
+  float* d_bpt;              // body-pair table of the self-collision mid phase
+  float* d_meshadj;          // adjacency blocks of the hull vertices (convex-pair collider)
   std::vector<float> nominal;  // [3][nv] damping | stiffness | frictionloss of the model
   lm::Params P; Task T;
   int nroot;
@@ -63,6 +65,8 @@ static int family_of(const lm_batch* b) {
   static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
   const bool pyr3 = T.all_pyr3 && !generic;
   if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;
+  // five-link humanoids whose lowering carries self-collision tables (bone hulls, link meshes, cylinders): the pair families
+  if (big && T.npair > 0 && pyr3) return rk4 ? (T.na == 0 ? 8 : 6) : (T.na == 0 ? 9 : 10);
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return 0;
   if (big && rk4 && T.na == 0 && few && pyr3) return 1;
   if (big && rk4 && T.na == 0 && pyr3) return 2;
@@ -81,7 +85,9 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
       {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {lmk::launch_f1p0, lmk::launch_f1p1, lmk::launch_f1p2},
       {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {lmk::launch_f3p0, lmk::launch_f3p1, lmk::launch_f3p2},
       {lmk::launch_f4p0, lmk::launch_f4p1, lmk::launch_f4p2}, {lmk::launch_f5p0, lmk::launch_f5p1, lmk::launch_f5p2},
-      {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}, {lmk::launch_f7p0, lmk::launch_f7p1, lmk::launch_f7p2}};
+      {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}, {lmk::launch_f7p0, lmk::launch_f7p1, lmk::launch_f7p2},
+      {lmk::launch_f8p0, lmk::launch_f8p1, lmk::launch_f8p2}, {lmk::launch_f9p0, lmk::launch_f9p1, lmk::launch_f9p2},
+      {lmk::launch_f10p0, lmk::launch_f10p1, lmk::launch_f10p2}};
   const int fam = family_of(b);
   if (fam < 0) { g_launch_err = "chains of six links are compiled for Euler, condim-3 pyramids, no muscles only"; return; }
   const LaunchCtx L = {b->stream, b->N, b->epb};
@@ -172,6 +178,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   T.nsub = (int)cmod[LM_H_NSUBSTEPS]; T.reward_type = (int)cmod[LM_H_REWARD_TYPE];
   T.n_chains = (int)cmod[LM_H_NCHAINS]; T.max_links = (int)cmod[LM_H_MAXLINKS]; T.ngrf = (int)cmod[LM_H_NGRF];
   T.max_contacts = (int)cmod[LM_H_MAXCONTACTS];
+  T.npair = (int)cmod[LM_H_NGPAIR];
   {
     // every geom with a device collider is a condim-3 contact under pyramidal cones?
     T.all_pyr3 = (int)cmod[LM_H_CONE] == LM_CONE_PYRAMIDAL;
@@ -192,9 +199,8 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.nv = T.nv;
   P.integrator = (int)cmod[LM_H_INTEGRATOR]; P.cone = (int)cmod[LM_H_CONE]; P.act_position = (int)cmod[LM_H_ACTMODE];
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
-  P.off_runsup = (int)cmod[LM_H_OFF_RUNSUP]; P.off_cunsup = (int)cmod[LM_H_OFF_CUNSUP]; P.off_prune = (int)cmod[LM_H_OFF_PRUNE];
+  P.off_runsup = (int)cmod[LM_H_OFF_RUNSUP];
   P.gt = m->d_gt;
-  P.off_lgroup = (int)cmod[LM_H_OFF_LGROUP]; P.off_lpair = (int)cmod[LM_H_OFF_LPAIR];
   {
     const size_t ngp = (size_t)cmod[LM_H_NGPAIR], off = (size_t)cmod[LM_H_OFF_GPT];
     if (ngp > 0 && n < off + ngp * LM_GPAIR_SIZE) return fail("chain model lacks the geom-pair table");
@@ -223,6 +229,24 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     HIPCHK(hipMemcpy(m->d_meshn, mn.data(), sizeof(float) * mn.size(), hipMemcpyHostToDevice));
     P.meshn = m->d_meshn;
   }
+  {
+    const size_t nbp = (size_t)cmod[LM_H_NBPAIR], off = (size_t)cmod[LM_H_OFF_BPT];
+    if (nbp > 0 && n < off + nbp * LM_BP_SIZE) return fail("chain model lacks the body-pair table");
+    std::vector<float> bp(nbp * LM_BP_SIZE + 1, 0.0f);
+    for (size_t i = 0; i < nbp * LM_BP_SIZE; i++) bp[i] = (float)cmod[off + i];
+    HIPCHK(hipMalloc(&m->d_bpt, sizeof(float) * bp.size()));
+    HIPCHK(hipMemcpy(m->d_bpt, bp.data(), sizeof(float) * bp.size(), hipMemcpyHostToDevice));
+    P.bpt = m->d_bpt;
+  }
+  {
+    const size_t na = (size_t)cmod[LM_H_NMESHADJ], off = (size_t)cmod[LM_H_OFF_MESHADJ];
+    if (na > 0 && n < off + 4 * na) return fail("chain model lacks the hull adjacency blocks");
+    std::vector<float> ma(4 * na + 64, 0.0f);                  // padded: a step of the hill climbing fetches eight entries at once
+    for (size_t i = 0; i < 4 * na; i++) ma[i] = (float)cmod[off + i];
+    HIPCHK(hipMalloc(&m->d_meshadj, sizeof(float) * ma.size()));
+    HIPCHK(hipMemcpy(m->d_meshadj, ma.data(), sizeof(float) * ma.size(), hipMemcpyHostToDevice));
+    P.meshadj = m->d_meshadj;
+  }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
@@ -242,6 +266,8 @@ void lm_model_destroy(lm_model* m) {
   if (m->d_gpt) (void)hipFree(m->d_gpt);
   if (m->d_meshv) (void)hipFree(m->d_meshv);
   if (m->d_meshn) (void)hipFree(m->d_meshn);
+  if (m->d_bpt) (void)hipFree(m->d_bpt);
+  if (m->d_meshadj) (void)hipFree(m->d_meshadj);
   if (m->d_mt) (void)hipFree(m->d_mt);
   delete m;
 }

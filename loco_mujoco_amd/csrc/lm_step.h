@@ -81,7 +81,7 @@ struct QuadDppT {
 using QuadDpp = QuadDppT<1>;
 
 struct Task {
-  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts, all_pyr3;
+  int nv, nu, nobs, ngoal, nsub, reward_type, n_chains, max_links, na, ngrf, cm_used, max_contacts, all_pyr3, npair;
   float rp[8];
 };
 
@@ -449,7 +449,8 @@ struct LaunchCtx { hipStream_t stream; int N, epb; };
 
 // kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
 enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV, LMK_NKINDS };
-constexpr int LMK_NFAMILY = 8;      // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots)
+constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots),
+                                    // 8 / 9 / 10 = five-link humanoids WITH self-collisions (8 slots): RK4 | Euler | Euler + muscles
 
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
@@ -499,5 +500,8 @@ bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const La
 bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int); bool launch_f5p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int); bool launch_f6p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f7p0(const LaunchCtx&, const KArgs&, int); bool launch_f7p1(const LaunchCtx&, const KArgs&, int); bool launch_f7p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f8p0(const LaunchCtx&, const KArgs&, int); bool launch_f8p1(const LaunchCtx&, const KArgs&, int); bool launch_f8p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f9p0(const LaunchCtx&, const KArgs&, int); bool launch_f9p1(const LaunchCtx&, const KArgs&, int); bool launch_f9p2(const LaunchCtx&, const KArgs&, int);
+bool launch_f10p0(const LaunchCtx&, const KArgs&, int); bool launch_f10p1(const LaunchCtx&, const KArgs&, int); bool launch_f10p2(const LaunchCtx&, const KArgs&, int);
 
 }  // namespace lmk

@@ -50,7 +50,10 @@ LINK_SIZE = D_SIZE + L_SIZE
 # G_GRF: ground-reaction-force group of this geom within its chain (0/1), -1 = not reported
 # G_TRAN: elliptic: tran (R_normal = (1-imp)/imp * tran); pyramidal: 2 mu^2 (1+mu^2) tran (shared R of all edges)
 # ---- chain block (LDS, interleaved [field][chain]) = [nlinks, ngeoms, unsupported geoms (count), force-group slots, links...]
-C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_DUPROLE, C_LINKS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_DUPROLE = 0, 1, 2, 3, 4, 5, 6, 7
+# where this chain's tail lists start in the constant table (floats from its beginning): every chain's list is contiguous
+# ([entry][field]) and only as long as the chain needs — a humanoid's trunk has 40 geoms, its legs 8
+C_OFF_CUNSUP, C_OFF_PRUNE, C_OFF_LGROUP, C_OFF_LPAIR, C_LINKS = 8, 9, 10, 11, 12
 # C_DUPROLE: +1 = this chain's first link is SHARED with another chain and this lane owns its dof, -1 = this lane carries the
 # massless copy of that link (a torso with two arms: two chains [torso, arm], one dof for the torso), 0 = neither
 # C_NLPAIR: link-pair entries of the self-collision broad phase that involve this chain
@@ -66,21 +69,33 @@ MAXLG = MAXC + 1
 ROOT_SIZE = R_DOFS + NROOT * D_SIZE
 # ---- the LDS constant table: root block, the chain blocks interleaved [field][chain], then a TAIL whose offsets are
 # header fields (H_OFF_*): it starts right behind the last link slot the model uses, so a robot with 3-link chains and a
-# few geoms ships a short table: [root unsupported geoms x U_SIZE][chain unsupported geoms, interleaved][prune records]
+# few geoms ships a short table: [root unsupported geoms x U_SIZE][chain unsupported geoms, chain by chain][prune records, chain by chain] ...
 CM_ROOT = 0
 CM_CHAINS = ROOT_SIZE
-# ---- self-collisions (kernels compiled with PAIRS): per lane a list of link pairs (LP_SIZE floats each, interleaved
-# [entry][field][chain] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane + 256 * (own link
-# is the pair's SECOND link), range = first geom pair + 4096 * number of geom pairs, squared reach of the two bounding spheres
-MAXLP = 48
+# ---- self-collisions (kernels compiled with PAIRS): per lane a list of link pairs (LP_SIZE floats each, chain by chain
+# [entry][field] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane + 256 * (own link
+# is the pair's SECOND link), range = first body pair + 65536 * number of body pairs (<= 24), squared reach of the two bounding spheres
+MAXLP = 64
 PAIR_PAD = 0.03   # metres: link pairs closer than touching + PAIR_PAD go through the narrow phase (csrc/lm_core.h LM_PAIR_PAD)
 LP_SIZE = 3
-# geom-pair records (global memory): kind (0 sphere/capsule pair with a collider, 1 counted only: bounding capsules of a box /
-# cylinder pair), geom 1 on the pair's second link?, geom 1 / geom 2 as capsules in their link frames (centre, axis, half length,
+# geom-pair records (global memory): kind (0 sphere/capsule pair with a collider, 1 counted only: bounding capsules of a pair the
+# engine collides natively with a box or a sphere against a cylinder, 2 convex pair: MPR), geom 1 on the pair's second link?, geom 1 / geom 2 as capsules in their link frames (centre, axis, half length,
 # radius), then the contact parameters after the engine's mixing rules
 (GP_KIND, GP_G1Q, GP_P1, GP_P1Y, GP_P1Z, GP_A1, GP_A1Y, GP_A1Z, GP_H1, GP_R1, GP_P2, GP_P2Y, GP_P2Z, GP_A2, GP_A2Y, GP_A2Z, GP_H2,
  GP_R2, GP_MARGIN, GP_K, GP_B, GP_S0, GP_S1, GP_S2, GP_S3, GP_S4, GP_TRAN, GP_DIM, GP_MU, GP_F0, GP_F1, GP_F2, GP_F3, GP_F4,
- GP_RR1, GP_RR2, GP_RR3, GP_RR4, GP_RR5, GPAIR_SIZE) = range(40)
+ GP_RR1, GP_RR2, GP_RR3, GP_RR4, GP_RR5, GP_X1) = range(40)
+# kind 2 (convex pair: the engine's MPR collider, csrc/lm_core.h mpr_contact): the P/A/H/R fields above hold the geom's BOUNDING
+# capsule (exact for spheres and capsules, and for a cylinder's axis / radius / half length) for the mid phase; the extension
+# GP_X1 / GP_X2 (GX_SIZE floats per geom) holds what the support function needs: engine geom type, the centre MPR starts from
+# (link frame; a mesh's centre of mass), then for a box its half sizes and x / y axes (link frame), for a mesh the first vertex
+# and the vertex count of its convex hull in the mesh-vertex table (link frame)
+GX_TYPE, GX_CX, GX_CY, GX_CZ, GX_E0, GX_RBOUND, GX_SIZE = 0, 1, 2, 3, 4, 13, 14
+GP_X2 = GP_X1 + GX_SIZE
+GPAIR_SIZE = GP_X2 + GX_SIZE
+# body-pair records (global memory, the level between a link pair and its geom pairs): the geoms of ONE body of either link as a
+# bounding capsule (centre, axis, half length, radius in the link frames; "1" = the pair's first link), the geom pairs between the
+# two bodies [BP_FIRST, BP_FIRST + BP_N) (<= 24) and their largest margin. A link pair's entry points at its body pairs
+(BP_P1, BP_A1, BP_H1, BP_R1, BP_P2, BP_A2, BP_H2, BP_R2, BP_FIRST, BP_N, BP_MARGIN, BP_SIZE) = (0, 3, 6, 7, 8, 11, 14, 15, 16, 17, 18, 20)
 CM_SIZE = ROOT_SIZE + CHAIN_SIZE * NCHAIN + MAXRG * U_SIZE + MAXG * (U_SIZE + P_SIZE) * NCHAIN + MAXLG * LG_SIZE * NCHAIN + MAXLP * LP_SIZE * NCHAIN
 # ---- the geom table (global memory, read when a geom's bounding sphere reaches the floor): full records interleaved
 # [geom][field][chain]
@@ -154,13 +169,15 @@ def _fill_contact_params(blk, m, b, dim, fr):
         blk[G_RR1:G_RR1 + 5] = 1.0
 
 
-HEADER_SIZE = 48
+HEADER_SIZE = 56
 LMC_MAGIC = 0x4C4D4332  # "LMC2"
 (H_MAGIC, H_VERSION, H_NV, H_NU, H_NCHAINS, H_MAXLINKS, H_TIMESTEP, H_GX, H_GY, H_GZ, H_IMPRATIO, H_ITERATIONS,
  H_TOLERANCE, H_NSUBSTEPS, H_NOBS, H_NGOAL, H_REWARD_TYPE, H_REWARD_P0) = range(18)
 H_NGRF, H_MEANINERTIA, H_CM_SIZE, H_INTEGRATOR, H_CONE, H_MAXCONTACTS, H_NMUSCLE, H_CM_USED, H_ACTMODE = 25, 26, 27, 28, 29, 30, 31, 32, 33
 H_OFF_RUNSUP, H_OFF_CUNSUP, H_OFF_PRUNE, H_GT_SIZE, H_OFF_LPAIR, H_NGPAIR, H_OFF_GPT, H_OFF_LGROUP, H_NMESHV, H_OFF_MESHV = 34, 35, 36, 37, 38, 39, 40, 41, 42, 43
 H_NMESHN, H_OFF_MESHN = 44, 45     # neighbour table of the hull vertices (floats: hull-local indices, -1 ends a vertex's list)
+H_NBPAIR, H_OFF_BPT = 46, 47       # body-pair table of the self-collision mid phase (BP_SIZE floats per record)
+H_NMESHADJ, H_OFF_MESHADJ = 48, 49  # adjacency blocks of the hull vertices (4 floats per entry): convex-pair collider
 # H_NGPAIR geom-pair records start H_OFF_GPT floats into the chain-model array (behind the geom table and the muscle table)
 # H_OFF_*: offsets (floats from the start of the constant table) of the tail lists, see CM_SIZE
 # H_ACTMODE: 0 = joint motors (torque = gear * ctrl), 1 = position servos on every actuated joint
@@ -405,7 +422,7 @@ def lower(m, task):
             if t == mjcf.GEOM_MESH and hull_n > 0:
                 # plane vs convex hull: a contact at the support vertex (+ its neighbours). The hull's vertices go into the
                 # mesh-vertex table in the frame of the LINK; the prune sphere is the hull's bounding sphere
-                hv = p + m.hull_vert[m.geom_hull_adr[g]:m.geom_hull_adr[g] + hull_n].astype(np.float64) @ r.T
+                first_vert, hv = register_hull(g)
                 ctr = 0.5 * (hv.min(0) + hv.max(0))
                 blk = np.zeros(G_SIZE)
                 blk[G_GRF] = grf_of_geom.get(g, -1)
@@ -413,17 +430,10 @@ def lower(m, task):
                 blk[G_PX:G_PX + 3] = ctr
                 blk[G_R0:G_R0 + 9] = np.eye(3).reshape(9)
                 blk[G_RBOUND], blk[G_MARGIN] = float(np.linalg.norm(hv - ctr, axis=1).max()) * (1 + 1e-6), margin
-                blk[G_SX], blk[G_SY] = len(mesh_verts), hull_n           # first vertex, vertex count in the mesh-vertex table
-                # further contacts at the hull-graph neighbours of the support vertex keep this far from the contacts already
-                # found (0.3 x the bounding capsule's radius + half length: DESIGN.md §2 item 10)
+                blk[G_SX], blk[G_SY] = first_vert, hull_n                # first vertex, vertex count in the mesh-vertex table
+                # further contacts at the hull-graph neighbours of the support vertex keep this far from the support contact
+                # (0.3 x the bounding capsule's radius + half length: DESIGN.md §2 item 10)
                 blk[G_SZ] = 0.3 * (size[0] + size[1])
-                a0 = int(m.geom_hull_adr[g])
-                for i in range(hull_n):
-                    e0, e1 = int(m.hull_nbr_adr[a0 + i]), int(m.hull_nbr_adr[a0 + i + 1])
-                    mesh_nbr_first.append(len(mesh_nbr))                 # 4th component of the vertex: its neighbour list ...
-                    mesh_nbr.extend(int(j) for j in m.hull_nbr[e0:e1])
-                    mesh_nbr.append(-1)                                  # ... which a -1 ends
-                mesh_verts.extend(hv.tolist())
                 blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
                 blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
                 _fill_contact_params(blk, m, b, dim, fr)
@@ -457,6 +467,36 @@ def lower(m, task):
     info = dict(root=root, chains=chains, shared_first=shared_first)
     mesh_verts = []                    # hull vertices of the mesh colliders, link frame (device table, global memory)
     mesh_nbr_first, mesh_nbr = [], []  # per vertex: start of its neighbour list in the neighbour table (hull-local indices, -1 ends)
+    hull_slot = {}                     # geom -> (first vertex in the table, vertices in the link frame)
+    mesh_adj, hull_block = [], {}      # adjacency blocks (4 floats per entry), geom -> block start of every hull vertex
+
+    def register_hull(g):
+        """The convex hull of mesh geom g in the mesh-vertex table (once per geom): its vertices in the frame of the geom's LINK
+        (plane-hull contacts and the convex-pair collider read them there), each with the start of its neighbour list."""
+        if g not in hull_slot:
+            p_, r_ = rel_pose(m.geom_body[g])
+            a0, n_ = int(m.geom_hull_adr[g]), int(m.geom_hull_num[g])
+            hv_ = p_ + m.hull_vert[a0:a0 + n_].astype(np.float64) @ r_.T
+            hull_slot[g] = (len(mesh_verts), hv_)
+            nbrs = []
+            for i in range(n_):
+                e0, e1 = int(m.hull_nbr_adr[a0 + i]), int(m.hull_nbr_adr[a0 + i + 1])
+                mesh_nbr_first.append(len(mesh_nbr))                     # 4th component of the vertex: its neighbour list ...
+                nbrs.append([int(j) for j in m.hull_nbr[e0:e1]])
+                mesh_nbr.extend(nbrs[-1])
+                mesh_nbr.append(-1)                                      # ... which a -1 ends
+            mesh_verts.extend(hv_.tolist())
+            # adjacency blocks for the hill climbing of the convex-pair collider: per vertex [x y z degree] then one [x y z block] per
+            # neighbour (block = where that neighbour's own block starts, in 4-float entries): a step reads ONE contiguous block
+            starts, pos = [], len(mesh_adj)
+            for i in range(n_):
+                starts.append(pos)
+                pos += 1 + len(nbrs[i])
+            for i in range(n_):
+                mesh_adj.append([hv_[i][0], hv_[i][1], hv_[i][2], len(nbrs[i])])
+                mesh_adj.extend([hv_[j][0], hv_[j][1], hv_[j][2], starts[j]] for j in nbrs[i])
+            hull_block[g] = starts
+        return hull_slot[g]
 
     # ---- root block
     rb = cm[CM_ROOT:CM_ROOT + ROOT_SIZE]
@@ -691,44 +731,43 @@ def lower(m, task):
     for i, u in enumerate(root_unsup):
         cm[off + i * U_SIZE:off + (i + 1) * U_SIZE] = u
     off += len(root_unsup) * U_SIZE
+    def write_lists(lists, size, c_field):
+        """every chain's list contiguous ([entry][field]); its start goes into the chain block"""
+        nonlocal off
+        for c in range(NCHAIN):
+            cm[CM_CHAINS + c_field * NCHAIN + c] = off
+            for i, u in enumerate(lists[c]):
+                cm[off + i * size:off + (i + 1) * size] = u
+            off += len(lists[c]) * size
     h[H_OFF_CUNSUP] = off
-    nmax = max(len(u) for u in chain_unsup)
-    for c in range(NCHAIN):
-        for i, u in enumerate(chain_unsup[c]):
-            cm[off + (i * U_SIZE + np.arange(U_SIZE)) * NCHAIN + c] = u
-    off += nmax * U_SIZE * NCHAIN
+    write_lists(chain_unsup, U_SIZE, C_OFF_CUNSUP)
     h[H_OFF_PRUNE] = off
-    nmax = max(len(u) for u in chain_prune)
-    for c in range(NCHAIN):
-        for i, u in enumerate(chain_prune[c]):
-            cm[off + (i * P_SIZE + np.arange(P_SIZE)) * NCHAIN + c] = u
-    off += nmax * P_SIZE * NCHAIN
+    write_lists(chain_prune, P_SIZE, C_OFF_PRUNE)
     h[H_OFF_LGROUP] = off
-    nmax = max(len(u) for u in chain_groups_tab)
-    for c in range(NCHAIN):
-        for i, u in enumerate(chain_groups_tab[c]):
-            cm[off + (i * LG_SIZE + np.arange(LG_SIZE)) * NCHAIN + c] = u
-    off += nmax * LG_SIZE * NCHAIN
-    # self-collisions: the quadruped family's kernels (<= 3 links per chain, Euler, elliptic cones, no muscles) are compiled
-    # with the pair path; the other robots of the suite have no self-collision pair with a collider
-    pairs_on = (m.cone == mjcf.CONE_ELLIPTIC and max_links <= 3 and m.integrator == mjcf.INT_EULER and not muscles
-                and task.get("self_collisions", True))
-    pair_tab = _self_collision_tables(m, root, chains, kin) if pairs_on else None
+    write_lists(chain_groups_tab, LG_SIZE, C_OFF_LGROUP)
+    # self-collisions: the quadruped family (<= 3 links per chain, Euler, elliptic cones) and the five-link humanoid families
+    # (pyramids) have kernels with the pair path; a model without a candidate pair (Atlas, Talos: contype 0) keeps the plain ones
+    pairs_on = (task.get("self_collisions", True) and _count_self_pairs(m) > 0
+                and ((m.cone == mjcf.CONE_ELLIPTIC and max_links <= 3 and m.integrator == mjcf.INT_EULER and not muscles)
+                     or (m.cone == mjcf.CONE_PYRAMIDAL and 3 < max_links <= 5 and not shared_first)))
+    pair_tab = _self_collision_tables(m, root, chains, kin, register_hull, hull_block) if pairs_on else None
     h[H_OFF_LPAIR] = off
-    gpt = np.zeros(0)
+    gpt, bpt = np.zeros(0), np.zeros(0)
     if pair_tab is not None:
-        lanes_lp, gpt, spheres = pair_tab
+        lanes_lp, gpt, spheres, kinds, bpt = pair_tab
         for c in range(NCHAIN):
             cm[CM_CHAINS + C_NLPAIR * NCHAIN + c] = len(lanes_lp[c])
-            for i, e in enumerate(lanes_lp[c]):
-                cm[off + (i * LP_SIZE + np.arange(LP_SIZE)) * NCHAIN + c] = e
-        off += max(len(x) for x in lanes_lp) * LP_SIZE * NCHAIN
+        write_lists(lanes_lp, LP_SIZE, C_OFF_LPAIR)
         for (cl, li), ctr in spheres.items():
             if cl < 0:
                 rb[R_BSX:R_BSX + 3] = ctr[0]
             else:
                 cm[CM_CHAINS + (C_LINKS + li * LINK_SIZE + D_SIZE + L_BSX + np.arange(4)) * NCHAIN + cl] = list(ctr[0]) + [ctr[1]]
-        info["self_collision_tables"] = dict(link_pairs=[len(x) for x in lanes_lp], geom_pairs=len(gpt) // GPAIR_SIZE)
+        info["self_collision_tables"] = dict(link_pairs=[len(x) for x in lanes_lp], body_pairs=len(bpt) // BP_SIZE, geom_pairs=len(gpt) // GPAIR_SIZE,
+                                             closed_form=kinds[0], counted_only=kinds[1], convex=kinds[2])
+        if m.cone == mjcf.CONE_PYRAMIDAL:
+            max_contacts = 8                  # the pair families are compiled with eight slots per chain (floor + self-contacts)
+            h[H_MAXCONTACTS] = max_contacts
     assert off <= CM_SIZE
     h[H_CM_USED] = off
     h[H_GT_SIZE] = GT_SIZE
@@ -746,8 +785,14 @@ def lower(m, task):
     assert len(mesh_nbr) < 2 ** 24                         # the indices travel as float32
     h[H_NMESHV], h[H_OFF_MESHV] = len(mesh_verts), h[H_OFF_GPT] + len(gpt)
     h[H_NMESHN], h[H_OFF_MESHN] = len(mesh_nbr), h[H_OFF_MESHV] + 4 * len(mesh_verts)
+    h[H_NBPAIR], h[H_OFF_BPT] = len(bpt) // BP_SIZE, h[H_OFF_MESHN] + len(mesh_nbr)
+    if pair_tab is None:
+        mesh_adj = []                                      # only the convex-pair collider reads the adjacency blocks
+    assert len(mesh_adj) < 2 ** 24
+    h[H_NMESHADJ], h[H_OFF_MESHADJ] = len(mesh_adj), h[H_OFF_BPT] + len(bpt)
     info["mesh_vertices"] = len(mesh_verts)
-    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel(), np.array(mesh_nbr, dtype=np.float64)]), info
+    return np.concatenate([h, cm, gt] + ([mt] if mt is not None else []) + [gpt, meshv.ravel(), np.array(mesh_nbr, dtype=np.float64), bpt,
+                                                                           np.array(mesh_adj, dtype=np.float64).ravel()]), info
 
 
 # ---- model variants (inertial / armature / geom-friction randomisation): what differs between two lowerings of the same robot
@@ -801,17 +846,52 @@ def variant_tables(nominal, variant):
     return rec.ravel(), variant[g0:g0 + GT_SIZE].copy(), variant[o_gpt:o_gpt + n_gpt].copy()
 
 
-def _self_collision_tables(m, root, chains, kin):
+def _union_capsule(caps):
+    """Bounding capsule [centre 3, axis 3, half length, radius] of capsules (centre, axis, half, radius, ...): axis = principal direction
+    of their end points; every end point lies within (R - r) of the segment, and the distance to a segment is convex along a
+    capsule's own segment, so the union is covered."""
+    ends, rads = [], []
+    for c_, a_, h_, r_, *_ in caps:
+        ends += [np.asarray(c_) - h_ * np.asarray(a_), np.asarray(c_) + h_ * np.asarray(a_)]
+        rads += [r_, r_]
+    ends = np.array(ends)
+    ctr = ends.mean(0)
+    if len(caps) == 1:
+        c_, a_, h_, r_ = caps[0][:4]
+        return np.concatenate([c_, a_, [h_, r_]])
+    w, v = np.linalg.eigh(np.cov((ends - ctr).T) + 1e-18 * np.eye(3))
+    axis = v[:, 2]
+    t = (ends - ctr) @ axis
+    lo, hi = float(t.min()), float(t.max())
+    c0, half = ctr + 0.5 * (lo + hi) * axis, 0.5 * (hi - lo)
+    tt = np.clip((ends - c0) @ axis, -half, half)
+    d = np.linalg.norm((ends - c0) - np.outer(tt, axis), axis=1)
+    return np.concatenate([c0, axis, [half, float((d + np.array(rads)).max()) * (1 + 1e-9)]])
+
+
+def _engine_uses_ccd(t1, t2):
+    """Pair types (t1 <= t2 in the engine's order sphere < capsule < cylinder < box < mesh) the engine's collision table routes to its
+    general convex collider (mjc_Convex: libccd MPR); the others have native colliders."""
+    if t2 == mjcf.GEOM_MESH:
+        return True
+    if t1 == mjcf.GEOM_CAPSULE and t2 == mjcf.GEOM_CYLINDER:
+        return True
+    return t1 == mjcf.GEOM_CYLINDER and t2 in (mjcf.GEOM_CYLINDER, mjcf.GEOM_BOX)
+
+
+def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
     """
-    Tables of the self-collision path (kernels compiled with PAIRS; elliptic cones): candidate geom pairs after the engine's
-    filters (different weld groups, not parent and child, contype / conaffinity — the floor is handled elsewhere), grouped by
-    link pair. Sphere / capsule pairs get a collider; pairs with a box or a cylinder are kept as bounding capsules and only
-    COUNTED when they come within the margin (``self_proximity`` statistic).
-    Returns (per-lane link-pair entries [code, range, reach^2], geom-pair records (flat), {(lane, link): sphere centre}).
+    Tables of the self-collision path (kernels compiled with PAIRS): candidate geom pairs after the engine's filters (different
+    weld groups, not parent and child, contype / conaffinity — the floor is handled elsewhere), grouped by link pair.
+    Kind 0: sphere / capsule pairs (closed form). Kind 2: the pairs the engine collides through its general convex collider
+    (anything against a mesh, capsule / cylinder / box against a cylinder): MPR on the device, hull vertices in the mesh-vertex
+    table. Kind 1: pairs with a native collider that is not restated (sphere / capsule / box against a box, sphere against a
+    cylinder): kept as bounding capsules and only COUNTED when they come within the margin (``self_proximity`` statistic).
+    Two links of ONE chain may form a pair (UnitreeH1: hip-yaw cylinder against the thigh of the same leg): the entry then lives in
+    that lane only. Returns (per-lane link-pair entries [code, range, reach^2], geom-pair records (flat),
+    {(lane, link): bounding sphere}).
     """
-    if m.cone != mjcf.CONE_ELLIPTIC:
-        raise UnsupportedModel("self-collisions are built for elliptic cones only")
-    nb = m.nbody
+    pyramidal = m.cone != mjcf.CONE_ELLIPTIC
     where = {root: (-1, 7)}                                   # weld group -> (lane, link index after its last joint)
     for c, chain in enumerate(chains):
         li = -1
@@ -837,6 +917,28 @@ def _self_collision_tables(m, root, chains, kin):
             return pos, rot[:, k], size[k], rad, size[k] + rad
         return pos, rot[:, 2], size[1], size[0], size[0] + size[1]        # capsule, cylinder, mesh (bounding capsule)
 
+    def convex_of(g):
+        """GX_SIZE floats of geom g for the convex-pair collider (link frame)."""
+        p, r = rel_pose(m.geom_body[g])
+        rot = r @ mjcf.quat_to_mat(m.geom_quat[g])
+        t, size = int(m.geom_type[g]), m.geom_size[g]
+        x = np.zeros(GX_SIZE)
+        x[GX_TYPE] = t
+        x[GX_CX:GX_CX + 3] = p + r @ getattr(m, "geom_center", m.geom_pos)[g]
+        if t == mjcf.GEOM_MESH:
+            first, hv = register_hull(g)
+            x[GX_E0], x[GX_E0 + 1] = first, len(hv)
+            # where the hill climbing of the support search starts: the hull's extreme vertices along +x, -x, +y, -y, +z, -z (link frame)
+            # (as positions of their adjacency blocks in the table the climbing reads)
+            x[GX_E0 + 2:GX_E0 + 8] = [hull_block[g][int(np.argmax(sg * hv[:, k]))] for k in range(3) for sg in (1.0, -1.0)]
+        elif t == mjcf.GEOM_BOX:
+            x[GX_E0:GX_E0 + 3] = size
+            x[GX_E0 + 3:GX_E0 + 6], x[GX_E0 + 6:GX_E0 + 9] = rot[:, 0], rot[:, 1]
+        # radius of the engine's bounding sphere around the geom position (margin-less mid phase of a geom pair)
+        x[GX_RBOUND] = {mjcf.GEOM_SPHERE: size[0], mjcf.GEOM_CAPSULE: size[0] + size[1], mjcf.GEOM_MESH: size[0] + size[1],
+                          mjcf.GEOM_CYLINDER: float(np.hypot(size[0], size[1])), mjcf.GEOM_BOX: float(np.linalg.norm(size))}[t]
+        return x
+
     by_links = {}
     for g1 in range(m.ngeom):
         for g2 in range(g1 + 1, m.ngeom):
@@ -852,8 +954,9 @@ def _self_collision_tables(m, root, chains, kin):
             a, b = (g1, g2) if m.geom_type[g1] <= m.geom_type[g2] else (g2, g1)      # the engine's order: lower type first
             by_links.setdefault((min(w1, w2), max(w1, w2)), []).append((a, b))
     handled = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE)
+    has_hull = getattr(m, "geom_hull_num", np.zeros(m.ngeom, int))
     lanes_lp = [[] for _ in range(NCHAIN)]
-    records, spheres_r = [], {}
+    records, spheres_r, bodypairs = [], {}, []
     # bounding sphere per weld group over the geoms that take part in any pair
     members = {}
     for (wp, wq), pairs in by_links.items():
@@ -865,48 +968,95 @@ def _self_collision_tables(m, root, chains, kin):
         caps = [capsule_of(g) for g in gs]
         ctr = np.mean([cp[0] for cp in caps], axis=0)
         sphere[w] = (ctr, max(np.linalg.norm(cp[0] - ctr) + cp[4] for cp in caps))
+    kinds = [0, 0, 0]
     for (wp, wq), pairs in sorted(by_links.items()):
         if wp not in where or wq not in where:
             raise UnsupportedModel("self-collision pair outside the root+chains structure")
         (lp, kp), (lq, kq) = where[wp], where[wq]
-        first = len(records)
+        if lp < 0:                                                   # the root body is always the PARTNER of an entry
+            (wp, wq), (lp, kp), (lq, kq) = (wq, wp), (lq, kq), (lp, kp)
         margin_max = 0.0
+        # geom pairs grouped by the two BODIES they join (the mid phase tests one bounding capsule per body), <= 24 per group
+        def side(g):
+            return m.body_weldid[m.geom_body[g]] == wq
+        groups = {}
         for a, b in pairs:
-            dim, solref, solimp, fr, margin, gap = _mix_with_floor(m, a, b)
-            assert gap == 0
-            kind = 0 if (m.geom_type[a] in handled and m.geom_type[b] in handled) else 1
-            if kind == 0 and lp == lq:
-                raise UnsupportedModel("self-collision between two links of one chain")
-            rec = np.zeros(GPAIR_SIZE)
-            rec[GP_KIND], rec[GP_G1Q] = kind, float(m.body_weldid[m.geom_body[a]] == wq)
-            for base, g in ((GP_P1, a), (GP_P2, b)):
-                pos, axis, half, rad, _ = capsule_of(g)
-                rec[base:base + 3], rec[base + 3:base + 6], rec[base + 6], rec[base + 7] = pos, axis, half, rad
-            rec[GP_MARGIN] = margin
-            rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)
-            rec[GP_S0:GP_S0 + 5] = _clip_solimp(solimp)
-            rec[GP_TRAN] = m.body_invweight0[m.geom_body[a], 0] + m.body_invweight0[m.geom_body[b], 0]
-            if dim not in (1, 3, 4, 6):
-                raise UnsupportedModel("condim %d" % dim)
-            rec[GP_DIM] = dim
-            rec[GP_F0:GP_F0 + 5] = fr
-            rec[GP_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
-            rr1 = 1.0 / max(MINVAL, m.impratio)
-            rec[GP_RR1], rec[GP_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
-            rec[GP_RR3:GP_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
-            records.append(rec)
-            margin_max = max(margin_max, margin)
-        n = len(records) - first
-        assert first < 4096 and n <= 24           # the device exchanges the hits of a link pair as a 24-bit mask
+            gp_, gq_ = (b, a) if side(a) else (a, b)
+            groups.setdefault((int(m.geom_body[gp_]), int(m.geom_body[gq_])), []).append((a, b))
+        chunks = []
+        for key in sorted(groups):
+            for i0 in range(0, len(groups[key]), 24):
+                chunks.append(groups[key][i0:i0 + 24])
+        first_bp = len(bodypairs)
+        for chunk in chunks:
+            bp = np.zeros(BP_SIZE)
+            for base, want_q in ((BP_P1, False), (BP_P2, True)):
+                gs = sorted(set(g for ab in chunk for g in ab if side(g) == want_q))
+                bp[base:base + 8] = _union_capsule([capsule_of(g) for g in gs])
+            bp[BP_FIRST], bp[BP_N] = len(records), len(chunk)
+            bp_margin = 0.0
+            for a, b in chunk:
+                dim, solref, solimp, fr, margin, gap = _mix_with_floor(m, a, b)
+                assert gap == 0
+                ta, tb = int(m.geom_type[a]), int(m.geom_type[b])
+                if ta in handled and tb in handled:
+                    kind = 0
+                elif _engine_uses_ccd(ta, tb) and all(m.geom_type[g] != mjcf.GEOM_MESH or has_hull[g] > 0 for g in (a, b)):
+                    kind = 2
+                else:
+                    kind = 1
+                kinds[kind] += 1
+                rec = np.zeros(GPAIR_SIZE)
+                rec[GP_KIND], rec[GP_G1Q] = kind, float(m.body_weldid[m.geom_body[a]] == wq)
+                for base, g in ((GP_P1, a), (GP_P2, b)):
+                    pos, axis, half, rad, _ = capsule_of(g)
+                    rec[base:base + 3], rec[base + 3:base + 6], rec[base + 6], rec[base + 7] = pos, axis, half, rad
+                if kind == 2:
+                    rec[GP_X1:GP_X1 + GX_SIZE], rec[GP_X2:GP_X2 + GX_SIZE] = convex_of(a), convex_of(b)
+                rec[GP_MARGIN] = margin
+                rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)
+                rec[GP_S0:GP_S0 + 5] = _clip_solimp(solimp)
+                tran = m.body_invweight0[m.geom_body[a], 0] + m.body_invweight0[m.geom_body[b], 0]
+                rec[GP_F0:GP_F0 + 5] = fr
+                if pyramidal:
+                    # condim 3: the four edges of the pyramid share R = 2 mu^2 (1 + mu^2) tran (like the floor contacts, G_TRAN).
+                    # condim 1 (frictionless, the humanoid's bones): ONE row with R = tran, written as a pyramid with mu = 0 — its four
+                    # edges coincide, each with a quarter of the row's D — so that the kernels compiled for pyramids need no other row type
+                    if dim not in (1, 3):
+                        raise UnsupportedModel("pyramidal condim %d is not built on the device" % dim)
+                    if dim == 3 and fr[0] != fr[1]:
+                        raise UnsupportedModel("anisotropic sliding friction")
+                    mu = fr[0] if dim == 3 else 0.0
+                    rec[GP_DIM], rec[GP_MU] = 3, mu
+                    rec[GP_TRAN] = 2 * mu * mu * (1 + mu * mu) * tran if dim == 3 else 4.0 * tran
+                    rec[GP_RR1:GP_RR1 + 5] = 1.0
+                else:
+                    if dim not in (1, 3, 4, 6):
+                        raise UnsupportedModel("condim %d" % dim)
+                    rec[GP_TRAN] = tran
+                    rec[GP_DIM] = dim
+                    rec[GP_MU] = fr[0] / np.sqrt(max(MINVAL, m.impratio))
+                    rr1 = 1.0 / max(MINVAL, m.impratio)
+                    rec[GP_RR1], rec[GP_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
+                    rec[GP_RR3:GP_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
+                records.append(rec)
+                margin_max = max(margin_max, margin)
+                bp_margin = max(bp_margin, margin)
+            bp[BP_MARGIN] = bp_margin
+            bodypairs.append(bp)
         reach2 = (sphere[wp][1] + sphere[wq][1] + margin_max + PAIR_PAD) ** 2
-        if lp >= 0:
-            lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 4096 * n, reach2])
-        if lq >= 0 and lq != lp:
-            lanes_lp[lq].append([kq + 8 * kp + 64 * max(lp, 0) + 256, first + 4096 * n, reach2])
+        # the device exchanges the hits of an entry as a 24-bit mask: a link pair with more body pairs is several entries
+        n_all = len(bodypairs) - first_bp
+        for first in range(first_bp, first_bp + n_all, 24):
+            n = min(24, first_bp + n_all - first)
+            assert first < 65536
+            lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 65536 * n, reach2])
+            if lq >= 0 and lq != lp:
+                lanes_lp[lq].append([kq + 8 * kp + 64 * lp + 256, first + 65536 * n, reach2])
         spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp], sphere[wq]
     if max(len(x) for x in lanes_lp) > MAXLP:
-        raise UnsupportedModel("too many self-collision link pairs")
-    return lanes_lp, (np.concatenate(records) if records else np.zeros(0)), spheres_r
+        raise UnsupportedModel("too many self-collision link pairs (%s)" % [len(x) for x in lanes_lp])
+    return lanes_lp, (np.concatenate(records) if records else np.zeros(0)), spheres_r, kinds, (np.concatenate(bodypairs) if bodypairs else np.zeros(0))
 
 
 def _count_self_pairs(m):

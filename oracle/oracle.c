@@ -827,6 +827,7 @@ static int mpr_penetration(const mpr_obj* A, const mpr_obj* B, double* depth, do
     copy3(pdir, P[1].v); *depth = sqrt(dot3(pdir, pdir)); ccd_normalize(pdir);
     return 0;
   }
+  if (getenv("LMO_MPR_TRACE")) fprintf(stderr, " o discovered: v0 %.6f %.6f %.6f | v1 %.6f %.6f %.6f | v2 %.6f %.6f %.6f | v3 %.6f %.6f %.6f\n", P[0].v[0],P[0].v[1],P[0].v[2],P[1].v[0],P[1].v[1],P[1].v[2],P[2].v[0],P[2].v[1],P[2].v[2],P[3].v[0],P[3].v[1],P[3].v[2]);
   /* ---- portal refinement: until the portal's outward side holds the origin */
   for (;;) {
     mpr_portal_dir(P, dir);
@@ -841,6 +842,7 @@ static int mpr_penetration(const mpr_obj* A, const mpr_obj* B, double* depth, do
   for (unsigned long it = 0;; it++) {
     mpr_portal_dir(P, dir);
     mpr_support(A, B, dir, &v4);
+    if (getenv("LMO_MPR_TRACE")) fprintf(stderr, "  o pen it %lu dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f\n", it, dir[0], dir[1], dir[2], v4.v[0], v4.v[1], v4.v[2], dot3(v4.v, dir), dot3(P[1].v, dir));
     if (mpr_reach_tolerance(P, &v4, dir) || it > MPR_ITERATIONS) {
       *depth = sqrt(point_tri_dist2(origin, P[1].v, P[2].v, P[3].v, pdir));
       if (ccd_is_zero(pdir[0]) && ccd_is_zero(pdir[1]) && ccd_is_zero(pdir[2])) copy3(pdir, dir);

@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdint>
 #include <thread>
 #include <vector>
 #define LM_DEV inline
@@ -146,8 +147,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
-  P.off_runsup = (int)H[LM_H_OFF_RUNSUP]; P.off_cunsup = (int)H[LM_H_OFF_CUNSUP]; P.off_prune = (int)H[LM_H_OFF_PRUNE]; P.gt = gt.data();
-  P.off_lgroup = (int)H[LM_H_OFF_LGROUP]; P.off_lpair = (int)H[LM_H_OFF_LPAIR];
+  P.off_runsup = (int)H[LM_H_OFF_RUNSUP]; P.gt = gt.data();
   std::vector<float> gpt((size_t)H[LM_H_NGPAIR] * LM_GPAIR_SIZE + 1);
   for (size_t i = 0; i + 1 < gpt.size(); i++) gpt[i] = (float)H[(size_t)H[LM_H_OFF_GPT] + i];
   P.gpt = gpt.data();
@@ -157,6 +157,13 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   std::vector<float> meshn((size_t)H[LM_H_NMESHN] + 1, -1.0f);
   for (size_t i = 0; i + 1 < meshn.size(); i++) meshn[i] = (float)H[(size_t)H[LM_H_OFF_MESHN] + i];
   P.meshn = meshn.data();
+  std::vector<float> bpt((size_t)H[LM_H_NBPAIR] * LM_BP_SIZE + 1);
+  for (size_t i = 0; i + 1 < bpt.size(); i++) bpt[i] = (float)H[(size_t)H[LM_H_OFF_BPT] + i];
+  P.bpt = bpt.data();
+  std::vector<float> madj(4 * (size_t)H[LM_H_NMESHADJ] + 64 + 4, 0.0f);
+  float* madj_al = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(madj.data()) + 15) & ~uintptr_t(15));
+  for (size_t i = 0; i < 4 * (size_t)H[LM_H_NMESHADJ]; i++) madj_al[i] = (float)H[(size_t)H[LM_H_OFF_MESHADJ] + i];
+  P.meshadj = madj_al;
   int cnt_tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto lane_main = [&](int t) {
     const int c = t & 3;
@@ -239,7 +246,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       float pair_slack = 0.0f;
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4, PAIRS ? 1 : kEmuCone<MC>, NM, kEmuDR, PAIRS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+        lm::substep<QuadThreads, MC, NS, RK4, (PAIRS && MC <= 3) ? 1 : kEmuCone<MC>, NM, kEmuDR, PAIRS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                                       (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, &pair_slack);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
       if (NM > 0 && t_rep == 0) {
@@ -290,6 +297,12 @@ extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* q
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
   if ((int)chain_model[LM_H_MAXLINKS] > 5)
     return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters) : -1;
+  // the five-link humanoids with self-collision tables (bone hulls, UnitreeH1's cylinders and meshes): the pair families, 8 slots
+  if ((int)chain_model[LM_H_NGPAIR] > 0 && big) {
+    if ((int)chain_model[LM_H_NMUSCLE] > 0) return (act && !rk4) ? emu_run_t<5, 8, false, LM_MAXMUS, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
+    return rk4 ? emu_run_t<5, 8, true, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters)
+               : emu_run_t<5, 8, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+  }
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
     return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
   if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, 6, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);

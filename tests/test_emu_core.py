@@ -16,6 +16,19 @@ from emu import pyemu
 GOLD = np.load(__file__.replace("test_emu_core.py", "golden/reference_rollouts.npz"))
 
 
+def _tables_are_contiguous(cmod, with_muscles):
+    """The chain model = header, constant table, geom table, [muscle table], then the global tables one behind the other: geom pairs,
+    hull vertices, their neighbour lists, body pairs, adjacency blocks."""
+    L = lowering
+    off = L.HEADER_SIZE + L.CM_SIZE + L.GT_SIZE + (L.MT_SIZE if with_muscles else 0)
+    for h_off, n in ((L.H_OFF_GPT, L.GPAIR_SIZE * int(cmod[L.H_NGPAIR])), (L.H_OFF_MESHV, 4 * int(cmod[L.H_NMESHV])), (L.H_OFF_MESHN, int(cmod[L.H_NMESHN])),
+                     (L.H_OFF_BPT, L.BP_SIZE * int(cmod[L.H_NBPAIR])), (L.H_OFF_MESHADJ, 4 * int(cmod[L.H_NMESHADJ]))):
+        if int(cmod[h_off]) != off:
+            return False
+        off += n
+    return off == len(cmod)
+
+
 @pytest.fixture(scope="module")
 def setup():
     np.random.seed(0)
@@ -34,7 +47,7 @@ def actions(n):
 def test_lowering_structure(setup):
     env, cmod, info, o = setup
     assert info["n_chains"] == 4 and info["max_links"] == 3
-    assert len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.GPAIR_SIZE * int(cmod[lowering.H_NGPAIR]) + 4 * int(cmod[lowering.H_NMESHV])
+    assert _tables_are_contiguous(cmod, with_muscles=False)
     assert sorted(int(x) for x in info["dof_to_lane"][6:]) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
 
 
@@ -269,7 +282,7 @@ def test_core_muscles():
     env = LocoEnv.make("HumanoidMuscle.walk", debug=True)
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
-    assert info["muscles_per_chain"] == [43, 43, 6, 0] and len(cmod) == lowering.HEADER_SIZE + lowering.CM_SIZE + lowering.GT_SIZE + lowering.MT_SIZE + 4 * int(cmod[lowering.H_NMESHV]) + int(cmod[lowering.H_NMESHN])
+    assert info["muscles_per_chain"] == [43, 43, 6, 0] and _tables_are_contiguous(cmod, with_muscles=True)
     o = Oracle(pack_model(m))
     g = GOLD["HumanoidMuscle.walk.real"]
     qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]

@@ -23,9 +23,9 @@ lib.lm_debug_timers.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.lm_debug_timers(b._h, buf)
 st = b.rollout(50, action_mode=mode, seed=4)
 lib.lm_debug_timers(b._h, buf)
-t = np.array(list(buf)[:14], dtype=np.float64)
+t = np.array(list(buf)[:16], dtype=np.float64)
 names = ["self-collision pairs + slot bookkeeping", "M+bias", "rows+a0", "warmstart", "gradient", "hessian", "factor+solve", "jv/Mv", "linesearch", "integrate", "lockstep wait",
-         "kinematics", "floor: broad phase + primitives", "floor: hulls"]
+         "kinematics", "floor: broad phase + primitives", "floor: hulls", "pairs: tests", "pairs: MPR"]
 tot = t.sum()
 print(json.dumps(dict(task=task, n=N, ms_per_step=st["kernel_ms"] / 50, iters_per_forward=st["solver_iters"] / st["env_steps"] / (40 if env._model.integrator else 10),
                       share={n: round(v / tot, 3) for n, v in zip(names, t)})))
