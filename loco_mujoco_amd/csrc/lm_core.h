@@ -1394,7 +1394,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // step by step). One support call site: the phases of the algorithm are a small state machine around it. Both shapes are
       // inflated by margin / 2 along the search direction; result: normal from geom 1 to geom 2, contact point (relative to O)
       // midway between the two witness points, distance = margin - depth. The portal (4 points x (v, v1)) lives in the part of lane
-      // memory that holds the inertia matrix later in the pass (dead here); the support search of a hull climbs its vertex graph.
+      // memory that holds the inertia matrix later in the pass (dead here: the work queue); the support search of a hull climbs its vertex graph.
       // Both lanes of a cross-chain pair run it on the same numbers: identical results, mirror slots.
       // Work queue of the convex pairs: the passes over entries / body pairs / geom pairs only COLLECT the pairs whose bounding
       // capsules are within the margin; MPR then runs for all lanes of the wave at the same time, one queued pair per replica (in a
@@ -1402,25 +1402,46 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // results and portals sit in the part of lane memory that holds M, the twists and the link images later in the pass.
       constexpr int kQueue = (MC >= 5) ? 24 : 8;                      // queued pairs per lane and pass (more: counted as dropped contacts)
       constexpr int kQRes_n = (NS < 8) ? 4 : 8;                       // contacts the queue can hand back
-      constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue, kPortal = kQRes + 7 * kQRes_n;
-      static_assert(!PAIRS || kPortal + 18 * 4 <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
+      constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue;
+      static_assert(!PAIRS || kQRes + 7 * kQRes_n <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
       int nq = 0;
       auto mpr_contact = [&](const float* rec, bool g1own, V3 po_, const M3& Ro_, V3 pp_, const M3& Rp_, float pmargin,
                              V3& nrm, V3& cpo, float& dist_out) -> bool {
-        const V3 pw[2] = {(g1own ? po_ : pp_) - O, (g1own ? pp_ : po_) - O};
+        // FLOAT64 inside: the portal search takes hundreds of sign decisions on differences of nearly equal support values; in
+        // float32 their rounding alone sends it down another path (a cylinder against a hull: normals 1e-2 rad apart from one
+        // evaluation to the next of the same state, where the float64 collider does not move) — MI355X runs float64 vector code at
+        // half rate, and the search is bound by the latency of the hull-vertex fetches anyway. Inputs (link frames, float32 hull
+        // vertices) and outputs are float32.
+        struct D3 { double x, y, z; };
+        auto d3 = [](double x, double y, double z) -> D3 { D3 r; r.x = x; r.y = y; r.z = z; return r; };
+        auto dsub = [&](D3 a, D3 b) -> D3 { return d3(a.x - b.x, a.y - b.y, a.z - b.z); };
+        auto dadd = [&](D3 a, D3 b) -> D3 { return d3(a.x + b.x, a.y + b.y, a.z + b.z); };
+        auto dscl = [&](double k, D3 a) -> D3 { return d3(k * a.x, k * a.y, k * a.z); };
+        auto ddot = [](D3 a, D3 b) -> double { return a.x * b.x + a.y * b.y + a.z * b.z; };
+        auto dcross = [&](D3 a, D3 b) -> D3 { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); };
+        auto dunit = [&](D3 a) -> D3 { const double n = sqrt(ddot(a, a)); return (n > 0.0) ? dscl(1.0 / n, a) : a; };
+        auto up = [&](V3 a) -> D3 { return d3((double)a.x, (double)a.y, (double)a.z); };
+        auto rot = [&](const M3& Rm, D3 v) -> D3 {          // R v
+          return d3((double)Rm.a[0] * v.x + (double)Rm.a[1] * v.y + (double)Rm.a[2] * v.z, (double)Rm.a[3] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[5] * v.z,
+                    (double)Rm.a[6] * v.x + (double)Rm.a[7] * v.y + (double)Rm.a[8] * v.z);
+        };
+        auto rotT = [&](const M3& Rm, D3 v) -> D3 {         // R^T v
+          return d3((double)Rm.a[0] * v.x + (double)Rm.a[3] * v.y + (double)Rm.a[6] * v.z, (double)Rm.a[1] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[7] * v.z,
+                    (double)Rm.a[2] * v.x + (double)Rm.a[5] * v.y + (double)Rm.a[8] * v.z);
+        };
+        const D3 pw[2] = {up((g1own ? po_ : pp_) - O), up((g1own ? pp_ : po_) - O)};
         const M3* Rw[2] = {g1own ? &Ro_ : &Rp_, g1own ? &Rp_ : &Ro_};
-        const float hmg = 0.5f * pmargin, eps = 1.1920929e-7f;
-        auto sgn = [](float x) -> float { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); };
-        auto unit = [](V3 a) -> V3 { return (1.0f / sqrtf(fmaxf(dot(a, a), 1e-37f))) * a; };
+        const double hmg = 0.5 * (double)pmargin, eps = 2.220446049250313e-16;
+        auto is_zero = [&](double x) -> bool { return fabs(x) < eps; };
+        auto sgn = [](double x) -> double { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); };
         int hint[2] = {-1, -1};            // where the hill climbing of either hull starts: its previous support vertex
-        auto support1 = [&](int which, V3 d) -> V3 {
+        auto support1 = [&](int which, D3 d) -> D3 {
           const M3& Rl = *Rw[which];
           const float* cap = rec + (which ? LM_GP_P2 : LM_GP_P1);        // bounding capsule: centre 3, axis 3, half length, radius
           const float* x = rec + (which ? LM_GP_X2 : LM_GP_X1);
-          const V3 dl = v3(Rl.a[0] * d.x + Rl.a[3] * d.y + Rl.a[6] * d.z, Rl.a[1] * d.x + Rl.a[4] * d.y + Rl.a[7] * d.z,
-                           Rl.a[2] * d.x + Rl.a[5] * d.y + Rl.a[8] * d.z);
+          const D3 dl = rotT(Rl, d);
           const int type = (int)x[LM_GX_TYPE];
-          V3 loc = v3(0, 0, 0);
+          D3 loc = d3(0, 0, 0);
           if (type == LM_GEOM_MESH) {
             // hill climbing on the hull's vertex graph from the vertex the previous search of this geom ended at (the engine's own
             // support search for meshes with a graph): a handful of steps x ~6 neighbours instead of a scan over every vertex.
@@ -1429,12 +1450,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const F4* A = reinterpret_cast<const F4*>(P.meshadj);
             int cur = hint[which];
             if (cur < 0) {                  // first search of this pair: from the hull's extreme vertex along the dominant axis of the direction
-              const float ax_ = fabsf(dl.x), ay_ = fabsf(dl.y), az_ = fabsf(dl.z);
+              const double ax_ = fabs(dl.x), ay_ = fabs(dl.y), az_ = fabs(dl.z);
               const int k = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
-              const float comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
-              cur = (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0f) ? 1 : 0)];
+              const double comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
+              cur = (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0) ? 1 : 0)];
             }
-            float best = -3.0e38f;
+            double best = -1.0e300;
 #pragma nounroll
             for (int step = 0; step < 256; step++) {
               const F4 h = A[cur];
@@ -1442,127 +1463,131 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
               for (int j = 0; j < 8; j++) e[j] = A[cur + 1 + j];          // (beyond the block's end for a lower degree: ignored; the table is padded)
               const int deg = (int)h.w;
-              if (step == 0) { best = dl.x * h.x + dl.y * h.y + dl.z * h.z; loc = v3(h.x, h.y, h.z); }
+              if (step == 0) { best = dl.x * (double)h.x + dl.y * (double)h.y + dl.z * (double)h.z; loc = d3(h.x, h.y, h.z); }
               int nxt = cur;
 #pragma unroll
               for (int j = 0; j < 8; j++) {
-                const float dd = dl.x * e[j].x + dl.y * e[j].y + dl.z * e[j].z;
-                if (j < deg && dd > best) { best = dd; nxt = (int)e[j].w; loc = v3(e[j].x, e[j].y, e[j].z); }
+                const double dd = dl.x * (double)e[j].x + dl.y * (double)e[j].y + dl.z * (double)e[j].z;
+                if (j < deg && dd > best) { best = dd; nxt = (int)e[j].w; loc = d3(e[j].x, e[j].y, e[j].z); }
               }
 #pragma nounroll
               for (int j = 8; j < deg; j++) {
                 const F4 ej = A[cur + 1 + j];
-                const float dd = dl.x * ej.x + dl.y * ej.y + dl.z * ej.z;
-                if (dd > best) { best = dd; nxt = (int)ej.w; loc = v3(ej.x, ej.y, ej.z); }
+                const double dd = dl.x * (double)ej.x + dl.y * (double)ej.y + dl.z * (double)ej.z;
+                if (dd > best) { best = dd; nxt = (int)ej.w; loc = d3(ej.x, ej.y, ej.z); }
               }
               if (nxt == cur) break;
               cur = nxt;
             }
             hint[which] = cur;
           } else {
-            const V3 ctr = v3(cap[0], cap[1], cap[2]), ax = v3(cap[3], cap[4], cap[5]);
+            const D3 ctr = d3(cap[0], cap[1], cap[2]), ax = d3(cap[3], cap[4], cap[5]);
             if (type == LM_GEOM_BOX) {
-              const V3 ex = v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
-              const V3 ez = cross(ex, ey);
-              loc = ctr + (sgn(dot(dl, ex)) * x[LM_GX_E0]) * ex + (sgn(dot(dl, ey)) * x[LM_GX_E0 + 1]) * ey + (sgn(dot(dl, ez)) * x[LM_GX_E0 + 2]) * ez;
+              const D3 ex = d3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = d3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
+              const D3 ez = dcross(ex, ey);
+              loc = dadd(dadd(ctr, dscl(sgn(ddot(dl, ex)) * (double)x[LM_GX_E0], ex)), dadd(dscl(sgn(ddot(dl, ey)) * (double)x[LM_GX_E0 + 1], ey), dscl(sgn(ddot(dl, ez)) * (double)x[LM_GX_E0 + 2], ez)));
             } else if (type == LM_GEOM_CYLINDER) {
-              const float da = dot(dl, ax);
-              const V3 perp = dl + (-da) * ax;
-              const float t = sqrtf(dot(perp, perp));
-              loc = ctr + (sgn(da) * cap[6]) * ax;
-              if (t > 1e-15f) loc = loc + (cap[7] / t) * perp;
-            } else loc = ctr + cap[7] * dl + (sgn(dot(dl, ax)) * cap[6]) * ax;          // sphere (half length 0), capsule
+              const double da = ddot(dl, ax);
+              const D3 perp = dsub(dl, dscl(da, ax));
+              const double t = sqrt(ddot(perp, perp));
+              loc = dadd(ctr, dscl(sgn(da) * (double)cap[6], ax));
+              if (t > 1e-15) loc = dadd(loc, dscl((double)cap[7] / t, perp));
+            } else loc = dadd(dadd(ctr, dscl((double)cap[7], dl)), dscl(sgn(ddot(dl, ax)) * (double)cap[6], ax));          // sphere (half length 0), capsule
           }
-          return pw[which] + mul(Rl, loc) + hmg * d;
+          return dadd(dadd(pw[which], rot(Rl, loc)), dscl(hmg, d));
         };
-        const int pb = kPortal + 18 * Q::rep() - 6;          // every replica works on a pair of its own: a portal each (points 1..3; point 0 stays in registers)
-        auto pv = [&](int q) -> V3 { return v3(LMEM(pb + 6 * q), LMEM(pb + 6 * q + 1), LMEM(pb + 6 * q + 2)); };
-        auto pv1 = [&](int q) -> V3 { return v3(LMEM(pb + 6 * q + 3), LMEM(pb + 6 * q + 4), LMEM(pb + 6 * q + 5)); };
-        auto put = [&](int q, V3 v, V3 v1) {
-          LMEM(pb + 6 * q) = v.x; LMEM(pb + 6 * q + 1) = v.y; LMEM(pb + 6 * q + 2) = v.z;
-          LMEM(pb + 6 * q + 3) = v1.x; LMEM(pb + 6 * q + 4) = v1.y; LMEM(pb + 6 * q + 5) = v1.z;
+        // the portal: points 1..3 as (v, v1) in local arrays (dynamic index: private memory), point 0 in registers
+        double PV[3][6];
+        auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
+        auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
+        auto put = [&](int q, D3 v, D3 v1) {
+          PV[q - 1][0] = v.x; PV[q - 1][1] = v.y; PV[q - 1][2] = v.z; PV[q - 1][3] = v1.x; PV[q - 1][4] = v1.y; PV[q - 1][5] = v1.z;
         };
         const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
-        const V3 c1 = pw[0] + mul(*Rw[0], v3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ]));
-        const V3 c2 = pw[1] + mul(*Rw[1], v3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ]));
-        V3 v0 = c1 - c2;
-        if (fabsf(v0.x) < eps && fabsf(v0.y) < eps && fabsf(v0.z) < eps) v0.x += 10.0f * eps;
-        auto portal_dir = [&]() -> V3 { const V3 a1 = pv(1); return unit(cross(pv(2) - a1, pv(3) - a1)); };
-        auto expand = [&](V3 v4, V3 v41) {
-          const V3 cr = cross(v4, v0);
+        const D3 c1 = dadd(pw[0], rot(*Rw[0], d3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ])));
+        const D3 c2 = dadd(pw[1], rot(*Rw[1], d3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ])));
+        D3 v0 = dsub(c1, c2);
+        if (is_zero(v0.x) && is_zero(v0.y) && is_zero(v0.z)) v0.x += 10.0 * eps;
+        auto portal_dir = [&]() -> D3 { const D3 a1 = pv(1); return dunit(dcross(dsub(pv(2), a1), dsub(pv(3), a1))); };
+        auto expand = [&](D3 v4, D3 v41) {
+          const D3 cr = dcross(v4, v0);
           int q;
-          if (dot(pv(1), cr) > 0.0f) q = (dot(pv(2), cr) > 0.0f) ? 1 : 3;
-          else q = (dot(pv(3), cr) > 0.0f) ? 2 : 1;
+          if (ddot(pv(1), cr) > 0.0) q = (ddot(pv(2), cr) > 0.0) ? 1 : 3;
+          else q = (ddot(pv(3), cr) > 0.0) ? 2 : 1;
           put(q, v4, v41);
         };
         {
           // one-direction separation test first: along the line between the closest points of the two bounding capsules. Shapes
           // (inflated by margin / 2 each) that are apart along ANY direction do not overlap - the portal search below would say so
           // after five or six support searches, this says it after two, and most queued pairs end here
-          const V3 cA = pw[0] + mul(*Rw[0], v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2])), aA = mul(*Rw[0], v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
-          const V3 cB = pw[1] + mul(*Rw[1], v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2])), aB = mul(*Rw[1], v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
+          const V3 p1f = (g1own ? po_ : pp_) - O, p2f = (g1own ? pp_ : po_) - O;
+          const V3 cA = p1f + mul(*Rw[0], v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2])), aA = mul(*Rw[0], v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
+          const V3 cB = p2f + mul(*Rw[1], v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2])), aB = mul(*Rw[1], v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
           float sa, ta;
           segment_closest(cA, aA, rec[LM_GP_H1], cB, aB, rec[LM_GP_H2], sa, ta);
           const V3 dsep = (cB + ta * aB) - (cA + sa * aA);
           if (dot(dsep, dsep) > 1e-12f) {
-            const V3 du = unit(dsep);
-            V3 sp[2];
+            const D3 du = dunit(up(dsep));
+            D3 sp[2];
 #pragma nounroll
-            for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : -1.0f * du);
-            if (dot(sp[0] - sp[1], du) < 0.0f) return false;
+            for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : dscl(-1.0, du));
+            if (ddot(dsub(sp[0], sp[1]), du) < 0.0) return false;
           }
         }
-        V3 dir = unit(-1.0f * v0);
+        D3 dir = dunit(dscl(-1.0, v0));
         int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
         int nsupport = 0; (void)nsupport;
 #pragma nounroll
-        for (int guard = 0; guard < 128 && result == 0; guard++) {
+        for (int guard = 0; guard < 192 && result == 0; guard++) {
           nsupport++;
-          V3 sup[2];
+          D3 sup[2];
 #pragma nounroll
-          for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : -1.0f * dir);
-          const V3 sv = sup[0] - sup[1];
-          const float dt = dot(sv, dir);
+          for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : dscl(-1.0, dir));
+          const D3 sv = dsub(sup[0], sup[1]);
+          const double dt = ddot(sv, dir);
           if (stage == 0) {
             put(1, sv, sup[0]);
-            if (dt < eps) { result = -1; break; }
-            dir = cross(v0, sv);
-            if (dot(dir, dir) < eps * eps) { result = (dot(sv, sv) < eps * eps) ? -1 : 2; break; }     // touching at v1: no normal | origin on v0-v1
-            dir = unit(dir);
+            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
+            dir = dcross(v0, sv);
+            if (is_zero(ddot(dir, dir))) { result = (is_zero(sv.x) && is_zero(sv.y) && is_zero(sv.z)) ? -1 : 2; break; }     // touching at v1: no normal | origin on v0-v1
+            dir = dunit(dir);
             stage = 1;
           } else if (stage == 1) {
-            if (dt < eps) { result = -1; break; }
+            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
             put(2, sv, sup[0]);
-            dir = unit(cross(pv(1) - v0, sv - v0));
-            if (dot(dir, v0) > 0.0f) { const V3 a = pv(1), a1 = pv1(1); put(1, sv, sup[0]); put(2, a, a1); dir = -1.0f * dir; }
+            dir = dunit(dcross(dsub(pv(1), v0), dsub(sv, v0)));
+            if (ddot(dir, v0) > 0.0) { const D3 a = pv(1), a1 = pv1(1); put(1, sv, sup[0]); put(2, a, a1); dir = dscl(-1.0, dir); }
             stage = 2;
           } else if (stage == 2) {
-            if (dt < eps) { result = -1; break; }
+            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
             put(3, sv, sup[0]);
             bool cont = false;
-            if (dot(cross(pv(1), sv), v0) < -eps) { put(2, sv, sup[0]); cont = true; }
-            else if (dot(cross(sv, pv(2)), v0) < -eps) { put(1, sv, sup[0]); cont = true; }
-            if (cont) dir = unit(cross(pv(1) - v0, pv(2) - v0));
+            double tp = ddot(dcross(pv(1), sv), v0);
+            if (tp < 0.0 && !is_zero(tp)) { put(2, sv, sup[0]); cont = true; }
+            else {
+              tp = ddot(dcross(sv, pv(2)), v0);
+              if (tp < 0.0 && !is_zero(tp)) { put(1, sv, sup[0]); cont = true; }
+            }
+            if (cont) dir = dunit(dcross(dsub(pv(1), v0), dsub(pv(2), v0)));
             else {
               dir = portal_dir();
-#ifdef LM_PAIR_TRACE
-              if (getenv("LM_MPR_TRACE")) { const V3 a_ = pv(1), b_ = pv(2), c_ = pv(3); printf(" d discovered: v0 %.6f %.6f %.6f | v1 %.6f %.6f %.6f | v2 %.6f %.6f %.6f | v3 %.6f %.6f %.6f\n", v0.x, v0.y, v0.z, a_.x, a_.y, a_.z, b_.x, b_.y, b_.z, c_.x, c_.y, c_.z); }
-#endif
-              stage = (dot(dir, pv(1)) >= -eps) ? 4 : 3;          // the portal already holds the origin: straight to the penetration phase
+              const double de = ddot(dir, pv(1));
+              stage = (is_zero(de) || de > 0.0) ? 4 : 3;          // the portal already holds the origin: straight to the penetration phase
             }
           } else {
             // reach of the new support point beyond the portal along dir
-            const float reach = fminf(fminf(dt - dot(pv(1), dir), dt - dot(pv(2), dir)), dt - dot(pv(3), dir));
+            const double reach = fmin(fmin(dt - ddot(pv(1), dir), dt - ddot(pv(2), dir)), dt - ddot(pv(3), dir));
 #ifdef LM_PAIR_TRACE
-            if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, dot(pv(1), dir), reach);
+            if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, ddot(pv(1), dir), reach);
 #endif
             if (stage == 3) {
-              if (dt < -eps || reach <= 1e-6f) { result = -1; break; }
+              if (!(is_zero(dt) || dt > 0.0) || reach <= 1e-6) { result = -1; break; }
               expand(sv, sup[0]);
               dir = portal_dir();
-              if (dot(dir, pv(1)) >= -eps) stage = 4;
+              const double de = ddot(dir, pv(1));
+              if (is_zero(de) || de > 0.0) stage = 4;
             } else {
-              if (reach <= 1e-6f || iter > 50) { result = 1; break; }
+              if (reach <= 1e-6 || iter > 50) { result = 1; break; }
               expand(sv, sup[0]);
               dir = portal_dir();
               iter++;
@@ -1573,72 +1598,75 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         printf("   mpr lane %d rep %d result %d stage %d iter %d supports %d types %d %d\n", c, Q::rep(), result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
 #endif
         if (result <= 0) return false;
-        float depth; V3 pdir, pos;
+        double depth; D3 pdir, pos;
         if (result == 2) {
-          const V3 v1 = pv(1), s1 = pv1(1);
-          depth = sqrtf(dot(v1, v1)); pdir = unit(v1);
-          pos = 0.5f * (s1 + (s1 - v1));
+          const D3 v1 = pv(1), s1 = pv1(1);
+          depth = sqrt(ddot(v1, v1)); pdir = dunit(v1);
+          pos = dscl(0.5, dadd(s1, dsub(s1, v1)));
         } else {
           // closest point of the portal triangle to the origin (libccd: ccdVec3PointTriDist2) -> depth and direction
-          const V3 a = pv(1), b = pv(2), cc = pv(3);
-          const V3 d1 = b - a, d2 = cc - a;
-          const float v = dot(d1, d1), w = dot(d2, d2), pq = dot(a, d1), qq = dot(a, d2), r = dot(d1, d2);
-          const float det = w * v - r * r;
-          float sb = -1.0f, tb = -1.0f;
-          if (fabsf(det) > 1e-30f) { sb = (qq * r - w * pq) / det; tb = (-sb * r - qq) / w; }
-          V3 wit;
-          if (sb >= -eps && sb <= 1.0f + eps && tb >= -eps && tb <= 1.0f + eps && sb + tb <= 1.0f + eps) wit = a + sb * d1 + tb * d2;
+          const D3 a = pv(1), b = pv(2), cc = pv(3);
+          const D3 d1 = dsub(b, a), d2 = dsub(cc, a);
+          const double v = ddot(d1, d1), w = ddot(d2, d2), pq = ddot(a, d1), qq = ddot(a, d2), r = ddot(d1, d2);
+          const double det = w * v - r * r;
+          double sb = -1.0, tb = -1.0;
+          if (!is_zero(det)) { sb = (qq * r - w * pq) / det; tb = (-sb * r - qq) / w; }
+          auto ccd_eq1 = [&](double x) -> bool { const double ab = fabs(x - 1.0); return ab < eps || ab < eps * fmax(fabs(x), 1.0); };
+          D3 wit;
+          if ((is_zero(sb) || sb > 0.0) && (ccd_eq1(sb) || sb < 1.0) && (is_zero(tb) || tb > 0.0) && (ccd_eq1(tb) || tb < 1.0) && (ccd_eq1(tb + sb) || tb + sb < 1.0))
+            wit = dadd(a, dadd(dscl(sb, d1), dscl(tb, d2)));
           else {
-            auto seg = [&](V3 x0, V3 x1e, V3& wout) -> float {
-              const V3 dd = x1e - x0;
-              float t = -dot(x0, dd) / fmaxf(dot(dd, dd), 1e-37f);
-              t = fminf(fmaxf(t, 0.0f), 1.0f);
-              wout = x0 + t * dd;
-              return dot(wout, wout);
+            auto seg = [&](D3 x0, D3 x1e, D3& wout) -> double {
+              const D3 dd = dsub(x1e, x0);
+              const double t = -ddot(x0, dd) / ddot(dd, dd);
+              if (t < 0.0 || is_zero(t)) wout = x0;
+              else if (t > 1.0 || ccd_eq1(t)) wout = x1e;
+              else wout = dadd(x0, dscl(t, dd));
+              return ddot(wout, wout);
             };
-            V3 w2;
-            float best = seg(a, b, wit);
-            float d = seg(a, cc, w2); if (d < best) { best = d; wit = w2; }
+            D3 w2;
+            double best = seg(a, b, wit);
+            double d = seg(a, cc, w2); if (d < best) { best = d; wit = w2; }
             d = seg(b, cc, w2); if (d < best) { best = d; wit = w2; }
           }
-          depth = sqrtf(dot(wit, wit));
-          pdir = (dot(wit, wit) < eps * eps) ? dir : unit(wit);
+          depth = sqrt(ddot(wit, wit));
+          pdir = (is_zero(wit.x) && is_zero(wit.y) && is_zero(wit.z)) ? dir : dunit(wit);
           // barycentric coordinates of the origin in the portal tetrahedron -> witness points on the two shapes
-          const V3 p0 = v0;
-          float bc[4];
-          bc[0] = dot(cross(a, b), cc); bc[1] = dot(cross(cc, b), p0); bc[2] = dot(cross(p0, a), cc); bc[3] = dot(cross(b, a), p0);
-          float sum = (bc[0] + bc[1]) + (bc[2] + bc[3]);
-          if (!(sum > 1e-24f)) {
-            const V3 pd = portal_dir();
-            bc[0] = 0.0f; bc[1] = dot(cross(b, cc), pd); bc[2] = dot(cross(cc, a), pd); bc[3] = dot(cross(a, b), pd);
+          const D3 p0 = v0;
+          double bc[4];
+          bc[0] = ddot(dcross(a, b), cc); bc[1] = ddot(dcross(cc, b), p0); bc[2] = ddot(dcross(p0, a), cc); bc[3] = ddot(dcross(b, a), p0);
+          double sum = bc[0] + bc[1] + bc[2] + bc[3];
+          if (is_zero(sum) || sum < 0.0) {
+            const D3 pd = portal_dir();
+            bc[0] = 0.0; bc[1] = ddot(dcross(b, cc), pd); bc[2] = ddot(dcross(cc, a), pd); bc[3] = ddot(dcross(a, b), pd);
             sum = bc[1] + bc[2] + bc[3];
           }
-          const float inv = 1.0f / sum;
-          V3 q1 = bc[0] * c1, q2 = bc[0] * c2;
+          const double inv = 1.0 / sum;
+          D3 q1 = dscl(bc[0], c1), q2 = dscl(bc[0], c2);
 #pragma unroll
-          for (int q = 1; q < 4; q++) { const V3 s1 = pv1(q), vv = pv(q); q1 = q1 + bc[q] * s1; q2 = q2 + bc[q] * (s1 - vv); }
-          pos = (0.5f * inv) * (q1 + q2);
+          for (int q = 1; q < 4; q++) { const D3 s1 = pv1(q), vv = pv(q); q1 = dadd(q1, dscl(bc[q], s1)); q2 = dadd(q2, dscl(bc[q], dsub(s1, vv))); }
+          pos = dscl(0.5, dadd(dscl(inv, q1), dscl(inv, q2)));
         }
         // the engine's mjc_fixNormal: a sphere / capsule in the pair takes the direction from its centre line to the contact point
         {
-          V3 nn[2]; bool have[2] = {false, false};
+          D3 nn[2]; bool have[2] = {false, false};
 #pragma unroll
           for (int w = 0; w < 2; w++) {
             const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
             const int type = (int)x[LM_GX_TYPE];
             if (type == LM_GEOM_SPHERE || type == LM_GEOM_CAPSULE) {
               const float* cap = rec + (w ? LM_GP_P2 : LM_GP_P1);
-              const V3 ctr = pw[w] + mul(*Rw[w], v3(cap[0], cap[1], cap[2])), ax = mul(*Rw[w], v3(cap[3], cap[4], cap[5]));
-              const V3 rel = pos - ctr;
-              const float t = fminf(fmaxf(dot(rel, ax), -cap[6]), cap[6]);
-              nn[w] = unit(rel + (-t) * ax); have[w] = true;
+              const D3 ctr = dadd(pw[w], rot(*Rw[w], d3(cap[0], cap[1], cap[2]))), ax = rot(*Rw[w], d3(cap[3], cap[4], cap[5]));
+              const D3 rel = dsub(pos, ctr);
+              const double t = fmin(fmax(ddot(rel, ax), -(double)cap[6]), (double)cap[6]);
+              nn[w] = dunit(dsub(rel, dscl(t, ax))); have[w] = true;
             }
           }
-          if (have[0] && have[1]) pdir = unit(nn[0] - nn[1]);
+          if (have[0] && have[1]) pdir = dunit(dsub(nn[0], nn[1]));
           else if (have[0]) pdir = nn[0];
-          else if (have[1]) pdir = -1.0f * nn[1];
+          else if (have[1]) pdir = dscl(-1.0, nn[1]);
         }
-        nrm = pdir; cpo = pos; dist_out = pmargin - depth;
+        nrm = v3((float)pdir.x, (float)pdir.y, (float)pdir.z); cpo = v3((float)pos.x, (float)pos.y, (float)pos.z); dist_out = (float)((double)pmargin - depth);
         return true;
       };
       struct EntryCtx { int ka, kb, lb, own_q, dl; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
@@ -1829,13 +1857,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int j = Q::rep(); j < npairs; j += Q::kRep) {
             const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
             const bool counted_only = rec[LM_GP_KIND] == 1.0f;
-            if (counted_only && !first_detect) continue;
+            if (counted_only && !first_detect && MC <= 3) continue;       // (the quadruped's 76 counted-only pairs: first pass of a control step only)
             const PairGeom G = pair_geom(rec);
             const float pmargin = rec[LM_GP_MARGIN];
 #ifdef LM_PAIR_TRACE
             if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f\n", c, i, first + j, rec[LM_GP_KIND], G.dist);
 #endif
-            if (!counted_only) gap_min = fminf(gap_min, G.dist - pmargin);
+            if (!counted_only || MC > 3) gap_min = fminf(gap_min, G.dist - pmargin);      // (the humanoids' one counted pair — foot on foot — is watched like the others)
             if (G.dist < pmargin) hit += (float)(1 << j);
           }
           if (Q::kRep > 1) hit = Q::rep_sum(hit);                  // disjoint bits: the sum is the union (npairs <= 24: exact)
@@ -1845,17 +1873,50 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
             const PairGeom G = pair_geom(rec);
             const int kind = (int)rec[LM_GP_KIND];
-            if (kind == 1) {                                          // no collider for this pair of geom types: counted (once)
-              if ((G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
-              continue;
-            }
             // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
             // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
             {
               const V3 cc = G.c2 - G.c1;
-              const float rb1 = (kind == 2) ? rec[LM_GP_X1 + LM_GX_RBOUND] : rec[LM_GP_H1] + G.r1;
-              const float rb2 = (kind == 2) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
+              const float rb1 = (rec[LM_GP_X1 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X1 + LM_GX_RBOUND] : rec[LM_GP_H1] + G.r1;
+              const float rb2 = (rec[LM_GP_X2 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
               if (sqrtf(dot(cc, cc)) - rb1 - rb2 > 0.0f) continue;
+            }
+            if (kind == 1) {                                          // no collider for this pair of geom types: counted (once)
+              bool reach = true;
+              if ((int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_BOX && (int)rec[LM_GP_X2 + LM_GX_TYPE] == LM_GEOM_BOX) {
+                // two boxes (the humanoid's feet): the largest gap over the 15 candidate separating axes, like the oracle's count
+                const M3& R1 = G.g1own ? Ro : Rp; const M3& R2 = G.g1own ? Rp : Ro;
+                V3 ax[6]; float hs[6];
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                  const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
+                  const M3& Rw_ = w ? R2 : R1;
+                  const V3 ex = mul(Rw_, v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5])), ey = mul(Rw_, v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]));
+                  ax[3 * w] = ex; ax[3 * w + 1] = ey; ax[3 * w + 2] = cross(ex, ey);
+                  hs[3 * w] = x[LM_GX_E0]; hs[3 * w + 1] = x[LM_GX_E0 + 1]; hs[3 * w + 2] = x[LM_GX_E0 + 2];
+                }
+                const V3 dcen = G.c2 - G.c1;
+                float gap = -3.0e38f;
+                auto test_axis = [&](V3 n) {
+                  float r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+                  for (int k = 0; k < 3; k++) { r1 += hs[k] * fabsf(dot(n, ax[k])); r2 += hs[3 + k] * fabsf(dot(n, ax[3 + k])); }
+                  gap = fmaxf(gap, fabsf(dot(dcen, n)) - r1 - r2);
+                };
+#pragma unroll
+                for (int k = 0; k < 6; k++) test_axis(ax[k]);
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                  for (int l = 0; l < 3; l++) {
+                    const V3 cr = cross(ax[k], ax[3 + l]);
+                    const float n2 = dot(cr, cr);
+                    if (n2 > 1e-18f) test_axis((1.0f / sqrtf(n2)) * cr);
+                  }
+                reach = gap < rec[LM_GP_MARGIN];
+              }
+              if (reach && (G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
+              continue;
             }
             if (kind == 2) {
               if (nq >= kQueue) { n_over++; continue; }                // more convex pairs of this lane in reach than the queue holds: dropped, counted

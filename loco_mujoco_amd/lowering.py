@@ -1011,7 +1011,7 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
                 for base, g in ((GP_P1, a), (GP_P2, b)):
                     pos, axis, half, rad, _ = capsule_of(g)
                     rec[base:base + 3], rec[base + 3:base + 6], rec[base + 6], rec[base + 7] = pos, axis, half, rad
-                if kind == 2:
+                if kind == 2 or (kind == 1 and ta == mjcf.GEOM_BOX and tb == mjcf.GEOM_BOX):      # (box pairs are counted by their exact gap)
                     rec[GP_X1:GP_X1 + GX_SIZE], rec[GP_X2:GP_X2 + GX_SIZE] = convex_of(a), convex_of(b)
                 rec[GP_MARGIN] = margin
                 rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)

@@ -273,6 +273,7 @@ typedef struct {
   double act_dot[LMO_MAXU], actuator_force[LMO_MAXU], actuator_length[LMO_MAXU], actuator_velocity[LMO_MAXU];
   int solver_iter;
   int unhandled_pairs;
+  int convex_contacts; double max_self_depth;     /* per forward pass: MPR contacts, deepest non-floor penetration */
 } work;
 
 enum { ROW_FRICTION = 0, ROW_LIMIT = 1, ROW_CONTACT_PLAIN = 2, ROW_CONTACT_PYR = 3, ROW_CONTACT_ELL = 4 };
@@ -882,7 +883,7 @@ static void fix_normal(const cvx* A, const cvx* B, const double* pos, double* no
 }
 
 static void collide(const lmo_model* m, work* w) {
-  w->ncon = 0; w->unhandled_pairs = 0;
+  w->ncon = 0; w->unhandled_pairs = 0; w->convex_contacts = 0; w->max_self_depth = 0;
   for (int pi = 0; pi < m->npair; pi++) {
     int g1 = m->pair_g1[pi], g2 = m->pair_g2[pi];
     int t1 = IDX(m->geom_type, g1), t2 = IDX(m->geom_type, g2);
@@ -1054,6 +1055,7 @@ static void collide(const lmo_model* m, work* w) {
       if (mpr_penetration(&oa, &ob, &depth, dir, pos) == 0 && !(dir[0] == 0 && dir[1] == 0 && dir[2] == 0)) {
         fix_normal(&A, &B, pos, dir);
         add_contact(w, &tm, margin - depth, pos, dir, NULL);
+        w->convex_contacts++;
       }
     } else if (m->skip_pair_counter) {
       /* timing runs: the pair has no collider here, and whether the engine would have a contact is not asked */
@@ -1548,6 +1550,8 @@ static void forward(const lmo_model* m, const double* qpos, const double* qvel, 
   mass_matrix(m, w);
   cholesky(w->L, w->M, nv);
   collide(m, w);
+  for (int ci = 0; ci < w->ncon; ci++)
+    if (IDX(m->geom_type, w->con[ci].geom1) != LM_GEOM_PLANE && -w->con[ci].dist > w->max_self_depth) w->max_self_depth = -w->con[ci].dist;
   make_constraints(m, qpos, w);
   /* velocity stage */
   for (int d = 0; d < nv; d++) w->passive[d] = -m->jnt_stiffness[d] * qpos[d] - m->dof_damping[d] * qvel[d];
@@ -1662,6 +1666,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
   for (int s = 0; s < nsub; s++) {
     if (m->integrator == LM_INT_EULER) {
       forward(m, qpos, qvel, ctrl, act, warmstart, w);
+      if (stats) { stats->convex_contacts += w->convex_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
       if (warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
       euler(m, qpos, qvel, w);
       for (int i = 0; i < m->na; i++) act[i] += m->timestep * w->act_dot[i];      /* explicit Euler on activations */
@@ -1674,6 +1679,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
       memcpy(X, q0, sizeof(double) * nv); memcpy(V, v0, sizeof(double) * nv);
       for (int st = 0; st < 4; st++) {
         forward(m, X, V, ctrl, NULL, warmstart, w);
+        if (stats) { stats->convex_contacts += w->convex_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
         if (st == 0 && warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
         for (int d = 0; d < nv; d++) { dq[d] += Bw[st] * V[d]; dv[d] += Bw[st] * w->qacc[d]; }
         if (st < 3) for (int d = 0; d < nv; d++) { double vn = v0[d] + h * A[st] * w->qacc[d]; X[d] = q0[d] + h * A[st] * V[d]; V[d] = vn; }

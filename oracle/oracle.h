@@ -27,6 +27,8 @@ typedef struct {
 
 typedef struct {
   int ncon, nefc, solver_iter_total, solver_iter_max, unhandled_pairs;
+  int convex_contacts;        /* contacts from the convex-convex collider (MPR), summed over the forward passes */
+  double max_self_depth;      /* deepest penetration (-dist) of a contact between two bodies of the robot over all forward passes */
 } lmo_stats;
 
 typedef struct {

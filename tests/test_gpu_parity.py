@@ -1240,14 +1240,14 @@ def _worker_oracle_steps(args):
             dv = v[i] + e * rs.uniform(-1, 1, v[i].shape) * np.maximum(1.0, np.abs(v[i]))
             qp, vp, _, _ = _oracle_step(env, oracle, dq, dv, actions[i], a0)
             sq, sv = max(sq, np.abs(qp - qo).max()), max(sv, np.abs(vp - vo).max())
-        out.append((qo, vo, ao, st["unhandled_pairs"], sq, sv))
+        out.append((qo, vo, ao, st["unhandled_pairs"], sq, sv, st["max_self_depth"], st["convex_contacts"]))
     return out
 
 
 @pytest.mark.parametrize("task,kw,policy,nroll,min_ok", [("UnitreeA1.simple", {}, "zero", 12, 0.97), ("UnitreeA1.simple", {}, "random", 12, 0.97),
-                                                         ("HumanoidTorque.run", {}, "random", 12, 0.35), ("HumanoidTorque.run", {}, "random", 3, 0.6),
-                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.85),
-                                                         ("Talos.walk", {}, "random", 12, 0.9), ("UnitreeH1.walk", {}, "random", 3, 0.4),
+                                                         ("HumanoidTorque.run", {}, "random", 12, 0.85), ("HumanoidTorque.run", {}, "random", 3, 0.95),
+                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.9),
+                                                         ("Talos.walk", {}, "random", 12, 0.9), ("UnitreeH1.walk", {}, "random", 3, 0.9),
                                                          ("UnitreeG1.walk", {}, "random", 3, 0.4)])
 def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok):
     """the error distribution over 4096 REACHABLE states per configuration. The states come from a device
@@ -1260,9 +1260,7 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     by float32-sized noise (24 probes per state beyond the tolerance, 1e-7 .. 3e-6 relative: the input rounding and what ten
     substeps of float32 arithmetic add to it; four probes let two such states of 4096 slip through, profiles/r2_ab_probes.md):
     a contact or a joint limit that switches on within a hair of a substep boundary — the engine's contact damping acts at full strength from the first pass in which dist < margin,
-    so a foot arriving at 2 m/s gains or loses ~0.05 m/s with the pass in which it is first seen, in float64 as in float32. The humanoid's bone meshes collide as convex hulls in the reference (libccd); neither side restates that:
-    a humanoid that has folded up under 12 steps of random torques has bone pairs in reach in most states (`min_ok`), which is
-    why it is also run after 3 steps."""
+    so a foot arriving at 2 m/s gains or loses ~0.05 m/s with the pass in which it is first seen, in float64 as in float32. The humanoid's bone meshes, the box feet against them and UnitreeH1's cylinders and link meshes collide through the engine's convex collider (MPR) on both sides now; what the oracle still only counts is box against box (one foot on the other)."""
     from multiprocessing.pool import ThreadPool
     from loco_mujoco_amd.backend import HipBatch, HipModel
     np.random.seed(0)
@@ -1272,7 +1270,9 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     tab = env._reset_table()
     rs = np.random.RandomState(2024)
     rows = tab[rs.randint(0, len(tab), n)]
-    b = HipBatch(HipModel(env._chain_model()), n)
+    cmod = env._chain_model()
+    no_device_pairs = int(cmod[lowering.H_NGPAIR]) == 0 and lowering._count_self_pairs(m) > 0
+    b = HipBatch(HipModel(cmod), n)
     b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
     if rows.shape[1] > 2 * m.nv:
         b.set_goal(rows[:, 2 * m.nv:])
@@ -1299,6 +1299,8 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
         eq = np.array([np.abs(q1[i] - res[i][0]).max() for i in range(n)])
         ev = np.array([np.abs(v1[i] - res[i][1]).max() for i in range(n)])
         unhandled = np.array([r[3] > 0 for r in res])
+        if no_device_pairs:      # (UnitreeG1: 117 link pairs per chain do not fit the device's pair list) the oracle's convex contacts have no counterpart
+            unhandled |= np.array([r[7] > 0 for r in res])
         # conditioning probes for the states beyond the tolerance: 24 of them, 1e-7 .. 3e-6 relative (the input rounding and
         # what ten substeps of float32 arithmetic add to it)
         beyond = np.nonzero(((eq > QTOL) | (ev > VTOL)) & ~unhandled)[0]
@@ -1307,17 +1309,40 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
         pres = [r[0] for r in pool.map(_worker_oracle_steps, pj)]
     illcond = np.zeros(n, dtype=bool)
     for i, r in zip(beyond, pres):
-        illcond[i] = (r[4] > QTOL) or (r[5] > VTOL)
+        # ... or moves by at least half of what the device is off by: the difference is then inside the band the reference's own
+        # output covers under float32-sized input noise (a cylinder in the engine's convex collider: the portal search ends on
+        # another triangle of the curved surface, the normal turns by 1e-2 rad — in float64, under 1e-9 noise)
+        illcond[i] = (r[4] > QTOL) or (r[5] > VTOL) or ((eq[i] <= QTOL or r[4] >= 0.5 * eq[i]) and (ev[i] <= VTOL or r[5] >= 0.5 * ev[i]))
     dropped = (flags & 1) != 0
+    # bodies of the robot driven deep into each other during the step (random torques at full range push a shin through a thigh):
+    # reported as a class of their own. With the device's convex collider in float64 they agree like the rest (in float32 the
+    # portal search took other paths: normals tens of degrees apart, profiles/r3_notes.md §3); DEEP only splits the report.
+    DEEP = 0.003
+    depth = np.array([r[6] for r in res])
+    deep = depth > DEEP
     ok = ~unhandled & ~illcond & ~dropped
+    okd = ok & deep
+    nself = int((np.array([r[7] for r in res]) > 0).sum())
     print("%s / %s policy, 4096 reachable states, one control step: compared %d (no collider on the oracle's side %d, beyond the tolerance AND "
-          "ill-conditioned for float32 inputs %d, a contact dropped on the device %d); qpos median %.2e p99 %.2e max %.2e | qvel median %.2e p99 %.2e max %.2e | "
+          "ill-conditioned for float32 inputs %d, a contact dropped on the device %d; of the compared: self-penetration deeper than %g mm %d); qpos median %.2e p99 %.2e max %.2e | "
+          "qvel median %.2e p99 %.2e max %.2e | states with convex self-contacts on the oracle's side %d (compared: %d) | deep states: qpos median %.2e p90 %.2e, qvel median %.2e p90 %.2e | "
           "ALL 4096: qpos p99 %.2e max %.2e qvel p99 %.2e max %.2e | device: contacts dropped %d, self-contacts %d, uncollidable pairs in reach %d, collider-less geoms at the floor %d"
-          % (task, policy, ok.sum(), unhandled.sum(), (illcond & ~unhandled).sum(), (dropped & ~unhandled & ~illcond).sum(), np.median(eq[ok]), np.percentile(eq[ok], 99), eq[ok].max(),
-             np.median(ev[ok]), np.percentile(ev[ok], 99), ev[ok].max(), np.percentile(eq, 99), eq.max(), np.percentile(ev, 99), ev.max(),
+          % (task, policy, ok.sum(), unhandled.sum(), (illcond & ~unhandled).sum(), (dropped & ~unhandled & ~illcond).sum(), 1e3 * DEEP, okd.sum(),
+             np.median(eq[ok]), np.percentile(eq[ok], 99), eq[ok].max(), np.median(ev[ok]), np.percentile(ev[ok], 99), ev[ok].max(),
+             nself, int((ok & (np.array([r[7] for r in res]) > 0)).sum()),
+             np.median(eq[okd]) if okd.any() else 0.0, np.percentile(eq[okd], 90) if okd.any() else 0.0, np.median(ev[okd]) if okd.any() else 0.0, np.percentile(ev[okd], 90) if okd.any() else 0.0,
+             np.percentile(eq, 99), eq.max(), np.percentile(ev, 99), ev.max(),
              st["overflow_contacts"], st["self_contacts"], st["self_proximity"], st["unhandled_geoms"]))
+    if os.environ.get("LM_DUMP_OUTLIERS"):          # diagnostics: the comparable states farthest beyond the tolerance, for a look on the CPU
+        worst = [i for i in np.argsort(-(ev / VTOL + eq / QTOL)) if ok[i]][:48]
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r3_outliers"), exist_ok=True)
+        np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r3_outliers", "%s_%s_%d.npz" % (task, policy, nroll)),
+                 q0=q0[worst], v0=v0[worst], act=actions[worst], q1=q1[worst], v1=v1[worst], qo=np.array([res[i][0] for i in worst]), vo=np.array([res[i][1] for i in worst]),
+                 eq=eq[worst], ev=ev[worst], flags=flags[worst], depth=depth[worst])
     assert ok.sum() >= min_ok * n
-    assert ((flags & 2) != 0).sum() <= unhandled.sum() + 8      # the device's own proximity flag fires no more often than the oracle's
+    # the device says when it leaves its collision model, and not more often than the oracle finds a pair without a collider
+    prox = (flags & 2) != 0
+    assert no_device_pairs or (prox.sum() <= 1.1 * unhandled.sum() + 8 and (unhandled.sum() < 20 or (prox & unhandled).sum() >= 0.9 * unhandled.sum()))
     assert eq[ok].max() <= QTOL and ev[ok].max() <= VTOL
 
 
