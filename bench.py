@@ -167,6 +167,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="testing only: run all ranks on GPU 0 with the gloo backend "
                     "(checks the multi-rank control flow on a one-GPU box; the numbers mean nothing)")
     ap.add_argument("--dump-states", default=None, help=argparse.SUPPRESS)              # tests: <prefix>.rank<r>.npz with the final states
+    ap.add_argument("--require-rccl", action="store_true", help="exit non-zero instead of reducing the metrics over TCP sockets when the RCCL "
+                    "communicator does not come up (N > 1)")
+    ap.add_argument("--sustained", type=int, default=200, help="control steps of the extra sustained leg (per-step launches, one "
+                    "timed block of at least this many steps; 0 = skip; skipped when --steps already covers it)")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
@@ -191,7 +195,8 @@ def main():
     from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
     if args.share_gpu:
         local_rank = 0
-    coll = Collective(backend="tcp" if args.share_gpu else "rccl", rank=rank, world=world, device=local_rank)
+    coll = Collective(backend="tcp" if args.share_gpu else "rccl", rank=rank, world=world, device=local_rank,
+                      require_rccl=args.require_rccl and not args.share_gpu)
 
     from loco_mujoco_amd import LocoEnv
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -254,9 +259,20 @@ def main():
         barrier()
         fused = [time.perf_counter() - t1, stf["kernel_ms"]]
 
+    # second extra leg: a sustained block of per-step launches (thermal / clock steady state rather than a short burst);
+    # the timed region above already is one when --steps >= --sustained
+    sustained = None
+    if args.sustained > args.steps:
+        barrier()
+        t2 = time.perf_counter()
+        sts = b.rollout(args.sustained, action_mode=action_mode, seed=15)
+        barrier()
+        sustained = [time.perf_counter() - t2, sts["env_steps"]]
+
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
-                     fused[0] if fused is not None else 0.0, st["self_proximity"], st["self_contacts"]], dtype=np.float64)
+                     fused[0] if fused is not None else 0.0, st["self_proximity"], st["self_contacts"],
+                     sustained[0] if sustained is not None else 0.0, sustained[1] if sustained is not None else 0.0], dtype=np.float64)
     tmax = coll.all_reduce(vals, MAX)
     vals = coll.all_reduce(vals, SUM)
     elapsed, kernel_ms, fused_elapsed = float(tmax[0]), float(tmax[8]), float(tmax[9])
@@ -282,8 +298,8 @@ def main():
     import hashlib
     from loco_mujoco_amd import backend as _backend
     lib_sha = hashlib.sha256(open(_backend.LIB_PATH, "rb").read()).hexdigest()[:16]
-    # profiles/<tag>_pmc.json: "r2" for the bench line, "r2_<task>[.dr][<envs>]" for the other configurations
-    tag = "r2" if (default_task and n == 4096) else "r2_%s%s%s" % (args.task, ".dr" if args.dr else "", "" if n == 4096 else str(n))
+    # profiles/<tag>_pmc.json: "r3" for the bench line, "r3_<task>[.dr][<envs>]" for the other configurations
+    tag = "r3" if (default_task and n == 4096) else "r3_%s%s%s" % (args.task, ".dr" if args.dr else "", "" if n == 4096 else str(n))
     prof = os.path.join(ROOT, "profiles", tag + "_pmc.json")
     prof_name = "profiles/%s_pmc.json" % tag
     prof_note = "no committed profile for this workload"
@@ -316,8 +332,8 @@ def main():
                                % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else ""), n,
                                   "zero-action" if default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 12 doubles at report time",
-                                  "tcp": "socket reduction of 12 doubles at report time (RCCL not used)"}[coll.backend]},
+                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 14 doubles at report time",
+                                  "tcp": "socket reduction of 14 doubles at report time (RCCL not used)"}[coll.backend]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -345,6 +361,14 @@ def main():
                                 "note": "policy-free rollout with %d control steps per launch (lm_rollout_fused): every "
                                         "environment advances on its own, results bitwise those of single-step launches; "
                                         "a policy in the loop gets `value`" % args.fuse}
+    if sustained is not None and tmax[12] > 0:
+        out["sustained"] = {"steps": args.sustained, "value": vals[13] / float(tmax[12]), "unit": "env-steps/s",
+                            "ms_per_step": 1e3 * float(tmax[12]) / args.sustained,
+                            "note": "one timed block of %d per-step launches after the timed region (same policy, same "
+                                    "state mixture); `value` is the --steps block" % args.sustained}
+    elif args.sustained:
+        out["sustained"] = {"steps": args.steps, "value": value, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / args.steps,
+                            "note": "the timed region itself (--steps >= --sustained)"}
     if world == 1 and not args.no_cpu_baseline:
         out["parity"] = parity_sample(env, hm, table, not default_task)
         one = cpu_baseline(env, table, args.task, not default_task, budget_s=6.0)

@@ -94,6 +94,9 @@ int lm_model_dims(const lm_model* m, lm_dims* out);
 
 int lm_batch_create(lm_model* m, int n_envs, lm_batch** out);
 void lm_batch_destroy(lm_batch* b);
+/* Launch geometry (no counterpart in the reference: its step is one MjData at a time, base.py:185). envs_per_workgroup = 4: one wave
+   per 4 environments, each replicated over 4 quads (default); 8 or 16: plain layout without replicas. Same physics either way. */
+int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup);
 
 /* mask: [n_envs] bytes, NULL = all environments. Setting a state clears that env's warm start. */
 int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask);

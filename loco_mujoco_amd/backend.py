@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
-           "lm_batch_create", "lm_batch_destroy", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
+           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
            "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows"]
@@ -63,6 +63,7 @@ def load_library():
     lib.lm_model_destroy.restype = None
     lib.lm_model_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
     lib.lm_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.lm_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.lm_batch_destroy.argtypes = [C.c_void_p]
     lib.lm_batch_destroy.restype = None
     lib.lm_set_state.argtypes = [C.c_void_p, _F, _F, _U8]
@@ -139,13 +140,16 @@ class HipModel:
 class HipBatch:
     """A batch of ``n_envs`` lock-step environments resident on one GPU."""
 
-    def __init__(self, model, n_envs):
+    def __init__(self, model, n_envs, envs_per_workgroup=None):
+        """``envs_per_workgroup``: None / 4 = the replicated layout (default), 8 or 16 = the plain layout (lm_batch_set_layout)."""
         self.model = model
         self.n = int(n_envs)
         self._lib = load_library()
         h = C.c_void_p()
         _check(self._lib.lm_batch_create(model._h, self.n, C.byref(h)))
         self._h = h
+        if envs_per_workgroup is not None:
+            _check(self._lib.lm_batch_set_layout(self._h, int(envs_per_workgroup)))
         d = model.dims
         self.nq, self.nv, self.nu, self.nobs, self.ngoal = d.nq, d.nv, d.nu, d.nobs, d.ngoal
         self.na = d.na

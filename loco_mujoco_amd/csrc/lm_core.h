@@ -30,6 +30,9 @@
 #include "../../include/lm_layout.h"
 
 #define LM_PAIR_PAD 0.03f     // metres added to the reach of the link-pair list (lowering.PAIR_PAD)
+#ifndef LM_DEV_COLD
+#define LM_DEV_COLD LM_DEV    // the includer may make the rare, register-hungry helpers real functions (lm_step.h: noinline)
+#endif
 #ifndef LM_LMEM_T
 #define LM_LMEM_T float       // element type of lane memory (A/B probe: `volatile float`)
 #endif
@@ -961,6 +964,282 @@ LM_DEV void segment_closest(V3 p1, V3 d1, float h1, V3 p2, V3 d2, float h2, floa
   s_out = s; t_out = t;
 }
 
+// ---- convex pairs (geom-pair kind 2): the engine's general convex collider = libccd's Minkowski Portal Refinement driven by the
+// engine's support / centre callbacks (oracle/oracle.c: mpr_penetration is the float64 restatement this follows step by step).
+// One support call site: the phases of the algorithm are a small state machine around it. Both shapes are inflated by
+// margin / 2 along the search direction; result: normal from geom 1 to geom 2, contact point (relative to O) midway between the
+// two witness points, distance = margin - depth. The support search of a hull climbs its vertex graph (adjacency blocks).
+// OUT OF LINE on the device (LM_DEV_COLD = noinline): float64 arithmetic, a private portal array and ~100 live values of its own —
+// inlined into the step kernel they cost every launch 500 B of scratch per lane (the quadruped's bench rollout, which never
+// calls it, ran 17 % slower); as a function the kernel's own registers are saved once around the rare call.
+struct MprOut { float nx, ny, nz, px, py, pz, dist; int found; };
+LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int lane_c) {
+  MprOut out; out.nx = out.ny = out.nz = out.px = out.py = out.pz = out.dist = 0.0f; out.found = 0;
+  (void)lane_c;
+    // FLOAT64 inside: the portal search takes hundreds of sign decisions on differences of nearly equal support values; in
+    // float32 their rounding alone sends it down another path (a cylinder against a hull: normals 1e-2 rad apart from one
+    // evaluation to the next of the same state, where the float64 collider does not move) — MI355X runs float64 vector code at
+    // half rate, and the search is bound by the latency of the hull-vertex fetches anyway. Inputs (link frames, float32 hull
+    // vertices) and outputs are float32.
+    struct D3 { double x, y, z; };
+    auto d3 = [](double x, double y, double z) -> D3 { D3 r; r.x = x; r.y = y; r.z = z; return r; };
+    auto dsub = [&](D3 a, D3 b) -> D3 { return d3(a.x - b.x, a.y - b.y, a.z - b.z); };
+    auto dadd = [&](D3 a, D3 b) -> D3 { return d3(a.x + b.x, a.y + b.y, a.z + b.z); };
+    auto dscl = [&](double k, D3 a) -> D3 { return d3(k * a.x, k * a.y, k * a.z); };
+    auto ddot = [](D3 a, D3 b) -> double { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    auto dcross = [&](D3 a, D3 b) -> D3 { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); };
+    auto dunit = [&](D3 a) -> D3 { const double n = sqrt(ddot(a, a)); return (n > 0.0) ? dscl(1.0 / n, a) : a; };
+    auto up = [&](V3 a) -> D3 { return d3((double)a.x, (double)a.y, (double)a.z); };
+    auto rot = [&](const M3& Rm, D3 v) -> D3 {          // R v
+      return d3((double)Rm.a[0] * v.x + (double)Rm.a[1] * v.y + (double)Rm.a[2] * v.z, (double)Rm.a[3] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[5] * v.z,
+                (double)Rm.a[6] * v.x + (double)Rm.a[7] * v.y + (double)Rm.a[8] * v.z);
+    };
+    auto rotT = [&](const M3& Rm, D3 v) -> D3 {         // R^T v
+      return d3((double)Rm.a[0] * v.x + (double)Rm.a[3] * v.y + (double)Rm.a[6] * v.z, (double)Rm.a[1] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[7] * v.z,
+                (double)Rm.a[2] * v.x + (double)Rm.a[5] * v.y + (double)Rm.a[8] * v.z);
+    };
+    const D3 pw[2] = {up((g1own ? po_ : pp_) - O), up((g1own ? pp_ : po_) - O)};
+    const M3* Rw[2] = {g1own ? &Ro_ : &Rp_, g1own ? &Rp_ : &Ro_};
+    const double hmg = 0.5 * (double)pmargin, eps = 2.220446049250313e-16;
+    auto is_zero = [&](double x) -> bool { return fabs(x) < eps; };
+    auto sgn = [](double x) -> double { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); };
+    int hint[2] = {-1, -1};            // where the hill climbing of either hull starts: its previous support vertex
+    auto support1 = [&](int which, D3 d) -> D3 {
+      const M3& Rl = *Rw[which];
+      const float* cap = rec + (which ? LM_GP_P2 : LM_GP_P1);        // bounding capsule: centre 3, axis 3, half length, radius
+      const float* x = rec + (which ? LM_GP_X2 : LM_GP_X1);
+      const D3 dl = rotT(Rl, d);
+      const int type = (int)x[LM_GX_TYPE];
+      D3 loc = d3(0, 0, 0);
+      if (type == LM_GEOM_MESH) {
+        // hill climbing on the hull's vertex graph from the vertex the previous search of this geom ended at (the engine's own
+        // support search for meshes with a graph): a handful of steps x ~6 neighbours instead of a scan over every vertex.
+        // meshadj: per vertex a block [x y z degree][neighbour x y z, neighbour's block]...: one step = one contiguous block,
+        // its header and first eight neighbours fetched together (one memory round trip per step)
+        const F4* A = reinterpret_cast<const F4*>(meshadj);
+        int cur = hint[which];
+        if (cur < 0) {                  // first search of this pair: from the hull's extreme vertex along the dominant axis of the direction
+          const double ax_ = fabs(dl.x), ay_ = fabs(dl.y), az_ = fabs(dl.z);
+          const int k = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
+          const double comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
+          cur = (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0) ? 1 : 0)];
+        }
+        double best = -1.0e300;
+#pragma nounroll
+        for (int step = 0; step < 256; step++) {
+          const F4 h = A[cur];
+          F4 e[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) e[j] = A[cur + 1 + j];          // (beyond the block's end for a lower degree: ignored; the table is padded)
+          const int deg = (int)h.w;
+          if (step == 0) { best = dl.x * (double)h.x + dl.y * (double)h.y + dl.z * (double)h.z; loc = d3(h.x, h.y, h.z); }
+          int nxt = cur;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const double dd = dl.x * (double)e[j].x + dl.y * (double)e[j].y + dl.z * (double)e[j].z;
+            if (j < deg && dd > best) { best = dd; nxt = (int)e[j].w; loc = d3(e[j].x, e[j].y, e[j].z); }
+          }
+#pragma nounroll
+          for (int j = 8; j < deg; j++) {
+            const F4 ej = A[cur + 1 + j];
+            const double dd = dl.x * (double)ej.x + dl.y * (double)ej.y + dl.z * (double)ej.z;
+            if (dd > best) { best = dd; nxt = (int)ej.w; loc = d3(ej.x, ej.y, ej.z); }
+          }
+          if (nxt == cur) break;
+          cur = nxt;
+        }
+        hint[which] = cur;
+      } else {
+        const D3 ctr = d3(cap[0], cap[1], cap[2]), ax = d3(cap[3], cap[4], cap[5]);
+        if (type == LM_GEOM_BOX) {
+          const D3 ex = d3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = d3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
+          const D3 ez = dcross(ex, ey);
+          loc = dadd(dadd(ctr, dscl(sgn(ddot(dl, ex)) * (double)x[LM_GX_E0], ex)), dadd(dscl(sgn(ddot(dl, ey)) * (double)x[LM_GX_E0 + 1], ey), dscl(sgn(ddot(dl, ez)) * (double)x[LM_GX_E0 + 2], ez)));
+        } else if (type == LM_GEOM_CYLINDER) {
+          const double da = ddot(dl, ax);
+          const D3 perp = dsub(dl, dscl(da, ax));
+          const double t = sqrt(ddot(perp, perp));
+          loc = dadd(ctr, dscl(sgn(da) * (double)cap[6], ax));
+          if (t > 1e-15) loc = dadd(loc, dscl((double)cap[7] / t, perp));
+        } else loc = dadd(dadd(ctr, dscl((double)cap[7], dl)), dscl(sgn(ddot(dl, ax)) * (double)cap[6], ax));          // sphere (half length 0), capsule
+      }
+      return dadd(dadd(pw[which], rot(Rl, loc)), dscl(hmg, d));
+    };
+    // the portal: points 1..3 as (v, v1) in local arrays (dynamic index: private memory), point 0 in registers
+    double PV[3][6];
+    auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
+    auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
+    auto put = [&](int q, D3 v, D3 v1) {
+      PV[q - 1][0] = v.x; PV[q - 1][1] = v.y; PV[q - 1][2] = v.z; PV[q - 1][3] = v1.x; PV[q - 1][4] = v1.y; PV[q - 1][5] = v1.z;
+    };
+    const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
+    const D3 c1 = dadd(pw[0], rot(*Rw[0], d3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ])));
+    const D3 c2 = dadd(pw[1], rot(*Rw[1], d3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ])));
+    D3 v0 = dsub(c1, c2);
+    if (is_zero(v0.x) && is_zero(v0.y) && is_zero(v0.z)) v0.x += 10.0 * eps;
+    auto portal_dir = [&]() -> D3 { const D3 a1 = pv(1); return dunit(dcross(dsub(pv(2), a1), dsub(pv(3), a1))); };
+    auto expand = [&](D3 v4, D3 v41) {
+      const D3 cr = dcross(v4, v0);
+      int q;
+      if (ddot(pv(1), cr) > 0.0) q = (ddot(pv(2), cr) > 0.0) ? 1 : 3;
+      else q = (ddot(pv(3), cr) > 0.0) ? 2 : 1;
+      put(q, v4, v41);
+    };
+    {
+      // one-direction separation test first: along the line between the closest points of the two bounding capsules. Shapes
+      // (inflated by margin / 2 each) that are apart along ANY direction do not overlap - the portal search below would say so
+      // after five or six support searches, this says it after two, and most queued pairs end here
+      const V3 p1f = (g1own ? po_ : pp_) - O, p2f = (g1own ? pp_ : po_) - O;
+      const V3 cA = p1f + mul(*Rw[0], v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2])), aA = mul(*Rw[0], v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
+      const V3 cB = p2f + mul(*Rw[1], v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2])), aB = mul(*Rw[1], v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
+      float sa, ta;
+      segment_closest(cA, aA, rec[LM_GP_H1], cB, aB, rec[LM_GP_H2], sa, ta);
+      const V3 dsep = (cB + ta * aB) - (cA + sa * aA);
+      if (dot(dsep, dsep) > 1e-12f) {
+        const D3 du = dunit(up(dsep));
+        D3 sp[2];
+#pragma nounroll
+        for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : dscl(-1.0, du));
+        if (ddot(dsub(sp[0], sp[1]), du) < 0.0) return out;
+      }
+    }
+    D3 dir = dunit(dscl(-1.0, v0));
+    int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
+    int nsupport = 0; (void)nsupport;
+#pragma nounroll
+    for (int guard = 0; guard < 192 && result == 0; guard++) {
+      nsupport++;
+      D3 sup[2];
+#pragma nounroll
+      for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : dscl(-1.0, dir));
+      const D3 sv = dsub(sup[0], sup[1]);
+      const double dt = ddot(sv, dir);
+      if (stage == 0) {
+        put(1, sv, sup[0]);
+        if (is_zero(dt) || dt < 0.0) { result = -1; break; }
+        dir = dcross(v0, sv);
+        if (is_zero(ddot(dir, dir))) { result = (is_zero(sv.x) && is_zero(sv.y) && is_zero(sv.z)) ? -1 : 2; break; }     // touching at v1: no normal | origin on v0-v1
+        dir = dunit(dir);
+        stage = 1;
+      } else if (stage == 1) {
+        if (is_zero(dt) || dt < 0.0) { result = -1; break; }
+        put(2, sv, sup[0]);
+        dir = dunit(dcross(dsub(pv(1), v0), dsub(sv, v0)));
+        if (ddot(dir, v0) > 0.0) { const D3 a = pv(1), a1 = pv1(1); put(1, sv, sup[0]); put(2, a, a1); dir = dscl(-1.0, dir); }
+        stage = 2;
+      } else if (stage == 2) {
+        if (is_zero(dt) || dt < 0.0) { result = -1; break; }
+        put(3, sv, sup[0]);
+        bool cont = false;
+        double tp = ddot(dcross(pv(1), sv), v0);
+        if (tp < 0.0 && !is_zero(tp)) { put(2, sv, sup[0]); cont = true; }
+        else {
+          tp = ddot(dcross(sv, pv(2)), v0);
+          if (tp < 0.0 && !is_zero(tp)) { put(1, sv, sup[0]); cont = true; }
+        }
+        if (cont) dir = dunit(dcross(dsub(pv(1), v0), dsub(pv(2), v0)));
+        else {
+          dir = portal_dir();
+          const double de = ddot(dir, pv(1));
+          stage = (is_zero(de) || de > 0.0) ? 4 : 3;          // the portal already holds the origin: straight to the penetration phase
+        }
+      } else {
+        // reach of the new support point beyond the portal along dir
+        const double reach = fmin(fmin(dt - ddot(pv(1), dir), dt - ddot(pv(2), dir)), dt - ddot(pv(3), dir));
+#ifdef LM_PAIR_TRACE
+        if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, ddot(pv(1), dir), reach);
+#endif
+        if (stage == 3) {
+          if (!(is_zero(dt) || dt > 0.0) || reach <= 1e-6) { result = -1; break; }
+          expand(sv, sup[0]);
+          dir = portal_dir();
+          const double de = ddot(dir, pv(1));
+          if (is_zero(de) || de > 0.0) stage = 4;
+        } else {
+          if (reach <= 1e-6 || iter > 50) { result = 1; break; }
+          expand(sv, sup[0]);
+          dir = portal_dir();
+          iter++;
+        }
+      }
+    }
+#ifdef LM_PAIR_TRACE
+    printf("   mpr lane %d rep %d result %d stage %d iter %d supports %d types %d %d\n", lane_c, 0, result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
+#endif
+    if (result <= 0) return out;
+    double depth; D3 pdir, pos;
+    if (result == 2) {
+      const D3 v1 = pv(1), s1 = pv1(1);
+      depth = sqrt(ddot(v1, v1)); pdir = dunit(v1);
+      pos = dscl(0.5, dadd(s1, dsub(s1, v1)));
+    } else {
+      // closest point of the portal triangle to the origin (libccd: ccdVec3PointTriDist2) -> depth and direction
+      const D3 a = pv(1), b = pv(2), cc = pv(3);
+      const D3 d1 = dsub(b, a), d2 = dsub(cc, a);
+      const double v = ddot(d1, d1), w = ddot(d2, d2), pq = ddot(a, d1), qq = ddot(a, d2), r = ddot(d1, d2);
+      const double det = w * v - r * r;
+      double sb = -1.0, tb = -1.0;
+      if (!is_zero(det)) { sb = (qq * r - w * pq) / det; tb = (-sb * r - qq) / w; }
+      auto ccd_eq1 = [&](double x) -> bool { const double ab = fabs(x - 1.0); return ab < eps || ab < eps * fmax(fabs(x), 1.0); };
+      D3 wit;
+      if ((is_zero(sb) || sb > 0.0) && (ccd_eq1(sb) || sb < 1.0) && (is_zero(tb) || tb > 0.0) && (ccd_eq1(tb) || tb < 1.0) && (ccd_eq1(tb + sb) || tb + sb < 1.0))
+        wit = dadd(a, dadd(dscl(sb, d1), dscl(tb, d2)));
+      else {
+        auto seg = [&](D3 x0, D3 x1e, D3& wout) -> double {
+          const D3 dd = dsub(x1e, x0);
+          const double t = -ddot(x0, dd) / ddot(dd, dd);
+          if (t < 0.0 || is_zero(t)) wout = x0;
+          else if (t > 1.0 || ccd_eq1(t)) wout = x1e;
+          else wout = dadd(x0, dscl(t, dd));
+          return ddot(wout, wout);
+        };
+        D3 w2;
+        double best = seg(a, b, wit);
+        double d = seg(a, cc, w2); if (d < best) { best = d; wit = w2; }
+        d = seg(b, cc, w2); if (d < best) { best = d; wit = w2; }
+      }
+      depth = sqrt(ddot(wit, wit));
+      pdir = (is_zero(wit.x) && is_zero(wit.y) && is_zero(wit.z)) ? dir : dunit(wit);
+      // barycentric coordinates of the origin in the portal tetrahedron -> witness points on the two shapes
+      const D3 p0 = v0;
+      double bc[4];
+      bc[0] = ddot(dcross(a, b), cc); bc[1] = ddot(dcross(cc, b), p0); bc[2] = ddot(dcross(p0, a), cc); bc[3] = ddot(dcross(b, a), p0);
+      double sum = bc[0] + bc[1] + bc[2] + bc[3];
+      if (is_zero(sum) || sum < 0.0) {
+        const D3 pd = portal_dir();
+        bc[0] = 0.0; bc[1] = ddot(dcross(b, cc), pd); bc[2] = ddot(dcross(cc, a), pd); bc[3] = ddot(dcross(a, b), pd);
+        sum = bc[1] + bc[2] + bc[3];
+      }
+      const double inv = 1.0 / sum;
+      D3 q1 = dscl(bc[0], c1), q2 = dscl(bc[0], c2);
+#pragma unroll
+      for (int q = 1; q < 4; q++) { const D3 s1 = pv1(q), vv = pv(q); q1 = dadd(q1, dscl(bc[q], s1)); q2 = dadd(q2, dscl(bc[q], dsub(s1, vv))); }
+      pos = dscl(0.5, dadd(dscl(inv, q1), dscl(inv, q2)));
+    }
+    // the engine's mjc_fixNormal: a sphere / capsule in the pair takes the direction from its centre line to the contact point
+    {
+      D3 nn[2]; bool have[2] = {false, false};
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
+        const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
+        const int type = (int)x[LM_GX_TYPE];
+        if (type == LM_GEOM_SPHERE || type == LM_GEOM_CAPSULE) {
+          const float* cap = rec + (w ? LM_GP_P2 : LM_GP_P1);
+          const D3 ctr = dadd(pw[w], rot(*Rw[w], d3(cap[0], cap[1], cap[2]))), ax = rot(*Rw[w], d3(cap[3], cap[4], cap[5]));
+          const D3 rel = dsub(pos, ctr);
+          const double t = fmin(fmax(ddot(rel, ax), -(double)cap[6]), (double)cap[6]);
+          nn[w] = dunit(dsub(rel, dscl(t, ax))); have[w] = true;
+        }
+      }
+      if (have[0] && have[1]) pdir = dunit(dsub(nn[0], nn[1]));
+      else if (have[0]) pdir = nn[0];
+      else if (have[1]) pdir = dscl(-1.0, nn[1]);
+    }
+  out.nx = (float)pdir.x; out.ny = (float)pdir.y; out.nz = (float)pdir.z; out.px = (float)pos.x; out.py = (float)pos.y; out.pz = (float)pos.z;
+  out.dist = (float)((double)pmargin - depth); out.found = 1;
+  return out;
+}
+
 // ---- the substep ---------------------------------------------------------------------------------------------
 // cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
 // actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
@@ -1405,270 +1684,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue;
       static_assert(!PAIRS || kQRes + 7 * kQRes_n <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
       int nq = 0;
-      auto mpr_contact = [&](const float* rec, bool g1own, V3 po_, const M3& Ro_, V3 pp_, const M3& Rp_, float pmargin,
-                             V3& nrm, V3& cpo, float& dist_out) -> bool {
-        // FLOAT64 inside: the portal search takes hundreds of sign decisions on differences of nearly equal support values; in
-        // float32 their rounding alone sends it down another path (a cylinder against a hull: normals 1e-2 rad apart from one
-        // evaluation to the next of the same state, where the float64 collider does not move) — MI355X runs float64 vector code at
-        // half rate, and the search is bound by the latency of the hull-vertex fetches anyway. Inputs (link frames, float32 hull
-        // vertices) and outputs are float32.
-        struct D3 { double x, y, z; };
-        auto d3 = [](double x, double y, double z) -> D3 { D3 r; r.x = x; r.y = y; r.z = z; return r; };
-        auto dsub = [&](D3 a, D3 b) -> D3 { return d3(a.x - b.x, a.y - b.y, a.z - b.z); };
-        auto dadd = [&](D3 a, D3 b) -> D3 { return d3(a.x + b.x, a.y + b.y, a.z + b.z); };
-        auto dscl = [&](double k, D3 a) -> D3 { return d3(k * a.x, k * a.y, k * a.z); };
-        auto ddot = [](D3 a, D3 b) -> double { return a.x * b.x + a.y * b.y + a.z * b.z; };
-        auto dcross = [&](D3 a, D3 b) -> D3 { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); };
-        auto dunit = [&](D3 a) -> D3 { const double n = sqrt(ddot(a, a)); return (n > 0.0) ? dscl(1.0 / n, a) : a; };
-        auto up = [&](V3 a) -> D3 { return d3((double)a.x, (double)a.y, (double)a.z); };
-        auto rot = [&](const M3& Rm, D3 v) -> D3 {          // R v
-          return d3((double)Rm.a[0] * v.x + (double)Rm.a[1] * v.y + (double)Rm.a[2] * v.z, (double)Rm.a[3] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[5] * v.z,
-                    (double)Rm.a[6] * v.x + (double)Rm.a[7] * v.y + (double)Rm.a[8] * v.z);
-        };
-        auto rotT = [&](const M3& Rm, D3 v) -> D3 {         // R^T v
-          return d3((double)Rm.a[0] * v.x + (double)Rm.a[3] * v.y + (double)Rm.a[6] * v.z, (double)Rm.a[1] * v.x + (double)Rm.a[4] * v.y + (double)Rm.a[7] * v.z,
-                    (double)Rm.a[2] * v.x + (double)Rm.a[5] * v.y + (double)Rm.a[8] * v.z);
-        };
-        const D3 pw[2] = {up((g1own ? po_ : pp_) - O), up((g1own ? pp_ : po_) - O)};
-        const M3* Rw[2] = {g1own ? &Ro_ : &Rp_, g1own ? &Rp_ : &Ro_};
-        const double hmg = 0.5 * (double)pmargin, eps = 2.220446049250313e-16;
-        auto is_zero = [&](double x) -> bool { return fabs(x) < eps; };
-        auto sgn = [](double x) -> double { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); };
-        int hint[2] = {-1, -1};            // where the hill climbing of either hull starts: its previous support vertex
-        auto support1 = [&](int which, D3 d) -> D3 {
-          const M3& Rl = *Rw[which];
-          const float* cap = rec + (which ? LM_GP_P2 : LM_GP_P1);        // bounding capsule: centre 3, axis 3, half length, radius
-          const float* x = rec + (which ? LM_GP_X2 : LM_GP_X1);
-          const D3 dl = rotT(Rl, d);
-          const int type = (int)x[LM_GX_TYPE];
-          D3 loc = d3(0, 0, 0);
-          if (type == LM_GEOM_MESH) {
-            // hill climbing on the hull's vertex graph from the vertex the previous search of this geom ended at (the engine's own
-            // support search for meshes with a graph): a handful of steps x ~6 neighbours instead of a scan over every vertex.
-            // P.meshadj: per vertex a block [x y z degree][neighbour x y z, neighbour's block]...: one step = one contiguous block,
-            // its header and first eight neighbours fetched together (one memory round trip per step)
-            const F4* A = reinterpret_cast<const F4*>(P.meshadj);
-            int cur = hint[which];
-            if (cur < 0) {                  // first search of this pair: from the hull's extreme vertex along the dominant axis of the direction
-              const double ax_ = fabs(dl.x), ay_ = fabs(dl.y), az_ = fabs(dl.z);
-              const int k = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
-              const double comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
-              cur = (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0) ? 1 : 0)];
-            }
-            double best = -1.0e300;
-#pragma nounroll
-            for (int step = 0; step < 256; step++) {
-              const F4 h = A[cur];
-              F4 e[8];
-#pragma unroll
-              for (int j = 0; j < 8; j++) e[j] = A[cur + 1 + j];          // (beyond the block's end for a lower degree: ignored; the table is padded)
-              const int deg = (int)h.w;
-              if (step == 0) { best = dl.x * (double)h.x + dl.y * (double)h.y + dl.z * (double)h.z; loc = d3(h.x, h.y, h.z); }
-              int nxt = cur;
-#pragma unroll
-              for (int j = 0; j < 8; j++) {
-                const double dd = dl.x * (double)e[j].x + dl.y * (double)e[j].y + dl.z * (double)e[j].z;
-                if (j < deg && dd > best) { best = dd; nxt = (int)e[j].w; loc = d3(e[j].x, e[j].y, e[j].z); }
-              }
-#pragma nounroll
-              for (int j = 8; j < deg; j++) {
-                const F4 ej = A[cur + 1 + j];
-                const double dd = dl.x * (double)ej.x + dl.y * (double)ej.y + dl.z * (double)ej.z;
-                if (dd > best) { best = dd; nxt = (int)ej.w; loc = d3(ej.x, ej.y, ej.z); }
-              }
-              if (nxt == cur) break;
-              cur = nxt;
-            }
-            hint[which] = cur;
-          } else {
-            const D3 ctr = d3(cap[0], cap[1], cap[2]), ax = d3(cap[3], cap[4], cap[5]);
-            if (type == LM_GEOM_BOX) {
-              const D3 ex = d3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = d3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
-              const D3 ez = dcross(ex, ey);
-              loc = dadd(dadd(ctr, dscl(sgn(ddot(dl, ex)) * (double)x[LM_GX_E0], ex)), dadd(dscl(sgn(ddot(dl, ey)) * (double)x[LM_GX_E0 + 1], ey), dscl(sgn(ddot(dl, ez)) * (double)x[LM_GX_E0 + 2], ez)));
-            } else if (type == LM_GEOM_CYLINDER) {
-              const double da = ddot(dl, ax);
-              const D3 perp = dsub(dl, dscl(da, ax));
-              const double t = sqrt(ddot(perp, perp));
-              loc = dadd(ctr, dscl(sgn(da) * (double)cap[6], ax));
-              if (t > 1e-15) loc = dadd(loc, dscl((double)cap[7] / t, perp));
-            } else loc = dadd(dadd(ctr, dscl((double)cap[7], dl)), dscl(sgn(ddot(dl, ax)) * (double)cap[6], ax));          // sphere (half length 0), capsule
-          }
-          return dadd(dadd(pw[which], rot(Rl, loc)), dscl(hmg, d));
-        };
-        // the portal: points 1..3 as (v, v1) in local arrays (dynamic index: private memory), point 0 in registers
-        double PV[3][6];
-        auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
-        auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
-        auto put = [&](int q, D3 v, D3 v1) {
-          PV[q - 1][0] = v.x; PV[q - 1][1] = v.y; PV[q - 1][2] = v.z; PV[q - 1][3] = v1.x; PV[q - 1][4] = v1.y; PV[q - 1][5] = v1.z;
-        };
-        const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
-        const D3 c1 = dadd(pw[0], rot(*Rw[0], d3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ])));
-        const D3 c2 = dadd(pw[1], rot(*Rw[1], d3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ])));
-        D3 v0 = dsub(c1, c2);
-        if (is_zero(v0.x) && is_zero(v0.y) && is_zero(v0.z)) v0.x += 10.0 * eps;
-        auto portal_dir = [&]() -> D3 { const D3 a1 = pv(1); return dunit(dcross(dsub(pv(2), a1), dsub(pv(3), a1))); };
-        auto expand = [&](D3 v4, D3 v41) {
-          const D3 cr = dcross(v4, v0);
-          int q;
-          if (ddot(pv(1), cr) > 0.0) q = (ddot(pv(2), cr) > 0.0) ? 1 : 3;
-          else q = (ddot(pv(3), cr) > 0.0) ? 2 : 1;
-          put(q, v4, v41);
-        };
-        {
-          // one-direction separation test first: along the line between the closest points of the two bounding capsules. Shapes
-          // (inflated by margin / 2 each) that are apart along ANY direction do not overlap - the portal search below would say so
-          // after five or six support searches, this says it after two, and most queued pairs end here
-          const V3 p1f = (g1own ? po_ : pp_) - O, p2f = (g1own ? pp_ : po_) - O;
-          const V3 cA = p1f + mul(*Rw[0], v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2])), aA = mul(*Rw[0], v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
-          const V3 cB = p2f + mul(*Rw[1], v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2])), aB = mul(*Rw[1], v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
-          float sa, ta;
-          segment_closest(cA, aA, rec[LM_GP_H1], cB, aB, rec[LM_GP_H2], sa, ta);
-          const V3 dsep = (cB + ta * aB) - (cA + sa * aA);
-          if (dot(dsep, dsep) > 1e-12f) {
-            const D3 du = dunit(up(dsep));
-            D3 sp[2];
-#pragma nounroll
-            for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : dscl(-1.0, du));
-            if (ddot(dsub(sp[0], sp[1]), du) < 0.0) return false;
-          }
-        }
-        D3 dir = dunit(dscl(-1.0, v0));
-        int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
-        int nsupport = 0; (void)nsupport;
-#pragma nounroll
-        for (int guard = 0; guard < 192 && result == 0; guard++) {
-          nsupport++;
-          D3 sup[2];
-#pragma nounroll
-          for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : dscl(-1.0, dir));
-          const D3 sv = dsub(sup[0], sup[1]);
-          const double dt = ddot(sv, dir);
-          if (stage == 0) {
-            put(1, sv, sup[0]);
-            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
-            dir = dcross(v0, sv);
-            if (is_zero(ddot(dir, dir))) { result = (is_zero(sv.x) && is_zero(sv.y) && is_zero(sv.z)) ? -1 : 2; break; }     // touching at v1: no normal | origin on v0-v1
-            dir = dunit(dir);
-            stage = 1;
-          } else if (stage == 1) {
-            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
-            put(2, sv, sup[0]);
-            dir = dunit(dcross(dsub(pv(1), v0), dsub(sv, v0)));
-            if (ddot(dir, v0) > 0.0) { const D3 a = pv(1), a1 = pv1(1); put(1, sv, sup[0]); put(2, a, a1); dir = dscl(-1.0, dir); }
-            stage = 2;
-          } else if (stage == 2) {
-            if (is_zero(dt) || dt < 0.0) { result = -1; break; }
-            put(3, sv, sup[0]);
-            bool cont = false;
-            double tp = ddot(dcross(pv(1), sv), v0);
-            if (tp < 0.0 && !is_zero(tp)) { put(2, sv, sup[0]); cont = true; }
-            else {
-              tp = ddot(dcross(sv, pv(2)), v0);
-              if (tp < 0.0 && !is_zero(tp)) { put(1, sv, sup[0]); cont = true; }
-            }
-            if (cont) dir = dunit(dcross(dsub(pv(1), v0), dsub(pv(2), v0)));
-            else {
-              dir = portal_dir();
-              const double de = ddot(dir, pv(1));
-              stage = (is_zero(de) || de > 0.0) ? 4 : 3;          // the portal already holds the origin: straight to the penetration phase
-            }
-          } else {
-            // reach of the new support point beyond the portal along dir
-            const double reach = fmin(fmin(dt - ddot(pv(1), dir), dt - ddot(pv(2), dir)), dt - ddot(pv(3), dir));
-#ifdef LM_PAIR_TRACE
-            if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, ddot(pv(1), dir), reach);
-#endif
-            if (stage == 3) {
-              if (!(is_zero(dt) || dt > 0.0) || reach <= 1e-6) { result = -1; break; }
-              expand(sv, sup[0]);
-              dir = portal_dir();
-              const double de = ddot(dir, pv(1));
-              if (is_zero(de) || de > 0.0) stage = 4;
-            } else {
-              if (reach <= 1e-6 || iter > 50) { result = 1; break; }
-              expand(sv, sup[0]);
-              dir = portal_dir();
-              iter++;
-            }
-          }
-        }
-#ifdef LM_PAIR_TRACE
-        printf("   mpr lane %d rep %d result %d stage %d iter %d supports %d types %d %d\n", c, Q::rep(), result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
-#endif
-        if (result <= 0) return false;
-        double depth; D3 pdir, pos;
-        if (result == 2) {
-          const D3 v1 = pv(1), s1 = pv1(1);
-          depth = sqrt(ddot(v1, v1)); pdir = dunit(v1);
-          pos = dscl(0.5, dadd(s1, dsub(s1, v1)));
-        } else {
-          // closest point of the portal triangle to the origin (libccd: ccdVec3PointTriDist2) -> depth and direction
-          const D3 a = pv(1), b = pv(2), cc = pv(3);
-          const D3 d1 = dsub(b, a), d2 = dsub(cc, a);
-          const double v = ddot(d1, d1), w = ddot(d2, d2), pq = ddot(a, d1), qq = ddot(a, d2), r = ddot(d1, d2);
-          const double det = w * v - r * r;
-          double sb = -1.0, tb = -1.0;
-          if (!is_zero(det)) { sb = (qq * r - w * pq) / det; tb = (-sb * r - qq) / w; }
-          auto ccd_eq1 = [&](double x) -> bool { const double ab = fabs(x - 1.0); return ab < eps || ab < eps * fmax(fabs(x), 1.0); };
-          D3 wit;
-          if ((is_zero(sb) || sb > 0.0) && (ccd_eq1(sb) || sb < 1.0) && (is_zero(tb) || tb > 0.0) && (ccd_eq1(tb) || tb < 1.0) && (ccd_eq1(tb + sb) || tb + sb < 1.0))
-            wit = dadd(a, dadd(dscl(sb, d1), dscl(tb, d2)));
-          else {
-            auto seg = [&](D3 x0, D3 x1e, D3& wout) -> double {
-              const D3 dd = dsub(x1e, x0);
-              const double t = -ddot(x0, dd) / ddot(dd, dd);
-              if (t < 0.0 || is_zero(t)) wout = x0;
-              else if (t > 1.0 || ccd_eq1(t)) wout = x1e;
-              else wout = dadd(x0, dscl(t, dd));
-              return ddot(wout, wout);
-            };
-            D3 w2;
-            double best = seg(a, b, wit);
-            double d = seg(a, cc, w2); if (d < best) { best = d; wit = w2; }
-            d = seg(b, cc, w2); if (d < best) { best = d; wit = w2; }
-          }
-          depth = sqrt(ddot(wit, wit));
-          pdir = (is_zero(wit.x) && is_zero(wit.y) && is_zero(wit.z)) ? dir : dunit(wit);
-          // barycentric coordinates of the origin in the portal tetrahedron -> witness points on the two shapes
-          const D3 p0 = v0;
-          double bc[4];
-          bc[0] = ddot(dcross(a, b), cc); bc[1] = ddot(dcross(cc, b), p0); bc[2] = ddot(dcross(p0, a), cc); bc[3] = ddot(dcross(b, a), p0);
-          double sum = bc[0] + bc[1] + bc[2] + bc[3];
-          if (is_zero(sum) || sum < 0.0) {
-            const D3 pd = portal_dir();
-            bc[0] = 0.0; bc[1] = ddot(dcross(b, cc), pd); bc[2] = ddot(dcross(cc, a), pd); bc[3] = ddot(dcross(a, b), pd);
-            sum = bc[1] + bc[2] + bc[3];
-          }
-          const double inv = 1.0 / sum;
-          D3 q1 = dscl(bc[0], c1), q2 = dscl(bc[0], c2);
-#pragma unroll
-          for (int q = 1; q < 4; q++) { const D3 s1 = pv1(q), vv = pv(q); q1 = dadd(q1, dscl(bc[q], s1)); q2 = dadd(q2, dscl(bc[q], dsub(s1, vv))); }
-          pos = dscl(0.5, dadd(dscl(inv, q1), dscl(inv, q2)));
-        }
-        // the engine's mjc_fixNormal: a sphere / capsule in the pair takes the direction from its centre line to the contact point
-        {
-          D3 nn[2]; bool have[2] = {false, false};
-#pragma unroll
-          for (int w = 0; w < 2; w++) {
-            const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
-            const int type = (int)x[LM_GX_TYPE];
-            if (type == LM_GEOM_SPHERE || type == LM_GEOM_CAPSULE) {
-              const float* cap = rec + (w ? LM_GP_P2 : LM_GP_P1);
-              const D3 ctr = dadd(pw[w], rot(*Rw[w], d3(cap[0], cap[1], cap[2]))), ax = rot(*Rw[w], d3(cap[3], cap[4], cap[5]));
-              const D3 rel = dsub(pos, ctr);
-              const double t = fmin(fmax(ddot(rel, ax), -(double)cap[6]), (double)cap[6]);
-              nn[w] = dunit(dsub(rel, dscl(t, ax))); have[w] = true;
-            }
-          }
-          if (have[0] && have[1]) pdir = dunit(dsub(nn[0], nn[1]));
-          else if (have[0]) pdir = nn[0];
-          else if (have[1]) pdir = dscl(-1.0, nn[1]);
-        }
-        nrm = v3((float)pdir.x, (float)pdir.y, (float)pdir.z); cpo = v3((float)pos.x, (float)pos.y, (float)pos.z); dist_out = (float)((double)pmargin - depth);
-        return true;
-      };
       struct EntryCtx { int ka, kb, lb, own_q, dl; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
       auto entry_ctx = [&](int i, EntryCtx& E) {
         const int code = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 0];
@@ -1750,7 +1765,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
             const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
 #ifndef LM_NO_MPR
-            found = mpr_contact(rec, g1own, E.po, E.Ro, E.pp, E.Rp, rec[LM_GP_MARGIN], nrm, cp, dist);
+            const MprOut mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], c);
+            found = mo.found != 0; nrm = v3(mo.nx, mo.ny, mo.nz); cp = v3(mo.px, mo.py, mo.pz); dist = mo.dist;
 #endif
           }
           // where do my results go: behind those of this round's lower replicas

@@ -59,10 +59,18 @@ struct lm_batch {
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
 // condim-3 pyramids only (T.all_pyr3, checked when the model is created): the elliptic code compiles out and the contact
 // slots are compact. Everything else: generic kernels, cone read at run time, plain layout only.
+// A/B switches of the probe builds (tools/probes: `make EXTRA=-DLM_PROBES ...`). The shipped library reads NO environment variable:
+// tests/test_abi_exports.py checks that `getenv` is not among its undefined symbols.
+#ifdef LM_PROBES
+#define LM_PROBE_ENV(name) getenv(name)
+#else
+#define LM_PROBE_ENV(name) ((const char*)nullptr)
+#endif
+
 static int family_of(const lm_batch* b) {
   const Task& T = b->m->T;
   const bool big = T.max_links > 3, six = T.max_links > 5, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
-  static const bool generic = getenv("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
+  static const bool generic = LM_PROBE_ENV("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
   const bool pyr3 = T.all_pyr3 && !generic;
   if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;
   // five-link humanoids whose lowering carries self-collision tables (bone hulls, link meshes, cylinders): the pair families
@@ -80,7 +88,7 @@ static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
 
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
-  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;                  // A/B switch
+  static const bool no_replicas = LM_PROBE_ENV("LM_NO_REPLICAS") != nullptr;                  // A/B switch
   static const lmk::family_fn table[lmk::LMK_NFAMILY][3] = {
       {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {lmk::launch_f1p0, lmk::launch_f1p1, lmk::launch_f1p2},
       {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {lmk::launch_f3p0, lmk::launch_f3p1, lmk::launch_f3p2},
@@ -137,7 +145,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   m->device = device;
   std::vector<float> cm(LM_CM_SIZE);
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)cmod[LM_HEADER_SIZE + i];
-  if (getenv("LM_NO_PAIRS")) for (int c = 0; c < LM_NCHAIN; c++) cm[LM_CM_CHAINS + LM_C_NLPAIR * LM_NCHAIN + c] = 0.0f;      // A/B: self-collision broad phase off
+  if (LM_PROBE_ENV("LM_NO_PAIRS")) for (int c = 0; c < LM_NCHAIN; c++) cm[LM_CM_CHAINS + LM_C_NLPAIR * LM_NCHAIN + c] = 0.0f;      // A/B: self-collision broad phase off
   for (int i = 0; i < 6; i++) {
     const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
     if (blk[LM_D_LIMITED] != 0.0f) { return fail("limited root joints are not supported"); }
@@ -249,12 +257,12 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
-  if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
-  if (const char* v = getenv("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
-  if (const char* v = getenv("LM_ABLATE")) P.ablate = atoi(v);
-  if (const char* v = getenv("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes
-  if (const char* v = getenv("LM_LS_TOL")) P.ls_tol = (float)atof(v);
-  if (const char* v = getenv("LM_LS_ITERS")) P.ls_iters = atoi(v);
+  if (const char* v = LM_PROBE_ENV("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
+  if (const char* v = LM_PROBE_ENV("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
+  if (const char* v = LM_PROBE_ENV("LM_ABLATE")) P.ablate = atoi(v);
+  if (const char* v = LM_PROBE_ENV("LM_TOLERANCE")) P.tolerance = (float)atof(v);          // tuning knobs for A/B probes
+  if (const char* v = LM_PROBE_ENV("LM_LS_TOL")) P.ls_tol = (float)atof(v);
+  if (const char* v = LM_PROBE_ENV("LM_LS_ITERS")) P.ls_iters = atoi(v);
   *out = guard.release();
   return 0;
 }
@@ -309,16 +317,30 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   b->m = m; b->N = n_envs;
   // Four environments per workgroup: with the replicated layout that is one full wave (4 envs x 4 replicas x 4 chains).
   // Larger batches simply run more workgroups back to back (wider workgroups without replicas were 30-50 % slower at
-  // every size, profiles/r1_ab_probes.md). LM_ENVS_PER_BLOCK overrides.
+  // every size, profiles/r1_ab_probes.md); lm_batch_set_layout selects the plain layout.
   {
     int epb = n_envs < 4 ? n_envs : 4;
-    const char* ov = getenv("LM_ENVS_PER_BLOCK");
+    const char* ov = LM_PROBE_ENV("LM_ENVS_PER_BLOCK");
     if (ov && atoi(ov) >= 1 && atoi(ov) <= 16) epb = atoi(ov);
     b->epb = epb;
   }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
   if (batch_alloc(b)) { lm_batch_destroy(b); return 1; }     // g_err holds the failed call; nothing leaks
   *out = b;
+  return 0;
+}
+
+/* launch geometry: environments per workgroup. 4 (the default) = the replicated layout, one wave = 4 environments x 4 replicas x 4
+   chains; 8 or 16 = the plain layout, a workgroup of 8 / 16 quads without replicas (the only other layout the families are compiled
+   for; slower at every batch size measured, profiles/r1_ab_probes.md, kept for very large batches and as a cross-check of the
+   replicas' protocol). Statistics slots were allocated for the default: only coarser geometries are accepted. */
+int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup) {
+  if (!b) return fail("null batch");
+  const int def = b->N < 4 ? b->N : 4;
+  if (envs_per_workgroup != def && envs_per_workgroup != 8 && envs_per_workgroup != 16) return fail("environments per workgroup: 4 (replicated layout), 8 or 16 (plain layout)");
+  if (envs_per_workgroup > def && !family_has_replicas(b)) return fail("the generic kernel family has one layout only");
+  b->epb = envs_per_workgroup;
+  b->nblocks = (b->N + b->epb - 1) / b->epb;
   return 0;
 }
 
@@ -571,7 +593,7 @@ static KArgs make_args(lm_batch* b) {
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
-  static const bool no_xcd_map = getenv("LM_NO_XCD_MAP") != nullptr;
+  static const bool no_xcd_map = LM_PROBE_ENV("LM_NO_XCD_MAP") != nullptr;
   a.xcd_map = no_xcd_map ? 0 : 1;
   return a;
 }
@@ -661,7 +683,7 @@ int lm_rollout_fused(lm_batch* b, int n_steps, int steps_per_launch, int action_
   HIPCHK(hipSetDevice(b->m->device));
   if (action_mode != 0 && action_mode != 1) return fail("action_mode must be 0 (zero) or 1 (uniform random)");
   if (steps_per_launch < 1) return fail("steps_per_launch must be >= 1");
-  static const bool no_replicas = getenv("LM_NO_REPLICAS") != nullptr;
+  static const bool no_replicas = LM_PROBE_ENV("LM_NO_REPLICAS") != nullptr;
   if (b->epb > 4 || no_replicas || !family_has_replicas(b)) steps_per_launch = 1;     // no fused kernels for the full-wave layout
   KArgs a = make_args(b);
   a.action = nullptr; a.action_mode = action_mode == 0 ? 1 : 2;   // kernel: 1 = zero action, 2 = random

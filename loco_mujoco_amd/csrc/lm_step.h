@@ -22,6 +22,7 @@
 #include <vector>
 
 #define LM_DEV __device__ __forceinline__
+#define LM_DEV_COLD __device__ __attribute__((noinline))     // rare helpers with a large register appetite (the convex-pair collider)
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
 __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 #define LM_OPAQUE_ZERO() lm_opaque_zero()

@@ -37,7 +37,8 @@ def _recv_exact(sock, n):
 
 
 class Collective:
-    def __init__(self, backend="rccl", rank=None, world=None, device=None, timeout_s=120.0):
+    def __init__(self, backend="rccl", rank=None, world=None, device=None, timeout_s=120.0, require_rccl=False):
+        """``require_rccl``: with ``backend="rccl"`` raise on every rank instead of falling back to the sockets."""
         self.rank = int(os.environ.get("RANK", 0)) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else int(world)
         self.backend = backend if self.world > 1 else "none"
@@ -107,8 +108,7 @@ class Collective:
             err = None
             uid = (C.c_byte * 128)()
             try:                                         # phase A, local: libraries, device, (rank 0) the unique id
-                self._hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
-                self._nccl = C.CDLL("librccl.so")
+                self._load_libraries()
                 self._check_hip(self._hip.hipSetDevice(dev), "hipSetDevice")
                 if self.rank == 0:
                     self._check(self._nccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
@@ -134,8 +134,17 @@ class Collective:
                     print("collective: RCCL communicator not available (%s): metric reduction over TCP sockets instead"
                           % (err or "failure on another rank"), file=sys.stderr)
                 self._comm = None
+                if require_rccl:
+                    raise RuntimeError("RCCL was required for the metric reduction and is not available: %s" % (err or "failure on another rank"))
 
     # ------------------------------------------------------------------ RCCL (ctypes)
+    def _load_libraries(self):
+        try:                                             # the HIP runtime liblocohip.so has already mapped (RTLD_NOLOAD: no second copy) ...
+            self._hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL | getattr(os, "RTLD_NOLOAD", 4))
+        except OSError:                                  # ... or, before that library was loaded, the same soname
+            self._hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+        self._nccl = C.CDLL("librccl.so")
+
     def _init_rccl(self, uid):
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_byte * 128)]
@@ -160,6 +169,17 @@ class Collective:
         if rc != 0:
             raise RuntimeError("%s failed with HIP error %d" % (what, rc))
 
+    def _reduce_rccl(self, v, op):
+        assert v.size <= self._cap
+        nbytes = C.c_size_t(8 * v.size)
+        self._check_hip(self._hip.hipMemcpy(self._dbuf, v.ctypes.data_as(C.c_void_p), nbytes, 1), "hipMemcpy H2D")
+        # THE call site: RCCL all-reduce over xGMI on the null stream
+        self._check(self._nccl.ncclAllReduce(self._dbuf, self._dbuf, v.size, _NCCL_FLOAT64, _NCCL_OP[op], self._comm, None), "ncclAllReduce")
+        self._check_hip(self._hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        out = np.empty_like(v)
+        self._check_hip(self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self._dbuf, nbytes, 2), "hipMemcpy D2H")
+        return out
+
     # ------------------------------------------------------------------ the collective
     def all_reduce(self, values, op=SUM):
         """float64 vector, reduced over the ranks; every rank gets the result."""
@@ -167,15 +187,7 @@ class Collective:
         if self.world == 1:
             return v.copy()
         if self.backend == "rccl":
-            assert v.size <= self._cap
-            nbytes = C.c_size_t(8 * v.size)
-            self._check_hip(self._hip.hipMemcpy(self._dbuf, v.ctypes.data_as(C.c_void_p), nbytes, 1), "hipMemcpy H2D")
-            # THE call site: RCCL all-reduce over xGMI on the null stream
-            self._check(self._nccl.ncclAllReduce(self._dbuf, self._dbuf, v.size, _NCCL_FLOAT64, _NCCL_OP[op], self._comm, None), "ncclAllReduce")
-            self._check_hip(self._hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
-            out = np.empty_like(v)
-            self._check_hip(self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self._dbuf, nbytes, 2), "hipMemcpy D2H")
-            return out
+            return self._reduce_rccl(v, op)
         # host reduction over the rendezvous sockets: gather on rank 0, reduce, send back
         if self.rank == 0:
             parts = [v] + [np.frombuffer(_recv_exact(p, 8 * v.size), dtype=np.float64) for p in self._peers]

@@ -21,6 +21,17 @@ def test_library_exports_all_declared_symbols():
     assert set(backend.EXPORTS) == declared
 
 
+def test_shipped_library_reads_no_environment_variable():
+    """The A/B switches of the probe builds (LM_NO_PAIRS, LM_TOLERANCE, LM_ABLATE, LM_LS_*, LM_NO_REPLICAS, LM_GENERIC_KERNELS,
+    LM_NO_XCD_MAP, LM_ENVS_PER_BLOCK) exist only under -DLM_PROBES: the default library does not import getenv at all."""
+    lib = os.path.join(ROOT, "loco_mujoco_amd", "csrc", "liblocohip.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms or "__hipRegisterFunction" in syms     # (the listing is the real one)
+    assert "getenv" not in syms
+    src = open(os.path.join(ROOT, "loco_mujoco_amd", "csrc", "lm_kernels.hip")).read()
+    assert src.count("getenv(") == 1 and "#define LM_PROBE_ENV(name) getenv(name)" in src
+
+
 def test_model_create_rejects_bad_input():
     from loco_mujoco_amd import backend
     import numpy as np

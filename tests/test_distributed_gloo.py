@@ -95,5 +95,76 @@ def test_product_collective_world2_through_the_launcher(tmp_path, backend):
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert res["world"] == 2 and res["backend"] == "tcp"
+    # (on a node with two GPUs and a working RCCL the "rccl" request is served by RCCL: either is correct here)
+    assert res["world"] == 2 and res["backend"] in (("tcp",) if backend == "tcp" else ("tcp", "rccl"))
+    assert res["tmax"] == [2.0, 800.0, 4.0, 0.5] and res["tsum"] == [3.0, 1600.0, 7.0, 0.75]
+
+
+def test_require_rccl_fails_loudly_without_gpus(tmp_path):
+    """`bench.py --require-rccl` / Collective(require_rccl=True): when the communicator cannot come up, every rank raises instead
+    of quietly reducing over the sockets (here: a box without GPUs)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs: RCCL comes up")
+    script = tmp_path / "worker3.py"
+    script.write_text(textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from loco_mujoco_amd.utils.collective import Collective
+        try:
+            Collective(backend="rccl", require_rccl=True)
+        except RuntimeError as e:
+            print("RAISED", e)
+            sys.exit(3)
+    """) % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "RAISED RCCL was required" in out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_binding_single_rank_communicator_on_the_gpu():
+    """The ctypes binding itself on hardware (the GPU box has ONE device, where RCCL admits a one-rank communicator):
+    ncclGetUniqueId, ncclCommInitRank with the 128-byte id BY VALUE, hipMalloc / hipMemcpy through the runtime liblocohip.so
+    mapped, ncclAllReduce for SUM and MAX, ncclCommDestroy."""
+    import ctypes as C
+    import numpy as np
+    from loco_mujoco_amd import backend as _b   # noqa: F401  (maps liblocohip.so and with it the HIP runtime)
+    from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
+    c = Collective.__new__(Collective)
+    c.rank, c.world, c.backend, c._peers, c._server, c._comm = 0, 1, "rccl", [], None, None
+    c._load_libraries()
+    c._check_hip(c._hip.hipSetDevice(0), "hipSetDevice")
+    uid = (C.c_byte * 128)()
+    c._check(c._nccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    c._init_rccl(uid)
+    v = np.array([1.5, -2.0, 800.0, 0.25])
+    assert np.array_equal(c._reduce_rccl(v, SUM), v) and np.array_equal(c._reduce_rccl(v, MAX), v)
+    c.close()
+    assert c._comm is None
+
+
+@pytest.mark.gpu
+def test_product_collective_world2_rccl_on_two_gpus(tmp_path):
+    """Two ranks, two devices, `require_rccl`: the reduction bench.py reports with must be RCCL's (skips on the 1-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs of one node")
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER2.replace('Collective(backend=os.environ.get("LM_TEST_COLLECTIVE", "tcp"))',
+                                      'Collective(backend="rccl", require_rccl=True)'))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["world"] == 2 and res["backend"] == "rccl"
     assert res["tmax"] == [2.0, 800.0, 4.0, 0.5] and res["tsum"] == [3.0, 1600.0, 7.0, 0.75]

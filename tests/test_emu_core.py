@@ -383,6 +383,77 @@ def test_core_self_contacts(rep):
 
 
 @pytest.mark.parametrize("rep", [1, 4])
+def test_core_convex_pairs_humanoid_bones(rep):
+    """Convex-convex self-contacts on the device code (float64 MPR as an out-of-line helper, hill climbing on the hull graph, work queue
+    worked off one pair per replica, condim-1 contacts as mu = 0 pyramids, mirror slots + cross block): HumanoidTorque.walk's golden
+    rows with the fingers of the left hand on the left femur (rows 19-28), one control step against the golden successor —
+    kernel <5 links, 8 slots, RK4, pyramids, PAIRS>."""
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    t = info["self_collision_tables"]
+    assert t["convex"] == 692 and t["counted_only"] == 1 and t["body_pairs"] < 200 and max(t["link_pairs"]) <= 16
+    o = Oracle(pack_model(m))
+    g = GOLD["HumanoidTorque.walk.real"]
+    qidx = [m.jnt_id(n) for k, n, tt in env.obs_helper.observation_spec if k.startswith("q_")]
+    np.random.seed(0)
+    np.random.randint(0, 1), np.random.randint(0, 1), np.random.randint(0, 100)
+    acts = [np.random.randn(13) * 0.1 for _ in range(len(g))]
+    for k in ((3, 19, 22, 28) if rep == 1 else (20, 25)):
+        qpos, qvel = np.zeros(m.nv), np.zeros(m.nv)
+        qpos[qidx[2:]] = g[k, :17]
+        qvel[qidx] = g[k, 17:36]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[k])
+        qo, vo, _, st = o.step(qpos, qvel, ctrl, nsub=10)
+        q, v, _, cnt, _ = pyemu.run(cmod, qpos, qvel, acts[k], nsub=10, rep=rep)
+        assert cnt["overflow"] == 0 and cnt["selfprox"] == 0 and (cnt["selfcon"] > 0) == (k >= 19) and st["convex_contacts"] == cnt["selfcon"]
+        assert np.abs(q[0][qidx[2:]] - g[k + 1, :17]).max() < 1e-5 and np.abs(v[0][qidx] - g[k + 1, 17:36]).max() < 1e-3, k
+        assert np.abs(q[0] - qo).max() < 1e-5 and np.abs(v[0] - vo).max() < 1e-3
+
+
+def test_core_convex_pairs_same_chain_and_every_coupling_pattern():
+    """(i) UnitreeH1's hip-yaw CYLINDER against the thigh mesh of the SAME leg (two links of one chain: one slot, no mirror, the joints
+    up to the nearer link cancel in its Jacobian), condim-3 pyramid in a general frame, golden walk row 13; (ii) a humanoid folded
+    up by random torques: bone hulls of the two legs and the trunk in contact with each other in every pattern — two pairs of
+    chains, and all three (tests/golden/ht_folded_states.npz, from oracle rollouts) — the factorisation carries a cross block for
+    every coupled pair of chains and the fill-in between them (arrow_factor_g), so the Newton iteration counts stay those of the
+    oracle instead of hitting the cap."""
+    from test_oracle_golden import _h1_kat_inputs
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeH1.walk", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["self_collision_tables"]["convex"] == 135
+    g, qidx, rows = _h1_kat_inputs(env, "walk")
+    qpos, qvel, a = rows[13]
+    q, v, _, cnt, _ = pyemu.run(cmod, qpos, qvel, a, nsub=10, rep=4)
+    assert cnt["selfcon"] == 10 and cnt["overflow"] == 0                      # one contact in each of the ten substeps
+    assert np.abs(q[0][qidx[2:]] - g[14, :15]).max() < 1e-5 and np.abs(v[0][qidx] - g[14, 15:32]).max() < 1e-3
+
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque.run", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    o = Oracle(pack_model(m))
+    d = np.load(__file__.replace("test_emu_core.py", "golden/ht_folded_states.npz"))
+    good = 0
+    for i in (0, 3, 7, 8, 9):                      # [(0,2),(1,2)], [(0,1),(1,2)], all three pairs, [(0,1),(0,2)], [(0,1),(1,2)]
+        q0, v0, a = d["q"][i], d["v"][i], d["a"][i]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        f = o.forward(q0, v0, ctrl)
+        _, _, _, cnt, dbg = pyemu.run(cmod, q0, v0, a, nsub=1, debug_env=0)
+        assert np.abs(dbg["qacc"] - f["qacc"]).max() < 1e-4 * max(1.0, np.abs(f["qacc"]).max()), i
+        qo, vo, _, st = o.step(q0, v0, ctrl, nsub=10)
+        qe, ve, _, c10, _ = pyemu.run(cmod, q0, v0, a, nsub=10)
+        assert c10["overflow"] == 0 and c10["solver_iters"] < 3 * st["solver_iter_total"] + 40
+        good += np.abs(qe[0] - qo).max() < 1e-5 and np.abs(ve[0] - vo).max() < 1e-3
+    assert good >= 4
+
+
+@pytest.mark.parametrize("rep", [1, 4])
 def test_core_plane_mesh_unitree_h1(rep):
     """Plane vs convex hull on the device code (one contact at the hull's support vertex; the vertices come from the mesh-vertex
     table, in the replicated layout every replica searches a quarter of the hull): UnitreeH1's golden rows whose only contacts

@@ -228,14 +228,14 @@ def test_a1_hard_rows_one_control_step_kats(setup):
 
 def test_ragged_batch_sizes_and_layouts(setup):
     """Edge cases of the launch geometry: batch sizes that are not multiples of the 4 environments of a workgroup (padding
-    quads), a single environment, sizes around the XCD count, and the full-wave layout (LM_ENVS_PER_BLOCK=16, no replicas).
+    quads), a single environment, sizes around the XCD count, and the full-wave layout (lm_batch_set_layout: 16 environments per workgroup, no replicas).
     Environment i with global id i must come out bitwise the same whatever batch it sits in (same kernel layout), and equal
     to float32 summation order across layouts."""
     env, hm, oracle, HipBatch = setup
     tab = env._reset_table()
 
-    def run(n, offset, steps=12, fuse=1):
-        b = HipBatch(hm, n)
+    def run(n, offset, steps=12, fuse=1, envs_per_workgroup=None):
+        b = HipBatch(hm, n, envs_per_workgroup=envs_per_workgroup)
         b.set_reset_table(tab, seed=7, global_env_offset=offset)
         b.set_auto_reset(True, horizon=9)
         rows = tab[(np.arange(offset, offset + n) * 37) % len(tab)]
@@ -253,11 +253,7 @@ def test_ragged_batch_sizes_and_layouts(setup):
         assert st["env_steps"] == n * 12
     q, v, st = run(45, 0, fuse=5)                       # fused launches of 5 + 5 + 2 control steps
     assert np.array_equal(q, qa) and np.array_equal(v, va) and st["episodes"] == sa["episodes"]
-    os.environ["LM_ENVS_PER_BLOCK"] = "16"              # full waves: 16 environments per workgroup, one-point line search
-    try:
-        q16, v16, s16 = run(45, 0, steps=2)
-    finally:
-        del os.environ["LM_ENVS_PER_BLOCK"]
+    q16, v16, s16 = run(45, 0, steps=2, envs_per_workgroup=16)     # full waves: 16 environments per workgroup, one-point line search
     q2, v2, s2 = run(45, 0, steps=2)
     assert s16["env_steps"] == 90 and np.abs(q16 - q2).max() < QTOL and np.abs(v16 - v2).max() < VTOL
 
