@@ -132,7 +132,11 @@ int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
 int lm_get_activation(lm_batch* b, float* act);
 
 /* one control step for every environment. action in [-1,1] (normalised, base.py:606-621).
-   obs [n_envs][nobs], reward [n_envs], done [n_envs] may each be NULL. Synchronous. */
+   obs [n_envs][nobs], reward [n_envs], done [n_envs] may each be NULL. Synchronous.
+   The done byte: bit 0 (value 1) = absorbing state (the reference's `absorbing`: is_absorbing(obs), base.py:274-282);
+   bit 1 (value 2) = the episode ended in this step on the device's side — it was restarted from the reset table (the
+   observation written is then the first of the NEW episode), or, without device-side restarts, this is the step that reached
+   the horizon. `done & 1` is what the reference's step() returns; `done != 0` mixes truncation into it. */
 int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t* done);
 
 /* the same step with DEVICE pointers (action [n_envs][nu], obs [n_envs][nobs], reward [n_envs], done [n_envs]; any may be

@@ -175,7 +175,12 @@ class HipBatch:
     def step_device(self, action=None, obs=None, reward=None, done=None, stream=None, sync=True):
         """One control step on DEVICE buffers: arguments are device pointers (ints) or objects with ``data_ptr()`` such as
         torch tensors — float32 action [n, nu], obs [n, nobs], reward [n], uint8 done [n]; None = zero action / library
-        buffers. ``stream``: raw hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        buffers. ``stream``: raw hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``).
+
+        The done byte is a bit field, NOT a boolean: bit 0 (``done & 1``) = absorbing state, what the reference's ``step()``
+        returns; bit 1 (``done & 2``) = the episode ended on the device in this step (restarted from the reset table — ``obs``
+        is then the first observation of the new episode — or, without auto-reset, the step that reached the horizon).
+        ``done.bool()`` mixes truncation and restarts into the terminal flag; mask the bits."""
         def ptr(x):
             if x is None:
                 return None

@@ -21,7 +21,7 @@
 // implicit joint damping or RK4, spatial tendons and muscles.
 //
 // This header has no HIP dependency: the includer defines LM_DEV (function qualifier) and supplies the quad
-// policy Q {sum(float), any(bool), kRep, kPoints, rep(), rep_bcast(x, r), rep_sum(x), fence(), peer(lmem, ls, i, dl),
+// policy Q {sum(float), any(bool), kRep, kPoints, rep(), rep_bcast(x, r), rep_sum(x), fence(), peer(lmem, ls, i, dl), peer_write(lmem, ls, i, dl, v), env_ballot(bool),
 // quad_read(x, lane), quad_sync()}. csrc/lm_step.h instantiates it with DPP / ds_bpermute intrinsics (the step kernel),
 // tests/emu/emu.cpp with OS threads.
 #pragma once
@@ -163,6 +163,7 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
   long long t[16];
+  long long m[8];    // convex collider: calls, ended at the one-direction test, no contact, contact, support pairs, hill steps, refinement iterations, rounds
 #endif
 };
 #ifdef LM_TIMERS
@@ -973,9 +974,18 @@ LM_DEV void segment_closest(V3 p1, V3 d1, float h1, V3 p2, V3 d2, float h2, floa
 // inlined into the step kernel they cost every launch 500 B of scratch per lane (the quadruped's bench rollout, which never
 // calls it, ran 17 % slower); as a function the kernel's own registers are saved once around the rare call.
 struct MprOut { float nx, ny, nz, px, py, pz, dist; int found; };
-LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int lane_c) {
+#ifdef LM_TIMERS
+#define LM_MPR_COUNT(i, n) (mc[i] += (n))
+#define LM_MPR_ARG , long long* mc
+#else
+#define LM_MPR_COUNT(i, n) do {} while (0)
+#define LM_MPR_ARG
+#endif
+// mode 0: the one-direction separation test only (found = 1: not separated along it, the portal search has to decide);
+// mode 1: the portal search without that test (the caller ran it: stage A / stage B of the work queue).
+LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int mode LM_MPR_ARG) {
+  LM_MPR_COUNT(0, mode == 0 ? 1 : 0);
   MprOut out; out.nx = out.ny = out.nz = out.px = out.py = out.pz = out.dist = 0.0f; out.found = 0;
-  (void)lane_c;
     // FLOAT64 inside: the portal search takes hundreds of sign decisions on differences of nearly equal support values; in
     // float32 their rounding alone sends it down another path (a cylinder against a hull: normals 1e-2 rad apart from one
     // evaluation to the next of the same state, where the float64 collider does not move) — MI355X runs float64 vector code at
@@ -1027,6 +1037,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
         double best = -1.0e300;
 #pragma nounroll
         for (int step = 0; step < 256; step++) {
+          LM_MPR_COUNT(5, 1);
           const F4 h = A[cur];
           F4 e[8];
 #pragma unroll
@@ -1085,7 +1096,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       else q = (ddot(pv(3), cr) > 0.0) ? 2 : 1;
       put(q, v4, v41);
     };
-    {
+    if (mode == 0) {
       // one-direction separation test first: along the line between the closest points of the two bounding capsules. Shapes
       // (inflated by margin / 2 each) that are apart along ANY direction do not overlap - the portal search below would say so
       // after five or six support searches, this says it after two, and most queued pairs end here
@@ -1100,8 +1111,11 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
         D3 sp[2];
 #pragma nounroll
         for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : dscl(-1.0, du));
-        if (ddot(dsub(sp[0], sp[1]), du) < 0.0) return out;
+        LM_MPR_COUNT(4, 1);
+        if (ddot(dsub(sp[0], sp[1]), du) < 0.0) { LM_MPR_COUNT(1, 1); return out; }
       }
+      out.found = 1;
+      return out;
     }
     D3 dir = dunit(dscl(-1.0, v0));
     int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
@@ -1109,6 +1123,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
 #pragma nounroll
     for (int guard = 0; guard < 192 && result == 0; guard++) {
       nsupport++;
+      LM_MPR_COUNT(4, 1);
       D3 sup[2];
 #pragma nounroll
       for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : dscl(-1.0, dir));
@@ -1164,9 +1179,11 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       }
     }
 #ifdef LM_PAIR_TRACE
-    printf("   mpr lane %d rep %d result %d stage %d iter %d supports %d types %d %d\n", lane_c, 0, result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
+    printf("   mpr result %d stage %d iter %d supports %d types %d %d\n", result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
 #endif
-    if (result <= 0) return out;
+    LM_MPR_COUNT(6, iter);
+    if (result <= 0) { LM_MPR_COUNT(2, 1); return out; }
+    LM_MPR_COUNT(3, 1);
     double depth; D3 pdir, pos;
     if (result == 2) {
       const D3 v1 = pv(1), s1 = pv1(1);
@@ -1684,20 +1701,24 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue;
       static_assert(!PAIRS || kQRes + 7 * kQRes_n <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
       int nq = 0;
-      struct EntryCtx { int ka, kb, lb, own_q, dl; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
-      auto entry_ctx = [&](int i, EntryCtx& E) {
-        const int code = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 0];
-        E.ka = code & 7; E.kb = (code >> 3) & 7; E.lb = (code >> 6) & 3; E.own_q = (code >> 8) & 1; E.dl = E.lb - c;
-        E.same_lane = E.kb != 7 && E.lb == c;             // two links of my own chain: the entry (and its slots) live in this lane only
+      // entry i of chain cs's link-pair list, seen from lane c: `dlo` / `dl` = where the lane memory of the entry's own / partner chain
+      // sits relative to mine (the work queue hands a pair to ANY lane of the environment; the collection loop uses cs = c, dlo = 0)
+      struct EntryCtx { int ka, kb, lb, own_q, dl, dlo; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
+      auto entry_ctx_of = [&](int cs, int i, EntryCtx& E) {
+        const int off = (cs == c) ? off_lpair_c : (int)cm[oz + LM_CM_CHAINS + LM_C_OFF_LPAIR * LM_NCHAIN + cs];
+        const int code = (int)cm[oz + off + i * LM_LP_SIZE + 0];
+        E.ka = code & 7; E.kb = (code >> 3) & 7; E.lb = (code >> 6) & 3; E.own_q = (code >> 8) & 1; E.dl = E.lb - c; E.dlo = cs - c;
+        E.same_lane = E.kb != 7 && E.lb == cs;            // two links of one chain: the entry (and its slots) live in that lane only
       };
+      auto entry_ctx = [&](int i, EntryCtx& E) { entry_ctx_of(c, i, E); };
       auto entry_frames = [&](EntryCtx& E) {               // own / partner link frame and velocity
         E.pp = O; E.Rp = R; E.Vp = Vroot;
         {
-          const int fb = LMm::kFrame + E.ka * 18;
-          E.po = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+          const int fb = LMm::kFrame + E.ka * 18, dlo = E.dlo;
+          E.po = v3(PEER(dlo, fb), PEER(dlo, fb + 1), PEER(dlo, fb + 2));
 #pragma unroll
-          for (int j = 0; j < 9; j++) E.Ro.a[j] = LMEM(fb + 3 + j);
-          E.Vo.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); E.Vo.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));
+          for (int j = 0; j < 9; j++) E.Ro.a[j] = PEER(dlo, fb + 3 + j);
+          E.Vo.w = v3(PEER(dlo, fb + 12), PEER(dlo, fb + 13), PEER(dlo, fb + 14)); E.Vo.v = v3(PEER(dlo, fb + 15), PEER(dlo, fb + 16), PEER(dlo, fb + 17));
         }
         if (E.kb != 7) {
           const int fb = LMm::kFrame + E.kb * 18, dl = E.dl;
@@ -1743,74 +1764,113 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         if (Q::rep() == 0 && (g1own || E.kb == 7 || E.same_lane)) cnt.selfcon++;
       };
-      // work the queue off in rounds: replica r takes pair kRep * round + r. A pair first meets a one-direction separation test (the
-      // direction between the closest points of the two bounding capsules: when the hulls, inflated by the margin, are apart along
-      // it, the convex collider would find them apart too — two support searches instead of five or six), then MPR. Contacts go
-      // to the result area in queue order (the replicas agree on the positions by exchanging their found flags each round);
-      // afterwards every replica records them as slots.
+      // The work queue of the ENVIRONMENT: the queues of its four chain lanes, one after the other, are dealt to all of its lanes
+      // (4 chains x kRep replicas), whoever collected them — a folded humanoid has most of its pairs in one chain. A cross-chain pair
+      // is queued by the lane of its FIRST link only; the partner lane takes the result over afterwards (mirror slot).
+      // Stage A: a one-direction separation test per pair (the direction between the closest points of the two bounding capsules:
+      // when the hulls, inflated by the margin, are apart along it, the convex collider would find them apart too — two support
+      // searches instead of five or six); the survivors are compacted in place. Stage B: MPR for the survivors. In both stages a
+      // round costs what its slowest lane costs, hence the separation of cheap and dear work. Contacts go to the result area of
+      // the chain that queued the pair, in queue order (the lanes agree on the positions through a ballot of their found flags).
       auto flush_queue = [&]() {
-        Q::fence();
-        int nres = 0;
-        const int nrounds = (nq + Q::kRep - 1) / Q::kRep;
+        Q::fence(); Q::quad_sync();
+        constexpr int kW = 4 * Q::kRep;
+        const int me = Q::rep() * 4 + c;
+        int n_of[4], base[5], nres_of[4] = {0, 0, 0, 0};
+        auto set_bases = [&]() { base[0] = 0; for (int cs = 0; cs < 4; cs++) base[cs + 1] = base[cs] + n_of[cs]; };
+#pragma unroll
+        for (int cs = 0; cs < 4; cs++) n_of[cs] = (int)Q::quad_read((float)nq, cs);
+        set_bases();
+        // bits [lo, hi) of a ballot: the lanes that work on chain cs's items in this round
+        auto chain_bits = [&](int cs, int round) -> unsigned {
+          int lo = base[cs] - round * kW, hi = base[cs + 1] - round * kW;
+          lo = (lo < 0) ? 0 : lo; hi = (hi > kW) ? kW : hi;
+          return (hi > lo) ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+        };
 #pragma nounroll
-        for (int round = 0; round < nrounds; round++) {
-          const int t = round * Q::kRep + Q::rep();
-          bool found = false;
-          V3 nrm = v3(0, 0, 0), cp = v3(0, 0, 0); float dist = 0.0f;
-          if (t < nq) {
-            const int item = (int)LMEM(kQItem + t);
+        for (int stage = 0; stage < 2; stage++) {
+          int kept[4] = {0, 0, 0, 0};
+          const int T = base[4], nrounds = (T + kW - 1) / kW;
+#pragma nounroll
+          for (int round = 0; round < nrounds; round++) {
+#ifdef LM_TIMERS
+            cnt.m[7]++;
+#endif
+            const int g = round * kW + me;
+            int cs = 0, t = 0;
+            float raw = 0.0f;
+            MprOut mo; mo.found = 0;
+            if (g < T) {
+              cs = (g >= base[1] ? 1 : 0) + (g >= base[2] ? 1 : 0) + (g >= base[3] ? 1 : 0); t = g - base[cs];
+              raw = PEER(cs - c, kQItem + t);
+              const int item = (int)raw;
+              EntryCtx E;
+              entry_ctx_of(cs, item >> 16, E);
+              entry_frames(E);
+              const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
+              const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
+#ifndef LM_NO_MPR
+#ifdef LM_TIMERS
+              mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
+#else
+              mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
+#endif
+#endif
+            }
+            const bool found = mo.found != 0;
+            const unsigned fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
+            if (found) {
+              const int k = kept[cs] + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
+              if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
+              else if (k < kQRes_n) {
+                const int rb_ = kQRes + 7 * k, dlw = cs - c;
+                Q::peer_write(lmem, ls, rb_, dlw, mo.dist);
+                Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.nx); Q::peer_write(lmem, ls, rb_ + 2, dlw, mo.ny); Q::peer_write(lmem, ls, rb_ + 3, dlw, mo.nz);
+                Q::peer_write(lmem, ls, rb_ + 4, dlw, mo.px); Q::peer_write(lmem, ls, rb_ + 5, dlw, mo.py); Q::peer_write(lmem, ls, rb_ + 6, dlw, mo.pz);
+                Q::peer_write(lmem, ls, kQItem + t, dlw, -raw - 1.0f);       // mark: this item has a result (the marked items own the results in order)
+              }
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) kept[c2] += __builtin_popcount(fm & chain_bits(c2, round));
+            Q::fence(); Q::quad_sync();
+          }
+          if (stage == 0) { for (int c2 = 0; c2 < 4; c2++) n_of[c2] = kept[c2]; set_bases(); }
+          else for (int c2 = 0; c2 < 4; c2++) nres_of[c2] = kept[c2];
+        }
+        if (nres_of[c] > kQRes_n) n_over += nres_of[c] - kQRes_n;
+        // every replica records the contacts as slots: those of my own queue (marked items, in queue order, own the results 0, 1, ...),
+        // then the mirrors of the cross-chain pairs the other chains queued with a link of mine as the partner
+#pragma nounroll
+        for (int cs0 = 0; cs0 < 4; cs0++) {
+          const int cs = (cs0 + c) & 3;                  // own queue first
+          const int nres = (nres_of[cs] < kQRes_n) ? nres_of[cs] : kQRes_n, dls = cs - c;
+          int k = 0;
+#pragma nounroll
+          for (int t = 0; t < n_of[cs] && k < nres; t++) {
+            const float raw = PEER(dls, kQItem + t);
+            if (!(raw < 0.0f)) continue;
+            const int item = (int)(-raw - 1.0f);
+            const int kk = k++;
             EntryCtx E;
-            entry_ctx(item >> 16, E);
+            entry_ctx_of(cs, item >> 16, E);
+            if (cs != c) {
+              if (E.kb == 7 || E.lb != c || E.same_lane) continue;          // not a pair with a link of mine
+              const int ka_o = E.ka;
+              E.ka = E.kb; E.kb = ka_o; E.lb = cs; E.own_q = 1 - E.own_q; E.dl = dls; E.dlo = 0; E.same_lane = false;       // my view of it
+            }
             entry_frames(E);
             const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
-            const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
-#ifndef LM_NO_MPR
-            const MprOut mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], c);
-            found = mo.found != 0; nrm = v3(mo.nx, mo.ny, mo.nz); cp = v3(mo.px, mo.py, mo.pz); dist = mo.dist;
-#endif
-          }
-          // where do my results go: behind those of this round's lower replicas
-          int before = 0, total = found ? 1 : 0;
-          if (Q::kRep > 1) {
-            total = 0;
-#pragma unroll
-            for (int r = 0; r < Q::kRep; r++) { const int f_r = (int)Q::rep_bcast(found ? 1.0f : 0.0f, r); if (r < Q::rep()) before += f_r; total += f_r; }
-          }
-          if (found) {
-            const int k = nres + before;
-            if (k < kQRes_n) {
-              LMEM(kQRes + 7 * k) = dist;
-              LMEM(kQRes + 7 * k + 1) = nrm.x; LMEM(kQRes + 7 * k + 2) = nrm.y; LMEM(kQRes + 7 * k + 3) = nrm.z;
-              LMEM(kQRes + 7 * k + 4) = cp.x; LMEM(kQRes + 7 * k + 5) = cp.y; LMEM(kQRes + 7 * k + 6) = cp.z;
-              LMEM(kQItem + t) = -LMEM(kQItem + t) - 1.0f;       // mark: this item has a result (the marked items own the results in order)
-            }
-          }
-          nres += total;
-        }
-        if (nres > kQRes_n) { n_over += nres - kQRes_n; nres = kQRes_n; }
-        Q::fence();
-        // the marked items, in queue order, own the results 0, 1, ... in the same order
-        int k = 0;
-#pragma nounroll
-        for (int t = 0; t < nq && k < nres; t++) {
-          const float raw = LMEM(kQItem + t);
-          if (!(raw < 0.0f)) continue;
-          const int item = (int)(-raw - 1.0f);
-          EntryCtx E;
-          entry_ctx(item >> 16, E);
-          entry_frames(E);
-          const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
-          const float dist = LMEM(kQRes + 7 * k);
-          const V3 nrm = v3(LMEM(kQRes + 7 * k + 1), LMEM(kQRes + 7 * k + 2), LMEM(kQRes + 7 * k + 3));
-          const V3 cp = v3(LMEM(kQRes + 7 * k + 4), LMEM(kQRes + 7 * k + 5), LMEM(kQRes + 7 * k + 6));
-          k++;
+            const float dist = PEER(dls, kQRes + 7 * kk);
+            const V3 nrm = v3(PEER(dls, kQRes + 7 * kk + 1), PEER(dls, kQRes + 7 * kk + 2), PEER(dls, kQRes + 7 * kk + 3));
+            const V3 cp = v3(PEER(dls, kQRes + 7 * kk + 4), PEER(dls, kQRes + 7 * kk + 5), PEER(dls, kQRes + 7 * kk + 6));
 #ifdef LM_PAIR_TRACE
-          if (Q::rep() == 0) printf("   contact lane %d entry %d rec %d kind 2 dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, item >> 16, item & 65535, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
+            if (Q::rep() == 0) printf("   contact lane %d (queue of lane %d) entry %d rec %d kind 2 dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, cs, item >> 16, item & 65535, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
 #endif
-          emit_pair_slot(E, rec, ((int)rec[LM_GP_G1Q] == E.own_q), nrm, cp, dist);
+            emit_pair_slot(E, rec, ((int)rec[LM_GP_G1Q] == E.own_q), nrm, cp, dist);
+          }
         }
         nq = 0;
-        Q::fence();
+        Q::fence(); Q::quad_sync();
       };
       for (int i = 0; i < nlp; i++) {
         EntryCtx E;
@@ -1935,6 +1995,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               continue;
             }
             if (kind == 2) {
+              if (own_q) continue;                                     // cross-chain pair seen from its second link: the first link's lane queues it
               if (nq >= kQueue) { n_over++; continue; }                // more convex pairs of this lane in reach than the queue holds: dropped, counted
               LMEM(kQItem + nq) = (float)(i * 65536 + first + j);
               nq++;

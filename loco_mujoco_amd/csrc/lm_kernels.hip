@@ -52,7 +52,7 @@ struct lm_batch {
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
   hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
-  float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats, var_rows;   // model variants (lm_set_model_variants, lm_set_variant_rows)
+  float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats, var_rows; bool dofprm_of_variants;   // model variants (lm_set_model_variants, lm_set_variant_rows)
   float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
@@ -303,7 +303,7 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
   HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
-  HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (16 + 16 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (16 + 16 * (size_t)b->nblocks)));
+  HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks)));
   HIPCHK(hipStreamCreate(&b->stream));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); HIPCHK(hipEventCreateWithFlags(&b->ev_ext, hipEventDisableTiming));
   return 0;
@@ -469,6 +469,10 @@ int lm_set_dof_params(lm_batch* b, const float* damping, const float* stiffness,
   HIPCHK(hipSetDevice(b->m->device));
   const int N = b->N, nv = b->m->T.nv;
   if (!b->dofprm) {
+    // fail HERE, not at the first launch: the generic kernels (and six-link RK4 models, which have no kernel at all) are not
+    // compiled for per-environment joint parameters / model variants
+    if (family_of(b) < 0 || family_of(b) == 6)
+      return fail("per-environment joint parameters and model variants are not compiled for this model's kernel family (generic kernels)");
     std::vector<float> init((size_t)3 * nv * N);
     for (int p = 0; p < 3; p++) for (int d = 0; d < nv; d++) for (int e = 0; e < N; e++) init[((size_t)p * nv + d) * N + e] = b->m->nominal[(size_t)p * nv + d];
     HIPCHK(hipMalloc(&b->dofprm, sizeof(float) * 3 * nv * N));
@@ -514,11 +518,18 @@ int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_t
   HIPCHK(hipStreamSynchronize(b->stream));
   for (float** p : {&b->vrec, &b->vgt, &b->vgpt}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   b->nvar = 0; b->gpt_floats = 0;
-  if (n_variants <= 0) return 0;
+  if (n_variants <= 0) {       // pool removed: the joint-parameter rows go with it when this call had created them
+    if (b->dofprm_of_variants && b->dofprm && !b->drspec) { (void)hipFree(b->dofprm); b->dofprm = nullptr; }
+    b->dofprm_of_variants = false;
+    return 0;
+  }
   if (!records || !geom_tables) return fail("model variants need inertial records and geom tables");
   if ((pair_tables != nullptr) != (b->m->n_gpt_floats > 0) || (pair_tables && pair_floats != b->m->n_gpt_floats))
     return fail("geom-pair tables of the variants do not match the model's");
-  if (!b->dofprm && lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;   // the kernels with per-environment parameters
+  if (!b->dofprm) {                                  // the kernels with per-environment parameters
+    if (lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;
+    b->dofprm_of_variants = true;
+  }
   const size_t nr = (size_t)n_variants * LM_IR_SIZE * LM_NCHAIN, ng = (size_t)n_variants * LM_GT_SIZE, np_ = (size_t)n_variants * pair_floats;
   HIPCHK(hipMalloc(&b->vrec, sizeof(float) * nr)); HIPCHK(hipMemcpy(b->vrec, records, sizeof(float) * nr, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&b->vgt, sizeof(float) * ng)); HIPCHK(hipMemcpy(b->vgt, geom_tables, sizeof(float) * ng, hipMemcpyHostToDevice));
@@ -770,6 +781,24 @@ int lm_debug_wg_records(lm_batch* b, unsigned long long* out, int nblocks) {
   HIPCHK(hipStreamSynchronize(b->stream));
   if (nblocks != b->nblocks) return fail("nblocks mismatch");
   HIPCHK(hipMemcpy(out, b->timers + 16, sizeof(unsigned long long) * 16 * (size_t)nblocks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* profiling builds: per workgroup of the LAST launch [nblocks][16] = cycles per solver region */
+int lm_debug_wg_regions(lm_batch* b, unsigned long long* out, int nblocks) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (nblocks != b->nblocks) return fail("nblocks mismatch");
+  HIPCHK(hipMemcpy(out, b->timers + 16 + 16 * (size_t)nblocks, sizeof(unsigned long long) * 16 * (size_t)nblocks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* profiling builds: counters of the convex collider since the last call (8 values, summed over all lanes) */
+int lm_debug_mpr_counters(lm_batch* b, unsigned long long* out8) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out8, b->timers + 16 + 32 * (size_t)b->nblocks, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->timers + 16 + 32 * (size_t)b->nblocks, 0, sizeof(unsigned long long) * 8));
   return 0;
 }
 

@@ -67,6 +67,12 @@ struct QuadDppT {
   // away ([field][16 lanes] groups); a value of a named lane of the quad; and the point where lane memory written by the
   // quad's other lanes becomes readable — lock step and the in-order LDS make that a compiler-only fence, like fence()
   static __device__ __forceinline__ float peer(const LM_LMEM_T* lmem, int ls, int i, int dl) { return lmem[i * ls + dl]; }
+  static __device__ __forceinline__ void peer_write(LM_LMEM_T* lmem, int ls, int i, int dl, float v) { lmem[i * ls + dl] = v; }
+  // one bit per lane of my environment (bit 4 * replica + chain): the wave's ballot, my environment's part of it
+  static __device__ __forceinline__ unsigned env_ballot(bool b) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(b);
+    return (REP == 4) ? (unsigned)((m >> (__lane_id() & 48u)) & 0xffffull) : (unsigned)((m >> (__lane_id() & 60u)) & 0xfull);
+  }
   static __device__ __forceinline__ float quad_read(float x, int src) {
     const int lane = (int)((__lane_id() & ~3u) | (unsigned)src);
     return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(x)));
@@ -310,7 +316,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   bool zero_act = false;                     // a restarted episode starts with zero muscle activation (mj_resetData)
   // done byte: bit 0 = absorbing state; bit 1 = the episode ended in this step on the device's side (restarted from the
   // reset table — the observation written below is then the first of the NEW episode — or the horizon was reached)
-  const unsigned char done_byte = (unsigned char)((absorbing ? 1 : 0) | ((trunc || (absorbing && a.auto_reset && a.table_rows > 0)) ? 2 : 0));
+  // Without device-side restarts bit 1 is set in the ONE step that reaches the horizon, not in every later one.
+  const bool restarts = a.auto_reset && a.table_rows > 0;
+  const unsigned char done_byte = (unsigned char)((absorbing ? 1 : 0) | (((restarts && (trunc || absorbing)) || (!restarts && step_no == a.horizon)) ? 2 : 0));
   if (absorbing || trunc) {
     // without device-side restarts an episode that runs past its horizon (or stays absorbed) is counted once
     episodes = (a.auto_reset && a.table_rows > 0) || step_no == a.horizon || (absorbing && !trunc) ? 1.0f : 0.0f;
@@ -422,10 +430,12 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     }
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
+    for (int i = 0; i < 8; i++) if (cnt.m[i]) atomicAdd(&a.timers[16 + 32 * (long long)gridDim.x + i], (unsigned long long)cnt.m[i]);        // every lane
     {
       unsigned long long* rec = a.timers + 16 + 16 * (long long)wg;       // wg: the workgroup after the XCD mapping (environments 4 wg .. 4 wg + 3)
       const float ncon_env = QuadDpp::sum((float)cnt.ncon);
       if (threadIdx.x == 0) { long long tot = 0; for (int i = 0; i < 16; i++) tot += cnt.t[i]; rec[0] = (unsigned long long)tot; }
+      if (threadIdx.x == 0) for (int i = 0; i < 16; i++) a.timers[16 + 16 * (long long)gridDim.x + 16 * (long long)wg + i] = (unsigned long long)cnt.t[i];
       if (c == 0 && QuadDpp::rep() == 0 && e_local < 4) {
         rec[1 + e_local] = (unsigned long long)cnt.solver_iters; rec[5 + e_local] = (unsigned long long)ncon_env;
         rec[9 + e_local] = (unsigned long long)cnt.ls_evals; rec[13 + (e_local & 1)] = (unsigned long long)(absorbing ? 1 : 0);

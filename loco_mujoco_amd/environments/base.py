@@ -48,12 +48,21 @@ class LocoEnv:
                  n_substeps=10, reward_type=None, reward_params=None, traj_params=None, random_start=True,
                  init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
                  use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
-                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=32, **viewer_params):
+                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=32, model_variants_per_reset=4,
+                 **viewer_params):
         self._model = model
         # models compiled per batch for the randomisation rules that change compile-time constants (inertial, armature, geom
         # friction): a pool the environments draw from per episode, see utils/domain_randomization.py
+        # The reference compiles one freshly drawn model at every reset (base.py:183-185). Here: a pool of `n_model_variants`
+        # models, of which every reset() REPLACES `model_variants_per_reset` (round-robin; 0 = fixed pool), so that a long training
+        # is not limited to the first pool; a batch of at most that many environments runs one brand-new model per environment
+        # and episode — the reference's behaviour exactly. Device-side restarts (auto-reset inside a rollout) draw from the pool.
         self._n_model_variants = int(n_model_variants)
+        self._variants_per_reset = int(model_variants_per_reset)
         self._variant_models = {}          # model index -> [CompiledModel] (kept for inspection and the parity tests)
+        self._variant_tables = None        # the pool, lowered (built at the first reset(), rebuilt after seed())
+        self._variant_cursor = 0
+        self._variant_dirty = False
         # joint-parameter randomisation per episode (reference base.py:103-107,183-185). The reference draws in worker
         # processes, i.e. outside the main np.random stream — so does this (own RandomState, reseeded by seed()).
         self._domain_rand = None
@@ -61,6 +70,11 @@ class LocoEnv:
             from ..utils.domain_randomization import JointRandomization
             self._domain_rand = JointRandomization(model, domain_randomization_config)
             self._domain_rand_rs = np.random.RandomState(0)
+            if self._domain_rand.has_model_rules and self._n_model_variants < 1:
+                raise ValueError("n_model_variants must be >= 1 with randomisation rules that change compile-time constants "
+                                 "(inertial, armature, geom friction), got %d" % self._n_model_variants)
+            if not 0 <= self._variants_per_reset:
+                raise ValueError("model_variants_per_reset must be >= 0")
         assert abs(model.timestep - timestep) < 1e-12, "compile the model with the environment's timestep"
         self._timestep = timestep
         # foot forces: the reference turns the control step into n_substeps intermediate steps of one substep each and
@@ -156,25 +170,53 @@ class LocoEnv:
             self._hip_model = HipModel(nominal, self._device)
             self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if self._blocks else self.n_envs)
             if self._pooled:
-                if self._domain_rand is not None and self._domain_rand.has_model_rules:
-                    raise NotImplementedError("several models in one batch AND randomised compile-time constants: both use the model variants")
                 from ..lowering import variant_tables
                 self._backend.set_model_variants([variant_tables(nominal, self._chain_model(m)) for m in self._models])
             elif self._domain_rand is not None and self._domain_rand.has_model_rules:
-                self._backend.set_model_variants(self._build_model_variants(nominal))
+                self._ensure_variant_pool()
+                self._backend.set_model_variants(self._variant_tables)
+                self._variant_dirty = False
         return self._backend
 
-    def _build_model_variants(self, nominal):
-        """The pool of randomised models of the current model's batch: drawn with the randomisation's own generator, compiled
-        (``mjcf.model_variant``), lowered, reduced to what differs from the nominal tables (``lowering.variant_tables``)."""
+    def _build_model_variants(self, nominal, count=None):
+        """`count` (default: the whole pool) randomised models of the current model's batch: drawn with the randomisation's own
+        generator, compiled (``mjcf.model_variant``), lowered, reduced to what differs from the nominal tables
+        (``lowering.variant_tables``). Returns (models, tables)."""
         from ..lowering import variant_tables
         state = np.random.get_state()
         np.random.set_state(self._domain_rand_rs.get_state())
-        models = [self._domain_rand.sample_model_variant(self._model) for _ in range(self._n_model_variants)]
+        models = [self._domain_rand.sample_model_variant(self._model) for _ in range(self._n_model_variants if count is None else count)]
         self._domain_rand_rs.set_state(np.random.get_state())
         np.random.set_state(state)
-        self._variant_models[self._current_model_idx] = models
-        return [variant_tables(nominal, self._chain_model(v)) for v in models]
+        return models, [variant_tables(nominal, self._chain_model(v)) for v in models]
+
+    def _ensure_variant_pool(self):
+        """Host-only and deterministic: the pool is a function of the randomisation generator's state (``seed()``) alone — built
+        at the first reset() before anything else is drawn from that generator, never as a side effect of the first step()."""
+        if self._variant_tables is None:
+            if self._n_models > 1:
+                raise NotImplementedError("several models in one batch AND randomised compile-time constants: both use the model variants")
+            models, self._variant_tables = self._build_model_variants(self._chain_model())
+            self._variant_models[self._current_model_idx] = models
+            self._variant_cursor = 0
+            self._variant_dirty = True
+
+    def refresh_model_variants(self, count=None):
+        """Replace `count` models of the pool (default: all of them) by fresh draws, round-robin. Returns the pool indices that
+        were replaced. Takes effect on the device at the next upload of a reset (environments in mid-episode on a replaced index
+        would change model: call it where every environment restarts, as reset() does)."""
+        self._ensure_variant_pool()
+        k = self._n_model_variants if count is None else min(int(count), self._n_model_variants)
+        if k <= 0:
+            return np.zeros(0, dtype=np.int64)
+        models, tables = self._build_model_variants(self._chain_model(), k)
+        idx = (self._variant_cursor + np.arange(k)) % self._n_model_variants
+        for j, mdl, tab in zip(idx, models, tables):
+            self._variant_models[self._current_model_idx][j] = mdl
+            self._variant_tables[j] = tab
+        self._variant_cursor = int((self._variant_cursor + k) % self._n_model_variants)
+        self._variant_dirty = True
+        return idx
 
     def _init_models(self, models):
         """Several models in one environment (the reference's ``MultiMuJoCo``: sizes of the humanoid, carried weights).
@@ -332,11 +374,20 @@ class LocoEnv:
         self._pending_dof_params = None
         self._pending_variants = None
         if self._domain_rand is not None and self._domain_rand.active:
+            fresh = None
+            if self._domain_rand.has_model_rules:
+                first = self._variant_tables is None
+                self._ensure_variant_pool()                 # first reset (or first after seed()): the whole pool, freshly drawn
+                if not first and self._variants_per_reset > 0:
+                    fresh = self.refresh_model_variants(self._variants_per_reset)
             state = np.random.get_state()
             np.random.set_state(self._domain_rand_rs.get_state())
             self._pending_dof_params = self._domain_rand.sample(self.n_envs)
             if self._domain_rand.has_model_rules:
-                self._pending_variants = np.random.randint(0, self._n_model_variants, self.n_envs)
+                if fresh is not None and self.n_envs <= len(fresh):
+                    self._pending_variants = fresh[:self.n_envs].copy()    # one brand-new model per environment and episode
+                else:
+                    self._pending_variants = np.random.randint(0, self._n_model_variants, self.n_envs)
             self._domain_rand_rs.set_state(np.random.get_state())
             np.random.set_state(state)
         if self._pooled:
@@ -441,7 +492,18 @@ class LocoEnv:
             # reward(cur_obs, action, obs, absorbing)): ONE environment's 1-D state and the UN-normalised action of
             # _preprocess_action (base.py:606-621), environment by environment
             ctrl = self._preprocess_action(a)
-            reward = np.array([float(self.reward(prev_obs[e], ctrl[e], obs[e], bool(done[e]))) for e in range(self.n_envs)], dtype=np.float64)
+            from ..utils.reward import CustomReward
+            overridden = type(self).reward is not LocoEnv.reward
+            if isinstance(self._reward_function, CustomReward) or overridden or self.n_envs == 1:
+                reward = np.array([float(self.reward(prev_obs[e], ctrl[e], obs[e], bool(done[e]))) for e in range(self.n_envs)], dtype=np.float64)
+            else:
+                # the built-in functors take (N, nobs) batches: one call, not a Python loop over 4096 environments
+                if not getattr(self, "_warned_host_reward", False):
+                    import warnings
+                    warnings.warn("%s: the reward is evaluated on the host every step (the step kernel's reward is bypassed, "
+                                  "e.g. because the observation carries foot forces)" % type(self).__name__)
+                    self._warned_host_reward = True
+                reward = np.broadcast_to(np.asarray(self._reward_function(prev_obs, ctrl, obs, done), dtype=np.float64), (self.n_envs,)).copy()
         else:
             reward = rew32.astype(np.float64)
         self._obs = obs
@@ -449,7 +511,10 @@ class LocoEnv:
         # episode; horizon reached): reported so that a learner does not bootstrap across them. Empty like the
         # reference's info dict otherwise.
         restarted = self._restarted_flags()
-        info = {} if restarted is None or not restarted.any() else {"episode_restarted": restarted if self.n_envs > 1 else bool(restarted[0])}
+        info = {}
+        if restarted is not None and (self._auto_reset or restarted.any()):
+            # always present with device-side restarts enabled (all False in most steps): a stable key for learners
+            info = {"episode_restarted": restarted if self.n_envs > 1 else bool(restarted[0])}
         if self.n_envs == 1:
             return obs[0].copy(), float(reward[0]), bool(done[0]), info
         return obs.copy(), reward, done, info
@@ -479,6 +544,9 @@ class LocoEnv:
             b.set_state(qpos[envs], qvel[envs])
             if prm is not None:
                 b.set_dof_params(damping=prm[0][envs], stiffness=prm[1][envs], frictionloss=prm[2][envs])
+            if self._variant_dirty and self._variant_tables is not None:      # pool entries replaced since the last upload
+                b.set_model_variants(self._variant_tables)
+                self._variant_dirty = False
             if getattr(self, "_pending_variants", None) is not None:
                 b.set_variant_index(self._pending_variants[envs])
             goal = self._goal_rows()
@@ -683,6 +751,7 @@ class LocoEnv:
         np.random.seed(seed)
         if self._domain_rand is not None:
             self._domain_rand_rs = np.random.RandomState(seed)
+            self._variant_tables = None          # the pool is a function of the seed: rebuilt at the next reset()
 
     def play_trajectory(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
         """Kinematic replay of the loaded trajectory (reference ``base.py:314-386``): yields the observation
@@ -706,7 +775,11 @@ class LocoEnv:
     def play_trajectory_from_velocity(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
         """Replay of the loaded trajectory from its joint VELOCITIES (reference ``base.py:388-476``): the positions of the
         first sample, then ``qpos += dt * qvel`` with the trajectory's velocities; the goal / site entries of every sample
-        are taken as they are. Returns the observation of every replayed step; no dynamics, no rendering."""
+        are taken as they are. Returns the observation of every replayed step; no dynamics, no rendering.
+
+        At the end of the trajectory the replay restarts from a new reset and continues, like the reference. The reference's
+        defaults are unbounded (it renders until stopped); this replay returns an array, so ``n_episodes`` defaults to 1 and an
+        episode without ``n_steps_per_episode`` ends at the end of the trajectory."""
         assert self.trajectories is not None
         self._cur_env = 0
         self.reset()
@@ -727,8 +800,12 @@ class LocoEnv:
                 out.append(self._create_observation(self.obs_helper._build_obs(self._host[0])))
                 steps += 1
                 sample = self.trajectories.get_next_sample()
-                if sample is None:                      # end of the trajectory: the episode ends here
-                    break
+                if sample is None:                      # end of the trajectory: restart and go on (reference base.py:452-455)
+                    if n_steps_per_episode is None:     # ... unbounded there; a replay that RETURNS its observations ends here
+                        break
+                    self.reset()
+                    sample = self.trajectories.get_current_sample()
+                    curr_qpos = np.array([np.asarray(x, dtype=np.float64).reshape(-1)[0] for x in sample[0:len_qpos]])
             self.reset()
             sample = self.trajectories.get_current_sample()
             curr_qpos = np.array([np.asarray(x, dtype=np.float64).reshape(-1)[0] for x in sample[0:len_qpos]])

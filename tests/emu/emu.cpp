@@ -92,6 +92,13 @@ struct QuadThreadsT {
   // the lanes of one quad (replica): peers' lane memory, values of a named lane, a join before / after peer reads
   static void quad_sync() { g_bar_rep[t_rep].arrive_and_wait(); }
   static float peer(const float* /*lmem*/, int /*ls*/, int i, int dl) { return g_lmem[t_rep][t_lane + dl][i]; }
+  static void peer_write(float* /*lmem*/, int /*ls*/, int i, int dl, float v) { g_lmem[t_rep][t_lane + dl][i] = v; }
+  static unsigned env_ballot(bool b) {      // bit 4 * replica + chain of every thread of the environment
+    g_ibuf[t_rep * 4 + t_lane] = b; g_bar.arrive_and_wait();
+    unsigned r = 0;
+    for (int i = 0; i < kThreads; i++) r |= (g_ibuf[i] ? 1u : 0u) << i;
+    g_bar.arrive_and_wait(); return r;
+  }
   static float quad_read(float x, int src) {
     g_buf[t_rep][t_lane] = x; g_bar_rep[t_rep].arrive_and_wait();
     float y = g_buf[t_rep][src];

@@ -1494,6 +1494,55 @@ def test_model_variants_one_control_step_vs_oracle():
     assert max(enom) > 10 * VTOL                         # the variants are different robots
 
 
+def test_model_variants_pool_refreshed_by_reset_reaches_the_device():
+    """Every reset() replaces `model_variants_per_reset` pool entries by fresh draws; a batch no larger than that runs one
+    brand-new model per environment and episode (the reference: a freshly compiled model at every reset, base.py:183-185).
+    Second episode: the device has to simulate the REPLACED models."""
+    n, k = 4, 6
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True, n_envs=n, domain_randomization_config=cfg, n_model_variants=k, model_variants_per_reset=4)
+    m = env._model
+    env.reset()
+    env.step(np.zeros((n, 12)))
+    old = [env._variant_models[0][j] for j in range(4)]
+    env.reset()
+    variants, prm = env._pending_variants.copy(), env._pending_dof_params.copy()
+    assert list(variants) == [0, 1, 2, 3] and all(env._variant_models[0][j] is not old[j] for j in range(4))
+    q0 = np.stack([h.qpos for h in env._host]).astype(np.float32).astype(np.float64)
+    v0 = np.stack([h.qvel for h in env._host]).astype(np.float32).astype(np.float64)
+    acts = np.random.RandomState(5).uniform(-0.3, 0.3, (n, 12))
+    env.step(acts)
+    assert np.array_equal(env.backend.get_variant_index(), variants)
+    q, v = env.backend.get_state()
+    eq, ev, eold = [], [], []
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        d, s_, f = (prm[p][i].astype(np.float32) for p in range(3))
+        qo, vo = Oracle(pack_model(_with_dof_params(env._variant_models[0][variants[i]], d, s_, f))).step(q0[i], v0[i], ctrl, nsub=10)[:2]
+        qn, vn = Oracle(pack_model(_with_dof_params(old[i], d, s_, f))).step(q0[i], v0[i], ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max()); eold.append(np.abs(v[i] - vn).max())
+    print("refreshed pool vs oracle: qpos %.2e qvel %.2e (vs the replaced models: qvel %.2e)" % (max(eq), max(ev), max(eold)))
+    assert max(eq) < QTOL and max(ev) < VTOL and max(eold) > 10 * VTOL
+
+
+def test_joint_parameters_on_a_generic_kernel_family_fail_at_the_call():
+    """lm_set_dof_params / lm_set_model_variants on a model served by the generic kernels (here: the quadruped with RK4) fail where
+    they are called, not at the next launch, and leave the batch usable."""
+    from loco_mujoco_amd.backend import BackendError, HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    env._model.integrator = 1
+    b = HipBatch(HipModel(env._chain_model()), 8)
+    with pytest.raises(BackendError, match="not compiled for this model's kernel family"):
+        b.set_dof_params(damping=np.ones((8, env._model.nv)))
+    tab = env._reset_table()
+    b.set_state(tab[:8, :env._model.nv], tab[:8, env._model.nv:2 * env._model.nv])
+    b.step(np.zeros((8, 12)))
+    assert np.isfinite(b.get_state()[0]).all()
+
+
 def test_model_variants_redrawn_at_device_side_restarts():
     n, k = 256, 6
     env = _talos_variant_env(n, k)
@@ -1519,7 +1568,7 @@ def test_model_variants_redrawn_at_device_side_restarts():
 
     def run(nenv, offset):
         bb = HipBatch(env._hip_model, nenv)
-        bb.set_model_variants(env._build_model_variants(env._chain_model()))
+        bb.set_model_variants(env._build_model_variants(env._chain_model())[1])
         tab = env._reset_table()
         rows = tab[(np.arange(offset, offset + nenv) * 7) % len(tab)]
         bb.set_state(rows[:, :env._model.nv], rows[:, env._model.nv:2 * env._model.nv])

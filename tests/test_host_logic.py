@@ -438,17 +438,37 @@ def test_domain_randomization_of_compile_time_constants(tmp_path):
     with pytest.raises(lowering.UnsupportedModel):
         lowering.variant_tables(nominal, other._chain_model())
     # the environment builds its pool with the randomisation's own generator: reproducible, untouched main stream
-    e = LocoEnv.make("Talos.walk", debug=True, n_envs=3, domain_randomization_config=cfg, n_model_variants=4)
+    e = LocoEnv.make("Talos.walk", debug=True, n_envs=3, domain_randomization_config=cfg, n_model_variants=4, model_variants_per_reset=0)
     state = np.random.get_state()[1].copy()
-    t1 = e._build_model_variants(e._chain_model())
-    assert np.array_equal(np.random.get_state()[1], state) and len(t1) == 4 and len(e._variant_models[0]) == 4
+    m1, t1 = e._build_model_variants(e._chain_model())
+    assert np.array_equal(np.random.get_state()[1], state) and len(t1) == 4 and len(m1) == 4
     e.seed(0); np.random.seed(0)
-    ta = e._build_model_variants(e._chain_model())
+    _, ta = e._build_model_variants(e._chain_model())
     e.seed(0)
-    tb = e._build_model_variants(e._chain_model())
+    _, tb = e._build_model_variants(e._chain_model())
     assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(ta, tb))
-    e.reset()
+    # the pool is built at the first reset() from the seed alone (no GPU, no dependence on what ran before the first step()) ...
+    e.seed(3); e.reset()
+    pool_a = [x[0].copy() for x in e._variant_tables]
     assert e._pending_variants.shape == (3,) and (e._pending_variants >= 0).all() and (e._pending_variants < 4).all()
+    e.reset(); e.reset()
+    assert all(np.array_equal(x, y[0]) for x, y in zip(pool_a, e._variant_tables))          # model_variants_per_reset=0: a fixed pool
+    e.seed(3); assert e._variant_tables is None
+    e.reset()
+    assert all(np.array_equal(x, y[0]) for x, y in zip(pool_a, e._variant_tables))
+    # ... and with the default rolling refresh every reset() replaces pool entries round-robin by fresh draws; a batch of at most
+    # that many environments runs one brand-new model per environment and episode (the reference: a new model at every reset)
+    r = LocoEnv.make("Talos.walk", debug=True, n_envs=2, domain_randomization_config=cfg, n_model_variants=6, model_variants_per_reset=2)
+    r.seed(1); r.reset()
+    p0 = [x[0].copy() for x in r._variant_tables]
+    r.reset()
+    changed = [j for j in range(6) if not np.array_equal(p0[j], r._variant_tables[j][0])]
+    assert changed == [0, 1] and list(r._pending_variants) == [0, 1] and r._variant_dirty
+    r.reset()
+    assert list(r._pending_variants) == [2, 3] and not np.array_equal(p0[2], r._variant_tables[2][0]) and np.array_equal(p0[4], r._variant_tables[4][0])
+    assert list(r.refresh_model_variants()) == [4, 5, 0, 1, 2, 3]
+    with pytest.raises(ValueError, match="n_model_variants must be >= 1"):
+        LocoEnv.make("Talos.walk", debug=True, n_envs=2, domain_randomization_config=cfg, n_model_variants=0)
     # the reference's own Talos file (data/talos/domain_randomization_talos.yaml:32-41) asks for `fullinertia` on a body whose
     # <inertial> has diaginertia + quat: its assertion fires (domain_randomization.py:497), and so does this one
     y = tmp_path / "dr.yaml"

@@ -23,7 +23,7 @@ for task, kw in (("UnitreeA1.simple", {}), ("UnitreeA1.simple", dict(action_mode
     nominal = env._chain_model()
     b = HipBatch(HipModel(nominal), n)
     if kw.get("domain_randomization_config") and env._domain_rand.has_model_rules:
-        b.set_model_variants(env._build_model_variants(nominal))
+        b.set_model_variants(env._build_model_variants(nominal)[1])
         b.set_variant_index(np.random.RandomState(1).randint(0, b.n_variants, n))
     rows = tab[np.random.RandomState(0).randint(0, len(tab), n)]
     b.set_reset_table(tab, seed=0)
