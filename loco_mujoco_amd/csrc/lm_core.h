@@ -163,7 +163,7 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
 #ifdef LM_TIMERS
   long long t[16];
-  long long m[8];    // convex collider: calls, ended at the one-direction test, no contact, contact, support pairs, hill steps, refinement iterations, rounds
+  long long m[16];   // [8..]: passes with detection, passes, geom pairs tested of kind 0 / 1 / 2, hits of kind 0 / 1 / 2;  [0..7] convex collider: calls, ended at the one-direction test, no contact, contact, support pairs, hill steps, refinement iterations, rounds
 #endif
 };
 #ifdef LM_TIMERS
@@ -1161,8 +1161,8 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       } else {
         // reach of the new support point beyond the portal along dir
         const double reach = fmin(fmin(dt - ddot(pv(1), dir), dt - ddot(pv(2), dir)), dt - ddot(pv(3), dir));
-#ifdef LM_PAIR_TRACE
-        if (getenv("LM_MPR_TRACE")) printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, ddot(pv(1), dir), reach);
+#ifdef LM_MPR_TRACE
+        printf("  d stage %d it %d dir %.6f %.6f %.6f v4 %.6f %.6f %.6f dv4 %.8f dv1 %.8f reach %.3g\n", stage, iter, dir.x, dir.y, dir.z, sv.x, sv.y, sv.z, dt, ddot(pv(1), dir), reach);
 #endif
         if (stage == 3) {
           if (!(is_zero(dt) || dt > 0.0) || reach <= 1e-6) { result = -1; break; }
@@ -1679,28 +1679,59 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #ifdef LM_NO_DETECT
     detect = false;
 #endif
+#ifdef LM_TIMERS
+    if (PAIRS && c == 0 && Q::rep() == 0) { cnt.m[9]++; if (detect) cnt.m[8]++; }
+#endif
     if (PAIRS && detect) {
       if (c == 0 && Q::rep() == 0) cnt.pair_passes++;
       Q::quad_sync();                // the peers' frames and sphere centres are read below
       const V3 rootc = O + mul(R, v3(rb[LM_R_BSX], rb[LM_R_BSY], rb[LM_R_BSZ]));
       const int nlp = (int)CH(LM_C_NLPAIR), off_lpair_c = (int)CH(LM_C_OFF_LPAIR);
       int n_over = 0;
-      // ---- convex pairs (geom-pair kind 2): the engine's general convex collider = libccd's Minkowski Portal Refinement driven
-      // by the engine's support / centre callbacks (oracle/oracle.c: mpr_penetration is the float64 restatement this follows
-      // step by step). One support call site: the phases of the algorithm are a small state machine around it. Both shapes are
-      // inflated by margin / 2 along the search direction; result: normal from geom 1 to geom 2, contact point (relative to O)
-      // midway between the two witness points, distance = margin - depth. The portal (4 points x (v, v1)) lives in the part of lane
-      // memory that holds the inertia matrix later in the pass (dead here: the work queue); the support search of a hull climbs its vertex graph.
-      // Both lanes of a cross-chain pair run it on the same numbers: identical results, mirror slots.
-      // Work queue of the convex pairs: the passes over entries / body pairs / geom pairs only COLLECT the pairs whose bounding
-      // capsules are within the margin; MPR then runs for all lanes of the wave at the same time, one queued pair per replica (in a
-      // SIMT machine the collider called from inside the divergent loops would run once per lane, one after the other). Queue,
-      // results and portals sit in the part of lane memory that holds M, the twists and the link images later in the pass.
-      constexpr int kQueue = (MC >= 5) ? 24 : 8;                      // queued pairs per lane and pass (more: counted as dropped contacts)
-      constexpr int kQRes_n = (NS < 8) ? 4 : 8;                       // contacts the queue can hand back
-      constexpr int kQItem = LMm::kMcc, kQRes = kQItem + kQueue;
-      static_assert(!PAIRS || kQRes + 7 * kQRes_n <= LMm::kFrame, "the convex-pair work area must fit the dead part of lane memory");
-      int nq = 0;
+      // ---- The pass is a sequence of FLAT work lists, each dealt to all lanes of the environment (4 chains x kRep replicas), because
+      // every level costs a round trip to global memory (body-pair table, geom-pair table, hull vertices) and nested loops pay them one
+      // after the other:
+      //   1. link pairs (per chain lane, LDS only): bounding spheres of the two links -> list W of the entries in reach. A cross-chain
+      //      pair is listed by the lane of its FIRST link only; the partner takes the results over at the end (mirror slots).
+      //   2. body pairs of W's entries: one bounding capsule per body -> list S of the body pairs within the largest margin.
+      //   3. geom pairs of S's body pairs: bounding capsules of the two geoms (closest points of the two segments). Within the margin:
+      //      a closed-form contact (kind 0) goes to the chain's result list R, a pair without a collider (kind 1) is counted, a convex
+      //      pair (kind 2) goes to the chain's queue.
+      //   4. the queue: a one-direction separation test per pair, survivors compacted; then MPR (the engine's general convex collider =
+      //      libccd's Minkowski Portal Refinement, oracle/oracle.c: mpr_penetration is the float64 restatement it follows step by step).
+      //      In both a round costs what its slowest lane costs, hence cheap and dear work in separate rounds. Contacts -> R.
+      //   5. every replica records its chain's results as slots, then the mirrors of the other chains' results with a link of its own.
+      // The lanes agree on list positions through ballots of their flags (lists are filled in work order, chain by chain). W, S, the
+      // queue and R sit in the part of lane memory that holds M, the twists and the link images later in the pass. Lists that fill up
+      // (W, S) make the pass run in chunks of entries; a full queue or result list drops contacts, counted in `overflow`.
+      constexpr int kQueue = (MC >= 5) ? 24 : 8;                      // convex pairs per chain and pass
+      constexpr int kWcap = (MC >= 5) ? 24 : 12;                      // link-pair entries per chain and chunk
+      constexpr int kScap = 24;                                       // body pairs in reach per chain and chunk (an entry has at most 24)
+      constexpr int kRcap = (NS < 8) ? NS : 8;                        // contacts per chain and pass (a chain has NS slots)
+      constexpr int kW1 = LMm::kMcc, kS1 = kW1 + kWcap, kQItem = kS1 + 2 * kScap, kRes = kQItem + kQueue;
+      static_assert(!PAIRS || kRes + 8 * kRcap <= LMm::kFrame, "the work lists of the pair pass must fit the dead part of lane memory");
+      constexpr int kW = 4 * Q::kRep;                                 // lanes of one environment
+      const int me = Q::rep() * 4 + c;
+      int base[5];
+      auto set_bases = [&](const int* n) { base[0] = 0; for (int cs = 0; cs < 4; cs++) base[cs + 1] = base[cs] + n[cs]; };
+      auto chain_of = [&](int g) -> int { return (g >= base[1] ? 1 : 0) + (g >= base[2] ? 1 : 0) + (g >= base[3] ? 1 : 0); };
+      // bits [lo, hi) of a ballot: the lanes that work on chain cs's units in this round
+      auto chain_bits = [&](int cs, int round) -> unsigned {
+        int lo = base[cs] - round * kW, hi = base[cs + 1] - round * kW;
+        lo = (lo < 0) ? 0 : lo; hi = (hi > kW) ? kW : hi;
+        return (hi > lo) ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+      };
+      auto share4 = [&](int x, int* out) {
+#pragma unroll
+        for (int cs = 0; cs < 4; cs++) out[cs] = (int)Q::quad_read((float)x, cs);
+      };
+      int nres_of[4] = {0, 0, 0, 0}, nq_of[4] = {0, 0, 0, 0};
+      float gap_of[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};        // smallest clearance seen for a pair of chain cs (this lane's share)
+      auto gap_note = [&](int cs, float g) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k == cs) gap_of[k] = fminf(gap_of[k], g);
+      };
+      auto off_lpair_of = [&](int cs) -> int { return (cs == c) ? off_lpair_c : (int)cm[oz + LM_CM_CHAINS + LM_C_OFF_LPAIR * LM_NCHAIN + cs]; };
       // entry i of chain cs's link-pair list, seen from lane c: `dlo` / `dl` = where the lane memory of the entry's own / partner chain
       // sits relative to mine (the work queue hands a pair to ANY lane of the environment; the collection loop uses cs = c, dlo = 0)
       struct EntryCtx { int ka, kb, lb, own_q, dl, dlo; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
@@ -1764,29 +1795,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         if (Q::rep() == 0 && (g1own || E.kb == 7 || E.same_lane)) cnt.selfcon++;
       };
-      // The work queue of the ENVIRONMENT: the queues of its four chain lanes, one after the other, are dealt to all of its lanes
-      // (4 chains x kRep replicas), whoever collected them — a folded humanoid has most of its pairs in one chain. A cross-chain pair
-      // is queued by the lane of its FIRST link only; the partner lane takes the result over afterwards (mirror slot).
-      // Stage A: a one-direction separation test per pair (the direction between the closest points of the two bounding capsules:
-      // when the hulls, inflated by the margin, are apart along it, the convex collider would find them apart too — two support
-      // searches instead of five or six); the survivors are compacted in place. Stage B: MPR for the survivors. In both stages a
-      // round costs what its slowest lane costs, hence the separation of cheap and dear work. Contacts go to the result area of
-      // the chain that queued the pair, in queue order (the lanes agree on the positions through a ballot of their found flags).
+      // ---- 4. the convex pairs of the queues
       auto flush_queue = [&]() {
         Q::fence(); Q::quad_sync();
-        constexpr int kW = 4 * Q::kRep;
-        const int me = Q::rep() * 4 + c;
-        int n_of[4], base[5], nres_of[4] = {0, 0, 0, 0};
-        auto set_bases = [&]() { base[0] = 0; for (int cs = 0; cs < 4; cs++) base[cs + 1] = base[cs] + n_of[cs]; };
+        int n_of[4];
 #pragma unroll
-        for (int cs = 0; cs < 4; cs++) n_of[cs] = (int)Q::quad_read((float)nq, cs);
-        set_bases();
-        // bits [lo, hi) of a ballot: the lanes that work on chain cs's items in this round
-        auto chain_bits = [&](int cs, int round) -> unsigned {
-          int lo = base[cs] - round * kW, hi = base[cs + 1] - round * kW;
-          lo = (lo < 0) ? 0 : lo; hi = (hi > kW) ? kW : hi;
-          return (hi > lo) ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
-        };
+        for (int cs = 0; cs < 4; cs++) n_of[cs] = (nq_of[cs] < kQueue) ? nq_of[cs] : kQueue;
+        set_bases(n_of);
 #pragma nounroll
         for (int stage = 0; stage < 2; stage++) {
           int kept[4] = {0, 0, 0, 0};
@@ -1801,7 +1816,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             float raw = 0.0f;
             MprOut mo; mo.found = 0;
             if (g < T) {
-              cs = (g >= base[1] ? 1 : 0) + (g >= base[2] ? 1 : 0) + (g >= base[3] ? 1 : 0); t = g - base[cs];
+              cs = chain_of(g); t = g - base[cs];
               raw = PEER(cs - c, kQItem + t);
               const int item = (int)raw;
               EntryCtx E;
@@ -1820,37 +1835,33 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const bool found = mo.found != 0;
             const unsigned fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
             if (found) {
-              const int k = kept[cs] + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
+              const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
               if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
-              else if (k < kQRes_n) {
-                const int rb_ = kQRes + 7 * k, dlw = cs - c;
-                Q::peer_write(lmem, ls, rb_, dlw, mo.dist);
-                Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.nx); Q::peer_write(lmem, ls, rb_ + 2, dlw, mo.ny); Q::peer_write(lmem, ls, rb_ + 3, dlw, mo.nz);
-                Q::peer_write(lmem, ls, rb_ + 4, dlw, mo.px); Q::peer_write(lmem, ls, rb_ + 5, dlw, mo.py); Q::peer_write(lmem, ls, rb_ + 6, dlw, mo.pz);
-                Q::peer_write(lmem, ls, kQItem + t, dlw, -raw - 1.0f);       // mark: this item has a result (the marked items own the results in order)
+              else if (k < kRcap) {
+                const int rb_ = kRes + 8 * k, dlw = cs - c;
+                Q::peer_write(lmem, ls, rb_, dlw, raw); Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.dist);
+                Q::peer_write(lmem, ls, rb_ + 2, dlw, mo.nx); Q::peer_write(lmem, ls, rb_ + 3, dlw, mo.ny); Q::peer_write(lmem, ls, rb_ + 4, dlw, mo.nz);
+                Q::peer_write(lmem, ls, rb_ + 5, dlw, mo.px); Q::peer_write(lmem, ls, rb_ + 6, dlw, mo.py); Q::peer_write(lmem, ls, rb_ + 7, dlw, mo.pz);
               }
             }
 #pragma unroll
             for (int c2 = 0; c2 < 4; c2++) kept[c2] += __builtin_popcount(fm & chain_bits(c2, round));
             Q::fence(); Q::quad_sync();
           }
-          if (stage == 0) { for (int c2 = 0; c2 < 4; c2++) n_of[c2] = kept[c2]; set_bases(); }
-          else for (int c2 = 0; c2 < 4; c2++) nres_of[c2] = kept[c2];
+          if (stage == 0) { for (int c2 = 0; c2 < 4; c2++) n_of[c2] = kept[c2]; set_bases(n_of); }
+          else for (int c2 = 0; c2 < 4; c2++) nres_of[c2] += kept[c2];
         }
-        if (nres_of[c] > kQRes_n) n_over += nres_of[c] - kQRes_n;
-        // every replica records the contacts as slots: those of my own queue (marked items, in queue order, own the results 0, 1, ...),
-        // then the mirrors of the cross-chain pairs the other chains queued with a link of mine as the partner
+      };
+      // ---- 5. results -> slots: my chain's, then the mirrors of the others' cross-chain results with a link of mine
+      auto emit_results = [&]() {
+        Q::fence(); Q::quad_sync();
 #pragma nounroll
         for (int cs0 = 0; cs0 < 4; cs0++) {
-          const int cs = (cs0 + c) & 3;                  // own queue first
-          const int nres = (nres_of[cs] < kQRes_n) ? nres_of[cs] : kQRes_n, dls = cs - c;
-          int k = 0;
+          const int cs = (cs0 + c) & 3;                  // own results first
+          const int nres = (nres_of[cs] < kRcap) ? nres_of[cs] : kRcap, dls = cs - c;
 #pragma nounroll
-          for (int t = 0; t < n_of[cs] && k < nres; t++) {
-            const float raw = PEER(dls, kQItem + t);
-            if (!(raw < 0.0f)) continue;
-            const int item = (int)(-raw - 1.0f);
-            const int kk = k++;
+          for (int k = 0; k < nres; k++) {
+            const int item = (int)PEER(dls, kRes + 8 * k);
             EntryCtx E;
             entry_ctx_of(cs, item >> 16, E);
             if (cs != c) {
@@ -1860,161 +1871,263 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             }
             entry_frames(E);
             const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
-            const float dist = PEER(dls, kQRes + 7 * kk);
-            const V3 nrm = v3(PEER(dls, kQRes + 7 * kk + 1), PEER(dls, kQRes + 7 * kk + 2), PEER(dls, kQRes + 7 * kk + 3));
-            const V3 cp = v3(PEER(dls, kQRes + 7 * kk + 4), PEER(dls, kQRes + 7 * kk + 5), PEER(dls, kQRes + 7 * kk + 6));
+            const float dist = PEER(dls, kRes + 8 * k + 1);
+            const V3 nrm = v3(PEER(dls, kRes + 8 * k + 2), PEER(dls, kRes + 8 * k + 3), PEER(dls, kRes + 8 * k + 4));
+            const V3 cp = v3(PEER(dls, kRes + 8 * k + 5), PEER(dls, kRes + 8 * k + 6), PEER(dls, kRes + 8 * k + 7));
 #ifdef LM_PAIR_TRACE
-            if (Q::rep() == 0) printf("   contact lane %d (queue of lane %d) entry %d rec %d kind 2 dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, cs, item >> 16, item & 65535, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
+            if (Q::rep() == 0) printf("   contact lane %d (list of lane %d) entry %d rec %d kind %d dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, cs, item >> 16, item & 65535, (int)rec[LM_GP_KIND], dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
 #endif
             emit_pair_slot(E, rec, ((int)rec[LM_GP_G1Q] == E.own_q), nrm, cp, dist);
           }
         }
-        nq = 0;
         Q::fence(); Q::quad_sync();
       };
-      for (int i = 0; i < nlp; i++) {
-        EntryCtx E;
-        entry_ctx(i, E);
-        const int ka = E.ka, kb = E.kb, lb = E.lb, own_q = E.own_q, dl = E.dl;
-        const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
-        const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
-        const V3 dc = cb - ca;
-        const float d2c = dot(dc, dc), thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
-        // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
-        if (!(d2c < thr2)) { gap_min = fminf(gap_min, sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD); continue; }
-        // ---- mid phase over the body pairs of this link pair, narrow phase over the geom pairs of those in reach
-        const int rng = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 1], bfirst = rng & 65535, nbp = rng >> 16;
-        entry_frames(E);
-        const V3 po = E.po, pp = E.pp; const M3& Ro = E.Ro; const M3& Rp = E.Rp;
-        // geometry of geom pair j: closest points of the two capsule segments (same arithmetic in both lanes of a cross pair)
-        struct PairGeom { V3 c1, c2, q1, dq; float r1, r2, dd, dist; bool g1own; };
-        auto pair_geom = [&](const float* rec) -> PairGeom {
-          PairGeom G;
-          G.g1own = ((int)rec[LM_GP_G1Q] == own_q);        // geom 1 sits on my link
-          const V3 p1 = G.g1own ? po : pp, p2 = G.g1own ? pp : po;
-          const M3& R1 = G.g1own ? Ro : Rp; const M3& R2 = G.g1own ? Rp : Ro;
-          G.c1 = p1 + mul(R1, v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2]));
-          const V3 a1 = mul(R1, v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
-          G.c2 = p2 + mul(R2, v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2]));
-          const V3 a2 = mul(R2, v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
-          G.r1 = rec[LM_GP_R1]; G.r2 = rec[LM_GP_R2];
-          float sa, ta;
-          segment_closest(G.c1, a1, rec[LM_GP_H1], G.c2, a2, rec[LM_GP_H2], sa, ta);
-          G.q1 = G.c1 + sa * a1;
-          G.dq = G.c2 + ta * a2 - G.q1;
-          G.dd = sqrtf(dot(G.dq, G.dq)); G.dist = G.dd - G.r1 - G.r2;
-          return G;
-        };
-        // ---- body pairs (dealt to the replicas): one bounding capsule per body; only body pairs within the largest margin of their
-        // geom pairs go on. The others hold the next detection back by their clearance.
-        float bhit = 0.0f;
-        for (int jb = Q::rep(); jb < nbp; jb += Q::kRep) {
-          const float* br = P.bpt + (bfirst + jb) * LM_BP_SIZE;
-          const float* bo = br + (own_q ? LM_BP_P2 : LM_BP_P1); const float* bq = br + (own_q ? LM_BP_P1 : LM_BP_P2);
-          const V3 co = po + mul(Ro, v3(bo[0], bo[1], bo[2])), ao = mul(Ro, v3(bo[3], bo[4], bo[5]));
-          const V3 cq = pp + mul(Rp, v3(bq[0], bq[1], bq[2])), aq = mul(Rp, v3(bq[3], bq[4], bq[5]));
-          float sa, ta;
-          segment_closest(co, ao, bo[6], cq, aq, bq[6], sa, ta);
-          const V3 dq = cq + ta * aq - (co + sa * ao);
-          const float bgap = sqrtf(dot(dq, dq)) - bo[7] - bq[7] - br[LM_BP_MARGIN];
-          if (bgap < 0.0f) bhit += (float)(1 << jb);
-          else gap_min = fminf(gap_min, bgap);
-        }
-        if (Q::kRep > 1) bhit = Q::rep_sum(bhit);
-        for (int bm = (int)bhit, jb = 0; bm != 0; bm >>= 1, jb++) {
-          if (!(bm & 1)) continue;
-          const float* brec = P.bpt + (bfirst + jb) * LM_BP_SIZE;
-          const int first = (int)brec[LM_BP_FIRST], npairs = (int)brec[LM_BP_N];
-          // ---- phase 1, dealt to the replicas (the records come from global memory: latency-bound): which geom pairs are within
-          // their margin? Bit j of `hit`. Only pairs WITH a collider hold the next detection back (gap_min): the bounding capsules
-          // of the counted-only pairs (trunk box against the thighs ...) sit millimetres apart in every gait; those are
-          // looked at in the first pass of a control step only.
-          float hit = 0.0f;
-          for (int j = Q::rep(); j < npairs; j += Q::kRep) {
-            const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
-            const bool counted_only = rec[LM_GP_KIND] == 1.0f;
-            if (counted_only && !first_detect && MC <= 3) continue;       // (the quadruped's 76 counted-only pairs: first pass of a control step only)
-            const PairGeom G = pair_geom(rec);
-            const float pmargin = rec[LM_GP_MARGIN];
-#ifdef LM_PAIR_TRACE
-            if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %g dist %.7f\n", c, i, first + j, rec[LM_GP_KIND], G.dist);
-#endif
-            if (!counted_only || MC > 3) gap_min = fminf(gap_min, G.dist - pmargin);      // (the humanoids' one counted pair — foot on foot — is watched like the others)
-            if (G.dist < pmargin) hit += (float)(1 << j);
+      // geometry of a geom pair: closest points of the two capsule segments
+      struct PairGeom { V3 c1, c2, q1, dq; float r1, r2, dd, dist; bool g1own; };
+      auto pair_geom = [&](const EntryCtx& E, const float* rec) -> PairGeom {
+        PairGeom G;
+        G.g1own = ((int)rec[LM_GP_G1Q] == E.own_q);        // geom 1 sits on the entry's own link
+        const V3 p1 = G.g1own ? E.po : E.pp, p2 = G.g1own ? E.pp : E.po;
+        const M3& R1 = G.g1own ? E.Ro : E.Rp; const M3& R2 = G.g1own ? E.Rp : E.Ro;
+        G.c1 = p1 + mul(R1, v3(rec[LM_GP_P1], rec[LM_GP_P1 + 1], rec[LM_GP_P1 + 2]));
+        const V3 a1 = mul(R1, v3(rec[LM_GP_A1], rec[LM_GP_A1 + 1], rec[LM_GP_A1 + 2]));
+        G.c2 = p2 + mul(R2, v3(rec[LM_GP_P2], rec[LM_GP_P2 + 1], rec[LM_GP_P2 + 2]));
+        const V3 a2 = mul(R2, v3(rec[LM_GP_A2], rec[LM_GP_A2 + 1], rec[LM_GP_A2 + 2]));
+        G.r1 = rec[LM_GP_R1]; G.r2 = rec[LM_GP_R2];
+        float sa, ta;
+        segment_closest(G.c1, a1, rec[LM_GP_H1], G.c2, a2, rec[LM_GP_H2], sa, ta);
+        G.q1 = G.c1 + sa * a1;
+        G.dq = G.c2 + ta * a2 - G.q1;
+        G.dd = sqrtf(dot(G.dq, G.dq)); G.dist = G.dd - G.r1 - G.r2;
+        return G;
+      };
+      int next = 0, n_prox = 0;
+#pragma nounroll
+      for (;;) {
+        // ---- 1. link pairs of my chain: the next chunk of entries in reach (every replica builds the same list)
+        int nw = 0, nunits = 0;
+#pragma nounroll
+        while (next < nlp && nw < kWcap) {
+          const int i = next;
+          EntryCtx E;
+          entry_ctx(i, E);
+          if (E.own_q) { next++; continue; }                 // cross-chain pair seen from its second link: the first link's lane lists it
+          const int nbp = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 1] >> 16;
+          if (nunits + nbp > kScap) break;                   // its body pairs would not fit S: next chunk (an entry alone always fits)
+          next++;
+          const int ka = E.ka, kb = E.kb, dl = E.dl;
+          const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
+          const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
+          const V3 dc = cb - ca;
+          const float d2c = dot(dc, dc), thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
+          // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
+          if (!(d2c < thr2)) {
+            const float gp_ = sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD;
+            gap_note(c, gp_);
+            if (kb != 7 && !E.same_lane) gap_note(E.lb, gp_);
+            continue;
           }
-          if (Q::kRep > 1) hit = Q::rep_sum(hit);                  // disjoint bits: the sum is the union (npairs <= 24: exact)
-          // ---- phase 2, every replica: closed-form contacts are recorded, convex pairs queued (rare)
-          for (int hm = (int)hit, j = 0; hm != 0; hm >>= 1, j++) {
-            if (!(hm & 1)) continue;
-            const float* rec = gptp + (first + j) * LM_GPAIR_SIZE;
-            const PairGeom G = pair_geom(rec);
-            const int kind = (int)rec[LM_GP_KIND];
-            // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
-            // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
-            {
-              const V3 cc = G.c2 - G.c1;
-              const float rb1 = (rec[LM_GP_X1 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X1 + LM_GX_RBOUND] : rec[LM_GP_H1] + G.r1;
-              const float rb2 = (rec[LM_GP_X2 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
-              if (sqrtf(dot(cc, cc)) - rb1 - rb2 > 0.0f) continue;
-            }
-            if (kind == 1) {                                          // no collider for this pair of geom types: counted (once)
-              bool reach = true;
-              if ((int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_BOX && (int)rec[LM_GP_X2 + LM_GX_TYPE] == LM_GEOM_BOX) {
-                // two boxes (the humanoid's feet): the largest gap over the 15 candidate separating axes, like the oracle's count
-                const M3& R1 = G.g1own ? Ro : Rp; const M3& R2 = G.g1own ? Rp : Ro;
-                V3 ax[6]; float hs[6];
-#pragma unroll
-                for (int w = 0; w < 2; w++) {
-                  const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
-                  const M3& Rw_ = w ? R2 : R1;
-                  const V3 ex = mul(Rw_, v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5])), ey = mul(Rw_, v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]));
-                  ax[3 * w] = ex; ax[3 * w + 1] = ey; ax[3 * w + 2] = cross(ex, ey);
-                  hs[3 * w] = x[LM_GX_E0]; hs[3 * w + 1] = x[LM_GX_E0 + 1]; hs[3 * w + 2] = x[LM_GX_E0 + 2];
-                }
-                const V3 dcen = G.c2 - G.c1;
-                float gap = -3.0e38f;
-                auto test_axis = [&](V3 n) {
-                  float r1 = 0.0f, r2 = 0.0f;
-#pragma unroll
-                  for (int k = 0; k < 3; k++) { r1 += hs[k] * fabsf(dot(n, ax[k])); r2 += hs[3 + k] * fabsf(dot(n, ax[3 + k])); }
-                  gap = fmaxf(gap, fabsf(dot(dcen, n)) - r1 - r2);
-                };
-#pragma unroll
-                for (int k = 0; k < 6; k++) test_axis(ax[k]);
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                  for (int l = 0; l < 3; l++) {
-                    const V3 cr = cross(ax[k], ax[3 + l]);
-                    const float n2 = dot(cr, cr);
-                    if (n2 > 1e-18f) test_axis((1.0f / sqrtf(n2)) * cr);
-                  }
-                reach = gap < rec[LM_GP_MARGIN];
+          LMEM(kW1 + nw) = (float)(i + 64 * nbp);
+          nw++; nunits += nbp;
+        }
+        if (!(Q::sum((nw > 0) ? 1.0f : 0.0f) > 0.0f)) break;          // no chain of the environment has entries in reach left (quad-uniform)
+        int nw_of[4], nu_of[4];
+        share4(nw, nw_of); share4(nunits, nu_of);
+#ifdef LM_PAIR_TRACE
+        if (me == 0) printf("  chunk: entries %d %d %d %d body pairs %d %d %d %d (next %d of %d)\n", nw_of[0], nw_of[1], nw_of[2], nw_of[3], nu_of[0], nu_of[1], nu_of[2], nu_of[3], next, nlp);
+#endif
+        Q::fence(); Q::quad_sync();
+        // ---- 2. body pairs: one bounding capsule per body; those within the largest margin of their geom pairs go on, the others
+        // hold the next detection back by their clearance
+        int ns_of[4] = {0, 0, 0, 0};
+        set_bases(nu_of);
+        {
+          const int T = base[4], nrounds = (T + kW - 1) / kW;
+#pragma nounroll
+          for (int round = 0; round < nrounds; round++) {
+            const int g = round * kW + me;
+            bool hitb = false;
+            int cs = 0;
+            float s0 = 0.0f, s1 = 0.0f;
+            if (g < T) {
+              cs = chain_of(g);
+              int u = g - base[cs], i = 0, jb = 0;
+#pragma nounroll
+              for (int t = 0; t < nw_of[cs]; t++) {
+                const int w = (int)PEER(cs - c, kW1 + t), nb = w >> 6;
+                if (u < nb) { i = w & 63; jb = u; break; }
+                u -= nb;
               }
-              if (reach && (G.g1own || kb == 7 || lb == c) && Q::rep() == 0) cnt.selfprox++;
-              continue;
+              EntryCtx E;
+              entry_ctx_of(cs, i, E);
+              entry_frames(E);
+              const int bfirst = (int)cm[oz + off_lpair_of(cs) + i * LM_LP_SIZE + 1] & 65535;
+              const float* br = P.bpt + (bfirst + jb) * LM_BP_SIZE;
+              const float* bo = br + (E.own_q ? LM_BP_P2 : LM_BP_P1); const float* bq = br + (E.own_q ? LM_BP_P1 : LM_BP_P2);
+              const V3 co = E.po + mul(E.Ro, v3(bo[0], bo[1], bo[2])), ao = mul(E.Ro, v3(bo[3], bo[4], bo[5]));
+              const V3 cq = E.pp + mul(E.Rp, v3(bq[0], bq[1], bq[2])), aq = mul(E.Rp, v3(bq[3], bq[4], bq[5]));
+              float sa, ta;
+              segment_closest(co, ao, bo[6], cq, aq, bq[6], sa, ta);
+              const V3 dq = cq + ta * aq - (co + sa * ao);
+              const float bgap = sqrtf(dot(dq, dq)) - bo[7] - bq[7] - br[LM_BP_MARGIN];
+              if (bgap < 0.0f) { hitb = true; s0 = (float)(i * 32 + jb + 4096 * (int)br[LM_BP_N]); s1 = br[LM_BP_FIRST]; }
+              else { gap_note(cs, bgap); if (E.kb != 7 && !E.same_lane) gap_note(E.lb, bgap); }
             }
-            if (kind == 2) {
-              if (own_q) continue;                                     // cross-chain pair seen from its second link: the first link's lane queues it
-              if (nq >= kQueue) { n_over++; continue; }                // more convex pairs of this lane in reach than the queue holds: dropped, counted
-              LMEM(kQItem + nq) = (float)(i * 65536 + first + j);
-              nq++;
-              continue;
+            const unsigned sm = Q::env_ballot(hitb);
+            if (hitb) {
+              const int k = ns_of[cs] + __builtin_popcount(sm & chain_bits(cs, round) & ((1u << me) - 1u));
+              Q::peer_write(lmem, ls, kS1 + 2 * k, cs - c, s0); Q::peer_write(lmem, ls, kS1 + 2 * k + 1, cs - c, s1);
             }
-            const float dist = G.dist;
-            const V3 nrm = (G.dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / G.dd) * G.dq;
-            const V3 cp = G.q1 + (G.r1 + 0.5f * dist) * nrm - O;
-#ifdef LM_PAIR_TRACE
-            if (Q::rep() == 0) printf("   contact lane %d entry %d rec %d kind %d dist %.8f nrm %.6f %.6f %.6f pos %.6f %.6f %.6f\n", c, i, first + j, kind, dist, nrm.x, nrm.y, nrm.z, cp.x + O.x, cp.y + O.y, cp.z + O.z);
-#endif
-            emit_pair_slot(E, rec, G.g1own, nrm, cp, dist);
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) ns_of[c2] += __builtin_popcount(sm & chain_bits(c2, round));
           }
         }
+        Q::fence(); Q::quad_sync();
+        // ---- 3. geom pairs of the body pairs in reach
+        int nv = 0, nv_of[4];
+#pragma nounroll
+        for (int t = 0; t < ns_of[c]; t++) nv += (int)LMEM(kS1 + 2 * t) >> 12;
+        share4(nv, nv_of);
+#ifdef LM_PAIR_TRACE
+        if (me == 0) printf("  body pairs in reach %d %d %d %d geom pairs %d %d %d %d\n", ns_of[0], ns_of[1], ns_of[2], ns_of[3], nv_of[0], nv_of[1], nv_of[2], nv_of[3]);
+#endif
+        set_bases(nv_of);
+        {
+          const int T = base[4], nrounds = (T + kW - 1) / kW;
+#pragma nounroll
+          for (int round = 0; round < nrounds; round++) {
+            const int g = round * kW + me;
+            bool has_res = false, want_q = false, is_prox = false;
+            int cs = 0;
+            float code = 0.0f, rdist = 0.0f;
+            V3 rn = v3(0, 0, 0), rp = v3(0, 0, 0);
+            if (g < T) {
+              cs = chain_of(g);
+              int v = g - base[cs], i = 0, first = 0;
+#pragma nounroll
+              for (int t = 0; t < ns_of[cs]; t++) {
+                const int w = (int)PEER(cs - c, kS1 + 2 * t), np_ = w >> 12;
+                if (v < np_) { i = (w & 4095) >> 5; first = (int)PEER(cs - c, kS1 + 2 * t + 1); break; }
+                v -= np_;
+              }
+              const float* rec = gptp + (first + v) * LM_GPAIR_SIZE;
+              const int kind = (int)rec[LM_GP_KIND];
+              // the quadruped's counted-only pairs (trunk box against the thighs ...: their bounding capsules sit millimetres apart in
+              // every gait) are looked at in the first pass of a control step only, and do not hold the next detection back
+              const bool counted_only = kind == 1;
+              if (!(counted_only && !first_detect && MC <= 3)) {
+                EntryCtx E;
+                entry_ctx_of(cs, i, E);
+                entry_frames(E);
+                const PairGeom G = pair_geom(E, rec);
+                const float pmargin = rec[LM_GP_MARGIN];
+                const bool is_cross = E.kb != 7 && !E.same_lane;
+#ifdef LM_PAIR_TRACE
+                if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %d dist %.7f\n", cs, i, first + v, kind, G.dist);
+#endif
+#ifdef LM_TIMERS
+                cnt.m[10 + kind]++; if (G.dist < pmargin) cnt.m[13 + kind]++;
+#endif
+                if (!counted_only || MC > 3) { gap_note(cs, G.dist - pmargin); if (is_cross) gap_note(E.lb, G.dist - pmargin); }       // (the humanoids' one counted pair — foot on foot — is watched like the others)
+                bool in_reach = G.dist < pmargin;
+                if (in_reach) {
+                  // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
+                  // rollouts, restated the same way for geom pairs by the oracle): two foot spheres 0 < dist < margin apart make no contact
+                  const V3 cc = G.c2 - G.c1;
+                  const float rb1 = (rec[LM_GP_X1 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X1 + LM_GX_RBOUND] : rec[LM_GP_H1] + G.r1;
+                  const float rb2 = (rec[LM_GP_X2 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
+                  if (sqrtf(dot(cc, cc)) - rb1 - rb2 > 0.0f) in_reach = false;
+                }
+                if (in_reach && kind == 1) {                           // no collider for this pair of geom types: counted
+                  bool reach = true;
+                  if ((int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_BOX && (int)rec[LM_GP_X2 + LM_GX_TYPE] == LM_GEOM_BOX) {
+                    // two boxes (the humanoid's feet): the largest gap over the 15 candidate separating axes, like the oracle's count
+                    const M3& R1 = G.g1own ? E.Ro : E.Rp; const M3& R2 = G.g1own ? E.Rp : E.Ro;
+                    V3 ax[6]; float hs[6];
+#pragma unroll
+                    for (int w = 0; w < 2; w++) {
+                      const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
+                      const M3& Rw_ = w ? R2 : R1;
+                      const V3 ex = mul(Rw_, v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5])), ey = mul(Rw_, v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]));
+                      ax[3 * w] = ex; ax[3 * w + 1] = ey; ax[3 * w + 2] = cross(ex, ey);
+                      hs[3 * w] = x[LM_GX_E0]; hs[3 * w + 1] = x[LM_GX_E0 + 1]; hs[3 * w + 2] = x[LM_GX_E0 + 2];
+                    }
+                    const V3 dcen = G.c2 - G.c1;
+                    float gap = -3.0e38f;
+                    auto test_axis = [&](V3 n) {
+                      float r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+                      for (int k = 0; k < 3; k++) { r1 += hs[k] * fabsf(dot(n, ax[k])); r2 += hs[3 + k] * fabsf(dot(n, ax[3 + k])); }
+                      gap = fmaxf(gap, fabsf(dot(dcen, n)) - r1 - r2);
+                    };
+#pragma unroll
+                    for (int k = 0; k < 6; k++) test_axis(ax[k]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                      for (int l = 0; l < 3; l++) {
+                        const V3 cr = cross(ax[k], ax[3 + l]);
+                        const float n2 = dot(cr, cr);
+                        if (n2 > 1e-18f) test_axis((1.0f / sqrtf(n2)) * cr);
+                      }
+                    reach = gap < rec[LM_GP_MARGIN];
+                  }
+                  is_prox = reach;
+                } else if (in_reach && kind == 2) {
+                  want_q = true; code = (float)(i * 65536 + first + v);
+                } else if (in_reach) {
+                  has_res = true; code = (float)(i * 65536 + first + v);
+                  rdist = G.dist;
+                  rn = (G.dd < 1e-15f) ? v3(1, 0, 0) : (1.0f / G.dd) * G.dq;
+                  rp = G.q1 + (G.r1 + 0.5f * rdist) * rn - O;
+                }
+              }
+            }
+            const unsigned rm = Q::env_ballot(has_res), qm = Q::env_ballot(want_q), pm = Q::env_ballot(is_prox);
+            const unsigned below = chain_bits(cs, round) & ((1u << me) - 1u);
+            if (has_res) {
+              const int k = nres_of[cs] + __builtin_popcount(rm & below);
+              if (k < kRcap) {
+                const int rb_ = kRes + 8 * k, dlw = cs - c;
+                Q::peer_write(lmem, ls, rb_, dlw, code); Q::peer_write(lmem, ls, rb_ + 1, dlw, rdist);
+                Q::peer_write(lmem, ls, rb_ + 2, dlw, rn.x); Q::peer_write(lmem, ls, rb_ + 3, dlw, rn.y); Q::peer_write(lmem, ls, rb_ + 4, dlw, rn.z);
+                Q::peer_write(lmem, ls, rb_ + 5, dlw, rp.x); Q::peer_write(lmem, ls, rb_ + 6, dlw, rp.y); Q::peer_write(lmem, ls, rb_ + 7, dlw, rp.z);
+              }
+            }
+            if (want_q) {
+              const int k = nq_of[cs] + __builtin_popcount(qm & below);
+              if (k < kQueue) Q::peer_write(lmem, ls, kQItem + k, cs - c, code);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) { const unsigned cb_ = chain_bits(c2, round); nres_of[c2] += __builtin_popcount(rm & cb_); nq_of[c2] += __builtin_popcount(qm & cb_); }
+            n_prox += __builtin_popcount(pm);
+          }
+        }
+        Q::fence(); Q::quad_sync();
       }
+      if (c == 0 && Q::rep() == 0) cnt.selfprox += n_prox;
+#ifdef LM_PAIR_TRACE
+      if (me == 0) printf("  queued %d %d %d %d results %d %d %d %d gaps %.5f %.5f %.5f %.5f\n", nq_of[0], nq_of[1], nq_of[2], nq_of[3], nres_of[0], nres_of[1], nres_of[2], nres_of[3], gap_of[0], gap_of[1], gap_of[2], gap_of[3]);
+#endif
       LM_TICK(14);              // self-collisions: broad / mid / narrow-phase tests
       flush_queue();            // every lane of the wave arrives here together: the queued pairs of all of them run side by side
       LM_TICK(15);              // self-collisions: convex pairs (MPR)
-      if (Q::kRep > 1) gap_min = fminf(fminf(Q::rep_bcast(gap_min, 0), Q::rep_bcast(gap_min, 1)), fminf(Q::rep_bcast(gap_min, 2), Q::rep_bcast(gap_min, 3)));
+      emit_results();
+      // contacts beyond what the queue / the result list of my chain hold: dropped, counted
+      if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
+      if (nres_of[c] > kRcap) n_over += nres_of[c] - kRcap;
+      // the smallest clearance of any pair of my chain, whichever lane of the environment looked at it
+      {
+        float gmine = 3.0e38f;
+#pragma unroll
+        for (int cs = 0; cs < 4; cs++) {
+          float gq = gap_of[cs];
+          gq = fminf(fminf(Q::quad_read(gq, 0), Q::quad_read(gq, 1)), fminf(Q::quad_read(gq, 2), Q::quad_read(gq, 3)));
+          if (Q::kRep > 1) gq = fminf(fminf(Q::rep_bcast(gq, 0), Q::rep_bcast(gq, 1)), fminf(Q::rep_bcast(gq, 2), Q::rep_bcast(gq, 3)));
+          if (cs == c) gmine = gq;
+        }
+        gap_min = gmine;
+      }
       if (Q::rep() == 0) cnt.overflow += n_over;
       if (pair_slack) *pair_slack = gap_min;
       Q::fence();

@@ -793,12 +793,12 @@ int lm_debug_wg_regions(lm_batch* b, unsigned long long* out, int nblocks) {
   return 0;
 }
 
-/* profiling builds: counters of the convex collider since the last call (8 values, summed over all lanes) */
-int lm_debug_mpr_counters(lm_batch* b, unsigned long long* out8) {
+/* profiling builds: counters of the pair pass and the convex collider since the last call (16 values, summed over all lanes) */
+int lm_debug_mpr_counters(lm_batch* b, unsigned long long* out8 /* 16 values */) {
   HIPCHK(hipSetDevice(b->m->device));
   HIPCHK(hipStreamSynchronize(b->stream));
-  HIPCHK(hipMemcpy(out8, b->timers + 16 + 32 * (size_t)b->nblocks, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(b->timers + 16 + 32 * (size_t)b->nblocks, 0, sizeof(unsigned long long) * 8));
+  HIPCHK(hipMemcpy(out8, b->timers + 16 + 32 * (size_t)b->nblocks, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->timers + 16 + 32 * (size_t)b->nblocks, 0, sizeof(unsigned long long) * 16));
   return 0;
 }
 

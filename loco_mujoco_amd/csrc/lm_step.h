@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     }
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
-    for (int i = 0; i < 8; i++) if (cnt.m[i]) atomicAdd(&a.timers[16 + 32 * (long long)gridDim.x + i], (unsigned long long)cnt.m[i]);        // every lane
+    for (int i = 0; i < 16; i++) if (cnt.m[i]) atomicAdd(&a.timers[16 + 32 * (long long)gridDim.x + i], (unsigned long long)cnt.m[i]);        // every lane
     {
       unsigned long long* rec = a.timers + 16 + 16 * (long long)wg;       // wg: the workgroup after the XCD mapping (environments 4 wg .. 4 wg + 3)
       const float ncon_env = QuadDpp::sum((float)cnt.ncon);

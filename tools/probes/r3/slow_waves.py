@@ -46,7 +46,7 @@ for s in slow[:8]:
     print("  %.0f cycles  iters %s  contacts(sum over passes) %s  ls %s | %s" % (s[0], s[2].astype(int), s[3].astype(int), s[4].astype(int),
           " ".join("%s %.0f%%" % (n, 100 * v / s[0]) for n, v in zip(names, s[1]) if v / s[0] > 0.04)))
 if hasattr(lib, "lm_debug_mpr_counters"):
-    m8 = (ctypes.c_ulonglong * 8)()
+    m8 = (ctypes.c_ulonglong * 16)()
     lib.lm_debug_mpr_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lm_debug_mpr_counters(b._h, m8)
     st = b.rollout(10, action_mode=mode, seed=777)
@@ -57,3 +57,5 @@ if hasattr(lib, "lm_debug_mpr_counters"):
           "no contact %.1f%%, contact %.1f%%; support pairs per call %.2f, hill steps per support %.2f, refinement iterations per contact %.2f; "
           "rounds per wave and pass %.2f" % (m[0], m[0] / passes, 100 * m[1] / max(m[0], 1), 100 * m[2] / max(m[0], 1), 100 * m[3] / max(m[0], 1),
                                           m[4] / max(m[0], 1), m[5] / max(2 * m[4], 1), m[6] / max(m[3], 1), m[7] / 64 / (passes / 4)))
+    print("pair pass: detection ran in %.1f%% of the forward passes; geom pairs tested per detection (kind 0 / 1 / 2, all lanes and replicas): %.1f / %.1f / %.1f, "
+          "of which within the margin: %.2f / %.2f / %.2f" % (100 * m[8] / max(m[9], 1), *(m[10:13] / max(m[8], 1)), *(m[13:16] / max(m[8], 1))))
