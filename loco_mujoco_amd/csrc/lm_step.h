@@ -22,7 +22,17 @@
 #include <vector>
 
 #define LM_DEV __device__ __forceinline__
-#define LM_DEV_COLD __device__ __attribute__((noinline))     // rare helpers with a large register appetite (the convex-pair collider)
+// The convex-pair collider is INLINED into the step kernel. As a real function (noinline) it kept its float64 registers and its private
+// portal array out of the quadruped's kernel (-1.5 % on the bench rollout, which never calls it), but kernels that contain the CALL
+// and sit at the register ceiling came out wrong under one build setting or another — every environment off by O(1): <5,8,RK4,PAIRS>
+// at -Os with the default scheduler, the fused <5,8,Euler,muscles,PAIRS> with the max-ILP scheduler, <5,8,Euler,muscles,PAIRS> at
+// -O2 without the machine scheduler; the same builds WITHOUT the call (-DLM_NO_MPR) are right, and so is the same source with a
+// printf next to the call (profiles/r3_notes.md §4, tools/probes/r3/sched_repro.sh reproduces it with -DLM_MPR_CALL).
+#ifdef LM_MPR_CALL
+#define LM_DEV_COLD __device__ __attribute__((noinline))
+#else
+#define LM_DEV_COLD __device__ __forceinline__
+#endif
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
 __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 #define LM_OPAQUE_ZERO() lm_opaque_zero()

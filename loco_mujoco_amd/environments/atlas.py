@@ -38,8 +38,9 @@ class Atlas(BaseRobotHumanoid):
     def __init__(self, disable_arms=True, disable_back_joint=True, hold_weight=False, weight_mass=None,
                  xml_path=None, timestep=0.001, **kwargs):
         if not disable_arms:
-            raise NotImplementedError("Atlas with free arms is not built (SURVEY.md §8f rank 3): the arms would hang off "
-                                      "the end of the back chain (branching below the root)")
+            raise NotImplementedError("Atlas with free arms is not built: an Atlas arm has 7 joints (shz, shx, ely, elx, wry, wrx, wry2), the "
+                                      "step kernels are compiled for chains of at most 6 links; with the back joints the arms would also "
+                                      "branch behind a 3-dof chain (UnitreeH1 / UnitreeG1, one torso joint and shorter arms, run with free arms)")
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, hold_weight
         self._weight_mass = weight_mass
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()

@@ -35,10 +35,12 @@ class UnitreeH1(BaseRobotHumanoid):
 
     def __init__(self, disable_arms=True, disable_back_joint=False, hold_weight=False, weight_mass=None,
                  xml_path=None, timestep=0.001, **kwargs):
-        if not disable_arms:
-            raise NotImplementedError("UnitreeH1 with free arms is not built: the arms would branch off the back chain")
         if hold_weight:
             assert disable_arms is True, "If you want Unitree H1 to carry a weight, please disable the arms. They will be kept fixed."
+        if not disable_arms:
+            # the reference takes the file as it is when the arms are free and no weight is held — `disable_back_joint` has no
+            # effect then (unitreeH1.py:265-296: the modifications sit inside `if disable_arms or hold_weight`). Same here.
+            disable_back_joint = False
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, hold_weight
         self._weight_mass = weight_mass
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
@@ -46,11 +48,11 @@ class UnitreeH1(BaseRobotHumanoid):
         observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
         action_spec = [a for a in self._get_action_specification() if a not in motors_to_remove]
         weights = self._weight_list(hold_weight, weight_mass, kwargs.get("n_envs", 1))
-        variant = "noback" if disable_back_joint else "default"
+        variant = "arms" if not disable_arms else ("noback" if disable_back_joint else "default")
         models = []
         for w in weights:
             if xml_path is not None:
-                models.append(self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, joints_to_remove, motors_to_remove, w))
+                models.append(self._compile(mjcf.MjcfHandle.from_path(xml_path), timestep, joints_to_remove, motors_to_remove, w, reorient=disable_arms))
                 continue
             name = "UnitreeH1.%s.model.npz" % variant if w is None else "UnitreeH1.carry.%s.w%g.model.npz" % (variant, w)
             if not (_PKG / "assets" / name).exists():
@@ -62,11 +64,11 @@ class UnitreeH1(BaseRobotHumanoid):
         self._init_weight_models(models, weights)
 
     @classmethod
-    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, weight=None):
+    def _compile(cls, handle, timestep, joints_to_remove, motors_to_remove, weight=None, reorient=True):
         Atlas._delete_from_xml_handle(handle, joints_to_remove, motors_to_remove, [])
         if weight is not None:
             cls._add_weight(handle, weight)
-        else:
+        elif reorient:
             cls._reorient_arms(handle)
         return mjcf.compile_mjcf(handle, timestep=timestep, drop_mesh_geoms=True)       # meshes kept with their convex hulls
 

@@ -625,6 +625,10 @@ def lower(m, task):
 
     if (dof_to_lane == -1).any():
         raise UnsupportedModel("some dofs are outside the root+chains structure")
+    if shared_first:
+        # a first link shared by two chains (tie_shared_dof) is compiled in the six-link kernels only: a robot with shorter chains
+        # (UnitreeH1 with its torso joint and free arms: 1 + 4 links) runs there with an idle link slot per chain
+        max_links = MAXC
 
     # ---- muscles: every tendon must run over the root body and ONE chain, so that lane c owns it
     mt = None

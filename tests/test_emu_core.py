@@ -588,3 +588,32 @@ def test_core_shared_first_link_with_per_environment_joint_parameters():
         qo, vo = Oracle(pack_model(m2)).step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)[:2]
         qn, vn = Oracle(pack_model(m)).step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)[:2]
         assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3 and np.abs(vo - vn).max() > 0.1
+
+
+def test_core_unitree_h1_free_arms_shared_torso_link():
+    """UnitreeH1 with `disable_arms=False` (reference unitreeH1.py:235-296: the file as it is — torso joint + two
+    4-dof arms): the arm chains share the torso link like UnitreeG1's, the five-link chains run in the six-link kernels with an idle
+    link slot. One control step of three reset-table states with random actions against the oracle (self-collisions masked on both
+    sides: this family has no pair tables, the device counts proximity)."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeH1.walk", debug=True, disable_arms=False)
+    m = env._model
+    assert m.nv == 25 and m.nu == 19 and env.info.action_space.shape == (19,)
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["shared_first"] == {3: 2} and info["max_links"] == 6 and info["n_chains"] == 4
+    tab = env._reset_table()
+    rs = np.random.RandomState(3)
+    rows = tab[rs.randint(0, len(tab), 3)]
+    acts = rs.uniform(-0.3, 0.3, (3, 19))
+    q, v, _, cnt, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], acts, nsub=10, rep=4)
+    o = Oracle(pack_model(m))
+    compared = 0
+    for i in range(3):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo, _, st = o.step(rows[i, :m.nv], rows[i, m.nv:2 * m.nv], ctrl, 10)
+        if st["convex_contacts"] or st["unhandled_pairs"]:
+            continue
+        compared += 1
+        assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3, (i, np.abs(q[i] - qo).max(), np.abs(v[i] - vo).max())
+    assert compared >= 2

@@ -150,14 +150,22 @@ def test_random_states_one_step_vs_oracle(setup):
         qo, vo, _, _ = oracle.step(q0, v0, acts[k].astype(np.float32), 10)
         for e in (1e-7, 1e-7, 1e-6, 1e-6, 1e-6, 1e-6):
             qp, vp, _, _ = oracle.step(q0 + e * prs.uniform(-1, 1, 18), v0 + e * prs.uniform(-1, 1, 18), acts[k].astype(np.float32), 10)
-            if np.abs(qp - qo).max() > QTOL or np.abs(vp - vo).max() > VTOL or flags[k]:
+            sq, sv = np.abs(qp - qo).max(), np.abs(vp - vo).max()
+            # the conditioning rule of test_4096_...: the oracle's own response to float32-sized input noise exceeds the tolerance, or
+            # explains at least half of the device's error in every quantity that is over the tolerance
+            if sq > QTOL or sv > VTOL or flags[k] or ((eq[k] <= QTOL or sq >= 0.5 * eq[k]) and (ev[k] <= VTOL or sv >= 0.5 * ev[k])):
                 keep[k] = False
     print("random states: qpos Linf max %.2e p99 %.2e median %.2e | qvel Linf max %.2e p99 %.2e median %.2e | %d knife-edge / dropped-contact states left out of the max: max %.2e / %.2e"
           % (eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev), (~keep).sum(), eq[keep].max(), ev[keep].max()))
     assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
     # (these start states are NOT reachable: trajectory states with every joint moved by up to 0.03 rad and the trunk pushed up to
     # 3 cm into the floor — the stiffest contacts of the suite; the reachable-state distributions are in test_4096_...)
-    assert eq[keep].max() <= 2 * QTOL and ev[keep].max() <= 2 * VTOL and keep.sum() >= n - 4
+    # 1x the stated tolerance for every state the oracle itself is stable on — but ONE (measured in round 3: state with the trunk 3 cm
+    # in the floor, 1.01x / 1.14x, the oracle moves by less than half of that under 1e-6 noise), held to 1.25x; at most 4 knife-edge
+    # states, and those bounded too
+    over = (eq[keep] > QTOL) | (ev[keep] > VTOL)
+    assert over.sum() <= 1 and eq[keep].max() <= 1.25 * QTOL and ev[keep].max() <= 1.25 * VTOL and keep.sum() >= n - 4
+    assert eq.max() <= 10 * QTOL and ev.max() <= 10 * VTOL
     st = b.stats()
     assert st["overflow_contacts"] == 0
 
@@ -1158,6 +1166,23 @@ def _oracle_step(env, oracle, q, v, act_norm, act_state=None):
     return qo, vo, None, st
 
 
+def _split_knife_edges(env, oracle, q0s, v0s, acts, eq, ev, seed=5):
+    """Which of the states beyond the tolerance are knife-edge states of the ORACLE itself: its own result moves by more than the
+    tolerance when its input moves by float32-sized noise (six perturbations of 1e-7 / 1e-6; a contact switching on within a hair
+    of a substep boundary). Returns the boolean mask of the states HELD to the tolerance."""
+    keep = np.ones(len(eq), dtype=bool)
+    prs = np.random.RandomState(seed)
+    for k in np.nonzero((eq > QTOL) | (ev > VTOL))[0]:
+        q0, v0 = q0s[k].astype(np.float32).astype(np.float64), v0s[k].astype(np.float32).astype(np.float64)
+        qo, vo = _oracle_step(env, oracle, q0, v0, acts[k])[:2]
+        for e in (1e-7, 1e-7, 1e-6, 1e-6, 1e-6, 1e-6):
+            qp, vp = _oracle_step(env, oracle, q0 + e * prs.uniform(-1, 1, len(q0)), v0 + e * prs.uniform(-1, 1, len(v0)), acts[k])[:2]
+            sq, sv = np.abs(qp - qo).max(), np.abs(vp - vo).max()
+            if sq > QTOL or sv > VTOL or ((eq[k] <= QTOL or sq >= 0.5 * eq[k]) and (ev[k] <= VTOL or sv >= 0.5 * ev[k])):
+                keep[k] = False
+    return keep
+
+
 def test_a1_self_contacts_vs_oracle(setup):
     """262 states of quadruped rollouts in which two legs touch (1..9 sphere / capsule self-contacts, up to three pairs of
     legs at once; tests/golden/a1_self_contact_states.npz), one control step in one batch against the fp64 oracle WITH
@@ -1171,15 +1196,16 @@ def test_a1_self_contacts_vs_oracle(setup):
     q1, v1 = b.get_state()
     flags = b.flags()
     st = b.stats()
-    eq, ev, dropped = [], [], 0
+    eq, ev, dropped, idx = [], [], 0, []
     for i in range(n):
         qo, vo, _, so = _oracle_step(env, oracle, d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64), d["a"][i].astype(np.float32))
         assert so["unhandled_pairs"] == 0
         if flags[i] & 1:                                 # a lane ran out of contact slots in this step (counted below)
             dropped += 1
             continue
-        eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max())
+        eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max()); idx.append(i)
     eq, ev = np.array(eq), np.array(ev)
+    keep = _split_knife_edges(env, oracle, d["q"][idx], d["v"][idx], d["a"][idx].astype(np.float32), eq, ev)
     print("A1 self-contact states: %d compared, %d with a dropped contact; qpos max %.2e p99 %.2e median %.2e | qvel max %.2e p99 %.2e median %.2e; "
           "self-contacts simulated %d, uncollidable pairs in reach %d, dropped contacts %d"
           % (len(eq), dropped, eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev),
@@ -1187,7 +1213,8 @@ def test_a1_self_contacts_vs_oracle(setup):
     assert st["self_contacts"] > 10 * n and st["self_proximity"] == 0
     assert len(eq) >= 0.9 * n
     assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
-    assert eq.max() < 3 * QTOL and ev.max() < 3 * VTOL
+    print("   knife-edge states of the oracle left out of the max: %d; the others: qpos max %.2e qvel max %.2e" % ((~keep).sum(), eq[keep].max(), ev[keep].max()))
+    assert eq[keep].max() < QTOL and ev[keep].max() < VTOL and (~keep).sum() <= 3 and eq.max() < 10 * QTOL and ev.max() < 10 * VTOL
 
 
 def test_atlas_cylinder_states_vs_oracle(atlas):
@@ -1204,19 +1231,22 @@ def test_atlas_cylinder_states_vs_oracle(atlas):
     b.step(acts)
     q1, v1 = b.get_state()
     flags = b.flags()
-    eq, ev, skipped = [], [], 0
+    eq, ev, skipped, idx = [], [], 0, []
     for i in range(n):
         q0, v0 = d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64)
         qo, vo, _, so = _oracle_step(env, oracle, q0, v0, np.zeros(10))
         if flags[i] or so["unhandled_pairs"]:
             skipped += 1
             continue
-        eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max())
+        eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max()); idx.append(i)
     eq, ev = np.array(eq), np.array(ev)
+    keep = _split_knife_edges(env, oracle, d["q"][idx], d["v"][idx], np.zeros((len(idx), 10)), eq, ev)
     print("Atlas cylinder states: %d compared, %d skipped; qpos max %.2e p99 %.2e | qvel max %.2e p99 %.2e"
           % (len(eq), skipped, eq.max(), np.percentile(eq, 99), ev.max(), np.percentile(ev, 99)))
     assert len(eq) >= 0.9 * n
-    assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL and eq.max() < 3 * QTOL and ev.max() < 3 * VTOL
+    print("   knife-edge states of the oracle left out of the max: %d; the others: qpos max %.2e qvel max %.2e" % ((~keep).sum(), eq[keep].max(), ev[keep].max()))
+    assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
+    assert eq[keep].max() < QTOL and ev[keep].max() < VTOL and (~keep).sum() <= 3 and eq.max() < 10 * QTOL and ev.max() < 10 * VTOL
 
 
 def _worker_oracle_steps(args):
@@ -1725,3 +1755,46 @@ def test_unitree_g1_welded_torso_vs_oracle_and_rollout():
     print("UnitreeG1 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, newton its/substep %.2f"
           % (st["kernel_ms"] / 40, 2048 * 40 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["solver_iters"] / st["env_steps"] / 10))
 
+
+
+def test_unitree_h1_free_arms_vs_oracle_and_env_surface():
+    """UnitreeH1 with `disable_arms=False` (reference unitreeH1.py:235-296: the file as it is, torso joint + two 4-dof arms; VERDICT r2
+    item 7): the constructor no longer raises, the arm chains share the torso link (six-link kernels, tie_shared_dof). 128 dataset
+    states with random actions, one control step against the oracle; states in which the oracle has a hull-against-hull or an
+    uncollidable pair within the margin are left to the proximity flag (this kernel family has no pair tables)."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeH1.walk", debug=True, disable_arms=False)
+    m = env._model
+    assert m.nv == 25 and len(env._action_indices) == 19 and env.info.observation_space.shape == (48,)
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    rs = np.random.RandomState(4)
+    n = 128
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-1, 1, (n, 19))
+    b = HipBatch(hm, n)
+    b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+    b.step(acts)
+    q, v = b.get_state()
+    flags = b.flags()
+    oracle = Oracle(pack_model(m))
+    eq, ev, left = [], [], 0
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i].astype(np.float32))
+        qo, vo, _, so = oracle.step(rows[i, :m.nv].astype(np.float32).astype(np.float64), rows[i, m.nv:2 * m.nv].astype(np.float32).astype(np.float64), ctrl, nsub=10)
+        if so["convex_contacts"] or so["unhandled_pairs"] or flags[i]:
+            left += 1
+            continue
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max())
+    print("UnitreeH1 (free arms), %d of 128 dataset states compared, one control step vs oracle: qpos max %.2e median %.2e | qvel max %.2e median %.2e"
+          % (len(eq), max(eq), np.median(eq), max(ev), np.median(ev)))
+    assert len(eq) >= 0.6 * n and max(eq) < QTOL and max(ev) < VTOL      # (a quarter of the dataset states have the hands within the margin of the thighs)
+    # the environment surface: reset / step through LocoEnv
+    np.random.seed(0)
+    o = env.reset()
+    assert o.shape == (48,)
+    for _ in range(5):
+        o, r, absorbing, info = env.step(np.random.randn(19) * 0.1)
+    assert np.isfinite(o).all() and o.shape == (48,)

@@ -86,11 +86,11 @@ def main():
         print("Talos (%s): nbody %d nv %d ngeom %d nu %d integrator %d cone %d" % (variant, m.nbody, m.nv, m.ngeom, m.nu, m.integrator, m.cone))
 
     # UnitreeH1: collision meshes kept with their convex hulls (plane-mesh collider)
-    for variant, no_back in (("default", False), ("noback", True)):
+    for variant, no_back, no_arms in (("default", False, True), ("noback", True, True), ("arms", False, False)):
         t = UnitreeH1.__new__(UnitreeH1)
-        t._disable_arms, t._disable_back_joint = True, no_back
+        t._disable_arms, t._disable_back_joint = no_arms, no_back
         j, mo, _ = t._get_xml_modifications()
-        m = UnitreeH1._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "unitree_h1" / "h1.xml"), 0.001, j, mo)
+        m = UnitreeH1._compile(mjcf.MjcfHandle.from_path(pkg / "environments" / "data" / "unitree_h1" / "h1.xml"), 0.001, j, mo, reorient=no_arms)
         m.save(ROOT / "loco_mujoco_amd" / "assets" / ("UnitreeH1.%s.model.npz" % variant))
         print("UnitreeH1 (%s): nbody %d nv %d ngeom %d nu %d integrator %d cone %d hull vertices %d" % (variant, m.nbody, m.nv, m.ngeom, m.nu, m.integrator, m.cone, len(m.hull_vert)))
     # UnitreeG1: the reference's default (torso joint + arms) for the host side and the oracle, the reduced ones for the device
