@@ -1,5 +1,6 @@
 #!/bin/bash
-# Reproducer of the pre-RA machine-scheduler miscompile (Makefile: SCHED; profiles/r3_notes.md §4).
+# Reproducer of the miscompile of kernels that CALL the convex-pair collider (csrc/lm_step.h LM_MPR_CALL; Makefile: SCHED;
+# profiles/r3_notes.md §4). The shipped library inlines the collider; -DLM_MPR_CALL makes it a real function again.
 # Builds kernel family 8 (<5 links, 8 slots, RK4, pyramids, PAIRS>) and family 10 (<5,8,Euler,pyramids,muscles,PAIRS>) of
 # csrc/lm_family.hip three times — default strategy (max-occupancy), max-ILP, scheduler off — links each against the shipped objects of
 # the other families and runs, on the GPU box:
@@ -7,12 +8,13 @@
 #   * test_fused_rollout_is_bitwise_the_single_step_rollout[HumanoidMuscle.run] (family 10, fused kernel)
 # Observed (ROCm 7.2.0 hipcc, gfx950, -Os): max-occupancy -> family 8 wrong by O(1) in EVERY environment (1.2 rad after one step; the
 # same source with printf statements in the pair pass is right); max-ILP -> family 8 right, the fused family-10 kernel wrong;
-# -enable-misched=false -> both right (what ships). The kernels sit at the register ceiling: 256 VGPR + 256 AGPR + ~480 B scratch.
+# -enable-misched=false -> both right at -Os (but <5,8,Euler,muscles,PAIRS> wrong at -O2). Every one of these builds is right WITHOUT the call
+# (-DLM_NO_MPR, or the collider inlined: what ships). The kernels sit at the register ceiling: 256 VGPR + 256 AGPR + ~480 B scratch.
 #   usage (from the repo root, CPU container):  bash tools/probes/r3/sched_repro.sh build      (three libraries, ~3 min on 8 cores)
 #         (GPU box, through gpurun):            bash tools/probes/r3/sched_repro.sh run
 set -e
 cd "$(dirname "$0")/../../../loco_mujoco_amd/csrc"
-F="--offload-arch=gfx950 -Os -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -Wno-unused-result -Wno-unused-value"
+F="-DLM_MPR_CALL --offload-arch=gfx950 -Os -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -Wno-unused-result -Wno-unused-value"
 declare -A SCHED=( [occ]="" [ilp]="-mllvm -amdgpu-sched-strategy=max-ilp" [off]="-mllvm -enable-misched=false" )
 if [ "$1" = build ]; then
   for v in occ ilp off; do
