@@ -1673,7 +1673,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
       first_detect = !pair_slack || *pair_slack == 0.0f;        // the first pass of a control step (the caller starts it at 0)
       float slack = (pair_slack ? *pair_slack : 0.0f) - P.h * (s_own + s_quad);
-      detect = Q::sum((slack <= 0.0f) ? 1.0f : 0.0f) > 0.0f;          // quad-uniform: mirror slots need both lanes
+      // WAVE-uniform: when one environment of the wave has to detect, its wave mates detect with it — they would wait for it anyway
+      // (one instruction stream), and their slack is refreshed for free, so the wave as a whole detects about as often as its
+      // neediest environment instead of whenever ANY of the four is due. A detection that was not due finds nothing (that is what
+      // the slack guarantees): the states are bitwise the same, whatever the composition of the wave.
+      detect = Q::any(slack <= 0.0f);
       if (pair_slack) *pair_slack = slack;
     }
 #ifdef LM_NO_DETECT
@@ -1901,40 +1905,77 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         G.dd = sqrtf(dot(G.dq, G.dq)); G.dist = G.dd - G.r1 - G.r2;
         return G;
       };
-      int next = 0, n_prox = 0;
+#if defined(LM_TIMERS) && defined(LM_PAIR_PHASES)
+      long long ph_ = LM_CLOCK();
+#define LM_PHASE(i) do { long long n_ = LM_CLOCK(); cnt.m[i] += n_ - ph_; ph_ = n_; } while (0)
+#else
+#define LM_PHASE(i) do {} while (0)
+#endif
+      // ---- 1a. link pairs of my chain, DEALT TO THE REPLICAS (an entry costs two dependent LDS round trips: its code, then the two
+      // sphere centres; measured 32 k cycles per detection for the quadruped with every lane walking all entries): replica r
+      // tests entries r, r + kRep, ... and keeps bit i / kRep of its mask for an entry in reach; the masks are exchanged
+      // (exact as floats: <= 64 / kRep bits... 16 with four replicas), every replica then builds the same lists from them.
+      unsigned long long reach_r = 0ull;
+      {
+        // branch-free body, unrolled: the LDS reads of several entries are in flight together
+        float gmy = 3.0e38f, gpart[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+#pragma unroll 4
+        for (int i = Q::rep(); i < nlp; i += Q::kRep) {
+          const int code = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 0];
+          const float thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
+          const int ka = code & 7, kb = (code >> 3) & 7, lb = (code >> 6) & 3, own_q = (code >> 8) & 1, dl = lb - c;
+          const int kbs = (kb == 7) ? 0 : kb, dls = (kb == 7) ? 0 : dl;
+          const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
+          const V3 cbp = v3(PEER(dls, LMm::kBS + kbs * 3), PEER(dls, LMm::kBS + kbs * 3 + 1), PEER(dls, LMm::kBS + kbs * 3 + 2));
+          const V3 cb = (kb == 7) ? rootc : cbp;
+          const V3 dc = cb - ca;
+          const float d2c = dot(dc, dc);
+          const bool mine = own_q == 0;                        // (a cross-chain pair seen from its second link is listed by the first link's lane)
+          const bool inr = d2c < thr2;
+          // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
+          const float gp_ = sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD;
+          const bool note = mine && !inr, notep = note && kb != 7 && lb != c;
+          gmy = note ? fminf(gmy, gp_) : gmy;
+#pragma unroll
+          for (int k = 0; k < 4; k++) gpart[k] = (notep && k == lb) ? fminf(gpart[k], gp_) : gpart[k];
+          reach_r |= (mine && inr) ? (1ull << (i / Q::kRep)) : 0ull;
+        }
+        gap_note(c, gmy);
+#pragma unroll
+        for (int k = 0; k < 4; k++) gap_of[k] = fminf(gap_of[k], gpart[k]);
+      }
+      // every replica's mask -> ONE mask of my chain's entries in reach, bit = entry (exact as floats: 16 bits with four replicas)
+      unsigned long long reach_all = reach_r;
+      if (Q::kRep > 1) {
+        reach_all = 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          unsigned m_ = (unsigned)Q::rep_bcast((float)(unsigned)reach_r, r);
+#pragma nounroll
+          while (m_) { const int b_ = __builtin_ctz(m_); reach_all |= 1ull << (4 * b_ + r); m_ &= m_ - 1u; }
+        }
+      }
+      LM_PHASE(15);
+      int n_prox = 0;
 #pragma nounroll
       for (;;) {
-        // ---- 1. link pairs of my chain: the next chunk of entries in reach (every replica builds the same list)
+        // ---- 1b. the next chunk of my chain's entries in reach (every replica builds the same list)
         int nw = 0, nunits = 0;
 #pragma nounroll
-        while (next < nlp && nw < kWcap) {
-          const int i = next;
-          EntryCtx E;
-          entry_ctx(i, E);
-          if (E.own_q) { next++; continue; }                 // cross-chain pair seen from its second link: the first link's lane lists it
+        while (reach_all != 0ull && nw < kWcap) {
+          const int i = __builtin_ctzll(reach_all);
           const int nbp = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 1] >> 16;
           if (nunits + nbp > kScap) break;                   // its body pairs would not fit S: next chunk (an entry alone always fits)
-          next++;
-          const int ka = E.ka, kb = E.kb, dl = E.dl;
-          const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
-          const V3 cb = (kb == 7) ? rootc : v3(PEER(dl, LMm::kBS + kb * 3), PEER(dl, LMm::kBS + kb * 3 + 1), PEER(dl, LMm::kBS + kb * 3 + 2));
-          const V3 dc = cb - ca;
-          const float d2c = dot(dc, dc), thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
-          // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
-          if (!(d2c < thr2)) {
-            const float gp_ = sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD;
-            gap_note(c, gp_);
-            if (kb != 7 && !E.same_lane) gap_note(E.lb, gp_);
-            continue;
-          }
+          reach_all &= reach_all - 1ull;
           LMEM(kW1 + nw) = (float)(i + 64 * nbp);
           nw++; nunits += nbp;
         }
         if (!(Q::sum((nw > 0) ? 1.0f : 0.0f) > 0.0f)) break;          // no chain of the environment has entries in reach left (quad-uniform)
+        LM_PHASE(10);
         int nw_of[4], nu_of[4];
         share4(nw, nw_of); share4(nunits, nu_of);
 #ifdef LM_PAIR_TRACE
-        if (me == 0) printf("  chunk: entries %d %d %d %d body pairs %d %d %d %d (next %d of %d)\n", nw_of[0], nw_of[1], nw_of[2], nw_of[3], nu_of[0], nu_of[1], nu_of[2], nu_of[3], next, nlp);
+        if (me == 0) printf("  chunk: entries %d %d %d %d body pairs %d %d %d %d (of %d entries)\n", nw_of[0], nw_of[1], nw_of[2], nw_of[3], nu_of[0], nu_of[1], nu_of[2], nu_of[3], nlp);
 #endif
         Q::fence(); Q::quad_sync();
         // ---- 2. body pairs: one bounding capsule per body; those within the largest margin of their geom pairs go on, the others
@@ -1983,6 +2024,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
         }
         Q::fence(); Q::quad_sync();
+        LM_PHASE(11);
         // ---- 3. geom pairs of the body pairs in reach
         int nv = 0, nv_of[4];
 #pragma nounroll
@@ -2025,7 +2067,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #ifdef LM_PAIR_TRACE
                 if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %d dist %.7f\n", cs, i, first + v, kind, G.dist);
 #endif
-#ifdef LM_TIMERS
+#if defined(LM_TIMERS) && !defined(LM_PAIR_PHASES)
                 cnt.m[10 + kind]++; if (G.dist < pmargin) cnt.m[13 + kind]++;
 #endif
                 if (!counted_only || MC > 3) { gap_note(cs, G.dist - pmargin); if (is_cross) gap_note(E.lb, G.dist - pmargin); }       // (the humanoids' one counted pair — foot on foot — is watched like the others)
@@ -2105,6 +2147,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         Q::fence(); Q::quad_sync();
       }
+      LM_PHASE(12);
       if (c == 0 && Q::rep() == 0) cnt.selfprox += n_prox;
 #ifdef LM_PAIR_TRACE
       if (me == 0) printf("  queued %d %d %d %d results %d %d %d %d gaps %.5f %.5f %.5f %.5f\n", nq_of[0], nq_of[1], nq_of[2], nq_of[3], nres_of[0], nres_of[1], nres_of[2], nres_of[3], gap_of[0], gap_of[1], gap_of[2], gap_of[3]);
@@ -2112,6 +2155,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       LM_TICK(14);              // self-collisions: broad / mid / narrow-phase tests
       flush_queue();            // every lane of the wave arrives here together: the queued pairs of all of them run side by side
       LM_TICK(15);              // self-collisions: convex pairs (MPR)
+      LM_PHASE(13);
       emit_results();
       // contacts beyond what the queue / the result list of my chain hold: dropped, counted
       if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
@@ -2128,6 +2172,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         }
         gap_min = gmine;
       }
+      LM_PHASE(14);
       if (Q::rep() == 0) cnt.overflow += n_over;
       if (pair_slack) *pair_slack = gap_min;
       Q::fence();

@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < hdr[4]; i++) {
     std::vector<double> q(nv), v(nv), w(nv, 0.0), a(nu), act(na > 0 ? na : 1, 0.0);
     fread(q.data(), sizeof(double), nv, f); fread(v.data(), sizeof(double), nv, f); fread(a.data(), sizeof(double), nu, f);
-    int cnt[6] = {0};
+    int cnt[16] = {0};   // emu_run reports 8 counters
     int rc = emu_run(cm.data(), 1, q.data(), v.data(), w.data(), a.data(), 3, -1, nullptr, nullptr, cnt, na > 0 ? act.data() : nullptr);
     printf("case %d rc %d iters %d ncon %d q0 %.6f\n", i, rc, cnt[0], cnt[3], q[2]);
   }
