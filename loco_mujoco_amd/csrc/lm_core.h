@@ -160,7 +160,7 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   int selfprox;      // forward passes x geom pairs without a collider (box / cylinder against something) within the margin
   int selfcon;       // self-contacts simulated, summed over the forward passes
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
-  float grf[2][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's two foot-force groups
+  float grf[4][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's foot-force groups (2; 4 in the six-link kernels)
 #ifdef LM_TIMERS
   long long t[16];
   long long m[16];   // [8..]: passes with detection, passes, geom pairs tested of kind 0 / 1 / 2, hits of kind 0 / 1 / 2;  [0..7] convex collider: calls, ended at the one-direction test, no contact, contact, support pairs, hill steps, refinement iterations, rounds
@@ -3137,11 +3137,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   if (want_grf) {
     // foot forces (reference base.py:623-631,667-679): contact-frame force of the FIRST contact of each force group,
     // from the residuals of the last gradient evaluation (= the solution)
-    bool seen0 = false, seen1 = false;
+    int seen = 0;
     for (int s = 0; s < nslot; s++) {
       const int gq = (int)SL(s, SL_GRF);
-      if (gq < 0 || (gq == 0 ? seen0 : seen1)) continue;
-      if (gq == 0) seen0 = true; else seen1 = true;
+      if (gq < 0 || ((seen >> gq) & 1)) continue;
+      seen |= 1 << gq;
       const int dim = (int)SL(s, SL_DIM);
       float f[6];
       if (PYR3(dim)) {
@@ -3160,7 +3160,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int j = 0; j < 3; j++) f[j] = (j < dim) ? e.f[j] : 0.0f;
       }
 #pragma unroll
-      for (int j = 0; j < 3; j++) { if (gq == 0) cnt.grf[0][j] += f[j]; else cnt.grf[1][j] += f[j]; }
+      for (int j = 0; j < 3; j++) {
+        if (gq == 0) cnt.grf[0][j] += f[j];
+        else if (MC < 6 || gq == 1) cnt.grf[1][j] += f[j];
+        else if (gq == 2) cnt.grf[2][j] += f[j];
+        else cnt.grf[3][j] += f[j];
+      }
     }
   }
   cnt.solver_iters += (c == 0) ? iters : 0;

@@ -420,6 +420,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       const int o0 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS0 * LM_NCHAIN + c], o1 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS1 * LM_NCHAIN + c];
 #pragma unroll
       for (int j = 0; j < 3; j++) { if (o0 >= 0) o[o0 + j] = cnt.grf[0][j] * scale; if (o1 >= 0) o[o1 + j] = cnt.grf[1][j] * scale; }
+      if (MC == 6) {          // UnitreeG1: four force points per foot
+        const int o2 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS2 * LM_NCHAIN + c], o3 = (int)cm[LM_CM_CHAINS + LM_C_GRF_OBS3 * LM_NCHAIN + c];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { if (o2 >= 0) o[o2 + j] = cnt.grf[2][j] * scale; if (o3 >= 0) o[o3 + j] = cnt.grf[3][j] * scale; }
+      }
     }
   }
   }

@@ -172,9 +172,6 @@ class UnitreeG1(BaseRobotHumanoid):
 
     def __init__(self, disable_arms=False, disable_back_joint=False, xml_path=None, timestep=0.001, **kwargs):
         self._disable_arms, self._disable_back_joint, self._hold_weight = disable_arms, disable_back_joint, False
-        if kwargs.get("use_foot_forces", False):
-            raise NotImplementedError("UnitreeG1 foot forces (four force points per foot, unitreeG1.py:292-311) are not built: "
-                                      "the device reports two force groups per chain")
         joints_to_remove, motors_to_remove, _ = self._get_xml_modifications()
         drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]
         observation_spec = [e for e in self._get_observation_specification() if e[0] not in drop]
@@ -228,6 +225,10 @@ class UnitreeG1(BaseRobotHumanoid):
 
     def _get_grf_size(self):
         return 24
+
+    def _grf_group_names(self):
+        """Four force points per foot, right foot first (``unitreeG1.py:295-317``): 8 groups x 3 = 24 entries."""
+        return ["%s_foot_%d" % (s, i) for s in ("right", "left") for i in (1, 2, 3, 4)]
 
     # ------------------------------------------------------------------ task factory
     @staticmethod

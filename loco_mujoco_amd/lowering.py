@@ -53,11 +53,12 @@ LINK_SIZE = D_SIZE + L_SIZE
 C_NLINKS, C_NGEOMS, C_NUNSUP, C_GRF_OBS0, C_GRF_OBS1, C_NLPAIR, C_NLGROUP, C_DUPROLE = 0, 1, 2, 3, 4, 5, 6, 7
 # where this chain's tail lists start in the constant table (floats from its beginning): every chain's list is contiguous
 # ([entry][field]) and only as long as the chain needs — a humanoid's trunk has 40 geoms, its legs 8
-C_OFF_CUNSUP, C_OFF_PRUNE, C_OFF_LGROUP, C_OFF_LPAIR, C_LINKS = 8, 9, 10, 11, 12
+C_OFF_CUNSUP, C_OFF_PRUNE, C_OFF_LGROUP, C_OFF_LPAIR, C_GRF_OBS2, C_GRF_OBS3, C_LINKS = 8, 9, 10, 11, 12, 13, 14
+C_GRF_OBS = (C_GRF_OBS0, C_GRF_OBS1, C_GRF_OBS2, C_GRF_OBS3)     # groups 2, 3: six-link kernels only (UnitreeG1: four force points per foot)
 # C_DUPROLE: +1 = this chain's first link is SHARED with another chain and this lane owns its dof, -1 = this lane carries the
 # massless copy of that link (a torso with two arms: two chains [torso, arm], one dof for the torso), 0 = neither
 # C_NLPAIR: link-pair entries of the self-collision broad phase that involve this chain
-# C_GRF_OBS0/1: observation index of the (normal, t1, t2) mean force of the chain's force group 0/1, -1 = none
+# C_GRF_OBS0..3: observation index of the (normal, t1, t2) mean force of the chain's force group 0..3, -1 = none
 CHAIN_SIZE = C_LINKS + MAXC * LINK_SIZE
 U_SIZE = 6        # collider-less ("unsupported") geom: (link, px,py,pz, rbound, margin)
 P_SIZE = 6        # prune record of a geom with a collider: (link, px,py,pz, rbound, type) — the full record is in the geom table
@@ -522,8 +523,10 @@ def lower(m, task):
 
     # ---- chains, interleaved [field][chain]
     for c in range(NCHAIN):                      # unused lanes report no foot force
-        cm[CM_CHAINS + C_GRF_OBS0 * NCHAIN + c] = cm[CM_CHAINS + C_GRF_OBS1 * NCHAIN + c] = -1
+        for k in C_GRF_OBS:
+            cm[CM_CHAINS + k * NCHAIN + c] = -1
     max_links = 0
+    max_groups_seen = 0
     standing = []
     for c, chain in enumerate(chains):
         blk = np.zeros(CHAIN_SIZE)
@@ -570,12 +573,14 @@ def lower(m, task):
                 geoms += s
                 unsup += u
         geoms += root_geoms[c::len(chains)]          # this lane's share of the root body's colliders (after the chain's own)
-        blk[C_GRF_OBS0] = blk[C_GRF_OBS1] = -1
+        for k in C_GRF_OBS:
+            blk[k] = -1
         chain_groups = sorted(set(int(gb[G_GRF]) for gb in geoms if gb[G_GRF] >= 0))
-        if len(chain_groups) > 2:
-            raise UnsupportedModel("more than two foot-force groups on one chain")
+        max_groups_seen = max(max_groups_seen, len(chain_groups))
+        if len(chain_groups) > 4:
+            raise UnsupportedModel("more than four foot-force groups on one chain")
         for slot, gi in enumerate(chain_groups):
-            blk[C_GRF_OBS0 + slot] = grf_obs_base + 3 * gi
+            blk[C_GRF_OBS[slot]] = grf_obs_base + 3 * gi
         for gb in geoms:
             gb[G_GRF] = chain_groups.index(int(gb[G_GRF])) if gb[G_GRF] >= 0 else -1
         if len(geoms) > MAXG:
@@ -776,7 +781,9 @@ def lower(m, task):
     h[H_CM_USED] = off
     h[H_GT_SIZE] = GT_SIZE
     h[H_NGRF] = n_grf
-    if n_grf and sum(1 for c in range(len(chains)) for k in (C_GRF_OBS0, C_GRF_OBS1) if cm[CM_CHAINS + k * NCHAIN + c] >= 0) != len(grf_groups):
+    if max_groups_seen > 2 and max_links < MAXC:
+        raise UnsupportedModel("more than two foot-force groups on one chain (four are compiled in the six-link kernels only)")
+    if n_grf and sum(1 for c in range(len(chains)) for k in C_GRF_OBS if cm[CM_CHAINS + k * NCHAIN + c] >= 0) != len(grf_groups):
         raise UnsupportedModel("a foot-force group has no geom with a device collider")
     info.update(dropped_root_limits=dropped_root_limits, n_chains=len(chains), max_links=max_links, max_contacts=max_contacts, dof_to_lane=dof_to_lane,
                 self_collision_pairs=_count_self_pairs(m))

@@ -984,11 +984,12 @@ def test_device_side_redraw_of_joint_parameters():
 # Foot-force observations: mean contact-frame force of each foot group over the control step.
 # ---------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("HumanoidTorque.walk", 13), ("Atlas.walk", 10), ("HumanoidMuscle.run", 92), ("Talos.walk", 12)])
+@pytest.mark.parametrize("task,nu", [("UnitreeA1.simple", 12), ("HumanoidTorque.walk", 13), ("Atlas.walk", 10), ("HumanoidMuscle.run", 92), ("Talos.walk", 12),
+                                     ("UnitreeG1.walk", 23)])       # G1: four force points per foot (unitreeG1.py:295-317), four groups per leg chain
 def test_foot_force_observations_vs_oracle(task, nu):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle_backend import attach
-    ng = 12 if task.split(".")[0] in ("UnitreeA1", "Atlas") else 6
+    ng = {"UnitreeA1": 12, "Atlas": 12, "UnitreeG1": 24}.get(task.split(".")[0], 6)
     np.random.seed(0)
     dev = LocoEnv.make(task, debug=True, use_foot_forces=True)
     np.random.seed(0)

@@ -641,8 +641,13 @@ def test_unitree_g1_surface():
     assert link0(2, lowering.D_DOF) == link0(3, lowering.D_DOF) == t and link0(2, lowering.D_DAMP) == 0.5 and link0(3, lowering.D_DAMP) == 0
     assert link0(2, lowering.D_SIZE + lowering.L_MASS) > 5 and link0(3, lowering.D_SIZE + lowering.L_MASS) == 0
     assert link0(2, lowering.D_LIMITED) == 1 and link0(3, lowering.D_LIMITED) == 0 and link0(3, lowering.D_QOBS) == -1
-    with pytest.raises(NotImplementedError):
-        LocoEnv.make("UnitreeG1.walk", debug=True, use_foot_forces=True)
+    # foot forces: four force points per foot, 8 groups x 3 entries behind the state (unitreeG1.py:295-317); four groups per leg chain
+    # are compiled in the six-link kernels
+    ff = LocoEnv.make("UnitreeG1.walk", debug=True, use_foot_forces=True)
+    assert ff.info.observation_space.shape == (56 + 24,) and ff._get_grf_size() == 24
+    cmf, inf = lowering.lower(ff._model, ff._device_task())
+    obs_slots = [int(cmf[lowering.HEADER_SIZE + lowering.CM_CHAINS + k * lowering.NCHAIN + c]) for c in range(4) for k in lowering.C_GRF_OBS]
+    assert sorted(x for x in obs_slots if x >= 0) == [56 + 3 * i for i in range(8)]
     with pytest.raises(ValueError):
         LocoEnv.make("UnitreeG1.carry")
     for kw, nv, nu, chains in ((dict(disable_back_joint=True), 28, 22, [5, 5, 6, 6]), (dict(disable_arms=True), 19, 13, [1, 6, 6]),
