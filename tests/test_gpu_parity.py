@@ -1799,3 +1799,36 @@ def test_unitree_h1_free_arms_vs_oracle_and_env_surface():
     for _ in range(5):
         o, r, absorbing, info = env.step(np.random.randn(19) * 0.1)
     assert np.isfinite(o).all() and o.shape == (48,)
+
+
+def test_done_byte_bit_layout_and_episode_restarted_key(setup):
+    """The done byte of lm_step is a bit field (include/locohip.h): bit 0 = absorbing state, bit 1 = the episode ended on the device in
+    this step. Without device-side restarts bit 1 is set in the ONE step that reaches the horizon, not in every later one (ADVICE r2);
+    with them, `LocoEnv.step()` always returns the `episode_restarted` key."""
+    import ctypes as C
+    env, hm, oracle, HipBatch = setup
+    tab = env._reset_table()
+    n = 16
+    b = HipBatch(hm, n)
+    b.set_auto_reset(False, horizon=3)
+    b.set_state(tab[:n, :18], tab[:n, 18:36])
+    b.set_goal(tab[:n, 36:39])
+    raw = []
+    for _ in range(5):
+        obs = np.zeros((n, b.nobs), dtype=np.float32); rew = np.zeros(n, dtype=np.float32); done = np.zeros(n, dtype=np.uint8)
+        assert b._lib.lm_step(b._h, None, obs.ctypes.data_as(C.POINTER(C.c_float)), rew.ctypes.data_as(C.POINTER(C.c_float)),
+                              done.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+        raw.append(done.copy())
+    raw = np.stack(raw)
+    standing = (raw & 1).sum(0) == 0                      # environments that never reach an absorbing state in these five steps
+    assert standing.sum() >= 8
+    assert ((raw[:, standing] & 2) != 0).sum(0).tolist() == [1] * int(standing.sum())      # exactly once ...
+    assert ((raw[2, standing] & 2) != 0).all()                                              # ... in the third step (horizon 3)
+    np.random.seed(0)
+    e2 = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=8)
+    e2.reset()
+    _, _, _, info = e2.step(np.zeros((8, 12)))
+    assert info == {}                                      # like the reference's info dict without device-side restarts
+    e2.enable_auto_reset(seed=1, horizon=2)
+    keys = [set(e2.step(np.zeros((8, 12)))[3].keys()) for _ in range(3)]
+    assert all(k == {"episode_restarted"} for k in keys)
