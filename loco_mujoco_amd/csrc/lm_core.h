@@ -1930,7 +1930,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           const V3 cb = (kb == 7) ? rootc : cbp;
           const V3 dc = cb - ca;
           const float d2c = dot(dc, dc);
-          const bool mine = own_q == 0;                        // (a cross-chain pair seen from its second link is listed by the first link's lane)
+          const bool mine = true; (void)own_q;                  // (every link pair is listed ONCE, in one of its two lanes: lowering._self_collision_tables)
           const bool inr = d2c < thr2;
           // (the list's reach is LM_PAIR_PAD beyond touching: a pruned link pair is at least that far from any contact)
           const float gp_ = sqrtf(d2c) - sqrtf(thr2) + LM_PAIR_PAD;

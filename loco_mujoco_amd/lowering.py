@@ -74,8 +74,8 @@ ROOT_SIZE = R_DOFS + NROOT * D_SIZE
 CM_ROOT = 0
 CM_CHAINS = ROOT_SIZE
 # ---- self-collisions (kernels compiled with PAIRS): per lane a list of link pairs (LP_SIZE floats each, chain by chain
-# [entry][field] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane + 256 * (own link
-# is the pair's SECOND link), range = first body pair + 65536 * number of body pairs (<= 24), squared reach of the two bounding spheres
+# [entry][field] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane (the own link is the pair's FIRST
+# link: a cross-chain pair is listed in that lane only; + 256 would mark the second link's view, which the device still decodes), range = first body pair + 65536 * number of body pairs (<= 24), squared reach of the two bounding spheres
 MAXLP = 64
 PAIR_PAD = 0.03   # metres: link pairs closer than touching + PAIR_PAD go through the narrow phase (csrc/lm_core.h LM_PAIR_PAD)
 LP_SIZE = 3
@@ -1061,9 +1061,13 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
         for first in range(first_bp, first_bp + n_all, 24):
             n = min(24, first_bp + n_all - first)
             assert first < 65536
-            lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 65536 * n, reach2])
-            if lq >= 0 and lq != lp:
+            # ONE entry per link pair, in the lane of its first link: that lane tests the pair, the partner lane takes the contacts over as
+            # mirror slots (round 2 listed a cross-chain pair in both lanes, code + 256 for the second link's view: both ran the tests)
+            # (either link's lane can hold it — the device decodes both views, + 256 = "my link is the pair's second": the shorter list gets it)
+            if lq >= 0 and lq != lp and len(lanes_lp[lq]) < len(lanes_lp[lp]):
                 lanes_lp[lq].append([kq + 8 * kp + 64 * lp + 256, first + 65536 * n, reach2])
+            else:
+                lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 65536 * n, reach2])
         spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp], sphere[wq]
     if max(len(x) for x in lanes_lp) > MAXLP:
         raise UnsupportedModel("too many self-collision link pairs (%s)" % [len(x) for x in lanes_lp])
