@@ -983,6 +983,7 @@ struct MprOut { float nx, ny, nz, px, py, pz, dist; int found; };
 #endif
 // mode 0: the one-direction separation test only (found = 1: not separated along it, the portal search has to decide);
 // mode 1: the portal search without that test (the caller ran it: stage A / stage B of the work queue).
+template <bool PAIRED>
 LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int mode LM_MPR_ARG) {
   LM_MPR_COUNT(0, mode == 0 ? 1 : 0);
   MprOut out; out.nx = out.ny = out.nz = out.px = out.py = out.pz = out.dist = 0.0f; out.found = 0;
@@ -1014,6 +1015,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
     auto is_zero = [&](double x) -> bool { return fabs(x) < eps; };
     auto sgn = [](double x) -> double { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); };
     int hint[2] = {-1, -1};            // where the hill climbing of either hull starts: its previous support vertex
+    // one shape's support (the sequential form: one copy of the climbing loop, run for either shape)
     auto support1 = [&](int which, D3 d) -> D3 {
       const M3& Rl = *Rw[which];
       const float* cap = rec + (which ? LM_GP_P2 : LM_GP_P1);        // bounding capsule: centre 3, axis 3, half length, radius
@@ -1076,6 +1078,108 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       }
       return dadd(dadd(pw[which], rot(Rl, loc)), dscl(hmg, d));
     };
+    // The supports of BOTH shapes for one direction: shape 0 along d, shape 1 along -d. A hull's support is a hill climb on its vertex
+    // graph (the engine's own search for meshes with a graph; meshadj: per vertex a block [x y z degree][neighbour x y z, neighbour's
+    // block]...: one step = header + first eight neighbours, one 144-byte fetch). The two hulls climb IN THE SAME LOOP: the fetches of
+    // a step of either are in flight together, so a support pair costs max(steps) memory round trips, not their sum (the loads are
+    // unconditional — a hull that has arrived re-reads its block — to keep them out of divergent branches).
+    auto support_pair = [&](D3 d, D3* sp_) {
+      if constexpr (!PAIRED) {
+        // (the quadruped's kernel: its convex pairs are primitives; anything else in this function costs its bench rollout 2-3 % through
+        // the register allocation of the kernel around it — this branch is the round's first version, untouched)
+#pragma nounroll
+        for (int w = 0; w < 2; w++) sp_[w] = support1(w, (w == 0) ? d : dscl(-1.0, d));
+      } else {
+        const float* const xg0 = rec + LM_GP_X1; const float* const xg1 = rec + LM_GP_X2;
+        const int type0 = (int)xg0[LM_GX_TYPE], type1 = (int)xg1[LM_GX_TYPE];
+        // support of a primitive (box, cylinder, capsule, sphere) in its link frame
+        auto prim_support = [&](const float* cap, const float* x, int type, D3 dl) -> D3 {
+          const D3 ctr = d3(cap[0], cap[1], cap[2]), ax = d3(cap[3], cap[4], cap[5]);
+          if (type == LM_GEOM_BOX) {
+            const D3 ex = d3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5]), ey = d3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]);
+            const D3 ez = dcross(ex, ey);
+            return dadd(dadd(ctr, dscl(sgn(ddot(dl, ex)) * (double)x[LM_GX_E0], ex)), dadd(dscl(sgn(ddot(dl, ey)) * (double)x[LM_GX_E0 + 1], ey), dscl(sgn(ddot(dl, ez)) * (double)x[LM_GX_E0 + 2], ez)));
+          }
+          if (type == LM_GEOM_CYLINDER) {
+            const double da = ddot(dl, ax);
+            const D3 perp = dsub(dl, dscl(da, ax));
+            const double t = sqrt(ddot(perp, perp));
+            D3 loc = dadd(ctr, dscl(sgn(da) * (double)cap[6], ax));
+            if (t > 1e-15) loc = dadd(loc, dscl((double)cap[7] / t, perp));
+            return loc;
+          }
+          return dadd(dadd(ctr, dscl((double)cap[7], dl)), dscl(sgn(ddot(dl, ax)) * (double)cap[6], ax));          // sphere (half length 0), capsule
+        };
+        // where the climb of a hull starts: the vertex its previous search ended at, or (first search of this pair) the hull's extreme
+        // vertex along the dominant axis of the direction
+        auto start_vertex = [&](const float* x, int hint, D3 dl) -> int {
+          if (hint >= 0) return hint;
+          const double ax_ = fabs(dl.x), ay_ = fabs(dl.y), az_ = fabs(dl.z);
+          const int k = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
+          const double comp = (k == 0) ? dl.x : ((k == 1) ? dl.y : dl.z);
+          return (int)x[LM_GX_E0 + 2 + 2 * k + ((comp < 0.0) ? 1 : 0)];
+        };
+      D3& s0 = sp_[0]; D3& s1 = sp_[1];
+      const D3 dm = dscl(-1.0, d);
+      const D3 dl0 = rotT(*Rw[0], d), dl1 = rotT(*Rw[1], dm);
+      const bool mesh0 = type0 == LM_GEOM_MESH, mesh1 = type1 == LM_GEOM_MESH;
+      D3 loc0 = d3(0, 0, 0), loc1 = d3(0, 0, 0);
+      if (!mesh0) loc0 = prim_support(rec + LM_GP_P1, xg0, type0, dl0);
+      if (!mesh1) loc1 = prim_support(rec + LM_GP_P2, xg1, type1, dl1);
+      if (mesh0 || mesh1) {
+        const F4* A = reinterpret_cast<const F4*>(meshadj);
+        int cur0 = mesh0 ? start_vertex(xg0, hint[0], dl0) : 0, cur1 = mesh1 ? start_vertex(xg1, hint[1], dl1) : 0;
+        bool go0 = mesh0, go1 = mesh1;
+        double best0 = -1.0e300, best1 = -1.0e300;
+#pragma nounroll
+        for (int step = 0; step < 256 && (go0 || go1); step++) {
+          LM_MPR_COUNT(5, (go0 ? 1 : 0) + (go1 ? 1 : 0));
+          const F4 h0 = A[cur0], h1 = A[cur1];
+          F4 e0[8], e1[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) { e0[j] = A[cur0 + 1 + j]; e1[j] = A[cur1 + 1 + j]; }     // (beyond a block's end for a lower degree: ignored; the table is padded)
+          if (go0) {
+            const int deg = (int)h0.w;
+            if (step == 0) { best0 = dl0.x * (double)h0.x + dl0.y * (double)h0.y + dl0.z * (double)h0.z; loc0 = d3(h0.x, h0.y, h0.z); }
+            int nxt = cur0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const double dd = dl0.x * (double)e0[j].x + dl0.y * (double)e0[j].y + dl0.z * (double)e0[j].z;
+              if (j < deg && dd > best0) { best0 = dd; nxt = (int)e0[j].w; loc0 = d3(e0[j].x, e0[j].y, e0[j].z); }
+            }
+#pragma nounroll
+            for (int j = 8; j < deg; j++) {
+              const F4 ej = A[cur0 + 1 + j];
+              const double dd = dl0.x * (double)ej.x + dl0.y * (double)ej.y + dl0.z * (double)ej.z;
+              if (dd > best0) { best0 = dd; nxt = (int)ej.w; loc0 = d3(ej.x, ej.y, ej.z); }
+            }
+            if (nxt == cur0) go0 = false; else cur0 = nxt;
+          }
+          if (go1) {
+            const int deg = (int)h1.w;
+            if (step == 0) { best1 = dl1.x * (double)h1.x + dl1.y * (double)h1.y + dl1.z * (double)h1.z; loc1 = d3(h1.x, h1.y, h1.z); }
+            int nxt = cur1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const double dd = dl1.x * (double)e1[j].x + dl1.y * (double)e1[j].y + dl1.z * (double)e1[j].z;
+              if (j < deg && dd > best1) { best1 = dd; nxt = (int)e1[j].w; loc1 = d3(e1[j].x, e1[j].y, e1[j].z); }
+            }
+#pragma nounroll
+            for (int j = 8; j < deg; j++) {
+              const F4 ej = A[cur1 + 1 + j];
+              const double dd = dl1.x * (double)ej.x + dl1.y * (double)ej.y + dl1.z * (double)ej.z;
+              if (dd > best1) { best1 = dd; nxt = (int)ej.w; loc1 = d3(ej.x, ej.y, ej.z); }
+            }
+            if (nxt == cur1) go1 = false; else cur1 = nxt;
+          }
+        }
+        if (mesh0) hint[0] = cur0;
+        if (mesh1) hint[1] = cur1;
+      }
+      s0 = dadd(dadd(pw[0], rot(*Rw[0], loc0)), dscl(hmg, d));
+      s1 = dadd(dadd(pw[1], rot(*Rw[1], loc1)), dscl(hmg, dm));
+      }
+    };
     // the portal: points 1..3 as (v, v1) in local arrays (dynamic index: private memory), point 0 in registers
     double PV[3][6];
     auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
@@ -1109,8 +1213,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       if (dot(dsep, dsep) > 1e-12f) {
         const D3 du = dunit(up(dsep));
         D3 sp[2];
-#pragma nounroll
-        for (int w = 0; w < 2; w++) sp[w] = support1(w, (w == 0) ? du : dscl(-1.0, du));
+        support_pair(du, sp);
         LM_MPR_COUNT(4, 1);
         if (ddot(dsub(sp[0], sp[1]), du) < 0.0) { LM_MPR_COUNT(1, 1); return out; }
       }
@@ -1125,8 +1228,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       nsupport++;
       LM_MPR_COUNT(4, 1);
       D3 sup[2];
-#pragma nounroll
-      for (int w = 0; w < 2; w++) sup[w] = support1(w, (w == 0) ? dir : dscl(-1.0, dir));
+      support_pair(dir, sup);
       const D3 sv = dsub(sup[0], sup[1]);
       const double dt = ddot(sv, dir);
       if (stage == 0) {
@@ -1830,9 +1932,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
 #ifndef LM_NO_MPR
 #ifdef LM_TIMERS
-              mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
+              mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
 #else
-              mo = mpr_convex_pair(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
+              mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
 #endif
 #endif
             }
