@@ -434,11 +434,12 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     Compile an :class:`MjcfHandle` into a :class:`CompiledModel`.
 
     ``timestep`` overrides ``<option timestep>`` like the reference does (``base.py:33,109-111``).
-    ``drop_mesh_geoms``: collidable mesh geoms need a convex-hull collider that is not built yet; when True they
-    take no part in collision (counted in ``m.n_dropped_mesh_geoms``) instead of raising. When the mesh files can be
-    read (``handle.base_dir``), each such geom is kept as a ``GEOM_MESH`` PROXIMITY geom — a bounding capsule
-    (``geom_pos``/``geom_quat`` = capsule frame in the body frame, z along the capsule; ``geom_size`` = radius, half length) that the step only uses to count
-    how often a mesh came within reach of the floor (``unhandled_geoms`` statistic); without files they are removed.
+    ``drop_mesh_geoms`` (historical name: the flag says "mesh geoms are expected"): collidable mesh geoms collide as their CONVEX HULLS
+    (against the floor: support vertex + hull-graph neighbours; against other geoms: the convex collider), which needs the mesh files.
+    When they can be read (``handle.base_dir``), each such geom is kept as a ``GEOM_MESH`` geom with its hull vertices, vertex graph,
+    centre of mass and a bounding capsule (``geom_pos``/``geom_quat`` = capsule frame in the body frame, z along the capsule;
+    ``geom_size`` = radius, half length — the broad phases); without files the geom is removed and counted in
+    ``m.n_dropped_mesh_geoms``. Without the flag a model with collidable meshes raises.
     """
     root = handle.root
     comp = root.find("compiler")
@@ -650,7 +651,8 @@ def compile_mjcf(handle, timestep=None, drop_mesh_geoms=False):
     geoms = [g for g in geoms if (g["contype"] != 0 or g["conaffinity"] != 0)]
     m.n_dropped_mesh_geoms = sum(1 for g in geoms if g["type"] == GEOM_MESH)
     if m.n_dropped_mesh_geoms and not drop_mesh_geoms:
-        raise NotImplementedError("collidable mesh geoms need the convex-hull path (not built yet)")
+        raise NotImplementedError("this model has collidable mesh geoms: compile it with drop_mesh_geoms=True (they collide as convex hulls, "
+                                  "which needs the mesh files next to the XML)")
     hulls, graphs = {}, {}
     bounds = _mesh_bounds(root, comp, handle.base_dir, hulls, graphs) if m.n_dropped_mesh_geoms else {}
     kept = []
