@@ -1754,13 +1754,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (Q::kRep > 1) { n_overflow = (int)Q::rep_sum((float)n_overflow); n_unhandled = (int)Q::rep_sum((float)n_unhandled); }
       cnt.overflow += n_overflow; cnt.unhandled += n_unhandled;
     }
-    // ======== self-collisions (PAIRS): sphere / capsule pairs between links of different chains or a link and the root ========
-    // Broad phase per forward pass: bounding spheres of the two links (list in the constant-table tail, one entry per link
-    // pair and lane involved). A pair within reach walks its geom pairs in the geom-pair table (global memory): closest
-    // points of the two capsule segments, one contact when closer than the margin. BOTH lanes of a cross-chain pair run the
-    // same arithmetic on the same numbers and each records the contact as a slot of its own ("mirror" slots: same point,
-    // frame and parameters, opposite sign); every replica records all of them (identical words to identical addresses).
-    // Geom pairs without a collider (a box or a cylinder against something) are tested as bounding capsules and counted.
+    // ======== self-collisions (PAIRS): geom pairs between two links of the chains, or a link and the root body ========
+    // Per forward pass (when due, below): link pairs by their bounding spheres (one list entry per pair, in one of its two lanes),
+    // their body pairs by bounding capsules (body-pair table, global memory), their geom pairs by the closest points of the two
+    // bounding-capsule segments (geom-pair table): a sphere / capsule pair closer than its margin is a closed-form contact, a pair
+    // the engine sends to its general convex collider goes through MPR, a pair with one of the engine's native box colliders is
+    // counted. The lane that tested a cross-chain pair hands the contact to the partner lane; each records it as a slot of its own
+    // ("mirror" slots: same point, frame and parameters, opposite sign); every replica records all of them (identical words to
+    // identical addresses). The pass itself is described where its work lists are declared.
     int pair_mask = 0;               // partner lanes of this lane's cross-chain slots
     // The pass is SKIPPED while it provably cannot find anything: `pair_slack` is the smallest gap (distance minus margin)
     // over all pairs of this quad at the last detection, less the distance the links can have travelled since — per substep
