@@ -12,5 +12,6 @@ rew = torch.empty(4096, device="cuda"); done = torch.empty(4096, dtype=torch.uin
 for _ in range(5):
     b.step_device(act, obs_t, rew, done, stream=torch.cuda.current_stream().cuda_stream, sync=False)
 torch.cuda.synchronize()
+terminal, ended = (done & 1).bool(), (done & 2).bool()        # the done byte is a bit field (include/locohip.h)
 st = b.rollout(100, action_mode=1, steps_per_launch=25)
-print("ok", obs.shape, float(obs_t.abs().max()), int(done.sum()), st["env_steps"], st["nan_resets"])
+print("ok", obs.shape, float(obs_t.abs().max()), int(terminal.sum()), int(ended.sum()), st["env_steps"], st["nan_resets"])
