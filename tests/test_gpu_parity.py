@@ -1272,10 +1272,10 @@ def _worker_oracle_steps(args):
 
 
 @pytest.mark.parametrize("task,kw,policy,nroll,min_ok", [("UnitreeA1.simple", {}, "zero", 12, 0.97), ("UnitreeA1.simple", {}, "random", 12, 0.97),
-                                                         ("HumanoidTorque.run", {}, "random", 12, 0.85), ("HumanoidTorque.run", {}, "random", 3, 0.95),
-                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.9),
-                                                         ("Talos.walk", {}, "random", 12, 0.9), ("UnitreeH1.walk", {}, "random", 3, 0.9),
-                                                         ("UnitreeG1.walk", {}, "random", 3, 0.4)])
+                                                         ("HumanoidTorque.run", {}, "random", 12, 0.95), ("HumanoidTorque.run", {}, "random", 3, 0.95),
+                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.97),
+                                                         ("Talos.walk", {}, "random", 12, 0.97), ("UnitreeH1.walk", {}, "random", 3, 0.9),
+                                                         ("UnitreeG1.walk", {}, "random", 3, 0.9)])      # (measured in round 3: 4096 / 4091 / 3964 / 3943 / 4095 / 4090 / 4093 / 3782 / 3821)
 def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok):
     """the error distribution over 4096 REACHABLE states per configuration. The states come from a device
     rollout (dataset states, then `nroll` control steps under the configuration's policy, no restarts: walking, stumbling and
