@@ -1962,17 +1962,34 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // ---- 5. results -> slots: my chain's, then the mirrors of the others' cross-chain results with a link of mine
       auto emit_results = [&]() {
         Q::fence(); Q::quad_sync();
+        // ADMISSION is decided once for the environment, the same way in every lane: a contact between two chains takes a slot in BOTH
+        // lanes or in neither. (Each lane checking only its own room recorded half a contact when the partner was full — a force on one
+        // body without its reaction: momentum out of nothing. Found with tools/probes/r3/find_nonfinite.py: tangled quadrupeds with
+        // more self-contacts than slots ended non-finite, 2 in 12 M env-steps under the random policy, where the fp64 oracle stays sane.)
+        int free_of[4];
+        share4(NS - nslot, free_of);
+        auto room = [&](int k_) -> int { return (k_ == 0) ? free_of[0] : ((k_ == 1) ? free_of[1] : ((k_ == 2) ? free_of[2] : free_of[3])); };
+        auto take = [&](int k_) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) if (j == k_) free_of[j]--;
+        };
 #pragma nounroll
-        for (int cs0 = 0; cs0 < 4; cs0++) {
-          const int cs = (cs0 + c) & 3;                  // own results first
+        for (int cs = 0; cs < 4; cs++) {
           const int nres = (nres_of[cs] < kRcap) ? nres_of[cs] : kRcap, dls = cs - c;
 #pragma nounroll
           for (int k = 0; k < nres; k++) {
             const int item = (int)PEER(dls, kRes + 8 * k);
             EntryCtx E;
             entry_ctx_of(cs, item >> 16, E);
+            const int partner = (E.kb != 7 && !E.same_lane) ? E.lb : -1;
+            if (room(cs) <= 0 || (partner >= 0 && room(partner) <= 0)) {       // no room on one side: the whole contact is dropped, counted once
+              if (cs == c) n_over++;
+              continue;
+            }
+            take(cs);
+            if (partner >= 0) take(partner);
             if (cs != c) {
-              if (E.kb == 7 || E.lb != c || E.same_lane) continue;          // not a pair with a link of mine
+              if (partner != c) continue;                                        // not a pair with a link of mine
               const int ka_o = E.ka;
               E.ka = E.kb; E.kb = ka_o; E.lb = cs; E.own_q = 1 - E.own_q; E.dl = dls; E.dlo = 0; E.same_lane = false;       // my view of it
             }

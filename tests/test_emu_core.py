@@ -617,3 +617,24 @@ def test_core_unitree_h1_free_arms_shared_torso_link():
         compared += 1
         assert np.abs(q[i] - qo).max() < 1e-5 and np.abs(v[i] - vo).max() < 1e-3, (i, np.abs(q[i] - qo).max(), np.abs(v[i] - vo).max())
     assert compared >= 2
+
+
+def test_core_cross_chain_contacts_are_admitted_in_both_lanes_or_in_neither():
+    """Two tangled quadruped states with more self-contacts than contact slots (tests/golden/a1_tangled_states.npz, found on the GPU
+    with tools/probes/r3/find_nonfinite.py): a contact between two chains recorded in one lane only — the partner lane out of slots
+    — is a force without its reaction; the step went to |v| = 289 and to non-finite numbers where the fp64 oracle stays at 12-14 m/s.
+    With the admission decided once per environment the device code drops whole contacts and stays with the oracle's magnitudes."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    m = env._model
+    cmod = env._chain_model()
+    o = Oracle(pack_model(m))
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_tangled_states.npz"))
+    for i in range(len(d["q"])):
+        q0, v0, a = d["q"][i].astype(np.float64), d["v"][i].astype(np.float64), d["a"][i]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        qo, vo = o.step(q0, v0, ctrl, 10)[:2]
+        q, v, _, cnt, _ = pyemu.run(cmod, q0, v0, a, nsub=10, rep=4)
+        assert cnt["overflow"] > 0                                   # the states DO drop contacts (outside the validated model, flagged)
+        assert np.isfinite(q).all() and np.isfinite(v).all() and np.abs(v).max() < 1.5 * np.abs(vo).max()

@@ -1835,3 +1835,20 @@ def test_done_byte_bit_layout_and_episode_restarted_key(setup):
     e2.enable_auto_reset(seed=1, horizon=2)
     keys = [set(e2.step(np.zeros((8, 12)))[3].keys()) for _ in range(3)]
     assert all(k == {"episode_restarted"} for k in keys)
+
+
+def test_tangled_quadruped_states_stay_finite(setup):
+    """The two tangled quadruped states of tests/golden/a1_tangled_states.npz (more self-contacts than slots): a contact between two
+    chains is admitted in both lanes or in neither, so dropped contacts no longer inject momentum — the step stays finite and at the
+    oracle's speed scale (it went non-finite before; tests/test_emu_core.py has the same check for the device code on the CPU)."""
+    env, hm, oracle, HipBatch = setup
+    d = np.load(__file__.replace("test_gpu_parity.py", "golden/a1_tangled_states.npz"))
+    n = len(d["q"])
+    b = HipBatch(hm, n)
+    b.set_state(d["q"], d["v"])
+    b.step(d["a"])
+    q, v = b.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and (b.flags() & 1).all() and b.stats()["nan_resets"] == 0
+    for i in range(n):
+        vo = _oracle_step(env, oracle, d["q"][i].astype(np.float64), d["v"][i].astype(np.float64), d["a"][i])[1]
+        assert np.abs(v[i]).max() < 1.5 * np.abs(vo).max()
