@@ -573,8 +573,9 @@ def _h1_kat_inputs(env, task):
 
 
 # rows k -> k + 1 reproduced to qpos 1e-8 / qvel 5e-6 (28 of 58); the others: within 1e-3 (5 more) or listed with their error in
-# profiles/r3_notes.md §2 — all of them have a foot lying nearly flat, where the engine's further plane-hull contacts depend on its
-# own qhull triangulation of nearly planar quads of the sole
+# profiles/r3_notes.md §2 — 25 carry an MPR contact between two curved shapes (hip-yaw capsule on hip-pitch cylinder; libccd stops by
+# tolerance, the contact point depends on its iteration path), 5 have a foot lying nearly flat, where the engine's further plane-hull
+# contacts depend on its own hull graph of the sole
 H1_EXACT = {"run": [0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 25, 26, 27, 29], "walk": [0, 1, 2, 13, 15, 16, 17, 18, 19, 20, 21, 25, 26]}
 H1_WITHIN_1E3 = {"run": 17, "walk": 16}
 
