@@ -77,8 +77,16 @@ def parity_sample(env, hm, table, random_policy, n=64):
             continue                                         # a collider-less geom within reach of the floor on either side
         used += 1
         eq, ev = max(eq, np.abs(q[i] - qo).max()), max(ev, np.abs(v[i] - vo).max())
+    tol = dict(qpos=1e-4, qvel=1e-2)
     return dict(qpos_linf=eq, qvel_linf=ev, states=used, against="fp64 oracle port (CPU), one control step = 10 substeps, "
-                "same (qpos, qvel, ctrl)", tolerance=dict(qpos=1e-4, qvel=1e-2))
+                "same (qpos, qvel, ctrl)", tolerance=tol, within_tolerance=bool(used > 0 and eq <= tol["qpos"] and ev <= tol["qvel"]))
+
+
+def leg_rate(envs_per_gpu, world, steps, seconds):
+    """env-steps/s of ONE timed block: every environment of every rank advances `steps` control steps in `seconds` (the maximum
+    over the ranks). The only place a rate is computed — cumulative device counters never enter a rate (round 3 divided the
+    cumulative count of all legs by the last leg's time)."""
+    return dict(value=envs_per_gpu * world * steps / seconds, ms_per_step=1e3 * seconds / steps)
 
 
 def baseline_metric():
@@ -168,7 +176,9 @@ def main():
                     "(checks the multi-rank control flow on a one-GPU box; the numbers mean nothing)")
     ap.add_argument("--dump-states", default=None, help=argparse.SUPPRESS)              # tests: <prefix>.rank<r>.npz with the final states
     ap.add_argument("--require-rccl", action="store_true", help="exit non-zero instead of reducing the metrics over TCP sockets when the RCCL "
-                    "communicator does not come up (N > 1)")
+                    "communicator does not come up (N > 1). The DEFAULT whenever WORLD_SIZE > 1 and every rank has a GPU of its own")
+    ap.add_argument("--allow-tcp-fallback", action="store_true", help="N > 1: let the metric reduction fall back to the rendezvous sockets "
+                    "when the RCCL communicator does not come up (the bench line names the transport in config.collective)")
     ap.add_argument("--sustained", type=int, default=200, help="control steps of the extra sustained leg (per-step launches, one "
                     "timed block of at least this many steps; 0 = skip; skipped when --steps already covers it)")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
@@ -195,8 +205,12 @@ def main():
     from loco_mujoco_amd.utils.collective import Collective, MAX, SUM
     if args.share_gpu:
         local_rank = 0
+    from loco_mujoco_amd import backend as _be
+    # one rank per GPU on a node that has a GPU for every rank: the reduction IS RCCL or the run fails (no silent socket fallback)
+    own_gpu = world > 1 and not args.share_gpu and _be.load_library().lm_device_count() >= world
+    require_rccl = (args.require_rccl or (own_gpu and not args.allow_tcp_fallback)) and not args.share_gpu
     coll = Collective(backend="tcp" if args.share_gpu else "rccl", rank=rank, world=world, device=local_rank,
-                      require_rccl=args.require_rccl and not args.share_gpu)
+                      require_rccl=require_rccl)
 
     from loco_mujoco_amd import LocoEnv
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -239,13 +253,22 @@ def main():
         coll.barrier()                 # ... then every rank has arrived (no-op for one rank)
         b.sync()
 
+    def timed_leg(n_steps, seed, steps_per_launch=1):
+        """One timed block: barrier + device sync, this rank's clock around exactly `n_steps` control steps + device sync, barrier.
+        The clock stops BEFORE the closing barrier (a host-staged all-reduce): the maximum over the ranks of these per-rank times,
+        taken at report time, is what a clock around both barriers would show less the collective's own latency. The device
+        counters are reset first, so the returned statistics are this block's alone."""
+        b.stats(reset=True)
+        barrier()
+        t = time.perf_counter()
+        stats = b.rollout(n_steps, action_mode=action_mode, seed=seed, steps_per_launch=steps_per_launch)
+        b.sync()
+        dt = time.perf_counter() - t
+        barrier()
+        return dt, stats
+
     b.rollout(args.warmup, action_mode=action_mode, seed=11)
-    b.stats(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    st = b.rollout(args.steps, action_mode=action_mode, seed=12)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, st = timed_leg(args.steps, 12)
 
     # extra leg, reported beside `value`, never as `value`: the same number of control steps with --fuse steps per launch
     # (lm_rollout_fused: no device-wide join between control steps; bitwise the same results). Continues from the state
@@ -253,21 +276,15 @@ def main():
     fused = None
     if args.fuse > 1:
         b.rollout(args.fuse, action_mode=action_mode, seed=13, steps_per_launch=args.fuse)
-        barrier()
-        t1 = time.perf_counter()
-        stf = b.rollout(args.steps, action_mode=action_mode, seed=14, steps_per_launch=args.fuse)
-        barrier()
-        fused = [time.perf_counter() - t1, stf["kernel_ms"]]
+        dtf, stf = timed_leg(args.steps, 14, steps_per_launch=args.fuse)
+        fused = [dtf, stf["kernel_ms"]]
 
     # second extra leg: a sustained block of per-step launches (thermal / clock steady state rather than a short burst);
     # the timed region above already is one when --steps >= --sustained
     sustained = None
     if args.sustained > args.steps:
-        barrier()
-        t2 = time.perf_counter()
-        sts = b.rollout(args.sustained, action_mode=action_mode, seed=15)
-        barrier()
-        sustained = [time.perf_counter() - t2, sts["env_steps"]]
+        dts, sts = timed_leg(args.sustained, 15)
+        sustained = [dts, sts["env_steps"]]
 
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
@@ -283,7 +300,10 @@ def main():
     if rank != 0:
         return
     env_steps = vals[1]
-    value = env_steps / elapsed
+    main_leg = leg_rate(n, world, args.steps, elapsed)
+    value = main_leg["value"]
+    # the device's own count of this block (counters reset right before it) must be the same number of env-steps
+    assert abs(env_steps - n * world * args.steps) < 0.5, (env_steps, n, world, args.steps)
     m = env._model
     forwards = 40 if m.integrator else 10             # RK4: four forward passes per substep
     per_env_step = algorithmic_bytes_per_env_step(nv, nv, len(env._action_indices), b.nobs, getattr(m, "na", 0))
@@ -298,8 +318,8 @@ def main():
     import hashlib
     from loco_mujoco_amd import backend as _backend
     lib_sha = hashlib.sha256(open(_backend.LIB_PATH, "rb").read()).hexdigest()[:16]
-    # profiles/<tag>_pmc.json: "r3" for the bench line, "r3_<task>[.dr][<envs>]" for the other configurations
-    tag = "r3" if (default_task and n == 4096) else "r3_%s%s%s" % (args.task, ".dr" if args.dr else "", "" if n == 4096 else str(n))
+    # profiles/<tag>_pmc.json: "r4" for the bench line, "r4_<task>[.dr][<envs>]" for the other configurations
+    tag = "r4" if (default_task and n == 4096) else "r4_%s%s%s" % (args.task, ".dr" if args.dr else "", "" if n == 4096 else str(n))
     prof = os.path.join(ROOT, "profiles", tag + "_pmc.json")
     prof_name = "profiles/%s_pmc.json" % tag
     prof_note = "no committed profile for this workload"
@@ -325,7 +345,7 @@ def main():
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, %d envs/GPU, %s rollout, device-side auto-reset "
                                "(horizon 1000), 10 physics substeps per env-step"
@@ -355,15 +375,17 @@ def main():
     if valu is not None:
         out["roofline"]["valu"] = valu
     if fused is not None:
-        fel = fused_elapsed
-        out["rollout_fused"] = {"steps_per_launch": args.fuse, "value": n * world * args.steps / fel, "unit": "env-steps/s",
-                                "ms_per_step": 1e3 * fel / args.steps,
+        fl = leg_rate(n, world, args.steps, fused_elapsed)
+        out["rollout_fused"] = {"steps_per_launch": args.fuse, "value": fl["value"], "unit": "env-steps/s",
+                                "ms_per_step": fl["ms_per_step"],
                                 "note": "policy-free rollout with %d control steps per launch (lm_rollout_fused): every "
                                         "environment advances on its own, results bitwise those of single-step launches; "
                                         "a policy in the loop gets `value`" % args.fuse}
     if sustained is not None and tmax[12] > 0:
-        out["sustained"] = {"steps": args.sustained, "value": vals[13] / float(tmax[12]), "unit": "env-steps/s",
-                            "ms_per_step": 1e3 * float(tmax[12]) / args.sustained,
+        sl = leg_rate(n, world, args.sustained, float(tmax[12]))
+        assert abs(vals[13] - n * world * args.sustained) < 0.5, (vals[13], n, world, args.sustained)    # this block's own count
+        out["sustained"] = {"steps": args.sustained, "value": sl["value"], "unit": "env-steps/s",
+                            "ms_per_step": sl["ms_per_step"],
                             "note": "one timed block of %d per-step launches after the timed region (same policy, same "
                                     "state mixture); `value` is the --steps block" % args.sustained}
     elif args.sustained:
@@ -384,6 +406,12 @@ def main():
                                        % (allc["cores"], 8.0, allc["per_core"]))
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    if "parity" in out and not out["parity"]["within_tolerance"]:
+        # the second half of the metric failed: the line above says so ("within_tolerance": false), and so does the exit code
+        print("bench: device vs fp64 oracle beyond the stated tolerance: qpos %.3g (tol %.0e), qvel %.3g (tol %.0e)"
+              % (out["parity"]["qpos_linf"], out["parity"]["tolerance"]["qpos"], out["parity"]["qvel_linf"],
+                 out["parity"]["tolerance"]["qvel"]), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

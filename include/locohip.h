@@ -67,7 +67,9 @@ typedef struct {
   double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
   double self_proximity;   /* forward passes x geom pairs WITHOUT a collider (a box / cylinder against another geom of the robot)
                               within the contact margin: the state was outside the validated collision domain */
-  double self_contacts;    /* self-contacts (sphere / capsule pairs of two links) simulated, summed over the forward passes */
+  double self_contacts;    /* self-contacts (sphere / capsule pairs, convex pairs of two links) simulated, summed over the forward passes */
+  double replayed_env_steps; /* env-steps that left the regular kernel's capacity (contact slots, pair lists, convex collider) and were
+                              run by the family's replay kernel instead (lm_batch_set_replay); part of env_steps */
 } lm_stats;
 
 typedef struct {
@@ -97,6 +99,15 @@ void lm_batch_destroy(lm_batch* b);
 /* Launch geometry (no counterpart in the reference: its step is one MjData at a time, base.py:185). envs_per_workgroup = 4: one wave
    per 4 environments, each replicated over 4 quads (default); 8 or 16: plain layout without replicas. Same physics either way. */
 int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup);
+/* Speculate / replay (no counterpart in the reference: the engine it calls sizes its contact buffers for everything,
+   environments/data/humanoid/humanoid_torque.xml:19 njmax 1000 / nconmax 400, data/atlas/atlas.xml:23). The regular step kernels hold a few
+   contact slots per chain; a control step that needs more is abandoned unstored and run by the family's replay kernel (a slot for
+   every contact, long pair lists, the convex collider), launched behind every step launch. enabled = 1 (default); 0 = regular
+   kernels only: contacts beyond the slots are dropped and counted in overflow_contacts (A/B measurements). */
+int lm_batch_set_replay(lm_batch* b, int enabled);
+/* one byte per environment: 1 = the replay kernel ran at least one control step of this environment since the marks were last
+   cleared (reset = 1 clears them after the copy; out may be NULL). Diagnostics of THIS path, like lm_get_flags. */
+int lm_get_replay_marks(lm_batch* b, uint8_t* out, int reset);
 
 /* mask: [n_envs] bytes, NULL = all environments. Setting a state clears that env's warm start. */
 int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_t* mask);

@@ -23,7 +23,7 @@ class Dims(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("env_steps", "episodes", "reward_sum", "nan_resets", "solver_iters",
                                           "overflow_contacts", "unhandled_geoms", "linesearch_evals", "linesearch_capped", "steps_with_8plus_iters", "kernel_ms",
-                                          "self_proximity", "self_contacts")]
+                                          "self_proximity", "self_contacts", "replayed_env_steps")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
-           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
+           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
            "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows"]
@@ -64,6 +64,8 @@ def load_library():
     lib.lm_model_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
     lib.lm_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.lm_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
+    lib.lm_batch_set_replay.argtypes = [C.c_void_p, C.c_int]
+    lib.lm_get_replay_marks.argtypes = [C.c_void_p, _U8, C.c_int]
     lib.lm_batch_destroy.argtypes = [C.c_void_p]
     lib.lm_batch_destroy.restype = None
     lib.lm_set_state.argtypes = [C.c_void_p, _F, _F, _U8]
@@ -160,6 +162,17 @@ class HipBatch:
             self._h = None
 
     __del__ = close
+
+    def set_replay(self, enabled):
+        """Speculate / replay (``lm_batch_set_replay``): on by default; off = the regular kernels alone, contacts beyond their slots
+        are dropped and counted (A/B measurements)."""
+        _check(self._lib.lm_batch_set_replay(self._h, int(bool(enabled))))
+
+    def replay_marks(self, reset=False):
+        """Per environment: did the replay kernel run one of its control steps since the marks were last cleared?"""
+        out = np.empty(self.n, dtype=np.uint8)
+        _check(self._lib.lm_get_replay_marks(self._h, out.ctypes.data_as(_U8), int(bool(reset))))
+        return out != 0
 
     def set_state(self, qpos, qvel, mask=None):
         q, v = _f32(qpos, (self.n, self.nq)), _f32(qvel, (self.n, self.nv))

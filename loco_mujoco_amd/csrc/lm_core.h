@@ -160,6 +160,8 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   int selfprox;      // forward passes x geom pairs without a collider (box / cylinder against something) within the margin
   int selfcon;       // self-contacts simulated, summed over the forward passes
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
+  int need_full;     // a convex pair came within reach in a kernel compiled WITHOUT the convex collider (PM == 2): the control step is
+                     // abandoned and replayed by the full kernel (lm_step.h)
   float grf[4][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's foot-force groups (2; 4 in the six-link kernels)
 #ifdef LM_TIMERS
   long long t[16];
@@ -237,7 +239,14 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> 
   static constexpr int kAct = kFrame + MC * 18;    // muscle activations of this lane's chain (NM), then their controls (NM)
   static constexpr int kCtrl = kAct + NM;
   static constexpr int kBS = kCtrl + NM;         // world centres of the links' bounding spheres (self-collision broad phase)
-  static constexpr int kSize = kBS + (PAIRS ? MC * 3 : 0);
+  // BIG kernels (NS > 8: the replay kernels that take over a control step in which a regular kernel ran out of contact slots,
+  // lm_step.h): one slot per possible contact of the chain in any state the robots reach, and a queue / result list of the pair
+  // pass of their own (the regular kernels keep theirs in the part of lane memory that holds M and the twists later in the pass)
+  static constexpr bool kBig = NS > 8;
+  static constexpr int kQCap = kBig ? 128 : ((MC >= 5) ? 24 : 8);    // convex pairs per chain and pass
+  static constexpr int kRCap = kBig ? NS : ((NS < 8) ? NS : 8);      // contacts per chain and pass
+  static constexpr int kLists = kBS + (PAIRS ? MC * 3 : 0);
+  static constexpr int kSize = kLists + ((PAIRS && kBig) ? kQCap + 8 * kRCap : 0);
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -1369,7 +1378,9 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
 // NM > 0: the chain's muscles (table `mt`, lm_layout.h MT_*/MU_*) act on the chain dofs; their activations and
 // controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
 // DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
-template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, int DR = 0, bool PAIRS = false>
+// PM: 0 no self-collisions, 1 the pair pass with the convex collider, 2 the pair pass WITHOUT it (a convex pair within reach sets
+// cnt.need_full: the quadruped's kernels, whose regular gaits never touch one)
+template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, int DR = 0, int PM = 0>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
@@ -1377,6 +1388,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
+  constexpr bool PAIRS = PM != 0, NOMPR = PM == 2;
   int oz = LM_OPAQUE_ZERO();
   const bool pyramidal = (CONE < 0) ? (P.cone == 0) : (CONE == 0);
   // CONE == LM_CONE_PYRAMIDAL promises that every contact of the model is a condim-3 pyramid (checked by the launcher):
@@ -1811,12 +1823,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // The lanes agree on list positions through ballots of their flags (lists are filled in work order, chain by chain). W, S, the
       // queue and R sit in the part of lane memory that holds M, the twists and the link images later in the pass. Lists that fill up
       // (W, S) make the pass run in chunks of entries; a full queue or result list drops contacts, counted in `overflow`.
-      constexpr int kQueue = (MC >= 5) ? 24 : 8;                      // convex pairs per chain and pass
+      constexpr int kQueue = LMm::kQCap;                              // convex pairs per chain and pass
       constexpr int kWcap = (MC >= 5) ? 24 : 12;                      // link-pair entries per chain and chunk
       constexpr int kScap = 24;                                       // body pairs in reach per chain and chunk (an entry has at most 24)
-      constexpr int kRcap = (NS < 8) ? NS : 8;                        // contacts per chain and pass (a chain has NS slots)
-      constexpr int kW1 = LMm::kMcc, kS1 = kW1 + kWcap, kQItem = kS1 + 2 * kScap, kRes = kQItem + kQueue;
-      static_assert(!PAIRS || kRes + 8 * kRcap <= LMm::kFrame, "the work lists of the pair pass must fit the dead part of lane memory");
+      constexpr int kRcap = LMm::kRCap;                               // contacts per chain and pass (a chain has NS slots)
+      constexpr int kW1 = LMm::kMcc, kS1 = kW1 + kWcap;
+      constexpr int kQItem = LMm::kBig ? LMm::kLists : kS1 + 2 * kScap, kRes = kQItem + kQueue;
+      static_assert(!PAIRS || kS1 + 2 * kScap + (LMm::kBig ? 0 : kQueue + 8 * kRcap) <= LMm::kFrame, "the work lists of the pair pass must fit the dead part of lane memory");
       constexpr int kW = 4 * Q::kRep;                                 // lanes of one environment
       const int me = Q::rep() * 4 + c;
       int base[5];
@@ -1932,11 +1945,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
               const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
 #ifndef LM_NO_MPR
+              if constexpr (!NOMPR) {
 #ifdef LM_TIMERS
-              mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
+                mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
 #else
-              mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
+                mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
 #endif
+              }
 #endif
             }
             const bool found = mo.found != 0;
@@ -2236,7 +2251,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   }
                   is_prox = reach;
                 } else if (in_reach && kind == 2) {
-                  want_q = true; code = (float)(i * 65536 + first + v);
+                  if constexpr (NOMPR) cnt.need_full = 1;          // no collider in this kernel: the control step goes to the full one
+                  else { want_q = true; code = (float)(i * 65536 + first + v); }
                 } else if (in_reach) {
                   has_res = true; code = (float)(i * 65536 + first + v);
                   rdist = G.dist;
@@ -3371,13 +3387,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 
 // one physics substep with the model's integrator. RK4: classical 4-stage scheme on (qpos, qvel), every stage a full
 // forward pass incl. collision detection and constraint solve, no implicit damping (MuJoCo mj_RungeKutta semantics).
-template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, int DR = 0, bool PAIRS = false>
+template <class Q, int MC, int NS, bool RK4, int CONE = -1, int NM = 0, int DR = 0, int PM = 0>
 LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
                     Counters& cnt, const Debug* dbg, const float* mt = nullptr, const DofPrm<MC>* dp = nullptr,
                     bool want_grf = false, float* pair_slack = nullptr) {
   static_assert(!(RK4 && NM > 0), "muscle activations are only advanced by the Euler integrator");
-  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf, pair_slack); return; }
+  if (!RK4) { forward<Q, MC, NS, true, CONE, NM, DR, PM>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, dbg, mt, dp, want_grf, pair_slack); return; }
   float q0r[6], v0r[6], q0c[MC], v0c[MC], dqr[6], dvr[6], dqc[MC], dvc[MC];
 #pragma unroll
   for (int i = 0; i < 6; i++) { q0r[i] = qr[i]; v0r[i] = vr[i]; dqr[i] = 0; dvr[i] = 0; }
@@ -3385,7 +3401,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) { q0c[k] = qc[k]; v0c[k] = vc[k]; dqc[k] = 0; dvc[k] = 0; }
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
-    forward<Q, MC, NS, false, CONE, 0, DR, PAIRS>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
+    forward<Q, MC, NS, false, CONE, 0, DR, PM>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
                                            want_grf && st == 3);   // the engine's data hold the 4th stage when mj_step returns
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]

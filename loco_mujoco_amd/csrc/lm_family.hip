@@ -13,7 +13,11 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
 #define LM_A1_NS 6
 #endif
 #ifndef LM_A1_PAIRS
-#define LM_A1_PAIRS true
+// 1: the pair pass with the convex collider inlined. 2 (without it: a control step that brings a box / cylinder pair within reach is
+// abandoned and replayed by the family's replay kernel, lm_step.h) was measured in round 4: the regular kernel's scratch falls from
+// 608 to 44 bytes per lane, the bench rollout stays where it is (1.575 vs 1.585 ms, same box: what the pair pass costs is the
+// detection, not the collider), and under a random policy two environments per launch wait for their replay. Kept as a switch.
+#define LM_A1_PAIRS 1
 #endif
   return launch_family<3, LM_A1_NS, false, LM_CONE_ELLIPTIC, 0, LM_PART, LM_A1_PAIRS>(L, a, kind);
 #elif LM_FAMILY == 1    // humanoid, RK4, one box foot per leg (HumanoidTorque)
@@ -29,11 +33,11 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
 #elif LM_FAMILY == 7    // UnitreeG1 with the torso joint welded: two 6-link legs (four 1 mm spheres per foot), two 5-link arms
   return launch_family<6, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
 #elif LM_FAMILY == 8    // HumanoidTorque with its bone hulls colliding (RK4): floor + self-contacts in eight slots
-  return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART, true>(L, a, kind);
+  return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART, 1>(L, a, kind);
 #elif LM_FAMILY == 9    // UnitreeH1: hip-yaw cylinders and link meshes colliding (Euler)
-  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART, true>(L, a, kind);
+  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART, 1>(L, a, kind);
 #elif LM_FAMILY == 10   // HumanoidMuscle with its bone hulls colliding
-  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART, true>(L, a, kind);
+  return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART, 1>(L, a, kind);
 #elif LM_PART == 2
   return false;          // the generic family has no kernels with per-environment parameters
 #else

@@ -54,6 +54,10 @@ struct lm_batch {
   hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
   float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats, var_rows; bool dofprm_of_variants;   // model variants (lm_set_model_variants, lm_set_variant_rows)
   float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
+  // speculate / replay (lm_step.h): list of the environments whose control step left the regular kernel's capacity, its control
+  // words, the fused step at which each left; `replay` = 0 switches the mechanism off (contacts beyond the slots are then dropped)
+  int *replay_list, *replay_ctl, *stall; int replay;
+  unsigned char* replay_mark;
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
@@ -85,6 +89,7 @@ static int family_of(const lm_batch* b) {
 }
 
 static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
+static bool family_has_pairs(int fam) { return fam == 0 || fam == 8 || fam == 9 || fam == 10; }
 
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
@@ -114,7 +119,13 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   else if (b->nvar > 0) kind = rep ? lmk::LMK_DRV_REP4 : lmk::LMK_DRV_REP1;
   else if (b->dofprm) kind = rep ? lmk::LMK_DR_REP4 : lmk::LMK_DR_REP1;
   else kind = rep ? lmk::LMK_REP4 : lmk::LMK_REP1;
-  if (!table[fam][0](L, a, kind) && !table[fam][1](L, a, kind) && !table[fam][2](L, a, kind)) g_launch_err = "no kernel of this kind in the family";
+  if (!table[fam][0](L, a, kind) && !table[fam][1](L, a, kind) && !table[fam][2](L, a, kind)) { g_launch_err = "no kernel of this kind in the family"; return; }
+  // the replay kernel, right behind on the same stream: it runs the control steps the launch above abandoned (lm_step.h). An
+  // empty list costs a few microseconds (256 workgroups read one word and leave)
+  if (!FWD && a.replay_list) {
+    const int big = b->nvar > 0 ? lmk::LMK_BIG_DRV : (b->dofprm ? lmk::LMK_BIG_DR : lmk::LMK_BIG);
+    if (!table[fam][0](L, a, big) && !table[fam][1](L, a, big) && !table[fam][2](L, a, big)) g_launch_err = "no replay kernel in the family";
+  }
 }
 
 extern "C" {
@@ -299,6 +310,9 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
+  HIPCHK(hipMalloc(&b->replay_list, sizeof(int) * N)); HIPCHK(hipMalloc(&b->stall, sizeof(int) * N)); HIPCHK(hipMalloc(&b->replay_ctl, sizeof(int) * 4));
+  HIPCHK(hipMemset(b->replay_list, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->stall, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->replay_ctl, 0, sizeof(int) * 4));
+  HIPCHK(hipMalloc(&b->replay_mark, N)); HIPCHK(hipMemset(b->replay_mark, 0, N));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
@@ -325,8 +339,26 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
     b->epb = epb;
   }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
+  b->replay = 1;
+  {
+    // a model with self-collision tables needs a kernel family with the pair pass: anything else would silently not simulate them
+    const int fam = family_of(b);
+    if (m->T.npair > 0 && !family_has_pairs(fam)) {
+      delete b;
+      return fail("the model carries self-collision tables but its kernel family has no pair pass (RK4 with muscles, or a cone / condim the pair families are not compiled for)");
+    }
+  }
   if (batch_alloc(b)) { lm_batch_destroy(b); return 1; }     // g_err holds the failed call; nothing leaks
   *out = b;
+  return 0;
+}
+
+/* speculate / replay (lm_step.h): on (default) = a control step that needs more contact slots, longer pair lists or — the
+   quadruped — the convex collider is replayed by the family's big kernel instead of dropping contacts; off = the regular kernels
+   alone (contacts beyond the slots are dropped and counted: the behaviour of rounds 1-3, kept for A/B measurements). */
+int lm_batch_set_replay(lm_batch* b, int enabled) {
+  if (!b) return fail("null batch");
+  b->replay = enabled ? 1 : 0;
   return 0;
 }
 
@@ -337,6 +369,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
 int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup) {
   if (!b) return fail("null batch");
   const int def = b->N < 4 ? b->N : 4;
+  if (envs_per_workgroup == 4) envs_per_workgroup = def;      // the advertised default, also for a batch of fewer than four environments
   if (envs_per_workgroup != def && envs_per_workgroup != 8 && envs_per_workgroup != 16) return fail("environments per workgroup: 4 (replicated layout), 8 or 16 (plain layout)");
   if (envs_per_workgroup > def && !family_has_replicas(b)) return fail("the generic kernel family has one layout only");
   b->epb = envs_per_workgroup;
@@ -349,7 +382,7 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark,
                   b->vrec, b->vgt, b->vgpt, b->var};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -479,6 +512,7 @@ int lm_set_dof_params(lm_batch* b, const float* damping, const float* stiffness,
     HIPCHK(hipMemcpy(b->dofprm, init.data(), sizeof(float) * 3 * nv * N, hipMemcpyHostToDevice));
   }
   const float* src[3] = {damping, stiffness, frictionloss};
+  if (damping || stiffness || frictionloss) b->dofprm_of_variants = false;      // the caller's own values: they outlive the variant pool
   for (int p = 0; p < 3; p++) {
     if (!src[p]) continue;
     for (size_t i = 0; i < (size_t)N * nv; i++) if (!(src[p][i] >= 0.0f) && (!mask || mask[i / nv])) return fail("joint parameters must be non-negative");
@@ -604,6 +638,8 @@ static KArgs make_args(lm_batch* b) {
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
+  // speculate / replay: every family but the generic one has a replay kernel
+  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; }
   static const bool no_xcd_map = LM_PROBE_ENV("LM_NO_XCD_MAP") != nullptr;
   a.xcd_map = no_xcd_map ? 0 : 1;
   return a;
@@ -626,7 +662,7 @@ static int drain_stats(lm_batch* b) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
     b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
     b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals; b->acc.linesearch_capped += x.ls_capped; b->acc.steps_with_8plus_iters += x.it_ge8;
-    b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon;
+    b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon; b->acc.replayed_env_steps += x.replayed;
   }
   return 0;
 }
@@ -726,7 +762,7 @@ int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out) {
   HIPCHK(hipSetDevice(b->m->device));
   const int N = b->N; const Task& T = b->m->T; const int nv = T.nv;
   KArgs a = make_args(b);
-  a.stats = nullptr;
+  a.stats = nullptr; a.replay_list = nullptr;
   if (action) { HIPCHK(hipMemcpy(b->action, action, sizeof(float) * T.nu * N, hipMemcpyHostToDevice)); a.action = b->action; a.action_mode = 0; }
   else a.action_mode = 1;
   float* buf; int* ibuf;
@@ -754,6 +790,14 @@ int lm_get_flags(lm_batch* b, uint8_t* out) {
   HIPCHK(hipSetDevice(b->m->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(out, b->flags, b->N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lm_get_replay_marks(lm_batch* b, uint8_t* out, int reset) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (out) HIPCHK(hipMemcpy(out, b->replay_mark, b->N, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(b->replay_mark, 0, b->N));
   return 0;
 }
 

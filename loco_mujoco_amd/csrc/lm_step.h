@@ -102,7 +102,8 @@ struct Task {
   float rp[8];
 };
 
-struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, selfprox, selfcon; };
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, selfprox, selfcon, replayed, pad_[3]; };
+constexpr int kNStats = 13;
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
@@ -129,6 +130,11 @@ struct KArgs {
   lm::Params P; Task T;
   DevStats* stats;
   unsigned long long* timers;   // LM_TIMERS builds: cycle counters per solver region (lane 0 of each workgroup)
+  // speculate / replay (see step_kernel): environments whose control step left the regular kernel's capacity
+  int* replay_list;             // [N] environment ids, appended by the regular kernel (null: no replay kernel follows, drops are final)
+  int* replay_ctl;              // [0] number of entries, [1] workgroups of the replay kernel that are through (the last one clears both)
+  int* stall;                   // [N] the fused control step at which the environment left the regular kernel (0 for single-step launches)
+  unsigned char* replay_mark;   // [N] sticky: the replay kernel ran (part of) this environment's control steps since the marks were last cleared
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
 };
@@ -143,33 +149,55 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, int DR = 0, int REP = 1, bool FUSED = false, bool PAIRS = false>
+// SPECULATE / REPLAY. The regular kernels are sized for what a robot does in its gaits: NS contact slots per chain, a short queue
+// for convex pairs, and — the quadruped's (PM == 2) — no convex-pair collider at all. A control step that needs more (a chain with
+// more simultaneous contacts than slots, a full queue or result list of the pair pass, a convex pair within reach of a kernel
+// without the collider) is ABANDONED: nothing of it is stored, the environment is appended to `replay_list`, and the REPLAY kernel
+// launched right behind (the same code compiled with NS > 8: a slot for every contact, long lists, the collider; one persistent
+// grid that walks the list) runs that control step — and, in a fused rollout, the rest of the launch's control steps — from the
+// untouched state. The engine the reference calls never drops a contact (humanoid_torque.xml:19 njmax 1000 / nconmax 400):
+// neither does this. Whatever exceeds even the replay kernel's capacity is dropped, counted and flagged as before.
+template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, int DR = 0, int REP = 1, bool FUSED = false, int PM = 0>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
+  constexpr bool PAIRS = PM != 0;
+  constexpr bool REPLAY = NS > 8;        // (always compiled with FUSED: a replayed environment finishes the launch's control steps here)
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
   float* cm = dyn_lds;
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
   if (NM > 0) for (int i = threadIdx.x; i < LM_MT_SIZE; i += blockDim.x) mt[i] = a.mt[i];
-  __shared__ float blk_stats[12];
+  __shared__ float blk_stats[kNStats];
   float* lane_mem = dyn_lds + a.T.cm_used;                 // per 16 lanes: contact slot records, M, twists as [field][lane] (LaneMem<MC,NS>::kGroup floats)
   for (int i = threadIdx.x; i < a.T.cm_used && i < LM_CM_SIZE; i += blockDim.x) cm[i] = a.cm[i];
-  for (int i = threadIdx.x; i < 12; i += blockDim.x) blk_stats[i] = 0.0f;
+  for (int i = threadIdx.x; i < kNStats; i += blockDim.x) blk_stats[i] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 3;
   const int e_local = threadIdx.x / (4 * REP);               // REP quads per environment (replicas), see QuadDppT
+  // REPLAY: a persistent grid walks the list of abandoned environments, `epb` per workgroup and round
+  const int n_replay = REPLAY ? a.replay_ctl[0] : 0;
+  for (int item = REPLAY ? (int)blockIdx.x : 0; REPLAY ? item * a.epb < n_replay : item < 1; item += REPLAY ? (int)gridDim.x : 1) {
   // XCD-aware workgroup -> environment mapping. The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (own
   // L2 each), while neighbouring environments share 64-byte lines of the SoA state arrays ([dof][N]: 4 environments of a
   // workgroup use 16 B of a line). Handing every XCD a CONTIGUOUS range of environments keeps each line inside one L2:
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th group of that XCD's range (LM_NO_XCD_MAP: A/B switch).
   int wg = blockIdx.x;
-  if (a.xcd_map) {
+  if (!REPLAY && a.xcd_map) {
     const int nb = gridDim.x, x = wg & 7, per = nb >> 3, rem = nb & 7;
     wg = x * per + (x < rem ? x : rem) + (wg >> 3);
   }
-  const int e_raw = wg * a.epb + e_local;
-  // padding quads of the last workgroup recompute env N-1; they and the replicas 1..REP-1 store nothing
-  const bool valid = e_raw < a.N && QuadDpp::rep() == 0;
-  const int e = (e_raw < a.N) ? e_raw : a.N - 1;
+  int e_raw = wg * a.epb + e_local;
+  bool in_range = e_raw < a.N;
+  int first_step = 0;               // REPLAY: the fused control step at which the environment left the regular kernel
+  if (REPLAY) {
+    const int li = item * a.epb + e_local;
+    in_range = li < n_replay;
+    e_raw = a.replay_list[in_range ? li : n_replay - 1];
+    first_step = a.stall[e_raw];
+  }
+  // padding quads of the last workgroup recompute env N-1 (REPLAY: the last list entry); they and the replicas 1..REP-1 store nothing
+  const bool valid0 = in_range && QuadDpp::rep() == 0;
+  const int e = in_range ? e_raw : (REPLAY ? e_raw : a.N - 1);
+  bool gone = false;                // this environment left the launch: abandoned here and handed to the replay kernel
   const int N = a.N, nv = a.T.nv;
   const float* rb = cm + LM_CM_ROOT;
 #define RD(k, f) rb[LM_R_DOFS + (k) * LM_D_SIZE + (f)]
@@ -184,6 +212,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   for (int fused = 0; fused < (FUSED ? a.nfused : 1); fused++) {
   if (FUSED && fused > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   const unsigned step_index = a.step_index + (unsigned)fused;
+  bool valid = valid0 && !gone && (!REPLAY || fused >= first_step);
   // ---- load state (root replicated in the 4 lanes: same address -> one transaction)
   float qr[6], vr[6], war[6], qc[MC], vc[MC], wac[MC], goal[4];
   int dr[6], dc[MC];
@@ -289,16 +318,26 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   if (FORWARD_ONLY) {
     if (!valid) return;
     lm::Debug dbg = {a.dM + (long long)e * nv * nv, a.dbias + e * nv, a.dsmooth + e * nv, a.dqacc_smooth + e * nv, a.dqacc + e * nv, a.dqfrc + e * nv};
-    lm::forward<QuadDpp, MC, NS, false, -1, NM, false, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
+    lm::forward<QuadDpp, MC, NS, false, -1, NM, 0, PM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, &dbg, mt);
     int ncon = (int)(QuadDpp::sum((float)cnt.ncon) + 0.5f);
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
   float pair_slack = 0.0f;            // self-collision detection is due in the first pass of every control step (lm_core.h)
   for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PAIRS>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0, &pair_slack);
+    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0, &pair_slack);
 
   QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
+
+  // ---- did this control step stay inside the kernel's capacity? If not it is abandoned (nothing stored) and handed to the replay
+  // kernel. Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
+  if (!REPLAY && a.replay_list) {
+    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+    if (leave && valid) {
+      if (c == 0) { const int k = atomicAdd(&a.replay_ctl[0], 1); a.replay_list[k] = e; a.stall[e] = fused; }
+      gone = true; valid = false;
+    }
+  }
 
   // ---- validity flags of this control step: where the device left its collision model (tests and statistics)
   {
@@ -442,6 +481,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
       if (PAIRS && cnt.selfprox) atomicAdd(&blk_stats[10], (float)cnt.selfprox);
       if (PAIRS && cnt.selfcon) atomicAdd(&blk_stats[11], (float)cnt.selfcon);
+      if (REPLAY && c == 0) { atomicAdd(&blk_stats[12], 1.0f); if (a.replay_mark) a.replay_mark[e] = 1; }
     }
 #ifdef LM_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 16; i++) atomicAdd(&a.timers[i], (unsigned long long)cnt.t[i]);
@@ -459,11 +499,20 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #endif
   }
   }  // fused control steps
+  }  // REPLAY: list entries of this workgroup
   if (a.stats) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 12; i += blockDim.x) {
+    for (int i = threadIdx.x; i < kNStats; i += blockDim.x) {
       float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
       *dst += blk_stats[i];
+    }
+  }
+  if (REPLAY) {
+    // the last workgroup through clears the list for the next launch (every workgroup read the count when it started)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&a.replay_ctl[1], 1) == (int)gridDim.x - 1) { a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; __threadfence(); }
     }
   }
 #undef RD
@@ -474,9 +523,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 struct LaunchCtx { hipStream_t stream; int N, epb; };
 
 // kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
-enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV, LMK_NKINDS };
+enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV,
+       LMK_BIG, LMK_BIG_DR, LMK_BIG_DRV /* the replay kernels, one per part */, LMK_NKINDS };
 constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots),
                                     // 8 / 9 / 10 = five-link humanoids WITH self-collisions (8 slots): RK4 | Euler | Euler + muscles
+constexpr int kReplayGrid = 256;    // workgroups of the replay kernel (persistent: each walks the list with this stride)
 
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
@@ -487,30 +538,43 @@ static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, cons
   hipLaunchKernelGGL(kernel, grid, block, bytes, L.stream, a);
 }
 
-// one robot family = (links per chain MC, contact slots per chain NS, integrator, compiled-in cone, muscles per chain NM)
-template <int MC, int NS, bool RK4, int CONE, int NM, int PART, bool PAIRS = false>
+// one robot family = (links per chain MC, contact slots per chain NS, integrator, compiled-in cone, muscles per chain NM, pair
+// pass PM of the regular kernels: 0 none, 1 with the convex collider, 2 without — the replay kernel has it)
+template <int MC, int NS, bool RK4, int CONE, int NM, int PART, int PM = 0>
 static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const dim3 grid((L.N + L.epb - 1) / L.epb);
-  using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, CONE>;
+  using LMm = lm::LaneMemFor<MC, NS, NM, (PM != 0), CONE>;
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
+  // the replay kernel: a slot for every contact (32 per leg of the quadruped, 48 per chain of a humanoid), the convex collider,
+  // fused (it finishes the launch's control steps of its environments), four environments per workgroup whatever the batch's layout
+  constexpr int NSB = (MC <= 3) ? 32 : 48, PMB = (PM != 0) ? 1 : 0;
+  using LMb = lm::LaneMemFor<MC, NSB, NM, (PM != 0), CONE>;
+  if (kind == LMK_BIG || kind == LMK_BIG_DR || kind == LMK_BIG_DRV) {
+    if (kind != LMK_BIG + PART) return false;
+    KArgs b = a;
+    b.epb = 4; b.xcd_map = 0;
+    const int ngroups = (L.N + 3) / 4;
+    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < kReplayGrid ? ngroups : kReplayGrid), dim3(64), (size_t)LMb::kGroup, L, b);
+    return true;
+  }
   if constexpr (PART == 0) {
-    // the forward-only (debug) kernel reads the cone at run time: full slot records
-    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, 0, 1, false, PAIRS>, grid, dim3(4 * L.epb),
-                                    (size_t)lm::LaneMemFor<MC, NS, NM, PAIRS, -1>::kGroup * ((4 * L.epb + 15) / 16), L, a);
-    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
+    // the forward-only (debug) kernel reads the cone at run time: full slot records (and always carries the convex collider)
+    if (kind == LMK_FWD) launch_one(step_kernel<MC, NS, RK4, true, -1, NM, 0, 1, false, PMB>, grid, dim3(4 * L.epb),
+                                    (size_t)lm::LaneMemFor<MC, NS, NM, (PM != 0), -1>::kGroup * ((4 * L.epb + 15) / 16), L, a);
+    else if (kind == LMK_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, false, PM>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 1, false, PM>, grid, dim3(4 * L.epb), plain, L, a);
     else return false;
   } else if constexpr (PART == 1) {
-    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
-    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    if (kind == LMK_DR_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, false, PM>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DR_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 1, false, PM>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 0, 4, true, PM>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_FUSED_DR) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 1, 4, true, PM>, grid, dim3(16 * L.epb), rep, L, a);
     else return false;
   } else {
     // per-environment joint parameters AND model variants (lm_set_model_variants)
-    if (kind == LMK_DRV_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, false, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
-    else if (kind == LMK_DRV_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 1, false, PAIRS>, grid, dim3(4 * L.epb), plain, L, a);
-    else if (kind == LMK_FUSED_DRV) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, true, PAIRS>, grid, dim3(16 * L.epb), rep, L, a);
+    if (kind == LMK_DRV_REP4) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, false, PM>, grid, dim3(16 * L.epb), rep, L, a);
+    else if (kind == LMK_DRV_REP1) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 1, false, PM>, grid, dim3(4 * L.epb), plain, L, a);
+    else if (kind == LMK_FUSED_DRV) launch_one(step_kernel<MC, NS, RK4, false, CONE, NM, 2, 4, true, PM>, grid, dim3(16 * L.epb), rep, L, a);
     else return false;
   }
   return true;

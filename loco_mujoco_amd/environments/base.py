@@ -60,9 +60,10 @@ class LocoEnv:
         self._n_model_variants = int(n_model_variants)
         self._variants_per_reset = int(model_variants_per_reset)
         self._variant_models = {}          # model index -> [CompiledModel] (kept for inspection and the parity tests)
-        self._variant_tables = None        # the pool, lowered (built at the first reset(), rebuilt after seed())
-        self._variant_cursor = 0
-        self._variant_dirty = False
+        # the pools, lowered — ONE PER MODEL of the environment (the reference's MultiMuJoCo randomises whichever model the episode
+        # drew): model index -> {"tables", "cursor", "dirty"}; built at the first reset() of that model, rebuilt after seed().
+        # `_variant_tables` / `_variant_cursor` / `_variant_dirty` are the current model's.
+        self._variant_pools = {}
         # joint-parameter randomisation per episode (reference base.py:103-107,183-185). The reference draws in worker
         # processes, i.e. outside the main np.random stream — so does this (own RandomState, reseeded by seed()).
         self._domain_rand = None
@@ -178,6 +179,37 @@ class LocoEnv:
                 self._variant_dirty = False
         return self._backend
 
+    # the current model's pool (see __init__)
+    def _pool(self):
+        return self._variant_pools.setdefault(getattr(self, "_current_model_idx", 0), dict(tables=None, cursor=0, dirty=False))
+
+    @property
+    def _variant_tables(self):
+        return self._pool()["tables"]
+
+    @_variant_tables.setter
+    def _variant_tables(self, v):
+        if v is None:
+            self._variant_pools.clear()           # seed(): every model's pool is a function of the seed
+        else:
+            self._pool()["tables"] = v
+
+    @property
+    def _variant_cursor(self):
+        return self._pool()["cursor"]
+
+    @_variant_cursor.setter
+    def _variant_cursor(self, v):
+        self._pool()["cursor"] = v
+
+    @property
+    def _variant_dirty(self):
+        return self._pool()["dirty"]
+
+    @_variant_dirty.setter
+    def _variant_dirty(self, v):
+        self._pool()["dirty"] = v
+
     def _build_model_variants(self, nominal, count=None):
         """`count` (default: the whole pool) randomised models of the current model's batch: drawn with the randomisation's own
         generator, compiled (``mjcf.model_variant``), lowered, reduced to what differs from the nominal tables
@@ -194,8 +226,9 @@ class LocoEnv:
         """Host-only and deterministic: the pool is a function of the randomisation generator's state (``seed()``) alone — built
         at the first reset() before anything else is drawn from that generator, never as a side effect of the first step()."""
         if self._variant_tables is None:
-            if self._n_models > 1:
-                raise NotImplementedError("several models in one batch AND randomised compile-time constants: both use the model variants")
+            if self._pooled:
+                # (several models with one device batch per model — contiguous blocks, or n_envs = 1 — keep one pool per model)
+                raise NotImplementedError("several models in ONE device batch AND randomised compile-time constants: both use the model variants")
             models, self._variant_tables = self._build_model_variants(self._chain_model())
             self._variant_models[self._current_model_idx] = models
             self._variant_cursor = 0
@@ -374,20 +407,32 @@ class LocoEnv:
         self._pending_dof_params = None
         self._pending_variants = None
         if self._domain_rand is not None and self._domain_rand.active:
-            fresh = None
+            fresh = {}
+            # the models whose environments restart: every block's model, or the one this episode drew
+            idxs = list(range(self._n_models)) if self._blocks else [self._current_model_idx]
             if self._domain_rand.has_model_rules:
-                first = self._variant_tables is None
-                self._ensure_variant_pool()                 # first reset (or first after seed()): the whole pool, freshly drawn
-                if not first and self._variants_per_reset > 0:
-                    fresh = self.refresh_model_variants(self._variants_per_reset)
+                for idx in idxs:
+                    if self._blocks:
+                        self._select_model(idx)
+                    n_here = len(self._model_envs(idx)) if self._blocks else self.n_envs
+                    first = self._variant_tables is None
+                    self._ensure_variant_pool()             # first reset (or first after seed()): the whole pool, freshly drawn
+                    # a batch smaller than `model_variants_per_reset` compiles only what it can use (n_envs = 1: ONE model per episode)
+                    k = min(self._variants_per_reset, n_here)
+                    if not first and k > 0:
+                        fresh[idx] = self.refresh_model_variants(k)
             state = np.random.get_state()
             np.random.set_state(self._domain_rand_rs.get_state())
             self._pending_dof_params = self._domain_rand.sample(self.n_envs)
             if self._domain_rand.has_model_rules:
-                if fresh is not None and self.n_envs <= len(fresh):
-                    self._pending_variants = fresh[:self.n_envs].copy()    # one brand-new model per environment and episode
-                else:
-                    self._pending_variants = np.random.randint(0, self._n_model_variants, self.n_envs)
+                self._pending_variants = np.zeros(self.n_envs, dtype=np.int64)
+                for idx in idxs:
+                    envs = self._model_envs(idx) if self._blocks else np.arange(self.n_envs)
+                    fr = fresh.get(idx)
+                    if fr is not None and len(envs) <= len(fr):
+                        self._pending_variants[envs] = fr[:len(envs)]      # one brand-new model per environment and episode
+                    else:
+                        self._pending_variants[envs] = np.random.randint(0, self._n_model_variants, len(envs))
             self._domain_rand_rs.set_state(np.random.get_state())
             np.random.set_state(state)
         if self._pooled:

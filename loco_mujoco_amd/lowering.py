@@ -528,7 +528,10 @@ def lower(m, task):
     max_links = 0
     max_groups_seen = 0
     standing = []
-    for c, chain in enumerate(chains):
+    # every lane of the quad takes its share of the ROOT body's colliders, also the lanes without a chain (a two-legged robot
+    # without arm chains leaves two lanes idle: their contact slots and their share of the floor pass are free capacity)
+    for c in range(NCHAIN):
+        chain = chains[c] if c < len(chains) else []
         blk = np.zeros(CHAIN_SIZE)
         links = []
         for b in chain:
@@ -572,7 +575,7 @@ def lower(m, task):
                 s, u = geom_blocks(b, li)
                 geoms += s
                 unsup += u
-        geoms += root_geoms[c::len(chains)]          # this lane's share of the root body's colliders (after the chain's own)
+        geoms += root_geoms[c::NCHAIN]               # this lane's share of the root body's colliders (after the chain's own)
         for k in C_GRF_OBS:
             blk[k] = -1
         chain_groups = sorted(set(int(gb[G_GRF]) for gb in geoms if gb[G_GRF] >= 0))
@@ -1071,6 +1074,12 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
         spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp], sphere[wq]
     if max(len(x) for x in lanes_lp) > MAXLP:
         raise UnsupportedModel("too many self-collision link pairs (%s)" % [len(x) for x in lanes_lp])
+    # what the device packs into one float32 (csrc/lm_core.h: the pair pass): a work item = entry * 65536 + geom-pair record; a body
+    # pair in reach = entry * 32 + body pair of the entry + 4096 * its geom pairs; an entry in reach = entry + 64 * its body pairs
+    if len(records) >= 65536 or len(bodypairs) >= 65536 or max(len(x) for x in lanes_lp) > 64:
+        raise UnsupportedModel("self-collision tables beyond the device's packing (%d geom pairs, %d body pairs, %s link pairs per lane)"
+                               % (len(records), len(bodypairs), [len(x) for x in lanes_lp]))
+    assert all(int(bp[BP_N]) <= 24 for bp in bodypairs) and all((int(e[1]) >> 16) <= 24 for x in lanes_lp for e in x)
     return lanes_lp, (np.concatenate(records) if records else np.zeros(0)), spheres_r, kinds, (np.concatenate(bodypairs) if bodypairs else np.zeros(0))
 
 

@@ -134,9 +134,15 @@ template <int MC> constexpr int kEmuCone = -1;
 
 // chain_model: float64 [HEADER + CM]; state arrays [n][nv] double in/out; ctrl [n][nu] (already un-normalised)
 // act: muscle activations [n][na] double in/out (NM > 0 only)
-template <int MC, int NS, bool RK4, int NM = 0, bool PAIRS = false>
+// PM: the pair pass of the kernel (lm_core.h forward: 0 none, 1 with the convex collider, 2 without it).
+// leave / only: the device's speculate / replay protocol (lm_step.h). With `leave` a control step that runs out of contact slots or
+// list space, or meets a convex pair without having the collider, stores NOTHING and sets leave[e]; with `only` the environments
+// whose flag is 0 are skipped (the replay pass of the big instantiation over the flagged ones).
+template <int MC, int NS, bool RK4, int NM = 0, int PM = 0>
 static int emu_run_t(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
-                     int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act = nullptr) {
+                     int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act = nullptr,
+                     int* leave = nullptr, const int* only = nullptr) {
+  constexpr bool PAIRS = PM != 0;
   const double* H = chain_model;
   const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
   std::vector<float> cm(LM_CM_SIZE);
@@ -177,6 +183,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
     t_lane = c; t_rep = t >> 2;
     const float* rb = cm.data();
     for (int e = 0; e < n; e++) {
+      if (only && !only[e]) continue;
       float qr[6], vr[6], war[6], actr[6], qc[MC], vc[MC], wac[MC], actc[MC];
       int dr[6], dc[MC];
       const int nl = (int)cm[LM_CM_CHAINS + LM_C_NLINKS * LM_NCHAIN + c];
@@ -253,21 +260,33 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
       float pair_slack = 0.0f;
       for (int s = 0; s < nsub; s++)
-        lm::substep<QuadThreads, MC, NS, RK4, (PAIRS && MC <= 3) ? 1 : kEmuCone<MC>, NM, kEmuDR, PAIRS>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
+        lm::substep<QuadThreads, MC, NS, RK4, (PAIRS && MC <= 3) ? 1 : kEmuCone<MC>, NM, kEmuDR, PM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                                       (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, &pair_slack);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
-      if (NM > 0 && t_rep == 0) {
-        const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
-        for (int i = 0; i < nm; i++) act[e * na + (int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE]] = lmem[LMm::kAct + i];
+      static int acc[16][9];
+      {
+        int* A = acc[t_rep * 4 + c];
+        A[0] = cnt.solver_iters; A[1] = cnt.overflow; A[2] = cnt.unhandled; A[3] = cnt.ncon; A[4] = cnt.ls_evals; A[5] = cnt.ls_capped; A[6] = cnt.selfprox; A[7] = cnt.selfcon;
+        A[8] = cnt.need_full;
+      }
+      if (getenv("EMU_PAIR_TRACE") && c == 0 && t_rep == 0) fprintf(stderr, "env %d: pair detection passes %d, slack at the end %.4f\n", e, cnt.pair_passes, pair_slack);
+      g_bar.arrive_and_wait();
+      // the environment-wide vote of the step kernel: did the control step stay inside this instantiation's capacity?
+      bool left = false;
+      if (leave) for (int t2 = 0; t2 < kThreads; t2++) left = left || acc[t2][1] > 0 || acc[t2][8] > 0;
+      if (!left && t_rep == 0) {
+        if (NM > 0) {
+          const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
+          for (int i = 0; i < nm; i++) act[e * na + (int)mt[LM_MT_HEAD + (m0 + i) * LM_MU_SIZE + LM_MU_STATE]] = lmem[LMm::kAct + i];
+        }
+        if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
+        for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
       }
       g_bar.arrive_and_wait();
-      if (t_rep != 0) { g_bar.arrive_and_wait(); g_bar.arrive_and_wait(); continue; }     // replicas 1.. store nothing
-      if (c == 0) for (int i = 0; i < 6; i++) { qpos[e * nv + dr[i]] = qr[i]; qvel[e * nv + dr[i]] = vr[i]; warm[e * nv + dr[i]] = war[i]; }
-      for (int k = 0; k < MC; k++) if (dc[k] >= 0) { qpos[e * nv + dc[k]] = qc[k]; qvel[e * nv + dc[k]] = vc[k]; warm[e * nv + dc[k]] = wac[k]; }
-      static int acc[4][8];
-      acc[c][0] = cnt.solver_iters; acc[c][1] = cnt.overflow; acc[c][2] = cnt.unhandled; acc[c][3] = cnt.ncon; acc[c][4] = cnt.ls_evals; acc[c][5] = cnt.ls_capped; acc[c][6] = cnt.selfprox; acc[c][7] = cnt.selfcon; if (getenv("EMU_PAIR_TRACE") && c == 0) fprintf(stderr, "env %d: pair detection passes %d, slack at the end %.4f\n", e, cnt.pair_passes, pair_slack);
-      g_bar.arrive_and_wait();
-      if (c == 0) for (int l = 0; l < 4; l++) for (int j = 0; j < 8; j++) cnt_tot[j] += acc[l][j];
+      if (c == 0 && t_rep == 0) {
+        if (!left) for (int l = 0; l < 4; l++) for (int j = 0; j < 8; j++) cnt_tot[j] += acc[l][j];
+        if (leave) leave[e] = left ? 1 : 0;
+      }
       g_bar.arrive_and_wait();
     }
   };
@@ -296,27 +315,58 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
 extern "C" void emu_set_dof_params(const double* p) { g_dofprm = p; }
 extern "C" void emu_set_model_variant(const float* rec, const float* gt, const float* gpt) { g_vrec = rec; g_vgt = gt; g_vgpt = gpt; }
 
-extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
-                       int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
-                       int* counters /*8*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
-  // same family selection as the library's launch_variant()
+// same family selection as the library's launch_variant(); BIGK = the family's replay instantiation (lm_step.h launch_family: 32
+// slots per leg of the quadruped, 48 per chain of a humanoid, the convex collider)
+template <bool BIGK>
+static int emu_dispatch(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                        int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act, int* leave, const int* only) {
+  constexpr int N4 = BIGK ? 48 : 4, N8 = BIGK ? 48 : 8, N6 = BIGK ? 32 : 6;
+#define EMU_ARGS chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
   if ((int)chain_model[LM_H_MAXLINKS] > 5)
-    return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters) : -1;
+    return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, N8, false>(EMU_ARGS, nullptr, leave, only) : -1;
   // the five-link humanoids with self-collision tables (bone hulls, UnitreeH1's cylinders and meshes): the pair families, 8 slots
   if ((int)chain_model[LM_H_NGPAIR] > 0 && big) {
-    if ((int)chain_model[LM_H_NMUSCLE] > 0) return (act && !rk4) ? emu_run_t<5, 8, false, LM_MAXMUS, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
-    return rk4 ? emu_run_t<5, 8, true, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters)
-               : emu_run_t<5, 8, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+    if ((int)chain_model[LM_H_NMUSCLE] > 0) return (act && !rk4) ? emu_run_t<5, N8, false, LM_MAXMUS, 1>(EMU_ARGS, act, leave, only) : -1;
+    return rk4 ? emu_run_t<5, N8, true, 0, 1>(EMU_ARGS, nullptr, leave, only) : emu_run_t<5, N8, false, 0, 1>(EMU_ARGS, nullptr, leave, only);
   }
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
-    return (act && big && !rk4 && few) ? emu_run_t<5, 4, false, LM_MAXMUS>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act) : -1;
-  if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, 6, false, 0, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  if (!big && !rk4) return emu_run_t<3, 5, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  if (!big && rk4) return emu_run_t<3, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  if (!rk4 && few) return emu_run_t<5, 4, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  if (!rk4) return emu_run_t<5, 8, false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  if (few) return emu_run_t<5, 4, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
-  return emu_run_t<5, 8, true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters);
+    return (act && big && !rk4 && few) ? emu_run_t<5, N4, false, LM_MAXMUS>(EMU_ARGS, act, leave, only) : -1;
+  // the quadruped (LM_A1_PAIRS = 1 in lm_family.hip: the convex collider in the regular kernels too)
+  if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, N6, false, 0, 1>(EMU_ARGS, nullptr, leave, only);
+  if (!big && !rk4) return emu_run_t<3, 5, false>(EMU_ARGS, nullptr, BIGK ? nullptr : leave, only);          // (generic family: no replay kernel)
+  if (!big && rk4) return emu_run_t<3, 4, true>(EMU_ARGS, nullptr, BIGK ? nullptr : leave, only);
+  if (!rk4 && few) return emu_run_t<5, N4, false>(EMU_ARGS, nullptr, leave, only);
+  if (!rk4) return emu_run_t<5, N8, false>(EMU_ARGS, nullptr, leave, only);
+  if (few) return emu_run_t<5, N4, true>(EMU_ARGS, nullptr, leave, only);
+  return emu_run_t<5, N8, true>(EMU_ARGS, nullptr, leave, only);
+#undef EMU_ARGS
+}
+
+// replay = 0: the regular instantiation alone (contacts beyond its slots are dropped and counted, a convex pair of the quadruped is
+// NOT simulated); 1: speculate / replay like the library. replayed[n] (may be NULL): which environments the big instantiation ran.
+extern "C" int emu_run2(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                        int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act, int replay, int* replayed) {
+  if (!replay) return emu_dispatch<false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act, nullptr, nullptr);
+  std::vector<int> leave(n, 0);
+  int cnt1[8] = {0}, cnt2[8] = {0};
+  int rc = emu_dispatch<false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, cnt1, act, leave.data(), nullptr);
+  if (rc) return rc;
+  bool any = false;
+  for (int e = 0; e < n; e++) any = any || leave[e];
+  if (any) {
+    // the abandoned control steps, from the untouched state, in the big instantiation (whatever it still drops is final)
+    rc = emu_dispatch<true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, cnt2, act, nullptr, leave.data());
+    if (rc) return rc;
+  }
+  if (counters) for (int j = 0; j < 8; j++) counters[j] = cnt1[j] + cnt2[j];
+  if (replayed) for (int e = 0; e < n; e++) replayed[e] = leave[e];
+  return 0;
+}
+
+extern "C" int emu_run(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
+                       int nsub, int debug_env, float* dbgM, float* dbg5 /*bias,smooth,qacc_smooth,qacc,qfrc_c: 5*nv*/,
+                       int* counters /*8*/, double* act /* [n][na] muscle activations, may be NULL without muscles */) {
+  return emu_run2(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act, 1, nullptr);
 }

@@ -42,9 +42,10 @@ def build(ls_points=1, dr=False, rep=1):
 
 
 def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=None, ls_points=1, dof_params=None, dr=False, rep=1,
-        variant=None):
+        variant=None, replay=True):
     """variant: (record, geom table, geom-pair table) of ``lowering.variant_tables`` — one model variant for all environments
-    (implies dr). dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
+    (implies dr). replay: the library's speculate / replay protocol (a control step beyond the regular instantiation's capacity is run by
+    the big one; the counters' "replayed" says for how many environments); False = the regular instantiation alone. dof_params: (3, n, nv) per-environment damping / stiffness / frictionloss (implies dr); dr=True alone runs the
     per-environment code path on the table's nominal values."""
     dr = 2 if variant is not None else int(bool(dr or dof_params is not None))
     if rep > 1:
@@ -75,11 +76,12 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
             lib.emu_set_model_variant(dp(vt[0]), dp(vt[1]), dp(vt[2]) if len(vt[2]) else None)
         else:
             lib.emu_set_model_variant(None, None, None)
-    rc = lib.emu_run(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
-                     dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
-                     dp(actv) if actv is not None else None)
+    replayed = np.zeros(n, dtype=np.int32)
+    rc = lib.emu_run2(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
+                      dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
+                      dp(actv) if actv is not None else None, int(bool(replay)), dp(replayed))
     assert rc == 0, "emulator returned %d (-2: two replicas changed the same lane-memory word to different values)" % rc
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
     if actv is not None:
         dbg["act"] = actv
-    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5]), selfprox=int(cnt[6]), selfcon=int(cnt[7])), dbg
+    return q, v, w, dict(solver_iters=int(cnt[0]), overflow=int(cnt[1]), unhandled=int(cnt[2]), ncon=int(cnt[3]), ls_evals=int(cnt[4]), ls_capped=int(cnt[5]), selfprox=int(cnt[6]), selfcon=int(cnt[7]), replayed=int(replayed.sum())), dbg

@@ -338,6 +338,7 @@ def test_atlas_batch_rollout_properties(atlas):
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("Atlas 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))
+    assert st["overflow_contacts"] == 0            # round 4: nothing is dropped (replay kernel, lm_step.h)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -412,6 +413,7 @@ def test_talos_batch_rollout_properties(talos):
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("Talos 4096 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 10)))
+    assert st["overflow_contacts"] == 0            # round 4: nothing is dropped (replay kernel, lm_step.h)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -623,11 +625,19 @@ def test_fused_rollout_is_bitwise_the_single_step_rollout(task, kw):
         extra = [b.get_activation()] if m.na else []
         if kw.get("dr"):
             extra.append(b.get_dof_params()["damping"])
-        out.append((q, v, extra, {k: st[k] for k in ("env_steps", "episodes", "reward_sum", "solver_iters", "nan_resets")}))
-    (q1, v1, x1, s1), (q7, v7, x7, s7) = out
-    assert np.array_equal(q1, q7) and np.array_equal(v1, v7) and all(np.array_equal(a, b) for a, b in zip(x1, x7))
-    assert s1["env_steps"] == n * 20 and s1["episodes"] >= n and s1["episodes"] == s7["episodes"] and s1["solver_iters"] == s7["solver_iters"]
-    assert abs(s1["reward_sum"] - s7["reward_sum"]) <= 1e-3 * max(1.0, abs(s1["reward_sum"]))      # float32 block sums, other order
+        out.append((q, v, extra, {k: st[k] for k in ("env_steps", "episodes", "reward_sum", "solver_iters", "nan_resets", "overflow_contacts")}, b.replay_marks()))
+    (q1, v1, x1, s1, m1), (q7, v7, x7, s7, m7) = out
+    # an environment whose control step left the regular kernel (more contacts than slots) is finished by the REPLAY kernel: in a
+    # fused launch for the rest of the launch's control steps, in single-step launches for that step only — another instantiation
+    # of the same code, equal within rounding, not bitwise. Every other environment is bitwise the same.
+    same = ~(m1 | m7)
+    assert same.sum() >= 0.9 * n
+    assert np.array_equal(q1[same], q7[same]) and np.array_equal(v1[same], v7[same]) and all(np.array_equal(a[same], b[same]) for a, b in zip(x1, x7))
+    assert np.isfinite(q1).all() and np.isfinite(q7).all() and s1["overflow_contacts"] == 0 and s7["overflow_contacts"] == 0
+    assert s1["env_steps"] == n * 20 and s7["env_steps"] == n * 20 and s1["episodes"] >= n
+    if same.all():
+        assert s1["episodes"] == s7["episodes"] and s1["solver_iters"] == s7["solver_iters"]
+        assert abs(s1["reward_sum"] - s7["reward_sum"]) <= 1e-3 * max(1.0, abs(s1["reward_sum"]))      # float32 block sums, other order
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -806,6 +816,7 @@ def test_humanoid_torque_batch_rollout_properties(humanoid):
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("HumanoidTorque 4096 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep-stage %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 40)))
+    assert st["overflow_contacts"] == 0            # round 4: nothing is dropped (replay kernel, lm_step.h)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -896,6 +907,7 @@ def test_humanoid_muscle_batch_rollout_properties():
     assert st["env_steps"] == n * 30 and st["episodes"] > 0 and st["nan_resets"] == 0
     print("HumanoidMuscle 2048 envs: %.3f ms/step, %.0f env-steps/s, overflow %d, unhandled %d, newton its/substep %.2f"
           % (st["kernel_ms"] / 30, n * 30 / (st["kernel_ms"] * 1e-3), st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"] / (n * 30 * 10)))
+    assert st["overflow_contacts"] == 0            # round 4: nothing is dropped (replay kernel, lm_step.h)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1198,12 +1210,12 @@ def test_a1_self_contacts_vs_oracle(setup):
     flags = b.flags()
     st = b.stats()
     eq, ev, dropped, idx = [], [], 0, []
+    # round 4: no state is left out for a dropped contact — the two states with more self-contacts than a leg has slots are run by
+    # the replay kernel (lm_step.h), nothing is dropped
+    assert (flags & 1).sum() == 0 and st["overflow_contacts"] == 0 and st["replayed_env_steps"] >= 2
     for i in range(n):
         qo, vo, _, so = _oracle_step(env, oracle, d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64), d["a"][i].astype(np.float32))
         assert so["unhandled_pairs"] == 0
-        if flags[i] & 1:                                 # a lane ran out of contact slots in this step (counted below)
-            dropped += 1
-            continue
         eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max()); idx.append(i)
     eq, ev = np.array(eq), np.array(ev)
     keep = _split_knife_edges(env, oracle, d["q"][idx], d["v"][idx], d["a"][idx].astype(np.float32), eq, ev)
@@ -1212,7 +1224,7 @@ def test_a1_self_contacts_vs_oracle(setup):
           % (len(eq), dropped, eq.max(), np.percentile(eq, 99), np.median(eq), ev.max(), np.percentile(ev, 99), np.median(ev),
              st["self_contacts"], st["self_proximity"], st["overflow_contacts"]))
     assert st["self_contacts"] > 10 * n and st["self_proximity"] == 0
-    assert len(eq) >= 0.9 * n
+    assert len(eq) == n
     assert np.percentile(eq, 99) < QTOL and np.percentile(ev, 99) < VTOL
     print("   knife-edge states of the oracle left out of the max: %d; the others: qpos max %.2e qvel max %.2e" % ((~keep).sum(), eq[keep].max(), ev[keep].max()))
     assert eq[keep].max() < QTOL and ev[keep].max() < VTOL and (~keep).sum() <= 3 and eq.max() < 10 * QTOL and ev.max() < 10 * VTOL
@@ -1236,7 +1248,8 @@ def test_atlas_cylinder_states_vs_oracle(atlas):
     for i in range(n):
         q0, v0 = d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64)
         qo, vo, _, so = _oracle_step(env, oracle, q0, v0, np.zeros(10))
-        if flags[i] or so["unhandled_pairs"]:
+        assert not (flags[i] & 1)                       # nothing dropped (round 4: root geoms over all four lanes, replay kernel behind)
+        if (flags[i] & 6) or so["unhandled_pairs"]:
             skipped += 1
             continue
         eq.append(np.abs(q1[i] - qo).max()); ev.append(np.abs(v1[i] - vo).max()); idx.append(i)
@@ -1271,22 +1284,30 @@ def _worker_oracle_steps(args):
     return out
 
 
-@pytest.mark.parametrize("task,kw,policy,nroll,min_ok", [("UnitreeA1.simple", {}, "zero", 12, 0.97), ("UnitreeA1.simple", {}, "random", 12, 0.97),
-                                                         ("HumanoidTorque.run", {}, "random", 12, 0.95), ("HumanoidTorque.run", {}, "random", 3, 0.95),
-                                                         ("Atlas.walk", {}, "random", 12, 0.97), ("HumanoidMuscle.run", {}, "random", 12, 0.97),
-                                                         ("Talos.walk", {}, "random", 12, 0.97), ("UnitreeH1.walk", {}, "random", 3, 0.9),
-                                                         ("UnitreeG1.walk", {}, "random", 3, 0.9)])      # (measured in round 3: 4096 / 4091 / 3964 / 3943 / 4095 / 4090 / 4093 / 3782 / 3821)
-def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok):
+# measured in round 4 (gpurun_out/r4b): comparable 4096 / 4096 / 4034 / 3953 / 4096 / 4091 / 4096 / 4096 / 3821, failing 0 / 0 / 0 / 1 / 0 / 0 / 0 / 1 / 0
+_R4_4096_CASES = [("UnitreeA1.simple", {}, "zero", 12, 1.0, 0.0), ("UnitreeA1.simple", {}, "random", 12, 0.99, 0.0005),
+                  ("HumanoidTorque.run", {}, "random", 12, 0.97, 0.001), ("HumanoidTorque.run", {}, "random", 3, 0.95, 0.001),
+                  ("Atlas.walk", {}, "random", 12, 0.99, 0.0005), ("HumanoidMuscle.run", {}, "random", 12, 0.99, 0.0005),
+                  ("Talos.walk", {}, "random", 12, 0.99, 0.0005), ("UnitreeH1.walk", {}, "random", 3, 0.99, 0.001),
+                  ("UnitreeG1.walk", {}, "random", 3, 0.9, 0.0005)]
+
+
+# min_ok: comparable states (the oracle has a collider for every pair in reach) / 4096; max_fail: states beyond the tolerance that the
+# STRICT conditioning rule does not explain, as a fraction of 4096 (the number DESIGN.md §2 quotes per configuration)
+@pytest.mark.parametrize("task,kw,policy,nroll,min_ok,max_fail", _R4_4096_CASES)
+def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok, max_fail):
     """the error distribution over 4096 REACHABLE states per configuration. The states come from a device
     rollout (dataset states, then `nroll` control steps under the configuration's policy, no restarts: walking, stumbling and
     collapsing robots, self-contacts of the quadruped), then ONE control step with a fresh action on the device and in the
     fp64 oracle (all cores), no collision mask on either side. Reported: median / p99 / max. Asserted: max <= the stated
     tolerance (qpos 1e-4, qvel 1e-2) over every state where the comparison is meaningful — not meaningful are states (counted
-    and reported) where (i) the oracle has no collider for a geom pair in reach (`unhandled_pairs`), (ii) a lane ran out of
-    contact slots on the device, (iii) the fp64 oracle ITSELF jumps by more than the tolerance when its input is disturbed
-    by float32-sized noise (24 probes per state beyond the tolerance, 1e-7 .. 3e-6 relative: the input rounding and what ten
-    substeps of float32 arithmetic add to it; four probes let two such states of 4096 slip through, profiles/r2_ab_probes.md):
-    a contact or a joint limit that switches on within a hair of a substep boundary — the engine's contact damping acts at full strength from the first pass in which dist < margin,
+    and reported) where (i) the oracle has no collider for a geom pair in reach (`unhandled_pairs`), (ii) the fp64 oracle ITSELF
+    jumps by more than the tolerance when its input is disturbed by the rounding of its float32 INPUT alone (round 4: 8 probes per
+    state beyond the tolerance, 1.2e-7 relative = one float32 ulp; round 3 probed up to 3e-6 and also excused a state whose oracle
+    moved by half of the device's error — both gone). No state is left out for a dropped contact any more: the replay kernel
+    (lm_step.h) runs what the regular kernels cannot hold, `overflow_contacts` must be 0. What is still beyond the tolerance after
+    (i) and (ii) is counted as FAILING and bounded per configuration by `max_fail` — a number, quoted in DESIGN.md.
+    Knife edge: a contact or a joint limit that switches on within a hair of a substep boundary — the engine's contact damping acts at full strength from the first pass in which dist < margin,
     so a foot arriving at 2 m/s gains or loses ~0.05 m/s with the pass in which it is first seen, in float64 as in float32. The humanoid's bone meshes, the box feet against them and UnitreeH1's cylinders and link meshes collide through the engine's convex collider (MPR) on both sides now; what the oracle still only counts is box against box (one foot on the other)."""
     from multiprocessing.pool import ThreadPool
     from loco_mujoco_amd.backend import HipBatch, HipModel
@@ -1328,33 +1349,33 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
         unhandled = np.array([r[3] > 0 for r in res])
         if no_device_pairs:      # (UnitreeG1: 117 link pairs per chain do not fit the device's pair list) the oracle's convex contacts have no counterpart
             unhandled |= np.array([r[7] > 0 for r in res])
-        # conditioning probes for the states beyond the tolerance: 24 of them, 1e-7 .. 3e-6 relative (the input rounding and
-        # what ten substeps of float32 arithmetic add to it)
+        # conditioning probes for the states beyond the tolerance: 8 of them at one float32 ulp of the input (1.2e-7 relative)
         beyond = np.nonzero(((eq > QTOL) | (ev > VTOL)) & ~unhandled)[0]
-        probes = (1e-7,) * 4 + (1e-6,) * 12 + (3e-6,) * 8
+        probes = (1.2e-7,) * 8
         pj = [(env, oracle, f64(q0, [i]), f64(v0, [i]), f64(act0, [i]), f64(actions, [i]), probes) for i in beyond]
         pres = [r[0] for r in pool.map(_worker_oracle_steps, pj)]
     illcond = np.zeros(n, dtype=bool)
     for i, r in zip(beyond, pres):
-        # ... or moves by at least half of what the device is off by: the difference is then inside the band the reference's own
-        # output covers under float32-sized input noise (a cylinder in the engine's convex collider: the portal search ends on
-        # another triangle of the curved surface, the normal turns by 1e-2 rad — in float64, under 1e-9 noise)
-        illcond[i] = (r[4] > QTOL) or (r[5] > VTOL) or ((eq[i] <= QTOL or r[4] >= 0.5 * eq[i]) and (ev[i] <= VTOL or r[5] >= 0.5 * ev[i]))
+        illcond[i] = (r[4] > QTOL) or (r[5] > VTOL)        # the oracle's OWN jump under one-ulp input noise exceeds the tolerance
     dropped = (flags & 1) != 0
+    assert dropped.sum() == 0 and st["overflow_contacts"] == 0, (int(dropped.sum()), st["overflow_contacts"])
     # bodies of the robot driven deep into each other during the step (random torques at full range push a shin through a thigh):
     # reported as a class of their own. With the device's convex collider in float64 they agree like the rest (in float32 the
     # portal search took other paths: normals tens of degrees apart, profiles/r3_notes.md §3); DEEP only splits the report.
     DEEP = 0.003
     depth = np.array([r[6] for r in res])
     deep = depth > DEEP
-    ok = ~unhandled & ~illcond & ~dropped
+    failing = ((eq > QTOL) | (ev > VTOL)) & ~unhandled & ~illcond
+    ok = ~unhandled & ~illcond & ~failing
     okd = ok & deep
     nself = int((np.array([r[7] for r in res]) > 0).sum())
-    print("%s / %s policy, 4096 reachable states, one control step: compared %d (no collider on the oracle's side %d, beyond the tolerance AND "
-          "ill-conditioned for float32 inputs %d, a contact dropped on the device %d; of the compared: self-penetration deeper than %g mm %d); qpos median %.2e p99 %.2e max %.2e | "
+    print("%s / %s policy, 4096 reachable states, one control step: FAILING (beyond the tolerance, comparable, the oracle stable under one-ulp input noise) %d = %.4f of 4096, "
+          "replayed by the big kernel %d | within tolerance %d (no collider on the oracle's side %d, beyond the tolerance AND "
+          "the oracle itself jumps under one-ulp input noise %d, a contact dropped on the device %d; of the compared: self-penetration deeper than %g mm %d); qpos median %.2e p99 %.2e max %.2e | "
           "qvel median %.2e p99 %.2e max %.2e | states with convex self-contacts on the oracle's side %d (compared: %d) | deep states: qpos median %.2e p90 %.2e, qvel median %.2e p90 %.2e | "
           "ALL 4096: qpos p99 %.2e max %.2e qvel p99 %.2e max %.2e | device: contacts dropped %d, self-contacts %d, uncollidable pairs in reach %d, collider-less geoms at the floor %d"
-          % (task, policy, ok.sum(), unhandled.sum(), (illcond & ~unhandled).sum(), (dropped & ~unhandled & ~illcond).sum(), 1e3 * DEEP, okd.sum(),
+          % (task, policy, failing.sum(), failing.sum() / n, st["replayed_env_steps"],
+             ok.sum(), unhandled.sum(), (illcond & ~unhandled).sum(), (dropped & ~unhandled & ~illcond).sum(), 1e3 * DEEP, okd.sum(),
              np.median(eq[ok]), np.percentile(eq[ok], 99), eq[ok].max(), np.median(ev[ok]), np.percentile(ev[ok], 99), ev[ok].max(),
              nself, int((ok & (np.array([r[7] for r in res]) > 0)).sum()),
              np.median(eq[okd]) if okd.any() else 0.0, np.percentile(eq[okd], 90) if okd.any() else 0.0, np.median(ev[okd]) if okd.any() else 0.0, np.percentile(ev[okd], 90) if okd.any() else 0.0,
@@ -1366,7 +1387,7 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
         np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r3_outliers", "%s_%s_%d.npz" % (task, policy, nroll)),
                  q0=q0[worst], v0=v0[worst], act=actions[worst], q1=q1[worst], v1=v1[worst], qo=np.array([res[i][0] for i in worst]), vo=np.array([res[i][1] for i in worst]),
                  eq=eq[worst], ev=ev[worst], flags=flags[worst], depth=depth[worst])
-    assert ok.sum() >= min_ok * n
+    assert (~unhandled).sum() >= min_ok * n and failing.sum() <= max_fail * n, (int((~unhandled).sum()), int(failing.sum()))
     # the device says when it leaves its collision model, and not more often than the oracle finds a pair without a collider
     prox = (flags & 2) != 0
     assert no_device_pairs or (prox.sum() <= 1.1 * unhandled.sum() + 8 and (unhandled.sum() < 20 or (prox & unhandled).sum() >= 0.9 * unhandled.sum()))
@@ -1403,6 +1424,27 @@ def test_bench_two_ranks_on_one_gpu_shard_invariance(tmp_path):
         part = np.load(str(tmp_path / "two") + ".rank%d.npz" % r)
         assert int(part["offset"]) == 256 * r
         assert np.array_equal(part["qpos"], whole["qpos"][256 * r:256 * (r + 1)]) and np.array_equal(part["qvel"], whole["qvel"][256 * r:256 * (r + 1)])
+
+
+def test_bench_line_rates_are_their_own_legs():
+    """`python bench.py --steps 20 --warmup 5 --sustained 200` (what the driver runs): every rate in the line is the env-steps of
+    ITS OWN timed block over that block's time — value, rollout_fused.value and sustained.value all satisfy
+    rate * ms_per_step / 1e3 == envs (round 3 divided the cumulative counter of all legs by the last leg's time: 1.325x)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--sustained", "200", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=500, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    n = line["config"]["global_envs"]
+    assert n == 4096 and line["steps"] == 20 and line["warmup"] == 5
+    for leg in (line, line["rollout_fused"], line["sustained"]):
+        assert abs(leg["value"] * leg["ms_per_step"] * 1e-3 / n - 1.0) < 1e-9, leg
+    assert line["sustained"]["steps"] == 200
+    # per-step launches in both: the sustained block cannot be much faster than the 20-step block of the same state mixture
+    assert 0.5 * line["value"] < line["sustained"]["value"] < 1.5 * line["value"]
+    assert line["stats"]["overflow_contacts"] == 0 and line["stats"]["nan_resets"] == 0
 
 
 @pytest.mark.parametrize("task", ["run", "walk"])
@@ -1837,6 +1879,52 @@ def test_done_byte_bit_layout_and_episode_restarted_key(setup):
     assert all(k == {"episode_restarted"} for k in keys)
 
 
+def test_no_contact_is_dropped_folded_humanoid_states_and_rollouts(humanoid):
+    """VERDICT r3 item 1 ("never drop a contact"; the engine the reference calls sizes its buffers for everything,
+    environments/data/humanoid/humanoid_torque.xml:19 njmax 1000 / nconmax 400). (i) The folded HumanoidTorque states of
+    tests/golden/ht_folded_states.npz (two and three chains in mutual contact, up to 16 contacts on a chain): with the regular
+    kernels alone three of them drop 126 contacts and miss the oracle by 2e-2 / 2.8; with speculate / replay (the default) nothing is
+    dropped and every state is inside the stated tolerance. (ii) 1024 environments, 60 control steps under the random policy with
+    device-side restarts (robots fall and fold up before the restart): overflow_contacts == 0, single-step and fused launches."""
+    env, hm, oracle, HipBatch = humanoid
+    m = env._model
+    d = np.load(__file__.replace("test_gpu_parity.py", "golden/ht_folded_states.npz"))
+    n = len(d["q"])
+    ref = []
+    for i in range(n):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(d["a"][i].astype(np.float32))
+        ref.append(oracle.step(d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64), ctrl, 10)[:2])
+    res = {}
+    for replay in (False, True):
+        b = HipBatch(hm, n)
+        b.set_replay(replay)
+        b.set_state(d["q"], d["v"])
+        b.step(d["a"])
+        q, v = b.get_state()
+        st = b.stats()
+        res[replay] = (max(np.abs(q[i] - ref[i][0]).max() for i in range(n)), max(np.abs(v[i] - ref[i][1]).max() for i in range(n)),
+                       st["overflow_contacts"], st["replayed_env_steps"], int((b.flags() & 1).sum()))
+    print("folded HumanoidTorque states: regular kernels alone qpos %.2e qvel %.2e (dropped %d contacts in %d states) | with replay qpos %.2e qvel %.2e "
+          "(dropped %d, replayed %d states)" % (res[False][0], res[False][1], res[False][2], res[False][4], res[True][0], res[True][1], res[True][2], res[True][3]))
+    assert res[False][2] > 0 and res[False][4] > 0 and res[False][3] == 0            # the fixture does exceed the regular kernels' slots
+    assert res[True][2] == 0 and res[True][4] == 0 and res[True][3] == res[False][4]
+    assert res[True][0] < QTOL and res[True][1] < VTOL
+    tab = env._reset_table()
+    rows = tab[np.random.RandomState(0).randint(0, len(tab), 1024)]
+    for fuse in (1, 20):
+        b = HipBatch(hm, 1024)
+        b.set_reset_table(tab, seed=1)
+        b.set_auto_reset(True, horizon=1000)
+        b.set_state(rows[:, :19], rows[:, 19:38])
+        st = b.rollout(60, action_mode=1, seed=5, steps_per_launch=fuse)
+        q, v = b.get_state()
+        print("   HumanoidTorque.run 1024 envs x 60 steps (%d per launch): dropped %d, replayed env-steps %d, self-contacts %d, episodes %d"
+              % (fuse, st["overflow_contacts"], st["replayed_env_steps"], st["self_contacts"], st["episodes"]))
+        assert np.isfinite(q).all() and np.isfinite(v).all() and st["nan_resets"] == 0 and st["env_steps"] == 1024 * 60
+        assert st["overflow_contacts"] == 0 and st["replayed_env_steps"] > 0
+
+
 def test_tangled_quadruped_states_stay_finite(setup):
     """The two tangled quadruped states of tests/golden/a1_tangled_states.npz (more self-contacts than slots): a contact between two
     chains is admitted in both lanes or in neither, so dropped contacts no longer inject momentum — the step stays finite and at the
@@ -1844,11 +1932,23 @@ def test_tangled_quadruped_states_stay_finite(setup):
     env, hm, oracle, HipBatch = setup
     d = np.load(__file__.replace("test_gpu_parity.py", "golden/a1_tangled_states.npz"))
     n = len(d["q"])
+    # the regular kernels alone (replay off, rounds 1-3): whole contacts are dropped, flagged, the step stays sane
     b = HipBatch(hm, n)
+    b.set_replay(False)
     b.set_state(d["q"], d["v"])
     b.step(d["a"])
     q, v = b.get_state()
     assert np.isfinite(q).all() and np.isfinite(v).all() and (b.flags() & 1).all() and b.stats()["nan_resets"] == 0
+    ref = [_oracle_step(env, oracle, d["q"][i].astype(np.float32).astype(np.float64), d["v"][i].astype(np.float32).astype(np.float64), d["a"][i].astype(np.float32))[:2] for i in range(n)]
     for i in range(n):
-        vo = _oracle_step(env, oracle, d["q"][i].astype(np.float64), d["v"][i].astype(np.float64), d["a"][i])[1]
-        assert np.abs(v[i]).max() < 1.5 * np.abs(vo).max()
+        assert np.abs(v[i]).max() < 1.5 * np.abs(ref[i][1]).max()
+    # speculate / replay (the default): the control step is run by the replay kernel with a slot for every contact — nothing dropped,
+    # no flag, and the result is the oracle's within the stated tolerance
+    b = HipBatch(hm, n)
+    b.set_state(d["q"], d["v"])
+    b.step(d["a"])
+    q, v = b.get_state()
+    st = b.stats()
+    assert (b.flags() & 1).sum() == 0 and st["overflow_contacts"] == 0 and st["replayed_env_steps"] == n and b.replay_marks().all()
+    for i in range(n):
+        assert np.abs(q[i] - ref[i][0]).max() < QTOL and np.abs(v[i] - ref[i][1]).max() < VTOL, (i, np.abs(q[i] - ref[i][0]).max(), np.abs(v[i] - ref[i][1]).max())

@@ -701,3 +701,63 @@ def test_get_mask_of_the_four_sizes_and_wrapper_surface():
     g = GymnasiumWrapper("UnitreeA1.simple", debug=True)
     assert g._set_action_space().shape == (12,) and g._set_observation_space().shape == (37,)
     assert g.play_trajectory_from_velocity(n_steps_per_episode=3).shape == (3, 37)
+
+
+def test_bench_leg_rate_identity_and_parity_flag():
+    """bench.py computes every rate with ONE function from (environments, steps, seconds) of the leg itself, and the parity
+    sample says whether it is inside the stated tolerance (no GPU needed for either)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.leg_rate(4096, 1, 200, 0.3163)
+    assert abs(r["value"] - 4096 * 200 / 0.3163) < 1e-6 and abs(r["ms_per_step"] - 1.5815) < 1e-9
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 4096) < 1e-6
+    r2 = bench.leg_rate(2048, 4, 20, 0.05)
+    assert abs(r2["value"] - 2048 * 4 * 20 / 0.05) < 1e-6
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "within_tolerance" in src and "sys.exit(3)" in src
+    # no rate is formed from a cumulative counter any more
+    assert 'vals[13] / ' not in src and 'env_steps / elapsed' not in src
+
+
+def test_model_rule_randomisation_with_several_models(tmp_path):
+    """Several models in one environment (the reference's MultiMuJoCo) TOGETHER with randomisation rules that change compile-time
+    constants: one pool of model variants per model, for n_envs = 1 (one device batch per model, the model drawn per episode) and
+    for contiguous blocks. Only several models inside ONE device batch (the carried weights at n_envs > 1) exclude the pool."""
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    e = LocoEnv.make("Talos.carry", debug=True, domain_randomization_config=cfg, n_model_variants=2)
+    assert e._n_models == 4 and not e._pooled and not e._blocks
+    seen = set()
+    for _ in range(12):
+        e.reset()
+        idx = e._current_model_idx
+        seen.add(idx)
+        pool = e._variant_pools[idx]
+        assert len(pool["tables"]) == 2 and e._pending_variants.shape == (1,) and 0 <= int(e._pending_variants[0]) < 2
+        assert len(e._variant_models[idx]) == 2
+    assert len(seen) > 1 and set(e._variant_pools) == seen          # a pool per model the episodes drew, none for the others
+    # n_envs = 1 compiles ONE fresh model per reset, not model_variants_per_reset of them
+    e2 = LocoEnv.make("Talos.walk", debug=True, domain_randomization_config=cfg, n_model_variants=4, model_variants_per_reset=4)
+    e2.reset()
+    p0 = [x[0].copy() for x in e2._variant_tables]
+    e2.reset()
+    assert [j for j in range(4) if not np.array_equal(p0[j], e2._variant_tables[j][0])] == [0] and list(e2._pending_variants) == [0]
+    # blocks: the humanoid's four sizes with n_envs = 8 -> four device batches of two environments, four pools
+    y = tmp_path / "dr.yaml"
+    y.write_text("Joints:\n  knee_angle_r:\n    armature:\n      sigma: 0.005\n")
+    np.random.seed(0)
+    b = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8, domain_randomization_config=str(y), n_model_variants=3, model_variants_per_reset=2)
+    assert b._blocks and b._n_models == 4
+    b.reset()
+    assert sorted(b._variant_pools) == [0, 1, 2, 3] and all(len(p["tables"]) == 3 for p in b._variant_pools.values())
+    assert b._pending_variants.shape == (8,) and (b._pending_variants >= 0).all() and (b._pending_variants < 3).all()
+    first = {i: [t[0].copy() for t in b._variant_pools[i]["tables"]] for i in range(4)}
+    b.reset()
+    for i in range(4):
+        changed = [j for j in range(3) if not np.array_equal(first[i][j], b._variant_pools[i]["tables"][j][0])]
+        assert changed == [0, 1] and list(b._pending_variants[b._model_envs(i)]) == [0, 1]
+    # the four sizes differ in their inertial numbers: so do their pools
+    assert not np.array_equal(b._variant_pools[0]["tables"][2][0], b._variant_pools[3]["tables"][2][0])
