@@ -244,7 +244,7 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> 
   // pass of their own (the regular kernels keep theirs in the part of lane memory that holds M and the twists later in the pass)
   static constexpr bool kBig = NS > 8;
   static constexpr int kQCap = kBig ? 128 : ((MC >= 5) ? 24 : 8);    // convex pairs per chain and pass
-  static constexpr int kRCap = kBig ? NS : ((NS < 8) ? NS : 8);      // contacts per chain and pass
+  static constexpr int kRCap = kBig ? 64 : ((NS < 8) ? NS : 8);      // contacts per chain and pass
   static constexpr int kLists = kBS + (PAIRS ? MC * 3 : 0);
   static constexpr int kSize = kLists + ((PAIRS && kBig) ? kQCap + 8 * kRCap : 0);
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
@@ -1368,6 +1368,276 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
   return out;
 }
 
+// ---- native pairs (geom-pair kind 1): the engine's own colliders for a box or a cylinder against a sphere / capsule / box
+// (mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, mjc_BoxBox of the third-party mujoco==2.3.7). oracle/oracle.c nat_* is the
+// float64 restatement these follow step by step (same constructions, same order of the contacts); the box-box edge case is
+// pinned on the reference's golden rollout HumanoidTorque4Ages.run.all (tests/test_oracle_golden.py). A pair can have several
+// contacts (capsule-box 2, box-box 8): `sub` selects one, `ncon` says how many there are — the caller runs the collider once per
+// contact instead of keeping eight results alive in a kernel that has no registers to spare.
+struct NatGeom { int type; V3 c, ax; float half, rad; V3 ex, ey, ez, hs; };
+LM_DEV NatGeom nat_geom(const float* rec, bool second, V3 pl, const M3& Rl, V3 O) {
+  NatGeom g;
+  const float* cap = rec + (second ? LM_GP_P2 : LM_GP_P1);       // centre 3, axis 3, half length, radius (exact for sphere / capsule / cylinder)
+  const float* x = rec + (second ? LM_GP_X2 : LM_GP_X1);
+  g.type = (int)x[LM_GX_TYPE];
+  g.c = pl + mul(Rl, v3(cap[0], cap[1], cap[2])) - O;
+  g.ax = mul(Rl, v3(cap[3], cap[4], cap[5]));
+  g.half = cap[6]; g.rad = cap[7];
+  g.ex = mul(Rl, v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5])); g.ey = mul(Rl, v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]));
+  g.ez = cross(g.ex, g.ey);
+  g.hs = v3(x[LM_GX_E0], x[LM_GX_E0 + 1], x[LM_GX_E0 + 2]);
+  return g;
+}
+struct NatOut { float dist; V3 n, p; bool found; };
+LM_DEV NatOut nat_sphere_sphere(V3 c1, float r1, V3 c2, float r2, float margin) {
+  NatOut o; o.found = false; o.dist = 0.0f; o.n = v3(1, 0, 0); o.p = c1;
+  const V3 dv = c2 - c1;
+  const float d = sqrtf(dot(dv, dv)), dist = d - r1 - r2;
+  if (dist >= margin) return o;
+  o.n = (d < 1e-15f) ? v3(1, 0, 0) : (1.0f / d) * dv;
+  o.dist = dist; o.p = c1 + (r1 + 0.5f * dist) * o.n; o.found = true;
+  return o;
+}
+LM_DEV NatOut nat_sphere_box(V3 c, float r, const NatGeom& B, float margin) {
+  NatOut o; o.found = false; o.dist = 0.0f; o.n = v3(1, 0, 0); o.p = c;
+  const V3 rel = c - B.c;
+  const float ctr[3] = {dot(B.ex, rel), dot(B.ey, rel), dot(B.ez, rel)}, hs[3] = {B.hs.x, B.hs.y, B.hs.z};
+  float cl[3], d[3], d2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { cl[k] = fminf(fmaxf(ctr[k], -hs[k]), hs[k]); d[k] = cl[k] - ctr[k]; d2 = fmaf(d[k], d[k], d2); }
+  float dist = sqrtf(d2);
+  if (dist - r >= margin) return o;
+  float nl[3] = {0.0f, 0.0f, 0.0f}, pl[3];
+  if (dist <= 1e-15f) {               // centre inside the box: out through the nearest face
+    float closest = 2.0f * (hs[0] + hs[1] + hs[2]); int kk = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const float fd = fabsf(((i & 1) ? 1.0f : -1.0f) * hs[i >> 1] - ctr[i >> 1]); if (closest > fd) { closest = fd; kk = i; } }
+#pragma unroll
+    for (int k = 0; k < 3; k++) nl[k] = (k == (kk >> 1)) ? ((kk & 1) ? -1.0f : 1.0f) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) pl[k] = ctr[k] + nl[k] * (r - closest) * 0.5f;
+    dist = -closest;
+  } else {
+    const float id = 1.0f / dist;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { nl[k] = d[k] * id; pl[k] = 0.5f * (cl[k] + ctr[k] + nl[k] * r); }
+  }
+  o.dist = dist - r;
+  o.n = nl[0] * B.ex + nl[1] * B.ey + nl[2] * B.ez;
+  o.p = B.c + pl[0] * B.ex + pl[1] * B.ey + pl[2] * B.ez;
+  o.found = true;
+  return o;
+}
+LM_DEV NatOut nat_sphere_cylinder(V3 c, float r, const NatGeom& C, float margin) {
+  const float radius = C.rad, height = C.half;
+  const V3 vec = c - C.c;
+  const float x = dot(vec, C.ax);
+  const V3 ap = x * C.ax, pp = vec - ap;
+  const float pp2 = dot(pp, pp);
+  bool side = fabsf(x) < height, cap = pp2 < radius * radius;
+  if (side && cap) { if (height - fabsf(x) < radius - sqrtf(pp2)) side = false; else cap = false; }
+  if (side) return nat_sphere_sphere(c, r, C.c + ap, radius, margin);
+  if (cap) {
+    NatOut o; o.found = false; o.dist = 0.0f; o.n = v3(1, 0, 0); o.p = c;
+    const V3 n = ((x > 0.0f) ? 1.0f : -1.0f) * C.ax;
+    const float cd = dot(c - (C.c + height * n), n);
+    if (cd - r >= margin) return o;
+    o.dist = cd - r; o.p = c + (-0.5f * (cd - r) - r) * n; o.n = (-1.0f) * n; o.found = true;
+    return o;
+  }
+  const float sc = radius / sqrtf(fmaxf(pp2, 1e-15f));
+  return nat_sphere_sphere(c, r, C.c + ((x > 0.0f) ? height : -height) * C.ax + sc * pp, 0.0f, margin);
+}
+LM_DEV NatOut nat_capsule_box(const NatGeom& K, const NatGeom& B, float margin, int sub, int& ncon) {
+  const V3 rel = K.c - B.c;
+  const float p[3] = {dot(B.ex, rel), dot(B.ey, rel), dot(B.ez, rel)}, hs[3] = {B.hs.x, B.hs.y, B.hs.z};
+  const float a[3] = {dot(B.ex, K.ax) * K.half, dot(B.ey, K.ax) * K.half, dot(B.ez, K.ax) * K.half};
+  // g'(t) = (P(t) - clamp(P(t))) . a, non-decreasing along the axis segment: its leftmost non-negative point is the closest point
+  auto gp = [&](float t) -> float {
+    float s_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float P = fmaf(t, a[k], p[k]); s_ = fmaf(P - fminf(fmaxf(P, -hs[k]), hs[k]), a[k], s_); }
+    return s_;
+  };
+  float t1;
+  if (gp(-1.0f) >= 0.0f) t1 = -1.0f;
+  else if (gp(1.0f) < 0.0f) t1 = 1.0f;
+  else {
+    float lo = -1.0f, hi = 1.0f;
+#pragma nounroll
+    for (int it = 0; it < 30; it++) { const float mid = 0.5f * (lo + hi); if (gp(mid) < 0.0f) lo = mid; else hi = mid; }
+    t1 = hi;
+  }
+  NatOut o = nat_sphere_box(K.c + (K.half * t1) * K.ax, K.rad, B, margin);
+  ncon = o.found ? 1 : 0;
+  const float t2 = (t1 <= 0.0f) ? 1.0f : -1.0f;
+  if (o.found && fabsf(t2 - t1) * K.half > 1e-9f) {
+    const NatOut o2 = nat_sphere_box(K.c + (K.half * t2) * K.ax, K.rad, B, margin);
+    if (o2.found) { ncon = 2; if (sub == 1) return o2; }
+  }
+  if (sub != 0) o.found = false;
+  return o;
+}
+LM_DEV NatOut nat_box_box(const NatGeom& A, const NatGeom& B, float margin, int sub, int& ncon) {
+  NatOut o; o.found = false; o.dist = 0.0f; o.n = v3(1, 0, 0); o.p = A.c;
+  ncon = 0;
+  const V3 Aa[3] = {A.ex, A.ey, A.ez}, Ba[3] = {B.ex, B.ey, B.ez};
+  const float s1[3] = {A.hs.x, A.hs.y, A.hs.z}, s2[3] = {B.hs.x, B.hs.y, B.hs.z};
+  const V3 d = B.c - A.c;
+  float best_face = -3.0e38f, best_edge = -3.0e38f;
+  V3 nf = v3(0, 0, 0), ne = v3(0, 0, 0);
+  int face = 0, ei = 0, ej = 0;
+  auto gap_of = [&](V3 n, float& pr) -> float {
+    float rA = 0.0f, rB = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rA = fmaf(s1[k], fabsf(dot(n, Aa[k])), rA); rB = fmaf(s2[k], fabsf(dot(n, Ba[k])), rB); }
+    pr = dot(d, n);
+    return fabsf(pr) - rA - rB;
+  };
+#pragma unroll
+  for (int f = 0; f < 6; f++) {
+    const V3 n = (f < 3) ? Aa[f % 3] : Ba[f % 3];
+    float pr; const float gap = gap_of(n, pr);
+    if (gap > best_face) { best_face = gap; face = f; nf = ((pr >= 0.0f) ? 1.0f : -1.0f) * n; }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      V3 n = cross(Aa[i], Ba[j]);
+      const float l = sqrtf(dot(n, n));
+      if (l < 1e-6f) continue;
+      n = (1.0f / l) * n;
+      float pr; const float gap = gap_of(n, pr);
+      if (gap > best_edge) { best_edge = gap; ei = i; ej = j; ne = ((pr >= 0.0f) ? 1.0f : -1.0f) * n; }
+    }
+  if (best_face >= margin || best_edge >= margin) return o;
+  if (best_edge > best_face + 0.05f * fabsf(best_face) + 1e-6f) {       // an edge pair decides only when it separates clearly better than every face
+    V3 pa = A.c, pb = B.c, ai = Aa[0], bj = Ba[0];
+    float hi_ = s1[0], hj_ = s2[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) pa = pa + (((dot(ne, Aa[k]) > 0.0f) ? 1.0f : -1.0f) * s1[k]) * Aa[k]; else { ai = Aa[k]; hi_ = s1[k]; }
+      if (k != ej) pb = pb + (((dot(ne, Ba[k]) > 0.0f) ? -1.0f : 1.0f) * s2[k]) * Ba[k]; else { bj = Ba[k]; hj_ = s2[k]; }
+    }
+    float sa, ta;
+    segment_closest(pa, ai, hi_, pb, bj, hj_, sa, ta);
+    ncon = 1;
+    if (sub == 0) { o.dist = best_edge; o.n = ne; o.p = 0.5f * ((pa + sa * ai) + (pb + ta * bj)); o.found = true; }
+    return o;
+  }
+  // face contact: the incident face of the other box clipped against the reference face
+  const bool ref1 = face < 3; const int kr = face % 3;
+  const V3* Ar = ref1 ? Aa : Ba; const V3* Ai = ref1 ? Ba : Aa;
+  const float* sr = ref1 ? s1 : s2; const float* si = ref1 ? s2 : s1;
+  const V3 prc = ref1 ? A.c : B.c, pic = ref1 ? B.c : A.c;
+  const V3 nr = ref1 ? nf : (-1.0f) * nf;
+  V3 arn = Ar[0], aru = Ar[1], arv = Ar[2]; float srn = sr[0], sru = sr[1], srv = sr[2];
+  if (kr == 1) { arn = Ar[1]; aru = Ar[2]; arv = Ar[0]; srn = sr[1]; sru = sr[2]; srv = sr[0]; }
+  else if (kr == 2) { arn = Ar[2]; aru = Ar[0]; arv = Ar[1]; srn = sr[2]; sru = sr[0]; srv = sr[1]; }
+  (void)arn;
+  int ji = 0; float bj_ = -1.0f;
+#pragma unroll
+  for (int j = 0; j < 3; j++) { const float v = fabsf(dot(nr, Ai[j])); if (v > bj_) { bj_ = v; ji = j; } }
+  V3 ain = Ai[0], aiu = Ai[1], aiv = Ai[2]; float sin_ = si[0], siu = si[1], siv = si[2];
+  if (ji == 1) { ain = Ai[1]; aiu = Ai[2]; aiv = Ai[0]; sin_ = si[1]; siu = si[2]; siv = si[0]; }
+  else if (ji == 2) { ain = Ai[2]; aiu = Ai[0]; aiv = Ai[1]; sin_ = si[2]; siu = si[0]; siv = si[1]; }
+  const float sgi = (dot(nr, ain) > 0.0f) ? -1.0f : 1.0f;           // the incident face looks back at the reference box
+  float poly[16][3], tmp[16][3];
+  int np_ = 4;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float su = (q == 0 || q == 3) ? 1.0f : -1.0f, sv = (q < 2) ? 1.0f : -1.0f;
+    const V3 w = pic + (sgi * sin_) * ain + (su * siu) * aiu + (sv * siv) * aiv - prc;
+    poly[q][0] = dot(w, aru); poly[q][1] = dot(w, arv); poly[q][2] = dot(w, nr) - srn;        // (x, y) on the reference face, height above it
+  }
+#pragma nounroll
+  for (int side = 0; side < 4; side++) {
+    const int cc = side >> 1; const float sg = (side & 1) ? -1.0f : 1.0f, lim = cc ? srv : sru;
+    int nn = 0;
+#pragma nounroll
+    for (int q = 0; q < np_; q++) {
+      const int q2 = (q + 1 == np_) ? 0 : q + 1;
+      const float dp = lim - sg * poly[q][cc], dq = lim - sg * poly[q2][cc];
+      if (dp >= 0.0f) { tmp[nn][0] = poly[q][0]; tmp[nn][1] = poly[q][1]; tmp[nn][2] = poly[q][2]; nn++; }
+      if ((dp >= 0.0f) != (dq >= 0.0f)) {
+        const float f = dp / (dp - dq);
+#pragma unroll
+        for (int k = 0; k < 3; k++) tmp[nn][k] = fmaf(f, poly[q2][k] - poly[q][k], poly[q][k]);
+        nn++;
+      }
+    }
+    np_ = nn;
+#pragma nounroll
+    for (int q = 0; q < np_; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+    if (np_ == 0) break;
+  }
+#pragma nounroll
+  for (int q = 0; q < np_ && ncon < 8; q++) {
+    const float h = poly[q][2];
+    if (h >= margin) continue;
+    if (ncon == sub) { o.dist = h; o.n = nf; o.p = prc + poly[q][0] * aru + poly[q][1] * arv + (srn + 0.5f * h) * nr; o.found = true; }
+    ncon++;
+  }
+  return o;
+}
+// the pair's collider (geom 1 / geom 2 in the engine's type order), and a cheap LOWER BOUND of the pair's distance for the reach
+// test and the detection slack (sphere pairs: the exact distance; capsule-box: the box's three face normals as separating axes;
+// box-box: the 15 axes)
+// BOXBOX: the kernel family carries the box-box collider (the humanoids: one foot box on the other; the quadruped's kernels leave its
+// clipping arrays out — its model has no box pair, the lowering keeps one counted-only if a model of that family ever has)
+// CAPBOX: ... and the capsule-box collider (the quadruped's REGULAR kernels leave it to the replay kernel: a leg capsule reaches a
+// trunk box only far beyond the joint limits, and the collider's live values cost the regular kernel 500 bytes of scratch per lane)
+template <bool BOXBOX, bool CAPBOX>
+LM_DEV NatOut native_contact(const NatGeom& G1, const NatGeom& G2, float margin, int sub, int& ncon) {
+  if constexpr (BOXBOX) { if (G1.type == LM_GEOM_BOX) return nat_box_box(G1, G2, margin, sub, ncon); }
+  if constexpr (CAPBOX) { if (G1.type == LM_GEOM_CAPSULE) return nat_capsule_box(G1, G2, margin, sub, ncon); }
+  NatOut o = (G2.type == LM_GEOM_BOX) ? nat_sphere_box(G1.c, G1.rad, G2, margin) : nat_sphere_cylinder(G1.c, G1.rad, G2, margin);
+  ncon = o.found ? 1 : 0;
+  if (sub != 0) o.found = false;
+  return o;
+}
+template <bool BOXBOX>
+LM_DEV float native_lower_bound(const NatGeom& G1, const NatGeom& G2) {
+  if (G1.type == LM_GEOM_SPHERE && G2.type == LM_GEOM_CYLINDER) {
+    const V3 vec = G1.c - G2.c;
+    const float x = dot(vec, G2.ax);
+    const V3 pp = vec - x * G2.ax;
+    const float dr = fmaxf(sqrtf(dot(pp, pp)) - G2.rad, 0.0f), dh = fmaxf(fabsf(x) - G2.half, 0.0f);
+    return sqrtf(dr * dr + dh * dh) - G1.rad;
+  }
+  const V3 rel = G1.c - G2.c;
+  if (BOXBOX && G1.type == LM_GEOM_BOX) {
+    const V3 Aa[3] = {G1.ex, G1.ey, G1.ez}, Ba[3] = {G2.ex, G2.ey, G2.ez};
+    const float s1[3] = {G1.hs.x, G1.hs.y, G1.hs.z}, s2[3] = {G2.hs.x, G2.hs.y, G2.hs.z};
+    float gap = -3.0e38f;
+    auto test_axis = [&](V3 n) {
+      float r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { r1 += s1[k] * fabsf(dot(n, Aa[k])); r2 += s2[k] * fabsf(dot(n, Ba[k])); }
+      gap = fmaxf(gap, fabsf(dot(rel, n)) - r1 - r2);
+    };
+#pragma unroll
+    for (int k = 0; k < 3; k++) { test_axis(Aa[k]); test_axis(Ba[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int l = 0; l < 3; l++) {
+        const V3 cr = cross(Aa[k], Ba[l]);
+        const float n2 = dot(cr, cr);
+        if (n2 > 1e-12f) test_axis((1.0f / sqrtf(n2)) * cr);
+      }
+    return gap;
+  }
+  // sphere (half = 0) or capsule against a box: the box's face normals as separating axes
+  const float p[3] = {dot(G2.ex, rel), dot(G2.ey, rel), dot(G2.ez, rel)}, hs[3] = {G2.hs.x, G2.hs.y, G2.hs.z};
+  const float a[3] = {dot(G2.ex, G1.ax) * G1.half, dot(G2.ey, G1.ax) * G1.half, dot(G2.ez, G1.ax) * G1.half};
+  float gap = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) gap = fmaxf(gap, fabsf(p[k]) - hs[k] - fabsf(a[k]));
+  return gap - G1.rad;
+}
+
 // ---- the substep ---------------------------------------------------------------------------------------------
 // cm: constant table (LDS), c: chain id of this lane. State in/out: root (replicated) + chain.
 // actr/actc: actuator forces (already gear*clamped ctrl) per root / chain dof.
@@ -1389,6 +1659,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
   constexpr bool PAIRS = PM != 0, NOMPR = PM == 2;
+#ifdef LM_A1_CAPBOX_INLINE
+  constexpr bool kCapBox = true;
+#else
+  constexpr bool kCapBox = MC >= 5 || NS > 8 || CONE < 0;      // every humanoid kernel, the quadruped's replay kernel and its forward-only (debug) kernel
+#endif
   int oz = LM_OPAQUE_ZERO();
   const bool pyramidal = (CONE < 0) ? (P.cone == 0) : (CONE == 0);
   // CONE == LM_CONE_PYRAMIDAL promises that every contact of the model is a condim-3 pyramid (checked by the launcher):
@@ -1932,43 +2207,65 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             cnt.m[7]++;
 #endif
             const int g = round * kW + me;
-            int cs = 0, t = 0;
+            int cs = 0, t = 0, kind = 2, ncon_item = 1;
             float raw = 0.0f;
-            MprOut mo; mo.found = 0;
+            EntryCtx E;
+            const float* rec = gptp;
+            bool g1own = false;
             if (g < T) {
               cs = chain_of(g); t = g - base[cs];
               raw = PEER(cs - c, kQItem + t);
               const int item = (int)raw;
-              EntryCtx E;
               entry_ctx_of(cs, item >> 16, E);
               entry_frames(E);
-              const float* rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
-              const bool g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
+              rec = gptp + (item & 65535) * LM_GPAIR_SIZE;
+              g1own = ((int)rec[LM_GP_G1Q] == E.own_q);
+              kind = (int)rec[LM_GP_KIND];
+            }
+            // a native pair (kind 1) can have several contacts: one per pass of this loop, the collider run again for each
+            // (wave-uniform trip count; convex pairs and the separation stage take one pass)
+#pragma nounroll
+            for (int sub = 0;; sub++) {
+              MprOut mo; mo.found = 0; mo.nx = mo.ny = mo.nz = mo.px = mo.py = mo.pz = mo.dist = 0.0f;
+              if (g < T) {
+                if (kind == 1) {
+                  if (stage == 0) mo.found = (sub == 0) ? 1 : 0;          // no separation stage: the reach test was the tight bound already
+                  else {
+                    const NatGeom G1 = nat_geom(rec, false, g1own ? E.po : E.pp, g1own ? E.Ro : E.Rp, O);
+                    const NatGeom G2 = nat_geom(rec, true, g1own ? E.pp : E.po, g1own ? E.Rp : E.Ro, O);
+                    const NatOut no = native_contact<(MC >= 5), kCapBox>(G1, G2, rec[LM_GP_MARGIN], sub, ncon_item);
+                    mo.found = no.found ? 1 : 0; mo.dist = no.dist;
+                    mo.nx = no.n.x; mo.ny = no.n.y; mo.nz = no.n.z; mo.px = no.p.x; mo.py = no.p.y; mo.pz = no.p.z;
+                  }
+                } else if (sub == 0) {
 #ifndef LM_NO_MPR
-              if constexpr (!NOMPR) {
+                  if constexpr (!NOMPR) {
 #ifdef LM_TIMERS
-                mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
+                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
 #else
-                mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
+                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
 #endif
-              }
+                  }
 #endif
-            }
-            const bool found = mo.found != 0;
-            const unsigned fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
-            if (found) {
-              const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
-              if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
-              else if (k < kRcap) {
-                const int rb_ = kRes + 8 * k, dlw = cs - c;
-                Q::peer_write(lmem, ls, rb_, dlw, raw); Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.dist);
-                Q::peer_write(lmem, ls, rb_ + 2, dlw, mo.nx); Q::peer_write(lmem, ls, rb_ + 3, dlw, mo.ny); Q::peer_write(lmem, ls, rb_ + 4, dlw, mo.nz);
-                Q::peer_write(lmem, ls, rb_ + 5, dlw, mo.px); Q::peer_write(lmem, ls, rb_ + 6, dlw, mo.py); Q::peer_write(lmem, ls, rb_ + 7, dlw, mo.pz);
+                }
               }
-            }
+              const bool found = mo.found != 0;
+              const unsigned fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
+              if (found) {
+                const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
+                if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
+                else if (k < kRcap) {
+                  const int rb_ = kRes + 8 * k, dlw = cs - c;
+                  Q::peer_write(lmem, ls, rb_, dlw, raw); Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.dist);
+                  Q::peer_write(lmem, ls, rb_ + 2, dlw, mo.nx); Q::peer_write(lmem, ls, rb_ + 3, dlw, mo.ny); Q::peer_write(lmem, ls, rb_ + 4, dlw, mo.nz);
+                  Q::peer_write(lmem, ls, rb_ + 5, dlw, mo.px); Q::peer_write(lmem, ls, rb_ + 6, dlw, mo.py); Q::peer_write(lmem, ls, rb_ + 7, dlw, mo.pz);
+                }
+              }
 #pragma unroll
-            for (int c2 = 0; c2 < 4; c2++) kept[c2] += __builtin_popcount(fm & chain_bits(c2, round));
-            Q::fence(); Q::quad_sync();
+              for (int c2 = 0; c2 < 4; c2++) kept[c2] += __builtin_popcount(fm & chain_bits(c2, round));
+              Q::fence(); Q::quad_sync();
+              if (!Q::any(stage == 1 && g < T && kind == 1 && sub + 1 < ncon_item)) break;
+            }
           }
           if (stage == 0) { for (int c2 = 0; c2 < 4; c2++) n_of[c2] = kept[c2]; set_bases(n_of); }
           else for (int c2 = 0; c2 < 4; c2++) nres_of[c2] += kept[c2];
@@ -2189,10 +2486,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               }
               const float* rec = gptp + (first + v) * LM_GPAIR_SIZE;
               const int kind = (int)rec[LM_GP_KIND];
-              // the quadruped's counted-only pairs (trunk box against the thighs ...: their bounding capsules sit millimetres apart in
-              // every gait) are looked at in the first pass of a control step only, and do not hold the next detection back
-              const bool counted_only = kind == 1;
-              if (!(counted_only && !first_detect && MC <= 3)) {
+              {
                 EntryCtx E;
                 entry_ctx_of(cs, i, E);
                 entry_frames(E);
@@ -2205,7 +2499,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #if defined(LM_TIMERS) && !defined(LM_PAIR_PHASES)
                 cnt.m[10 + kind]++; if (G.dist < pmargin) cnt.m[13 + kind]++;
 #endif
-                if (!counted_only || MC > 3) { gap_note(cs, G.dist - pmargin); if (is_cross) gap_note(E.lb, G.dist - pmargin); }       // (the humanoids' one counted pair — foot on foot — is watched like the others)
+                float clearance = G.dist - pmargin;               // what holds the next detection back: a LOWER bound of the pair's distance
                 bool in_reach = G.dist < pmargin;
                 if (in_reach) {
                   // the engine's mid phase: bounding spheres of the two geoms WITHOUT the margin (pinned for plane pairs by the golden
@@ -2215,43 +2509,23 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   const float rb2 = (rec[LM_GP_X2 + LM_GX_RBOUND] > 0.0f) ? rec[LM_GP_X2 + LM_GX_RBOUND] : rec[LM_GP_H2] + G.r2;
                   if (sqrtf(dot(cc, cc)) - rb1 - rb2 > 0.0f) in_reach = false;
                 }
-                if (in_reach && kind == 1) {                           // no collider for this pair of geom types: counted
-                  bool reach = true;
-                  if ((int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_BOX && (int)rec[LM_GP_X2 + LM_GX_TYPE] == LM_GEOM_BOX) {
-                    // two boxes (the humanoid's feet): the largest gap over the 15 candidate separating axes, like the oracle's count
-                    const M3& R1 = G.g1own ? E.Ro : E.Rp; const M3& R2 = G.g1own ? E.Rp : E.Ro;
-                    V3 ax[6]; float hs[6];
-#pragma unroll
-                    for (int w = 0; w < 2; w++) {
-                      const float* x = rec + (w ? LM_GP_X2 : LM_GP_X1);
-                      const M3& Rw_ = w ? R2 : R1;
-                      const V3 ex = mul(Rw_, v3(x[LM_GX_E0 + 3], x[LM_GX_E0 + 4], x[LM_GX_E0 + 5])), ey = mul(Rw_, v3(x[LM_GX_E0 + 6], x[LM_GX_E0 + 7], x[LM_GX_E0 + 8]));
-                      ax[3 * w] = ex; ax[3 * w + 1] = ey; ax[3 * w + 2] = cross(ex, ey);
-                      hs[3 * w] = x[LM_GX_E0]; hs[3 * w + 1] = x[LM_GX_E0 + 1]; hs[3 * w + 2] = x[LM_GX_E0 + 2];
-                    }
-                    const V3 dcen = G.c2 - G.c1;
-                    float gap = -3.0e38f;
-                    auto test_axis = [&](V3 n) {
-                      float r1 = 0.0f, r2 = 0.0f;
-#pragma unroll
-                      for (int k = 0; k < 3; k++) { r1 += hs[k] * fabsf(dot(n, ax[k])); r2 += hs[3 + k] * fabsf(dot(n, ax[3 + k])); }
-                      gap = fmaxf(gap, fabsf(dot(dcen, n)) - r1 - r2);
-                    };
-#pragma unroll
-                    for (int k = 0; k < 6; k++) test_axis(ax[k]);
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-#pragma unroll
-                      for (int l = 0; l < 3; l++) {
-                        const V3 cr = cross(ax[k], ax[3 + l]);
-                        const float n2 = dot(cr, cr);
-                        if (n2 > 1e-18f) test_axis((1.0f / sqrtf(n2)) * cr);
-                      }
-                    reach = gap < rec[LM_GP_MARGIN];
-                  }
-                  is_prox = reach;
-                } else if (in_reach && kind == 2) {
-                  if constexpr (NOMPR) cnt.need_full = 1;          // no collider in this kernel: the control step goes to the full one
+                if (in_reach && kind == 1) {
+                  // a native pair (box / cylinder against a sphere, capsule or box): the bounding capsule of a box is loose — the
+                  // tight bound decides (and is what the slack remembers: a trunk box centimetres from a thigh does not call for
+                  // a detection in every pass)
+                  const NatGeom G1 = nat_geom(rec, false, G.g1own ? E.po : E.pp, G.g1own ? E.Ro : E.Rp, O);
+                  const NatGeom G2 = nat_geom(rec, true, G.g1own ? E.pp : E.po, G.g1own ? E.Rp : E.Ro, O);
+                  const float lb = native_lower_bound<(MC >= 5)>(G1, G2);
+                  clearance = fmaxf(clearance, lb - pmargin);
+                  in_reach = lb < pmargin;
+                }
+                gap_note(cs, clearance);
+                if (is_cross) gap_note(E.lb, clearance);
+                if (in_reach && kind == 3) is_prox = true;              // a pair without a collider (a mesh that came without a hull): counted
+                else if (!kCapBox && in_reach && kind == 1 && (int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_CAPSULE) cnt.need_full = 1;     // capsule against a box: the replay kernel's
+                else if (in_reach && kind != 0) {
+                  // convex pairs (the engine's MPR) and native pairs: queued, their colliders run side by side in flush_queue
+                  if constexpr (NOMPR) { if (kind == 2) cnt.need_full = 1; else { want_q = true; code = (float)(i * 65536 + first + v); } }
                   else { want_q = true; code = (float)(i * 65536 + first + v); }
                 } else if (in_reach) {
                   has_res = true; code = (float)(i * 65536 + first + v);

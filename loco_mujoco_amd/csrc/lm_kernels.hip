@@ -358,7 +358,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
    alone (contacts beyond the slots are dropped and counted: the behaviour of rounds 1-3, kept for A/B measurements). */
 int lm_batch_set_replay(lm_batch* b, int enabled) {
   if (!b) return fail("null batch");
-  b->replay = enabled ? 1 : 0;
+  b->replay = enabled == 2 ? 2 : (enabled ? 1 : 0);        // 2 (tests): every control step goes through the replay kernel
   return 0;
 }
 
@@ -639,7 +639,7 @@ static KArgs make_args(lm_batch* b) {
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
   // speculate / replay: every family but the generic one has a replay kernel
-  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; }
+  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; a.replay_all = b->replay == 2; }
   static const bool no_xcd_map = LM_PROBE_ENV("LM_NO_XCD_MAP") != nullptr;
   a.xcd_map = no_xcd_map ? 0 : 1;
   return a;

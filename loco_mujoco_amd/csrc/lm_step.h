@@ -134,6 +134,7 @@ struct KArgs {
   int* replay_list;             // [N] environment ids, appended by the regular kernel (null: no replay kernel follows, drops are final)
   int* replay_ctl;              // [0] number of entries, [1] workgroups of the replay kernel that are through (the last one clears both)
   int* stall;                   // [N] the fused control step at which the environment left the regular kernel (0 for single-step launches)
+  int replay_all;               // tests (lm_batch_set_replay(b, 2)): EVERY control step is abandoned and run by the replay kernel
   unsigned char* replay_mark;   // [N] sticky: the replay kernel ran (part of) this environment's control steps since the marks were last cleared
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
@@ -295,8 +296,10 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   lm::Counters cnt = {};
   using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, CONE>;
   const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
-  LM_LMEM_T* lmem = lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
-  constexpr int ls = 16;
+  // REPLAY: ONE environment per workgroup and four lane-memory columns instead of sixteen — the whole LDS of the workgroup for one
+  // robot's contact slots (128 per chain: more than the engine's own nconmax of 400 per robot, humanoid_torque.xml:19)
+  constexpr int ls = REPLAY ? 4 : 16;
+  LM_LMEM_T* lmem = REPLAY ? lane_mem + c : lane_mem + (lm_lane >> 4) * LMm::kGroup + (lm_lane & 15);
   if (NM > 0) {
     // this lane's muscles: activation state and un-normalised, clamped control into lane memory
     const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   // ---- did this control step stay inside the kernel's capacity? If not it is abandoned (nothing stored) and handed to the replay
   // kernel. Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
   if (!REPLAY && a.replay_list) {
-    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+    const bool leave = a.replay_all || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
     if (leave && valid) {
       if (c == 0) { const int k = atomicAdd(&a.replay_ctl[0], 1); a.replay_list[k] = e; a.stall[e] = fused; }
       gone = true; valid = false;
@@ -545,16 +548,16 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const dim3 grid((L.N + L.epb - 1) / L.epb);
   using LMm = lm::LaneMemFor<MC, NS, NM, (PM != 0), CONE>;
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
-  // the replay kernel: a slot for every contact (32 per leg of the quadruped, 48 per chain of a humanoid), the convex collider,
-  // fused (it finishes the launch's control steps of its environments), four environments per workgroup whatever the batch's layout
-  constexpr int NSB = (MC <= 3) ? 32 : 48, PMB = (PM != 0) ? 1 : 0;
+  // the replay kernel: 128 contact slots per chain (one environment per workgroup: its whole LDS), the convex collider,
+  // fused (it finishes the launch's control steps of its environments)
+  constexpr int NSB = 128, PMB = (PM != 0) ? 1 : 0;
   using LMb = lm::LaneMemFor<MC, NSB, NM, (PM != 0), CONE>;
   if (kind == LMK_BIG || kind == LMK_BIG_DR || kind == LMK_BIG_DRV) {
     if (kind != LMK_BIG + PART) return false;
     KArgs b = a;
-    b.epb = 4; b.xcd_map = 0;
-    const int ngroups = (L.N + 3) / 4;
-    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < kReplayGrid ? ngroups : kReplayGrid), dim3(64), (size_t)LMb::kGroup, L, b);
+    b.epb = 1; b.xcd_map = 0;
+    const int ngroups = (int)grid.x;          // (the statistics slots are one per workgroup of the REGULAR launch: not more workgroups than that)
+    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < kReplayGrid ? ngroups : kReplayGrid), dim3(16), (size_t)LMb::kPadded * 4, L, b);
     return true;
   }
   if constexpr (PART == 0) {

@@ -776,7 +776,7 @@ def lower(m, task):
             else:
                 cm[CM_CHAINS + (C_LINKS + li * LINK_SIZE + D_SIZE + L_BSX + np.arange(4)) * NCHAIN + cl] = list(ctr[0]) + [ctr[1]]
         info["self_collision_tables"] = dict(link_pairs=[len(x) for x in lanes_lp], body_pairs=len(bpt) // BP_SIZE, geom_pairs=len(gpt) // GPAIR_SIZE,
-                                             closed_form=kinds[0], counted_only=kinds[1], convex=kinds[2])
+                                             closed_form=kinds[0], native=kinds[1], convex=kinds[2])
         if m.cone == mjcf.CONE_PYRAMIDAL:
             max_contacts = 8                  # the pair families are compiled with eight slots per chain (floor + self-contacts)
             h[H_MAXCONTACTS] = max_contacts
@@ -899,8 +899,9 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
     weld groups, not parent and child, contype / conaffinity — the floor is handled elsewhere), grouped by link pair.
     Kind 0: sphere / capsule pairs (closed form). Kind 2: the pairs the engine collides through its general convex collider
     (anything against a mesh, capsule / cylinder / box against a cylinder): MPR on the device, hull vertices in the mesh-vertex
-    table. Kind 1: pairs with a native collider that is not restated (sphere / capsule / box against a box, sphere against a
-    cylinder): kept as bounding capsules and only COUNTED when they come within the margin (``self_proximity`` statistic).
+    table. Kind 1: pairs with one of the engine's NATIVE box / cylinder colliders (sphere / capsule / box against a box, sphere
+    against a cylinder): restated on the device (csrc/lm_core.h nat_*) like in the oracle; a mesh without a hull in such a pair
+    stays counted only (``self_proximity`` statistic).
     Two links of ONE chain may form a pair (UnitreeH1: hip-yaw cylinder against the thigh of the same leg): the entry then lives in
     that lane only. Returns (per-lane link-pair entries [code, range, reach^2], geom-pair records (flat),
     {(lane, link): bounding sphere}).
@@ -1017,15 +1018,18 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
                     kind = 0
                 elif _engine_uses_ccd(ta, tb) and all(m.geom_type[g] != mjcf.GEOM_MESH or has_hull[g] > 0 for g in (a, b)):
                     kind = 2
+                elif (ta, tb) in ((mjcf.GEOM_SPHERE, mjcf.GEOM_BOX), (mjcf.GEOM_SPHERE, mjcf.GEOM_CYLINDER), (mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX)) \
+                        or ((ta, tb) == (mjcf.GEOM_BOX, mjcf.GEOM_BOX) and pyramidal):      # (the quadruped family is compiled without the box-box collider)
+                    kind = 1                                           # the engine's native box / cylinder colliders
                 else:
-                    kind = 1
-                kinds[kind] += 1
+                    kind = 3                                           # a mesh without a convex hull: counted only
+                kinds[min(kind, 2) if kind != 3 else 1] += 1
                 rec = np.zeros(GPAIR_SIZE)
                 rec[GP_KIND], rec[GP_G1Q] = kind, float(m.body_weldid[m.geom_body[a]] == wq)
                 for base, g in ((GP_P1, a), (GP_P2, b)):
                     pos, axis, half, rad, _ = capsule_of(g)
                     rec[base:base + 3], rec[base + 3:base + 6], rec[base + 6], rec[base + 7] = pos, axis, half, rad
-                if kind == 2 or (kind == 1 and ta == mjcf.GEOM_BOX and tb == mjcf.GEOM_BOX):      # (box pairs are counted by their exact gap)
+                if kind != 0:      # convex pairs (MPR) and native pairs (the engine's box / cylinder colliders): type, centre, box axes of both geoms
                     rec[GP_X1:GP_X1 + GX_SIZE], rec[GP_X2:GP_X2 + GX_SIZE] = convex_of(a), convex_of(b)
                 rec[GP_MARGIN] = margin
                 rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)

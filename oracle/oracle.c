@@ -104,6 +104,7 @@ struct lmo_model {
   int disable_self_collision;
   int disable_ccd;             /* 1: no convex-convex (MPR) contacts; such pairs are counted instead (A/B tests) */
   int skip_pair_counter;       /* 1: pairs without a restated collider are not examined (no `unhandled_pairs`): timing runs */
+  int disable_native;          /* 1: no contacts from the native box / cylinder colliders; such pairs are counted instead (A/B tests) */
   /* convex hulls attached to mesh geoms (lmo_set_mesh): hull vertices in the frame of the geom's BODY */
   int mesh_nvert[LMO_MAXGEOM]; double* mesh_vert[LMO_MAXGEOM];
   /* hull-graph neighbours of every hull vertex (CSR, nearest first; from the model blob or lmo_set_mesh_graph) and the
@@ -215,6 +216,7 @@ void lmo_set_option(lmo_model* m, int what, double value) {
   if (what == 2) m->tolerance = value;
   if (what == 3) m->skip_pair_counter = (int)value;
   if (what == 4) m->disable_ccd = (int)value;
+  if (what == 5) m->disable_native = (int)value;
 }
 
 /* attach the convex hull of mesh geom g (nv hull vertices [nv][3] in the frame of the geom's body): the geom then collides
@@ -274,6 +276,7 @@ typedef struct {
   int solver_iter;
   int unhandled_pairs;
   int convex_contacts; double max_self_depth;     /* per forward pass: MPR contacts, deepest non-floor penetration */
+  int native_contacts;                            /* per forward pass: contacts of the native box / cylinder colliders */
 } work;
 
 enum { ROW_FRICTION = 0, ROW_LIMIT = 1, ROW_CONTACT_PLAIN = 2, ROW_CONTACT_PYR = 3, ROW_CONTACT_ELL = 4 };
@@ -509,6 +512,230 @@ static double box_box_gap(const double* p1, const double* R1, const double* s1,
     if (gap > best) best = gap;
   }
   return best;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* The engine's NATIVE colliders for box / cylinder pairs (mujoco 2.3.7 engine_collision_box.c,     */
+/* engine_collision_primitive.c: mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, mjc_BoxBox) —   */
+/* third party, not under /root/reference, not installed. Sphere-box and sphere-cylinder are fully    */
+/* determined by the geometry (closest feature, midpoint, signed distance) and restated as such.     */
+/* Capsule-box and box-box are the engine's own constructions (which contacts of a manifold are      */
+/* kept); they are restated from their published behaviour — capsule: the closest point of the axis  */
+/* segment as a sphere against the box + a second contact at the far end when that is within the     */
+/* margin too; boxes: separating-axis search over the 15 axes, then either the incident face clipped  */
+/* against the reference face (<= 8 contacts) or the closest points of the two edges — NOT pinned by  */
+/* any golden row of the reference (none has such a contact): "parity unpinned" for these two pair    */
+/* types. tests/test_oracle_golden.py checks every contact against brute-force geometry.              */
+/* out: rows of (dist, pos 3, normal 3); normal from geom 1 to geom 2. R: row-major, columns = axes.  */
+/* ------------------------------------------------------------------------------------------ */
+static int nat_sphere_box(const double* c, double r, const double* pb, const double* Rb, const double* sb, double margin, double (*out)[7]) {
+  double rel[3], ctr[3], cl[3], d[3];
+  sub3(rel, c, pb);
+  for (int k = 0; k < 3; k++) ctr[k] = Rb[k] * rel[0] + Rb[3 + k] * rel[1] + Rb[6 + k] * rel[2];
+  for (int k = 0; k < 3; k++) { cl[k] = ctr[k] < -sb[k] ? -sb[k] : (ctr[k] > sb[k] ? sb[k] : ctr[k]); d[k] = cl[k] - ctr[k]; }
+  double dist = norm3(d);
+  if (dist - r >= margin) return 0;
+  double nl[3] = {0, 0, 0}, pl[3];
+  if (dist <= MINVAL) {          /* centre inside the box: out through the nearest face */
+    double closest = 2 * (sb[0] + sb[1] + sb[2]); int kk = 0;
+    for (int i = 0; i < 6; i++) { double fd = fabs(((i % 2) ? 1.0 : -1.0) * sb[i / 2] - ctr[i / 2]); if (closest > fd) { closest = fd; kk = i; } }
+    nl[kk / 2] = (kk % 2) ? -1.0 : 1.0;
+    for (int k = 0; k < 3; k++) pl[k] = ctr[k] + nl[k] * (r - closest) * 0.5;
+    dist = -closest;
+  } else {
+    for (int k = 0; k < 3; k++) { nl[k] = d[k] / dist; pl[k] = 0.5 * (cl[k] + ctr[k] + nl[k] * r); }
+  }
+  out[0][0] = dist - r;
+  for (int k = 0; k < 3; k++) {
+    out[0][1 + k] = pb[k] + Rb[3 * k] * pl[0] + Rb[3 * k + 1] * pl[1] + Rb[3 * k + 2] * pl[2];
+    out[0][4 + k] = Rb[3 * k] * nl[0] + Rb[3 * k + 1] * nl[1] + Rb[3 * k + 2] * nl[2];
+  }
+  return 1;
+}
+
+/* sphere (centre c1, radius r1) against sphere (c2, r2): the engine's mjraw_SphereSphere */
+static int nat_sphere_sphere(const double* c1, double r1, const double* c2, double r2, double margin, double (*out)[7]) {
+  double n[3]; sub3(n, c2, c1);
+  double d = norm3(n), dist = d - r1 - r2;
+  if (dist >= margin) return 0;
+  if (d < MINVAL) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] /= d; n[1] /= d; n[2] /= d; }
+  out[0][0] = dist;
+  for (int k = 0; k < 3; k++) { out[0][1 + k] = c1[k] + n[k] * (r1 + 0.5 * dist); out[0][4 + k] = n[k]; }
+  return 1;
+}
+
+static int nat_sphere_cylinder(const double* c, double r, const double* pc, const double* Rc, const double* sc, double margin, double (*out)[7]) {
+  const double radius = sc[0], height = sc[1];
+  double axis[3] = { Rc[2], Rc[5], Rc[8] }, vec[3], ap[3], pp[3];
+  sub3(vec, c, pc);
+  const double x = dot3(vec, axis);
+  for (int k = 0; k < 3; k++) { ap[k] = axis[k] * x; pp[k] = vec[k] - ap[k]; }
+  const double pp2 = dot3(pp, pp);
+  int side = fabs(x) < height, cap = pp2 < radius * radius;
+  if (side && cap) {            /* centre inside the cylinder: out through the nearer of wall and cap */
+    if (height - fabs(x) < radius - sqrt(pp2)) side = 0; else cap = 0;
+  }
+  if (side) {                   /* against the wall: a sphere on the axis */
+    double tgt[3]; add3(tgt, pc, ap);
+    return nat_sphere_sphere(c, r, tgt, radius, margin, out);
+  }
+  if (cap) {                    /* against a cap: plane-sphere, the normal turned from the sphere to the cylinder */
+    const double sg = (x > 0) ? 1.0 : -1.0;
+    double n[3] = { sg * axis[0], sg * axis[1], sg * axis[2] }, pcap[3], rel[3];
+    for (int k = 0; k < 3; k++) pcap[k] = pc[k] + n[k] * height;
+    sub3(rel, c, pcap);
+    const double cd = dot3(rel, n);
+    if (cd - r >= margin) return 0;
+    out[0][0] = cd - r;
+    for (int k = 0; k < 3; k++) { out[0][1 + k] = c[k] + n[k] * (-0.5 * (cd - r) - r); out[0][4 + k] = -n[k]; }
+    return 1;
+  }
+  /* against the rim: a point */
+  double tgt[3];
+  const double sc_ = radius / sqrt(pp2 > MINVAL ? pp2 : MINVAL);
+  for (int k = 0; k < 3; k++) tgt[k] = pc[k] + axis[k] * (x > 0 ? height : -height) + pp[k] * sc_;
+  return nat_sphere_sphere(c, r, tgt, 0.0, margin, out);
+}
+
+/* capsule (centre pc, axis = third column of Rc, half length sc[1], radius sc[0]) against a box */
+static int nat_capsule_box(const double* pc, const double* Rc, const double* sc, const double* pb, const double* Rb, const double* sb,
+                           double margin, double (*out)[7]) {
+  const double r = sc[0], half = sc[1];
+  double axw[3] = { Rc[2], Rc[5], Rc[8] }, rel[3], p[3], a[3];
+  sub3(rel, pc, pb);
+  for (int k = 0; k < 3; k++) {
+    p[k] = Rb[k] * rel[0] + Rb[3 + k] * rel[1] + Rb[6 + k] * rel[2];
+    a[k] = (Rb[k] * axw[0] + Rb[3 + k] * axw[1] + Rb[6 + k] * axw[2]) * half;
+  }
+  /* g'(t) = (P(t) - clamp(P(t))) . a is non-decreasing along the segment P(t) = p + t a: its leftmost non-negative point is the
+     (leftmost) closest point of the axis to the box */
+#define NAT_GP(t, res) do { double s_ = 0; for (int k_ = 0; k_ < 3; k_++) { const double P_ = p[k_] + (t) * a[k_]; \
+    const double c_ = P_ < -sb[k_] ? -sb[k_] : (P_ > sb[k_] ? sb[k_] : P_); s_ += (P_ - c_) * a[k_]; } res = s_; } while (0)
+  double g0, g1, t1;
+  NAT_GP(-1.0, g0); NAT_GP(1.0, g1);
+  if (g0 >= 0) t1 = -1.0;
+  else if (g1 < 0) t1 = 1.0;
+  else {
+    double lo = -1.0, hi = 1.0;
+    for (int it = 0; it < 48; it++) { const double mid = 0.5 * (lo + hi); double gm; NAT_GP(mid, gm); if (gm < 0) lo = mid; else hi = mid; }
+    t1 = hi;
+  }
+#undef NAT_GP
+  int n = 0;
+  double c1[3];
+  for (int k = 0; k < 3; k++) c1[k] = pc[k] + axw[k] * half * t1;
+  n += nat_sphere_box(c1, r, pb, Rb, sb, margin, out + n);
+  /* the far end of the axis, when the capsule lies along the box (both within the margin): a second contact */
+  const double t2 = (t1 <= 0) ? 1.0 : -1.0;
+  if (n > 0 && fabs(t2 - t1) * half > 1e-9) {
+    double c2[3];
+    for (int k = 0; k < 3; k++) c2[k] = pc[k] + axw[k] * half * t2;
+    n += nat_sphere_box(c2, r, pb, Rb, sb, margin, out + n);
+  }
+  return n;
+}
+
+/* box against box */
+static int nat_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                       double margin, double (*out)[7]) {
+  double A[3][3], B[3][3], d[3];
+  for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) { A[k][j] = R1[3 * j + k]; B[k][j] = R2[3 * j + k]; }   /* axis k as a vector */
+  sub3(d, p2, p1);
+  double best_face = -1e300, best_edge = -1e300, nf[3] = {0, 0, 0}, ne[3] = {0, 0, 0};
+  int face = 0, ei = 0, ej = 0;
+  for (int f = 0; f < 6; f++) {
+    const double* n = (f < 3) ? A[f] : B[f - 3];
+    double rA = 0, rB = 0;
+    for (int k = 0; k < 3; k++) { rA += s1[k] * fabs(dot3(n, A[k])); rB += s2[k] * fabs(dot3(n, B[k])); }
+    const double pr = dot3(d, n), gap = fabs(pr) - rA - rB;
+    if (gap > best_face) { best_face = gap; face = f; const double sg = pr >= 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) nf[k] = sg * n[k]; }
+  }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double n[3]; cross3(n, A[i], B[j]);
+    const double l = norm3(n);
+    if (l < 1e-6) continue;
+    for (int k = 0; k < 3; k++) n[k] /= l;
+    double rA = 0, rB = 0;
+    for (int k = 0; k < 3; k++) { rA += s1[k] * fabs(dot3(n, A[k])); rB += s2[k] * fabs(dot3(n, B[k])); }
+    const double pr = dot3(d, n), gap = fabs(pr) - rA - rB;
+    if (gap > best_edge) { best_edge = gap; ei = i; ej = j; const double sg = pr >= 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) ne[k] = sg * n[k]; }
+  }
+  if (best_face >= margin || best_edge >= margin) return 0;
+  /* an edge pair decides only when it separates clearly better than every face (5 % + 1 um) */
+  if (best_edge > best_face + 0.05 * fabs(best_face) + 1e-6) {
+    double pa[3], pb_[3];
+    copy3(pa, p1); copy3(pb_, p2);
+    for (int k = 0; k < 3; k++) if (k != ei) addscl3(pa, A[k], (dot3(ne, A[k]) > 0 ? 1.0 : -1.0) * s1[k]);
+    for (int k = 0; k < 3; k++) if (k != ej) addscl3(pb_, B[k], (dot3(ne, B[k]) > 0 ? -1.0 : 1.0) * s2[k]);
+    double s, t;
+    segment_closest(pa, A[ei], s1[ei], pb_, B[ej], s2[ej], &s, &t);
+    double ca[3], cb[3];
+    copy3(ca, pa); addscl3(ca, A[ei], s); copy3(cb, pb_); addscl3(cb, B[ej], t);
+    out[0][0] = best_edge;
+    for (int k = 0; k < 3; k++) { out[0][1 + k] = 0.5 * (ca[k] + cb[k]); out[0][4 + k] = ne[k]; }
+    return 1;
+  }
+  /* face contact: the incident face of the other box clipped against the reference face */
+  const int ref1 = face < 3, kr = face % 3;
+  const double *pr_ = ref1 ? p1 : p2, *sr = ref1 ? s1 : s2, *pi_ = ref1 ? p2 : p1, *si = ref1 ? s2 : s1;
+  double (*Ar)[3] = ref1 ? A : B, (*Ai)[3] = ref1 ? B : A;
+  double nr[3];
+  for (int k = 0; k < 3; k++) nr[k] = ref1 ? nf[k] : -nf[k];           /* out of the reference face, towards the incident box */
+  int ji = 0; double bj = -1;
+  for (int j = 0; j < 3; j++) { const double v = fabs(dot3(nr, Ai[j])); if (v > bj) { bj = v; ji = j; } }
+  const double sgi = dot3(nr, Ai[ji]) > 0 ? -1.0 : 1.0;                  /* the incident face looks back at the reference box */
+  const int u = (ji + 1) % 3, v = (ji + 2) % 3, ur = (kr + 1) % 3, vr = (kr + 2) % 3;
+  double poly[16][3], tmp[16][3];
+  int np_ = 4;
+  for (int q = 0; q < 4; q++) {
+    const double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0;
+    double w[3];
+    for (int k = 0; k < 3; k++) w[k] = pi_[k] + sgi * si[ji] * Ai[ji][k] + su * si[u] * Ai[u][k] + sv * si[v] * Ai[v][k] - pr_[k];
+    poly[q][0] = dot3(w, Ar[ur]); poly[q][1] = dot3(w, Ar[vr]); poly[q][2] = dot3(w, nr) - sr[kr];     /* (x, y) on the reference face, height above it */
+  }
+  for (int side = 0; side < 4; side++) {
+    const int c = side >> 1; const double sg = (side & 1) ? -1.0 : 1.0, lim = sr[c ? vr : ur];
+    int nn = 0;
+    for (int q = 0; q < np_; q++) {
+      const double* P = poly[q]; const double* Q = poly[(q + 1) % np_];
+      const double dp = lim - sg * P[c], dq = lim - sg * Q[c];
+      if (dp >= 0) { copy3(tmp[nn], P); nn++; }
+      if ((dp >= 0) != (dq >= 0)) { const double f = dp / (dp - dq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f * (Q[k] - P[k]); nn++; }
+    }
+    np_ = nn;
+    for (int q = 0; q < np_; q++) copy3(poly[q], tmp[q]);
+    if (np_ == 0) break;
+  }
+  int n = 0;
+  for (int q = 0; q < np_ && n < 8; q++) {
+    const double h = poly[q][2];
+    if (h >= margin) continue;
+    out[n][0] = h;
+    for (int k = 0; k < 3; k++) {
+      out[n][1 + k] = pr_[k] + poly[q][0] * Ar[ur][k] + poly[q][1] * Ar[vr][k] + (sr[kr] + 0.5 * h) * nr[k];
+      out[n][4 + k] = nf[k];
+    }
+    n++;
+  }
+  return n;
+}
+
+/* the pair's native collider; types in the engine's order (t1 <= t2). Returns the number of contacts, -1 = no native collider */
+static int native_pair(int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2, const double* R2,
+                       const double* s2, double margin, double (*out)[7]) {
+  if (t1 == LM_GEOM_SPHERE && t2 == LM_GEOM_BOX) return nat_sphere_box(p1, s1[0], p2, R2, s2, margin, out);
+  if (t1 == LM_GEOM_SPHERE && t2 == LM_GEOM_CYLINDER) return nat_sphere_cylinder(p1, s1[0], p2, R2, s2, margin, out);
+  if (t1 == LM_GEOM_CAPSULE && t2 == LM_GEOM_BOX) return nat_capsule_box(p1, R1, s1, p2, R2, s2, margin, out);
+  if (t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX) return nat_box_box(p1, R1, s1, p2, R2, s2, margin, out);
+  return -1;
+}
+
+int lmo_test_native_pair(int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2, const double* R2,
+                         const double* s2, double margin, double* out /* [8][7] */) {
+  double buf[8][7];
+  const int n = native_pair(t1, p1, R1, s1, t2, p2, R2, s2, margin, buf);
+  for (int i = 0; i < n && i < 8; i++) memcpy(out + 7 * i, buf[i], sizeof(buf[i]));
+  return n;
 }
 
 static double rbound(int type, const double* size) {
@@ -883,7 +1110,7 @@ static void fix_normal(const cvx* A, const cvx* B, const double* pos, double* no
 }
 
 static void collide(const lmo_model* m, work* w) {
-  w->ncon = 0; w->unhandled_pairs = 0; w->convex_contacts = 0; w->max_self_depth = 0;
+  w->ncon = 0; w->unhandled_pairs = 0; w->convex_contacts = 0; w->max_self_depth = 0; w->native_contacts = 0;
   for (int pi = 0; pi < m->npair; pi++) {
     int g1 = m->pair_g1[pi], g2 = m->pair_g2[pi];
     int t1 = IDX(m->geom_type, g1), t2 = IDX(m->geom_type, g2);
@@ -1057,6 +1284,13 @@ static void collide(const lmo_model* m, work* w) {
         add_contact(w, &tm, margin - depth, pos, dir, NULL);
         w->convex_contacts++;
       }
+    } else if (!m->disable_native && ((t1 == LM_GEOM_SPHERE && (t2 == LM_GEOM_BOX || t2 == LM_GEOM_CYLINDER)) || (t1 == LM_GEOM_CAPSULE && t2 == LM_GEOM_BOX)
+                                      || (t1 == LM_GEOM_BOX && t2 == LM_GEOM_BOX))) {
+      /* the engine's native box / cylinder colliders (restated above) */
+      double buf[8][7];
+      const int nc = native_pair(t1, p1, R1, s1, t2, p2, R2, s2, margin, buf);
+      for (int i = 0; i < nc; i++) add_contact(w, &tm, buf[i][0], buf[i] + 1, buf[i] + 4, NULL);
+      w->native_contacts += nc > 0 ? nc : 0;
     } else if (m->skip_pair_counter) {
       /* timing runs: the pair has no collider here, and whether the engine would have a contact is not asked */
     } else if (t1 == LM_GEOM_MESH || t2 == LM_GEOM_MESH
@@ -1666,7 +1900,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
   for (int s = 0; s < nsub; s++) {
     if (m->integrator == LM_INT_EULER) {
       forward(m, qpos, qvel, ctrl, act, warmstart, w);
-      if (stats) { stats->convex_contacts += w->convex_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
+      if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
       if (warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
       euler(m, qpos, qvel, w);
       for (int i = 0; i < m->na; i++) act[i] += m->timestep * w->act_dot[i];      /* explicit Euler on activations */
@@ -1679,7 +1913,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
       memcpy(X, q0, sizeof(double) * nv); memcpy(V, v0, sizeof(double) * nv);
       for (int st = 0; st < 4; st++) {
         forward(m, X, V, ctrl, NULL, warmstart, w);
-        if (stats) { stats->convex_contacts += w->convex_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
+        if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
         if (st == 0 && warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
         for (int d = 0; d < nv; d++) { dq[d] += Bw[st] * V[d]; dv[d] += Bw[st] * w->qacc[d]; }
         if (st < 3) for (int d = 0; d < nv; d++) { double vn = v0[d] + h * A[st] * w->qacc[d]; X[d] = q0[d] + h * A[st] * V[d]; V[d] = vn; }

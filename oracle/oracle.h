@@ -29,6 +29,7 @@ typedef struct {
   int ncon, nefc, solver_iter_total, solver_iter_max, unhandled_pairs;
   int convex_contacts;        /* contacts from the convex-convex collider (MPR), summed over the forward passes */
   double max_self_depth;      /* deepest penetration (-dist) of a contact between two bodies of the robot over all forward passes */
+  int native_contacts;        /* contacts of the native box / cylinder colliders (sphere-box, sphere-cylinder, capsule-box, box-box) */
 } lmo_stats;
 
 typedef struct {
@@ -50,6 +51,10 @@ int lmo_set_mesh(lmo_model* m, int g, int nv, const double* vert);
 int lmo_set_mesh_graph(lmo_model* m, int g, const int* adr, const int* nbr, double tol);
 int lmo_mesh_nvert(const lmo_model* m, int g);
 void lmo_set_option(lmo_model* m, int what, double value);
+/* one native box / cylinder collider on its own (tests): geom types as in lm_layout.h, R row-major; out [8][7] = (dist, pos, normal
+   from geom 1 to geom 2); returns the number of contacts, -1 = the pair type has no native collider */
+int lmo_test_native_pair(int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2, const double* R2,
+                         const double* s2, double margin, double* out);
 int lmo_nv(const lmo_model* m);
 int lmo_nu(const lmo_model* m);
 int lmo_na(const lmo_model* m);   /* activation states (muscles) */

@@ -30,7 +30,7 @@ class Contact(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter_total", C.c_int),
                 ("solver_iter_max", C.c_int), ("unhandled_pairs", C.c_int), ("convex_contacts", C.c_int),
-                ("max_self_depth", C.c_double)]
+                ("max_self_depth", C.c_double), ("native_contacts", C.c_int)]
 
 
 _DP = C.POINTER(C.c_double)
@@ -105,7 +105,7 @@ class Oracle:
         assert lib().lmo_set_mesh_graph(self._h, int(geom), adr.ctypes.data, nbr.ctypes.data, 0.0) == 0
 
     def set_option(self, what, value):
-        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3, "disable_ccd": 4}[what], float(value))
+        lib().lmo_set_option(self._h, {"disable_self_collision": 0, "iterations": 1, "tolerance": 2, "skip_pair_counter": 3, "disable_ccd": 4, "disable_native": 5}[what], float(value))
 
     def step(self, qpos, qvel, ctrl, nsub=1, warmstart=None):
         """Returns new (qpos, qvel, warmstart, stats-dict). Inputs are not modified."""
@@ -180,3 +180,16 @@ class Oracle:
                            for i in range(nc)]
         res.update(ncon=nc, nefc=ne, solver_iter=out.solver_iter, unhandled_pairs=out.unhandled_pairs)
         return res
+
+
+def native_pair(t1, p1, R1, s1, t2, p2, R2, s2, margin):
+    """One of the oracle's native box / cylinder colliders on its own (tests): returns [(dist, pos, normal)] or None when the pair
+    type has no native collider. Geom types as in include/lm_layout.h, R 3x3 rotation (columns = geom axes)."""
+    f = lambda x, n: np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)[:n] if np.size(x) >= n else np.pad(np.asarray(x, dtype=np.float64).reshape(-1), (0, n - np.size(x))))
+    out = np.zeros((8, 7))
+    a = [f(p1, 3), f(R1, 9), f(s1, 3), f(p2, 3), f(R2, 9), f(s2, 3)]
+    lib().lmo_test_native_pair.argtypes = [C.c_int, _DP, _DP, _DP, C.c_int, _DP, _DP, _DP, C.c_double, _DP]
+    n = lib().lmo_test_native_pair(int(t1), _p(a[0]), _p(a[1]), _p(a[2]), int(t2), _p(a[3]), _p(a[4]), _p(a[5]), float(margin), _p(out))
+    if n < 0:
+        return None
+    return [(out[i, 0], out[i, 1:4].copy(), out[i, 4:7].copy()) for i in range(n)]

@@ -315,12 +315,12 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
 extern "C" void emu_set_dof_params(const double* p) { g_dofprm = p; }
 extern "C" void emu_set_model_variant(const float* rec, const float* gt, const float* gpt) { g_vrec = rec; g_vgt = gt; g_vgpt = gpt; }
 
-// same family selection as the library's launch_variant(); BIGK = the family's replay instantiation (lm_step.h launch_family: 32
-// slots per leg of the quadruped, 48 per chain of a humanoid, the convex collider)
+// same family selection as the library's launch_variant(); BIGK = the family's replay instantiation (lm_step.h launch_family: 128
+// slots per chain, the convex collider)
 template <bool BIGK>
 static int emu_dispatch(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                         int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act, int* leave, const int* only) {
-  constexpr int N4 = BIGK ? 48 : 4, N8 = BIGK ? 48 : 8, N6 = BIGK ? 32 : 6;
+  constexpr int N4 = BIGK ? 128 : 4, N8 = BIGK ? 128 : 8, N6 = BIGK ? 128 : 6;
 #define EMU_ARGS chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
@@ -348,6 +348,10 @@ static int emu_dispatch(const double* chain_model, int n, double* qpos, double* 
 // NOT simulated); 1: speculate / replay like the library. replayed[n] (may be NULL): which environments the big instantiation ran.
 extern "C" int emu_run2(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                         int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act, int replay, int* replayed) {
+  if (replay == 2) {          // tests: the big instantiation for EVERY environment
+    std::vector<int> all(n, 1);
+    return emu_dispatch<true>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act, nullptr, all.data());
+  }
   if (!replay) return emu_dispatch<false>(chain_model, n, qpos, qvel, warm, action, nsub, debug_env, dbgM, dbg5, counters, act, nullptr, nullptr);
   std::vector<int> leave(n, 0);
   int cnt1[8] = {0}, cnt2[8] = {0};

@@ -79,7 +79,7 @@ def run(chain_model, qpos, qvel, action, nsub=1, warm=None, debug_env=-1, act=No
     replayed = np.zeros(n, dtype=np.int32)
     rc = lib.emu_run2(dp(cmod), n, dp(q), dp(v), dp(w), dp(a), int(nsub), int(debug_env),
                       dp(M) if debug_env >= 0 else None, dp(d5) if debug_env >= 0 else None, dp(cnt),
-                      dp(actv) if actv is not None else None, int(bool(replay)), dp(replayed))
+                      dp(actv) if actv is not None else None, int(replay), dp(replayed))
     assert rc == 0, "emulator returned %d (-2: two replicas changed the same lane-memory word to different values)" % rc
     dbg = dict(M=M, bias=d5[0], smooth=d5[1], qacc_smooth=d5[2], qacc=d5[3], qfrc_constraint=d5[4])
     if actv is not None:

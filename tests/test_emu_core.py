@@ -393,7 +393,7 @@ def test_core_convex_pairs_humanoid_bones(rep):
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
     t = info["self_collision_tables"]
-    assert t["convex"] == 692 and t["counted_only"] == 1 and t["body_pairs"] < 200 and max(t["link_pairs"]) <= 16
+    assert t["convex"] == 692 and t["native"] == 1 and t["body_pairs"] < 200 and max(t["link_pairs"]) <= 16
     o = Oracle(pack_model(m))
     g = GOLD["HumanoidTorque.walk.real"]
     qidx = [m.jnt_id(n) for k, n, tt in env.obs_helper.observation_spec if k.startswith("q_")]
@@ -644,3 +644,32 @@ def test_core_cross_chain_contacts_are_admitted_in_both_lanes_or_in_neither():
         q, v, _, cnt, _ = pyemu.run(cmod, q0, v0, a, nsub=10, rep=4)
         assert cnt["overflow"] == 0 and cnt["replayed"] == 1
         assert np.abs(q[0] - qo).max() < 1e-4 and np.abs(v[0] - vo).max() < 1e-2, (np.abs(q[0] - qo).max(), np.abs(v[0] - vo).max())
+
+
+@pytest.mark.parametrize("robot", ["a1", "ht"])
+def test_core_native_box_and_cylinder_pairs_vs_oracle(robot):
+    """The engine's native colliders for box / cylinder pairs on the device code (lm_core.h nat_*: sphere-box, sphere-cylinder,
+    capsule-box of the quadruped's trunk boxes and hip cylinders against its legs, box-box of the humanoid's feet) against the
+    oracle's float64 restatement of the same constructions: states of tests/golden/native_pair_states.npz (tools/make_native_fixtures.py:
+    found in oracle rollouts, and sampled configurations in the air), one control step. Nothing is merely counted any more."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "native_pair_states.npz"))
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple" if robot == "a1" else "HumanoidTorque.run", debug=True)
+    m = env._model
+    cmod = env._chain_model()
+    o = Oracle(pack_model(m))
+    q0, v0, a0 = d[robot + "_q"], d[robot + "_v"], d[robot + "_a"]
+    pick = list(range(0, len(q0), 3 if robot == "a1" else 4))           # a third / a quarter of the fixture here (the GPU test runs all of it)
+    worst_q = worst_v = 0.0
+    replayed = selfcon = 0
+    for i in pick:
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a0[i])
+        qo, vo, _, st = o.step(q0[i], v0[i], ctrl, 10)
+        assert st["native_contacts"] > 0 and st["unhandled_pairs"] == 0
+        q, v, _, cnt, _ = pyemu.run(cmod, q0[i], v0[i], a0[i], nsub=10, rep=4)
+        assert cnt["selfprox"] == 0 and cnt["overflow"] == 0 and cnt["selfcon"] > 0, (i, cnt)
+        worst_q, worst_v = max(worst_q, np.abs(q[0] - qo).max()), max(worst_v, np.abs(v[0] - vo).max())
+        replayed += cnt["replayed"]; selfcon += cnt["selfcon"]
+        assert np.abs(q[0] - qo).max() < 1e-4 and np.abs(v[0] - vo).max() < 1e-2, (robot, i, np.abs(q[0] - qo).max(), np.abs(v[0] - vo).max())
+    print("native pairs (%s): %d states, qpos max %.2e qvel max %.2e, self-contacts %d, replayed %d" % (robot, len(pick), worst_q, worst_v, selfcon, replayed))
