@@ -181,6 +181,8 @@ def main():
                     "when the RCCL communicator does not come up (the bench line names the transport in config.collective)")
     ap.add_argument("--sustained", type=int, default=200, help="control steps of the extra sustained leg (per-step launches, one "
                     "timed block of at least this many steps; 0 = skip; skipped when --steps already covers it)")
+    ap.add_argument("--no-pollers", action="store_true", help="profiling runs (rocprofv3 runs one kernel at a time): the replay kernel only as the "
+                    "pass behind the regular launch, no polling workgroups beside it (lm_batch_set_replay(3))")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     args = ap.parse_args()
 
@@ -229,6 +231,8 @@ def main():
     table = env._reset_table()
     hm = HipModel(env._chain_model(), device=local_rank)
     b = HipBatch(hm, n)
+    if args.no_pollers:
+        b.set_replay(3)
     offset = rank * n
     nv = env._model.nv
     rs = np.random.RandomState(0)
@@ -289,7 +293,8 @@ def main():
     vals = np.array([elapsed, st["env_steps"], st["episodes"], st["reward_sum"], st["nan_resets"],
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
                      fused[0] if fused is not None else 0.0, st["self_proximity"], st["self_contacts"],
-                     sustained[0] if sustained is not None else 0.0, sustained[1] if sustained is not None else 0.0], dtype=np.float64)
+                     sustained[0] if sustained is not None else 0.0, sustained[1] if sustained is not None else 0.0,
+                     st.get("replayed_env_steps", 0.0)], dtype=np.float64)
     tmax = coll.all_reduce(vals, MAX)
     vals = coll.all_reduce(vals, SUM)
     elapsed, kernel_ms, fused_elapsed = float(tmax[0]), float(tmax[8]), float(tmax[9])
@@ -352,8 +357,8 @@ def main():
                                % (args.task + (" (back joints, joint-damping randomisation per episode)" if args.dr else ""), n,
                                   "zero-action" if default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 14 doubles at report time",
-                                  "tcp": "socket reduction of 14 doubles at report time (RCCL not used)"}[coll.backend]},
+                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 15 doubles at report time",
+                                  "tcp": "socket reduction of 15 doubles at report time (RCCL not used)"}[coll.backend]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -369,6 +374,8 @@ def main():
                   # where the device left its validated collision model (all ranks): forward passes x geom pairs of the robot
                   # without a pair collider (box / cylinder) within the margin, and self-contacts it did simulate
                   "self_proximity": vals[10], "self_contacts": vals[11],
+                  # control steps that left the regular kernel's capacity (contact slots, pair lists) and were run by the replay kernel
+                  "replayed_env_steps": vals[14],
                   "newton_iters_per_forward_pass": vals[7] / max(env_steps * forwards, 1),
                   "physics_substeps_per_s": 10 * value},
     }

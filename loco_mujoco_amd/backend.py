@@ -166,7 +166,8 @@ class HipBatch:
     def set_replay(self, enabled):
         """Speculate / replay (``lm_batch_set_replay``): on by default; off = the regular kernels alone, contacts beyond their slots
         are dropped and counted (A/B measurements)."""
-        _check(self._lib.lm_batch_set_replay(self._h, 2 if enabled == 2 else int(bool(enabled))))      # 2 (tests): everything through the replay kernel
+        # 2 (tests): everything through the replay kernel; 3 / 4: like 1 / 2 without the concurrent pollers (profilers)
+        _check(self._lib.lm_batch_set_replay(self._h, int(enabled) if enabled in (2, 3, 4) else int(bool(enabled))))
 
     def replay_marks(self, reset=False):
         """Per environment: did the replay kernel run one of its control steps since the marks were last cleared?"""

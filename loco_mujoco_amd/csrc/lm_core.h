@@ -162,6 +162,8 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
   int need_full;     // a convex pair came within reach in a kernel compiled WITHOUT the convex collider (PM == 2): the control step is
                      // abandoned and replayed by the full kernel (lm_step.h)
+  int peak_slots, peak_q, peak_res;   // largest number of contact slots / queued convex pairs / pair results of this lane's chain in a pass (the
+                     // replay kernel decides with them whether the environment fits the regular kernel again, lm_step.h)
   float grf[4][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's foot-force groups (2; 4 in the six-link kernels)
 #ifdef LM_TIMERS
   long long t[16];
@@ -2061,8 +2063,18 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     if (PAIRS) {
       const float s_own = pair_speed;
       const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
-      first_detect = !pair_slack || *pair_slack == 0.0f;        // the first pass of a control step (the caller starts it at 0)
-      float slack = (pair_slack ? *pair_slack : 0.0f) - P.h * (s_own + s_quad);
+      first_detect = !pair_slack || *pair_slack == 0.0f;        // nothing known yet (fresh state: the caller starts the slack at 0)
+      // Euler: the positions of this pass lie h x (this pass's velocities) from the next pass's. RK4 evaluates its stages at
+      // q0 + a h v(previous stage) and ends at q0 + h/6 (v1 + 2 v2 + 2 v3 + v4): two consecutive evaluation points are at most
+      // 1.5 h x (the largest speed bound among the passes involved) apart — all of them lie in this substep or the one before,
+      // whose maxima are carried in pair_slack[1] (this substep so far) and [2] (the previous one, moved there by substep()); the
+      // factor 2 leaves room for the second-order terms.
+      float travel = P.h * (s_own + s_quad);
+      if (!EULER && pair_slack) {
+        pair_slack[1] = fmaxf(pair_slack[1], s_own + s_quad);
+        travel = 2.0f * P.h * fmaxf(pair_slack[1], pair_slack[2]);
+      }
+      float slack = (pair_slack ? *pair_slack : 0.0f) - travel;
       // WAVE-uniform: when one environment of the wave has to detect, its wave mates detect with it — they would wait for it anyway
       // (one instruction stream), and their slack is refreshed for free, so the wave as a whole detects about as often as its
       // neediest environment instead of whenever ANY of the four is due. A detection that was not due finds nothing (that is what
@@ -2570,6 +2582,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // contacts beyond what the queue / the result list of my chain hold: dropped, counted
       if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
       if (nres_of[c] > kRcap) n_over += nres_of[c] - kRcap;
+      cnt.peak_q = (nq_of[c] > cnt.peak_q) ? nq_of[c] : cnt.peak_q; cnt.peak_res = (nres_of[c] > cnt.peak_res) ? nres_of[c] : cnt.peak_res;
       // the smallest clearance of any pair of my chain, whichever lane of the environment looked at it
       {
         float gmine = 3.0e38f;
@@ -2588,6 +2601,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       Q::fence();
     }
     cnt.ncon += nslot;
+    cnt.peak_slots = (nslot > cnt.peak_slots) ? nslot : cnt.peak_slots;
     LM_TICK(0);
     pair_mask_out = pair_mask;
     for (int s2 = 0; s2 < nslot; s2++) { if ((int)SL(s2, SL_LINK) < 0) nrootslot++; if (PAIRS && SL(s2, SL_PART) != 0.0f) npairslot++; }
@@ -3676,7 +3690,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma nounroll
   for (int st = 0; st < 4; st++) {
     forward<Q, MC, NS, false, CONE, 0, DR, PM>(cm, c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, (st == 0) ? dbg : nullptr, nullptr, dp,
-                                           want_grf && st == 3);   // the engine's data hold the 4th stage when mj_step returns
+                                           want_grf && st == 3, pair_slack);   // the engine's data hold the 4th stage when mj_step returns
     const float b = (st == 0 || st == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
     const float a = (st == 2) ? 1.0f : 0.5f;            // tableau entry A[st+1][st]
 #pragma unroll
@@ -3694,6 +3708,7 @@ LM_DEV void substep(const float* cm, int c, const Params& P, float* qr, float* v
   for (int i = 0; i < 6; i++) { qr[i] = fmaf(P.h, dqr[i], q0r[i]); vr[i] = fmaf(P.h, dvr[i], v0r[i]); }
 #pragma unroll
   for (int k = 0; k < MC; k++) { qc[k] = fmaf(P.h, dqc[k], q0c[k]); vc[k] = fmaf(P.h, dvc[k], v0c[k]); }
+  if (PM != 0 && pair_slack) { pair_slack[2] = pair_slack[1]; pair_slack[1] = 0.0f; }      // the speed memory of the detection's travel bound (forward)
 }
 
 }  // namespace lm

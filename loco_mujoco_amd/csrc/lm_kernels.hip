@@ -58,6 +58,11 @@ struct lm_batch {
   // words, the fused step at which each left; `replay` = 0 switches the mechanism off (contacts beyond the slots are then dropped)
   int *replay_list, *replay_ctl, *stall; int replay;
   unsigned char* replay_mark;
+  // the replay kernel's pollers run beside the regular launch on `stream2`, forked from / joined into the launch stream with the two
+  // events; `h_hint` (pinned) receives the number of abandoned control steps of a completed launch: how many pollers the next one gets
+  int stat_pre_off, nstat; int* h_hint; int hint, hint_seen; int epoch;
+  hipStream_t stream2; hipEvent_t ev_fork, ev_join;
+  float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
@@ -119,12 +124,40 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   else if (b->nvar > 0) kind = rep ? lmk::LMK_DRV_REP4 : lmk::LMK_DRV_REP1;
   else if (b->dofprm) kind = rep ? lmk::LMK_DR_REP4 : lmk::LMK_DR_REP1;
   else kind = rep ? lmk::LMK_REP4 : lmk::LMK_REP1;
-  if (!table[fam][0](L, a, kind) && !table[fam][1](L, a, kind) && !table[fam][2](L, a, kind)) { g_launch_err = "no kernel of this kind in the family"; return; }
-  // the replay kernel, right behind on the same stream: it runs the control steps the launch above abandoned (lm_step.h). An
-  // empty list costs a few microseconds (256 workgroups read one word and leave)
-  if (!FWD && a.replay_list) {
-    const int big = b->nvar > 0 ? lmk::LMK_BIG_DRV : (b->dofprm ? lmk::LMK_BIG_DR : lmk::LMK_BIG);
-    if (!table[fam][0](L, a, big) && !table[fam][1](L, a, big) && !table[fam][2](L, a, big)) g_launch_err = "no replay kernel in the family";
+  const int big = b->nvar > 0 ? lmk::LMK_BIG_DRV : (b->dofprm ? lmk::LMK_BIG_DR : lmk::LMK_BIG);
+  KArgs r = a;
+  r.reg_grid = (b->N + b->epb - 1) / b->epb; r.epoch = b->epoch; r.host_hint = b->h_hint;
+  const bool replay = !FWD && a.replay_list;
+  bool pollers = false;
+  if (replay) {
+    // How many control steps did recent launches abandon? (h_hint: pinned host memory, written by the drain pass of a launch that
+    // has completed by now — a hint, read without waiting for anything.) Launches that abandon some get pollers: replay workgroups on the second stream, launched
+    // BEFORE the regular kernel, that take the abandoned environments over while the launch is still running (lm_step.h). A batch
+    // whose robots stay inside the regular kernel (the quadruped's bench rollout) launches none.
+    // (a rollout queues hundreds of launches before the first has run: no news = no change; news = the latest count, decaying slowly)
+    const int last = b->h_hint[0], seen = b->h_hint[1];
+    if (seen != b->hint_seen) { b->hint_seen = seen; b->hint = last > b->hint ? last : (b->hint > 0 ? b->hint - 1 : 0); }
+    int want = a.replay_all ? lmk::kReplayGrid : (b->hint > 0 ? b->hint + 2 : 0);
+    if (want > lmk::kReplayGrid / 2 && !a.replay_all) want = lmk::kReplayGrid / 2;
+    if (b->replay >= 3) want = 0;
+    if (want > 0) {
+      KArgs p = r;
+      p.drain = 0; p.stats_off = b->stat_pre_off;
+      const LaunchCtx L2 = {b->stream2, b->N, want};
+      if (!table[fam][0](L2, p, big) && !table[fam][1](L2, p, big) && !table[fam][2](L2, p, big)) { g_launch_err = "no replay kernel in the family"; return; }
+      if (hipEventRecord(b->ev_join, b->stream2) != hipSuccess) { g_launch_err = "stream join failed"; return; }
+      pollers = true;
+    }
+  }
+  if (!table[fam][0](L, r, kind) && !table[fam][1](L, r, kind) && !table[fam][2](L, r, kind)) { g_launch_err = "no kernel of this kind in the family"; return; }
+  if (replay) {
+    // the drain pass, behind the regular launch AND the pollers: whatever is still listed; resets the control words. An empty
+    // list costs a few microseconds (64 workgroups read a word and leave)
+    if (pollers && hipStreamWaitEvent(b->stream, b->ev_join, 0) != hipSuccess) { g_launch_err = "stream join failed"; return; }
+    r.drain = 1; r.stats_off = 0;
+    const LaunchCtx L3 = {b->stream, b->N, lmk::kReplayGrid};
+    if (!table[fam][0](L3, r, big) && !table[fam][1](L3, r, big) && !table[fam][2](L3, r, big)) { g_launch_err = "no replay kernel in the family"; return; }
+    b->epoch++;
   }
 }
 
@@ -309,16 +342,20 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->flags, N)); HIPCHK(hipMemset(b->flags, 0, N));
   HIPCHK(hipMalloc(&b->ep_step, sizeof(int) * N)); HIPCHK(hipMalloc(&b->ep_count, sizeof(unsigned) * N));
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
-  HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nblocks));
-  HIPCHK(hipMalloc(&b->replay_list, sizeof(int) * N)); HIPCHK(hipMalloc(&b->stall, sizeof(int) * N)); HIPCHK(hipMalloc(&b->replay_ctl, sizeof(int) * 4));
-  HIPCHK(hipMemset(b->replay_list, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->stall, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->replay_ctl, 0, sizeof(int) * 4));
+  b->stat_pre_off = b->nblocks; b->nstat = b->nblocks + lmk::kReplayGrid;      // the concurrent replay kernel adds into slots of its own
+  HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nstat));
+  HIPCHK(hipHostMalloc((void**)&b->h_hint, sizeof(int) * 2, hipHostMallocDefault)); b->h_hint[0] = 0; b->h_hint[1] = 0;
+  HIPCHK(hipMalloc(&b->replay_list, sizeof(int) * N)); HIPCHK(hipMalloc(&b->stall, sizeof(int) * N)); HIPCHK(hipMalloc(&b->replay_ctl, sizeof(int) * 8));
+  HIPCHK(hipMemset(b->replay_list, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->stall, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->replay_ctl, 0, sizeof(int) * 8));
   HIPCHK(hipMalloc(&b->replay_mark, N)); HIPCHK(hipMemset(b->replay_mark, 0, N));
+  HIPCHK(hipMalloc(&b->slack, sizeof(float) * 12 * N)); HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * N));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
-  HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nblocks));
+  HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nstat));
   HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks)));
-  HIPCHK(hipStreamCreate(&b->stream));
+  HIPCHK(hipStreamCreate(&b->stream)); HIPCHK(hipStreamCreate(&b->stream2));
+  HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); HIPCHK(hipEventCreateWithFlags(&b->ev_ext, hipEventDisableTiming));
   return 0;
 }
@@ -358,7 +395,9 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
    alone (contacts beyond the slots are dropped and counted: the behaviour of rounds 1-3, kept for A/B measurements). */
 int lm_batch_set_replay(lm_batch* b, int enabled) {
   if (!b) return fail("null batch");
-  b->replay = enabled == 2 ? 2 : (enabled ? 1 : 0);        // 2 (tests): every control step goes through the replay kernel
+  // 2 (tests): every control step goes through the replay kernel; 3 / 4 = 1 / 2 without pollers: the replay kernel only as the pass
+  // behind the regular launch (profilers that run one kernel at a time would leave the pollers waiting for their time-out)
+  b->replay = (enabled >= 2 && enabled <= 4) ? enabled : (enabled ? 1 : 0);
   return 0;
 }
 
@@ -382,12 +421,16 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack,
                   b->vrec, b->vgt, b->vgpt, b->var};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev_ext) (void)hipEventDestroy(b->ev_ext);
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+  if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+  if (b->h_hint) (void)hipHostFree(b->h_hint);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -467,6 +510,7 @@ int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_
     if (scatter_masked(b, b->qvel, qvel, nv, idx)) return 1;
     if (scatter_masked(b, b->warm, nullptr, nv, idx)) return 1;
     if (b->act && scatter_masked(b, b->act, nullptr, na, idx)) return 1;
+    if (scatter_masked(b, b->slack, nullptr, 12, idx)) return 1;           // new positions: the self-collision detection is due
     if (!idx.empty()) {
       const int n = (int)idx.size();
       hipLaunchKernelGGL(zero_ints, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->ep_step, b->scr_idx, n);
@@ -480,6 +524,7 @@ int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_
   if (b->act) HIPCHK(hipMemsetAsync(b->act, 0, sizeof(float) * na * N, b->stream));
   HIPCHK(hipMemsetAsync(b->warm, 0, sizeof(float) * nv * N, b->stream));
   HIPCHK(hipMemsetAsync(b->ep_step, 0, sizeof(int) * N, b->stream));
+  HIPCHK(hipMemsetAsync(b->slack, 0, sizeof(float) * 12 * N, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -570,6 +615,7 @@ int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_t
   if (pair_tables) { HIPCHK(hipMalloc(&b->vgpt, sizeof(float) * np_)); HIPCHK(hipMemcpy(b->vgpt, pair_tables, sizeof(float) * np_, hipMemcpyHostToDevice)); }
   if (!b->var) HIPCHK(hipMalloc(&b->var, sizeof(int) * b->N));
   HIPCHK(hipMemset(b->var, 0, sizeof(int) * b->N));
+  HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * b->N));
   b->nvar = n_variants; b->gpt_floats = pair_floats;
   return 0;
 }
@@ -586,6 +632,7 @@ int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask)
     cur[e] = index[e];
   }
   HIPCHK(hipMemcpy(b->var, cur.data(), sizeof(int) * b->N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * b->N));       // another model: whatever the pair pass knew is void
   return 0;
 }
 
@@ -633,13 +680,13 @@ static KArgs make_args(lm_batch* b) {
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
   a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
-  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags;
+  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
   // speculate / replay: every family but the generic one has a replay kernel
-  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; a.replay_all = b->replay == 2; }
+  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; a.replay_all = b->replay == 2 || b->replay == 4; }
   static const bool no_xcd_map = LM_PROBE_ENV("LM_NO_XCD_MAP") != nullptr;
   a.xcd_map = no_xcd_map ? 0 : 1;
   return a;
@@ -654,9 +701,9 @@ static void launch_step(lm_batch* b, const KArgs& a) {
 }
 
 static int drain_stats(lm_batch* b) {
-  std::vector<DevStats> s(b->nblocks);
-  HIPCHK(hipMemcpyAsync(s.data(), b->stats, sizeof(DevStats) * b->nblocks, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipMemsetAsync(b->stats, 0, sizeof(DevStats) * b->nblocks, b->stream));
+  std::vector<DevStats> s(b->nstat);
+  HIPCHK(hipMemcpyAsync(s.data(), b->stats, sizeof(DevStats) * b->nstat, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemsetAsync(b->stats, 0, sizeof(DevStats) * b->nstat, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   for (const DevStats& x : s) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;

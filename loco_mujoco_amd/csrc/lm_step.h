@@ -131,11 +131,20 @@ struct KArgs {
   DevStats* stats;
   unsigned long long* timers;   // LM_TIMERS builds: cycle counters per solver region (lane 0 of each workgroup)
   // speculate / replay (see step_kernel): environments whose control step left the regular kernel's capacity
-  int* replay_list;             // [N] environment ids, appended by the regular kernel (null: no replay kernel follows, drops are final)
-  int* replay_ctl;              // [0] number of entries, [1] workgroups of the replay kernel that are through (the last one clears both)
+  int* replay_list;             // [N] environment id + 1 per entry (0 = empty / taken), appended by the regular kernel (null: no replay, drops are final)
+  int* replay_ctl;              // [0] entries appended, [1] tickets handed out (pollers), [2] regular workgroups that are through, [3] workgroups of the
+                                // drain pass that are through (the last one resets [0..3]), [5] the epoch: launches whose drain pass is complete
   int* stall;                   // [N] the fused control step at which the environment left the regular kernel (0 for single-step launches)
   int replay_all;               // tests (lm_batch_set_replay(b, 2)): EVERY control step is abandoned and run by the replay kernel
   unsigned char* replay_mark;   // [N] sticky: the replay kernel ran (part of) this environment's control steps since the marks were last cleared
+  int reg_grid;                 // workgroups of the regular launch (the pollers leave when all of them are through)
+  int epoch;                    // number of this launch among the batch's launches with a replay pass (the pollers wait for replay_ctl[5] to reach it)
+  int* host_hint;               // pinned host words: the drain pass leaves {entries of its launch, its epoch + 1} there
+  int drain;                    // replay kernel: 1 = the pass behind the regular launch (takes whatever is still listed, resets the control words)
+  int stats_off;                // first statistics slot of this launch (the concurrent replay kernel has a range of its own)
+  // self-collision detection (lm_core.h): per chain lane the clearance left since the last detection and the speed memory of its
+  // travel bound, SoA [3][4][N]; kept from one control step to the next (zeroed by state uploads and restarts: "detect now")
+  float* slack;
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
 };
@@ -153,16 +162,71 @@ __device__ __forceinline__ float wave_sum(float x) {
 // SPECULATE / REPLAY. The regular kernels are sized for what a robot does in its gaits: NS contact slots per chain, a short queue
 // for convex pairs, and — the quadruped's (PM == 2) — no convex-pair collider at all. A control step that needs more (a chain with
 // more simultaneous contacts than slots, a full queue or result list of the pair pass, a convex pair within reach of a kernel
-// without the collider) is ABANDONED: nothing of it is stored, the environment is appended to `replay_list`, and the REPLAY kernel
-// launched right behind (the same code compiled with NS > 8: a slot for every contact, long lists, the collider; one persistent
-// grid that walks the list) runs that control step — and, in a fused rollout, the rest of the launch's control steps — from the
-// untouched state. The engine the reference calls never drops a contact (humanoid_torque.xml:19 njmax 1000 / nconmax 400):
-// neither does this. Whatever exceeds even the replay kernel's capacity is dropped, counted and flagged as before.
+// without the collider) is ABANDONED at the end of the substep that found out: nothing of it is stored, the environment's lanes sit
+// the rest of the control step out, and the environment is appended to `replay_list`. The REPLAY kernel (the same code compiled with
+// NS > 8: a slot for every contact, long lists, the collider; ONE environment per workgroup) runs that control step — and, in a fused
+// rollout, the rest of the launch's control steps — from the untouched state. It is launched twice per step (lm_kernels.hip):
+//   * as POLLERS, a few workgroups on a second stream, BEFORE the regular kernel and only when recent launches had abandoned steps:
+//     they wait for entries (a ticket each) and work them off while the regular launch is still running — a replay behind the
+//     launch costs a whole control step's latency for a handful of environments, beside it next to nothing. Their stream does not
+//     wait for the previous launch: they become resident while that one tails off and wait for its drain pass on the device (epoch);
+//   * as the DRAIN pass behind the regular launch, on its stream: whatever is still listed (no pollers; more entries than they got
+//     through; a poller that gave up waiting), and the reset of the control words.
+// An entry is taken with an atomic exchange (0 = taken), so no environment is run twice or left behind whichever pass finds it.
+// The engine the reference calls never drops a contact (humanoid_torque.xml:19 njmax 1000 / nconmax 400): neither does this.
+// Whatever exceeds even the replay kernel's capacity is dropped, counted and flagged as before.
+// Next entry for a replay workgroup (thread 0): the environment id + 1, or 0 = leave.
+__device__ __forceinline__ int replay_next(const KArgs& a, int& cursor) {
+  if (a.drain) {
+    const int tail = a.replay_ctl[0];                  // complete: the producers finished before this pass started
+    for (; cursor < tail; cursor += (int)gridDim.x) {
+      if (a.replay_list[cursor] == 0) continue;
+      const int v = atomicExch(&a.replay_list[cursor], 0);
+      if (v) { cursor += (int)gridDim.x; return v; }
+    }
+    return 0;
+  }
+  const long long t0 = (long long)wall_clock64();      // 100 MHz
+  // The pollers are launched without waiting for the previous launch (gated on its completion they would start AFTER the regular
+  // kernel had taken every SIMD): they are resident early, and wait here until the previous launch's drain pass has reset the
+  // control words (epoch)
+  while (__hip_atomic_load(&a.replay_ctl[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+    if ((long long)wall_clock64() - t0 > 50000000ll) return 0;
+    __builtin_amdgcn_s_sleep(64);
+  }
+  const int ticket = atomicAdd(&a.replay_ctl[1], 1);
+  for (;;) {
+    if (ticket < a.N && __hip_atomic_load(&a.replay_list[ticket], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      const int v = atomicExch(&a.replay_list[ticket], 0);
+      if (v) return v;
+    }
+    // every regular workgroup is through and my ticket is beyond the last entry: nothing will come any more
+    if (__hip_atomic_load(&a.replay_ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= a.reg_grid &&
+        ticket >= __hip_atomic_load(&a.replay_ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+    if ((long long)wall_clock64() - t0 > 50000000ll) return 0;      // (0.5 s: never wait for ever — the drain pass takes what is left)
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+
 template <int MC, int NS, bool RK4, bool FORWARD_ONLY, int CONE = -1, int NM = 0, int DR = 0, int REP = 1, bool FUSED = false, int PM = 0>
 __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   using QuadDpp = QuadDppT<REP>;
   constexpr bool PAIRS = PM != 0;
   constexpr bool REPLAY = NS > 8;        // (always compiled with FUSED: a replayed environment finishes the launch's control steps here)
+  // REPLAY, drain pass: most launches leave nothing on the list — be counted and leave before the tables are copied (the last
+  // workgroup through resets the control words for the next launch)
+  if (REPLAY && a.drain) {
+    bool work = false;
+    const int tail = a.replay_ctl[0];
+    for (int i = (int)blockIdx.x; i < tail && !work; i += (int)gridDim.x) work = a.replay_list[i] != 0;
+    if (!work) {
+      if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      return;
+    }
+  }
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
   float* cm = dyn_lds;
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
@@ -174,9 +238,16 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   __syncthreads();
   const int c = threadIdx.x & 3;
   const int e_local = threadIdx.x / (4 * REP);               // REP quads per environment (replicas), see QuadDppT
-  // REPLAY: a persistent grid walks the list of abandoned environments, `epb` per workgroup and round
-  const int n_replay = REPLAY ? a.replay_ctl[0] : 0;
-  for (int item = REPLAY ? (int)blockIdx.x : 0; REPLAY ? item * a.epb < n_replay : item < 1; item += REPLAY ? (int)gridDim.x : 1) {
+  // REPLAY: the workgroup takes one listed environment after the other (replay_next)
+  int cursor = (int)blockIdx.x;
+  for (int item = 0; REPLAY || item < 1; item++) {
+  int entry = 0;
+  if (REPLAY) {
+    if (threadIdx.x == 0) entry = replay_next(a, cursor);
+    entry = __shfl(entry, 0, 64);
+    if (entry <= 0) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the state the regular kernel stored before it listed the environment
+  }
   // XCD-aware workgroup -> environment mapping. The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (own
   // L2 each), while neighbouring environments share 64-byte lines of the SoA state arrays ([dof][N]: 4 environments of a
   // workgroup use 16 B of a line). Handing every XCD a CONTIGUOUS range of environments keeps each line inside one L2:
@@ -189,12 +260,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   int e_raw = wg * a.epb + e_local;
   bool in_range = e_raw < a.N;
   int first_step = 0;               // REPLAY: the fused control step at which the environment left the regular kernel
-  if (REPLAY) {
-    const int li = item * a.epb + e_local;
-    in_range = li < n_replay;
-    e_raw = a.replay_list[in_range ? li : n_replay - 1];
-    first_step = a.stall[e_raw];
-  }
+  if (REPLAY) { in_range = true; e_raw = entry - 1; first_step = a.stall[e_raw]; }
   // padding quads of the last workgroup recompute env N-1 (REPLAY: the last list entry); they and the replicas 1..REP-1 store nothing
   const bool valid0 = in_range && QuadDpp::rep() == 0;
   const int e = in_range ? e_raw : (REPLAY ? e_raw : a.N - 1);
@@ -326,18 +392,48 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     if (c == 0 && valid) { a.dncon[e] = ncon; a.diter[e] = cnt.solver_iters; }
     return;
   }
-  float pair_slack = 0.0f;            // self-collision detection is due in the first pass of every control step (lm_core.h)
-  for (int s = 0; s < a.T.nsub; s++)
-    lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0, &pair_slack);
+  // self-collision detection is skipped while the clearance found by the last one cannot have been used up (lm_core.h): that
+  // knowledge survives the control step (a fresh state starts at 0 = "detect now")
+  float pair_slack[3] = {0.0f, 0.0f, 0.0f};
+  if (PAIRS && a.slack) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) pair_slack[j] = a.slack[((long long)j * 4 + c) * N + e];
+  }
+  // Did the control step stay inside the kernel's capacity? Checked after every substep: if not it is abandoned — nothing of it is
+  // stored, its lanes sit the rest out (the wave's other environments are no longer held up by the robot that needs the big kernel,
+  // usually the slowest of them) and the environment is listed for the replay kernel at once: a poller may already be waiting.
+  // Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
+  for (int s = 0; s < a.T.nsub; s++) {
+    if (!REPLAY && a.replay_list && !gone) {
+      const bool leave = (a.replay_all && s == 0) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+      if (leave) {
+        if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // what this wave stored in the launch's earlier control steps
+        if (valid && c == 0) {
+          a.stall[e] = fused;
+          __threadfence();
+          const int k = atomicAdd(&a.replay_ctl[0], 1);
+          atomicExch(&a.replay_list[k], e + 1);
+        }
+        gone = true; valid = false;
+      }
+    }
+    if (REPLAY ? fused >= first_step : !gone)        // (the replay kernel: the control steps before the one it takes over are the regular kernel's)
+      lm::substep<QuadDpp, MC, NS, RK4, CONE, NM, DR, PM>(cm, c, a.P, qr, vr, qc, vc, war, wac, actr, actc, lmem, ls, cnt, nullptr, mt, &dofp, a.T.ngrf > 0, pair_slack);
+  }
 
   QuadDpp::fence();          // the stores below read lane memory that other replicas wrote (muscle activations)
 
-  // ---- did this control step stay inside the kernel's capacity? If not it is abandoned (nothing stored) and handed to the replay
-  // kernel. Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
-  if (!REPLAY && a.replay_list) {
-    const bool leave = a.replay_all || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
-    if (leave && valid) {
-      if (c == 0) { const int k = atomicAdd(&a.replay_ctl[0], 1); a.replay_list[k] = e; a.stall[e] = fused; }
+  // ---- the last substep's verdict (see the loop above)
+  if (!REPLAY && a.replay_list && !gone) {
+    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+    if (leave) {
+      if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (valid && c == 0) {
+        a.stall[e] = fused;
+        __threadfence();
+        const int k = atomicAdd(&a.replay_ctl[0], 1);
+        atomicExch(&a.replay_list[k], e + 1);
+      }
       gone = true; valid = false;
     }
   }
@@ -439,6 +535,11 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < MC; k++) if (k < nl) { a.qpos[dc[k] * N + e] = qc[k]; a.qvel[dc[k] * N + e] = vc[k]; a.warm[dc[k] * N + e] = wac[k]; }
+  if (PAIRS && a.slack) {
+    const bool fresh = step_no == 0 || nonfinite;       // the episode restarted (or the state was zeroed): nothing is known about its pairs
+#pragma unroll
+    for (int j = 0; j < 3; j++) a.slack[((long long)j * 4 + c) * N + e] = fresh ? 0.0f : pair_slack[j];
+  }
   if (NM > 0) {
     const int m0 = (int)mt[c], nm = (int)mt[LM_NCHAIN + c];
     for (int i = 0; i < nm; i++) {
@@ -506,16 +607,23 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   if (a.stats) {
     __syncthreads();
     for (int i = threadIdx.x; i < kNStats; i += blockDim.x) {
-      float* dst = reinterpret_cast<float*>(a.stats + blockIdx.x) + i;
+      float* dst = reinterpret_cast<float*>(a.stats + a.stats_off + blockIdx.x) + i;
       *dst += blk_stats[i];
     }
   }
-  if (REPLAY) {
-    // the last workgroup through clears the list for the next launch (every workgroup read the count when it started)
+  if (!REPLAY && !FORWARD_ONLY && a.replay_list) {
+    // this regular workgroup is through: the pollers leave when all are (replay_next)
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); atomicAdd(&a.replay_ctl[2], 1); }
+  }
+  if (REPLAY && a.drain) {
+    // the last workgroup of the drain pass resets the control words for the next launch (the list itself is all zeros again:
+    // every entry was taken) and leaves the number of entries for the host
     __syncthreads();
     if (threadIdx.x == 0) {
       __threadfence();
-      if (atomicAdd(&a.replay_ctl[1], 1) == (int)gridDim.x - 1) { a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; __threadfence(); }
+      const int tail = a.replay_ctl[0];
+      if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
     }
   }
 #undef RD
@@ -530,7 +638,7 @@ enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK
        LMK_BIG, LMK_BIG_DR, LMK_BIG_DRV /* the replay kernels, one per part */, LMK_NKINDS };
 constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots),
                                     // 8 / 9 / 10 = five-link humanoids WITH self-collisions (8 slots): RK4 | Euler | Euler + muscles
-constexpr int kReplayGrid = 256;    // workgroups of the replay kernel (persistent: each walks the list with this stride)
+constexpr int kReplayGrid = 64;     // workgroups of the replay kernel's drain pass (each walks the list with this stride), and the most pollers
 
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
@@ -556,8 +664,10 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
     if (kind != LMK_BIG + PART) return false;
     KArgs b = a;
     b.epb = 1; b.xcd_map = 0;
-    const int ngroups = (int)grid.x;          // (the statistics slots are one per workgroup of the REGULAR launch: not more workgroups than that)
-    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < kReplayGrid ? ngroups : kReplayGrid), dim3(16), (size_t)LMb::kPadded * 4, L, b);
+    // L.epb carries the number of workgroups asked for here (pollers: a few; the drain pass: kReplayGrid). The statistics slots are
+    // one per workgroup of the REGULAR launch (+ kReplayGrid for the pollers): not more workgroups than that
+    const int ngroups = (int)((L.N + a.epb - 1) / a.epb), want = L.epb;
+    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < want ? ngroups : want), dim3(16), (size_t)LMb::kPadded * 4, L, b);
     return true;
   }
   if constexpr (PART == 0) {

@@ -22,6 +22,7 @@ header (``H_*``) followed by the constant table (``D_*``/``L_*``/``G_*``/``C_*``
 ``include/lm_layout.h`` is generated from these enums by ``tools/gen_layout_header.py``.
 """
 
+import os
 import numpy as np
 
 from . import mjcf
@@ -706,6 +707,12 @@ def lower(m, task):
     max_contacts = max([sum(cap for c2, b, cap in standing if c2 == c and b <= lowest + 0.02 * height) for c in range(NCHAIN)], default=0)
     if muscles:
         max_contacts = min(max_contacts, 4)       # the muscle family is compiled with four slots per chain (box feet)
+    elif max_links > 3 and max_contacts <= 4:
+        # five-link humanoids without muscles run in the eight-slot families even when they STAND on four contacts per leg (Talos'
+        # box feet): a control step that needs a fifth slot is abandoned and replayed (csrc/lm_step.h), which costs the launch a
+        # good part of a control step's latency — measured on Talos.walk at 4096 environments under the random policy: 1.46 ms per
+        # step with four slots (1.2 abandoned steps per launch), 1.34 ms with eight (0.2); profiles/r4_notes.md
+        max_contacts = 8
 
     def src_code(obs_idx):
         kind, i = obs_src[int(obs_idx) % task["nobs"]]

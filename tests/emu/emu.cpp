@@ -258,10 +258,10 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         g_bar.arrive_and_wait();
       }
       lm::Debug dbg = {dbgM, dbg5, dbg5 + nv, dbg5 + 2 * nv, dbg5 + 3 * nv, dbg5 + 4 * nv};
-      float pair_slack = 0.0f;
+      float pair_slack[3] = {0.0f, 0.0f, 0.0f};
       for (int s = 0; s < nsub; s++)
         lm::substep<QuadThreads, MC, NS, RK4, (PAIRS && MC <= 3) ? 1 : kEmuCone<MC>, NM, kEmuDR, PM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
-                                                      (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, &pair_slack);
+                                                      (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, pair_slack);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
       static int acc[16][9];
       {
@@ -269,7 +269,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         A[0] = cnt.solver_iters; A[1] = cnt.overflow; A[2] = cnt.unhandled; A[3] = cnt.ncon; A[4] = cnt.ls_evals; A[5] = cnt.ls_capped; A[6] = cnt.selfprox; A[7] = cnt.selfcon;
         A[8] = cnt.need_full;
       }
-      if (getenv("EMU_PAIR_TRACE") && c == 0 && t_rep == 0) fprintf(stderr, "env %d: pair detection passes %d, slack at the end %.4f\n", e, cnt.pair_passes, pair_slack);
+      if (getenv("EMU_PAIR_TRACE") && c == 0 && t_rep == 0) fprintf(stderr, "env %d: pair detection passes %d, slack at the end %.4f\n", e, cnt.pair_passes, pair_slack[0]);
       g_bar.arrive_and_wait();
       // the environment-wide vote of the step kernel: did the control step stay inside this instantiation's capacity?
       bool left = false;

@@ -101,12 +101,12 @@ def test_core_humanoids_rk4_pyramidal(task, nu, rows):
 
 @pytest.mark.parametrize("ls_points", [1, 4])
 def test_core_talos_euler_pyramidal(ls_points):
-    """kernel variant <5,4,Euler,pyramidal> (Talos: 3 chains, implicit damping, frictionloss rows) vs oracle and golden rows."""
+    """kernel variant <5,8,Euler,pyramidal> (Talos: 3 chains, implicit damping, frictionloss rows) vs oracle and golden rows."""
     np.random.seed(0)
     env = LocoEnv.make("Talos.walk", debug=True)
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
-    assert info["n_chains"] == 3 and info["max_links"] == 5 and info["max_contacts"] == 4
+    assert info["n_chains"] == 3 and info["max_links"] == 5 and info["max_contacts"] == 8      # (stands on four per leg; the eight-slot family: lowering.py)
     o = Oracle(pack_model(m))
     g = GOLD["Talos.walk.real"]
     qidx = [m.jnt_id(n) for k, n, t in env.obs_helper.observation_spec if k.startswith("q_")]

@@ -25,9 +25,12 @@ with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w", newline="") as 
     w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
     for r in rows:
         w.writerow([r[0], r[1], round(r[2] * 1.0), round(r[3], 1), round(r[4], 4)])
-# the step kernel with the most dispatches is the single-step kernel of the timed region; a fused-rollout kernel
-# (several control steps per launch, the extra leg of bench.py) is summarised separately
-names = [r[0] for r in db.execute("select name, count(*) c from kernels where name like '%step_kernel%' group by name order by c desc")]
+# the SINGLE-STEP kernel of the timed region = the step kernel with the largest total duration among those launched at least as
+# often as there are timed steps; the fused-rollout kernel (several control steps per launch, the extra leg of bench.py) and the
+# replay kernel (launched behind every step, empty most of the time: lm_step.h) are summarised separately
+rows_k = db.execute("select name, count(*) c, sum(duration) d from kernels where name like '%step_kernel%' group by name").fetchall()
+cmax = max(r[1] for r in rows_k)
+names = [r[0] for r in sorted(rows_k, key=lambda r: (r[1] * 2 < cmax, -r[2]))]
 kname = names[0]
 def kernel_row(name):
     return db.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, min(duration), "
