@@ -154,6 +154,8 @@ struct Params {
   const float* meshadj; // adjacency blocks of the hull vertices (global memory, 4 floats per entry): hill climbing of the convex-pair collider
   const float* bpt;   // body-pair table (global memory): records of LM_BP_SIZE floats, read when a link pair is within reach
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
+  const float* cmg;   // the constant table in GLOBAL memory: the six-link kernels read their link-pair lists from there (they do not fit
+                      // beside the lane memory in the workgroup's LDS share: lowering.py ends H_CM_USED before them)
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
@@ -1651,7 +1653,10 @@ LM_DEV float native_lower_bound(const NatGeom& G1, const NatGeom& G2) {
 // controls live in lane memory (kAct/kCtrl, filled by the caller) and are advanced here when EULER.
 // DR: joint damping / stiffness / frictionloss come from `dp` (per environment) instead of the constant table.
 // PM: 0 no self-collisions, 1 the pair pass with the convex collider, 2 the pair pass WITHOUT it (a convex pair within reach sets
-// cnt.need_full: the quadruped's kernels, whose regular gaits never touch one)
+// cnt.need_full: the quadruped's kernels, whose regular gaits never touch one), 3 DETECTION ONLY: the broad / mid phase of the pair
+// pass without any of its contact machinery — a geom pair within reach sets cnt.need_full and the control step goes to the
+// family's replay kernel (PM 1). The six-link family's regular kernels: UnitreeG1's 255 link pairs and the cross blocks of 6 x 6
+// chains do not fit beside its lane memory, and its gaits have no self-contact
 template <class Q, int MC, int NS, bool EULER, int CONE = -1, int NM = 0, int DR = 0, int PM = 0>
 LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* vr, float* qc, float* vc,
                     float* war, float* wac, const float* actr, const float* actc, LM_LMEM_T* lmem, int ls,
@@ -1660,7 +1665,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // `oz` is an opaque zero (LM_OPAQUE_ZERO, refreshed per loop iteration): constant-table reads are indexed
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
-  constexpr bool PAIRS = PM != 0, NOMPR = PM == 2;
+  constexpr bool PAIRS = PM == 1 || PM == 2, NOMPR = PM == 2, DETECT = PM != 0, DETECT_ONLY = PM == 3;
+  // the link-pair lists: in the constant table (LDS) — the six-link kernels' in its global copy (Params::cmg)
+#define LPE(off, i, f) ((MC == 6) ? P.cmg[(off) + (i) * LM_LP_SIZE + (f)] : cm[oz + (off) + (i) * LM_LP_SIZE + (f)])
 #ifdef LM_A1_CAPBOX_INLINE
   constexpr bool kCapBox = true;
 #else
@@ -1815,11 +1822,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           for (int i = 0; i < 9; i++) LMEM(LMm::kFrame + k * 18 + 3 + i) = Rk.a[i];
           LMEM(LMm::kFrame + k * 18 + 12) = V.w.x; LMEM(LMm::kFrame + k * 18 + 13) = V.w.y; LMEM(LMm::kFrame + k * 18 + 14) = V.w.z;
           LMEM(LMm::kFrame + k * 18 + 15) = V.v.x; LMEM(LMm::kFrame + k * 18 + 16) = V.v.y; LMEM(LMm::kFrame + k * 18 + 17) = V.v.z;
-          if (PAIRS) {
+          if (DETECT) {
             // self-collision broad phase: world centre of the link's bounding sphere, and the speed of the link's points
             // against the root body, |v_c| + |w| r with the twist relative to the root (the detection's travel bound)
             const V3 cw = pk + mul(Rk, v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ)));
-            LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z;
+            if (PAIRS) { LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z; }      // (detection only: from the frames, bs_centre)
             const V3 wr = V.w - Vroot.w;
             const V3 vcr = V.v - Vroot.v + cross(wr, cw - O);
             pair_speed = fmaxf(pair_speed, sqrtf(dot(vcr, vcr)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
@@ -2058,9 +2065,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     // the positions of a substep move by exactly h x the velocities this pass starts from. In a normal gait only the
     // trunk-thigh pairs are a few centimetres apart: one detection every 5-10 substeps.
     nfloor = nslot;
-    bool detect = PAIRS, first_detect = true;
+    bool detect = DETECT, first_detect = true;
     float gap_min = 3.0e38f;
-    if (PAIRS) {
+    if (DETECT) {
       const float s_own = pair_speed;
       const float s_quad = fmaxf(fmaxf(Q::quad_read(s_own, 0), Q::quad_read(s_own, 1)), fmaxf(Q::quad_read(s_own, 2), Q::quad_read(s_own, 3)));
       first_detect = !pair_slack || *pair_slack == 0.0f;        // nothing known yet (fresh state: the caller starts the slack at 0)
@@ -2086,9 +2093,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     detect = false;
 #endif
 #ifdef LM_TIMERS
-    if (PAIRS && c == 0 && Q::rep() == 0) { cnt.m[9]++; if (detect) cnt.m[8]++; }
+    if (DETECT && c == 0 && Q::rep() == 0) { cnt.m[9]++; if (detect) cnt.m[8]++; }
 #endif
-    if (PAIRS && detect) {
+    if (DETECT && detect) {
       if (c == 0 && Q::rep() == 0) cnt.pair_passes++;
       Q::quad_sync();                // the peers' frames and sphere centres are read below
       const V3 rootc = O + mul(R, v3(rb[LM_R_BSX], rb[LM_R_BSY], rb[LM_R_BSZ]));
@@ -2116,7 +2123,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       constexpr int kRcap = LMm::kRCap;                               // contacts per chain and pass (a chain has NS slots)
       constexpr int kW1 = LMm::kMcc, kS1 = kW1 + kWcap;
       constexpr int kQItem = LMm::kBig ? LMm::kLists : kS1 + 2 * kScap, kRes = kQItem + kQueue;
-      static_assert(!PAIRS || kS1 + 2 * kScap + (LMm::kBig ? 0 : kQueue + 8 * kRcap) <= LMm::kFrame, "the work lists of the pair pass must fit the dead part of lane memory");
+      static_assert(!DETECT || kS1 + 2 * kScap + (LMm::kBig ? 0 : kQueue + 8 * kRcap) <= LMm::kFrame, "the work lists of the pair pass must fit the dead part of lane memory");
       constexpr int kW = 4 * Q::kRep;                                 // lanes of one environment
       const int me = Q::rep() * 4 + c;
       int base[5];
@@ -2144,7 +2151,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       struct EntryCtx { int ka, kb, lb, own_q, dl, dlo; bool same_lane; V3 po, pp; M3 Ro, Rp; Sp Vo, Vp; };
       auto entry_ctx_of = [&](int cs, int i, EntryCtx& E) {
         const int off = (cs == c) ? off_lpair_c : (int)cm[oz + LM_CM_CHAINS + LM_C_OFF_LPAIR * LM_NCHAIN + cs];
-        const int code = (int)cm[oz + off + i * LM_LP_SIZE + 0];
+        const int code = (int)LPE(off, i, 0);
         E.ka = code & 7; E.kb = (code >> 3) & 7; E.lb = (code >> 6) & 3; E.own_q = (code >> 8) & 1; E.dl = E.lb - c; E.dlo = cs - c;
         E.same_lane = E.kb != 7 && E.lb == cs;            // two links of one chain: the entry (and its slots) live in that lane only
       };
@@ -2266,6 +2273,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               if (found) {
                 const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
                 if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
+                else if (DETECT_ONLY) cnt.need_full = 1;      // a contact: the replay kernel's business
                 else if (k < kRcap) {
                   const int rb_ = kRes + 8 * k, dlw = cs - c;
                   Q::peer_write(lmem, ls, rb_, dlw, raw); Q::peer_write(lmem, ls, rb_ + 1, dlw, mo.dist);
@@ -2359,18 +2367,34 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // sphere centres; measured 32 k cycles per detection for the quadruped with every lane walking all entries): replica r
       // tests entries r, r + kRep, ... and keeps bit i / kRep of its mask for an entry in reach; the masks are exchanged
       // (exact as floats: <= 64 / kRep bits... 16 with four replicas), every replica then builds the same lists from them.
-      unsigned long long reach_r = 0ull;
+      // (six-link chains: up to 128 entries per lane, a second mask word)
+      constexpr bool kWide = MC == 6;
+      constexpr int kEB = kWide ? 128 : 64;                          // an entry of W = entry index + kEB * its body pairs
+      unsigned long long reach_r = 0ull, reach_r2 = 0ull;
+      // world centre of a link's bounding sphere: kept in lane memory by the kernels with the full pair pass, from the link frame
+      // otherwise (detection only: no room for it beside the six-link lane memory)
+      auto bs_centre = [&](int dl, int lane, int k) -> V3 {
+        if constexpr (PAIRS) return v3(PEER(dl, LMm::kBS + k * 3), PEER(dl, LMm::kBS + k * 3 + 1), PEER(dl, LMm::kBS + k * 3 + 2));
+        else {
+          const int fb = LMm::kFrame + k * 18;
+          M3 Rl;
+#pragma unroll
+          for (int j = 0; j < 9; j++) Rl.a[j] = PEER(dl, fb + 3 + j);
+          const int lf = LM_CM_CHAINS + (LM_C_LINKS + k * LM_LINK_SIZE + LM_D_SIZE + LM_L_BSX) * LM_NCHAIN + lane;
+          return v3(PEER(dl, fb), PEER(dl, fb + 1), PEER(dl, fb + 2)) + mul(Rl, v3(cm[oz + lf], cm[oz + lf + LM_NCHAIN], cm[oz + lf + 2 * LM_NCHAIN]));
+        }
+      };
       {
         // branch-free body, unrolled: the LDS reads of several entries are in flight together
         float gmy = 3.0e38f, gpart[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
 #pragma unroll 4
         for (int i = Q::rep(); i < nlp; i += Q::kRep) {
-          const int code = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 0];
-          const float thr2 = cm[oz + off_lpair_c + i * LM_LP_SIZE + 2];
+          const int code = (int)LPE(off_lpair_c, i, 0);
+          const float thr2 = LPE(off_lpair_c, i, 2);
           const int ka = code & 7, kb = (code >> 3) & 7, lb = (code >> 6) & 3, own_q = (code >> 8) & 1, dl = lb - c;
           const int kbs = (kb == 7) ? 0 : kb, dls = (kb == 7) ? 0 : dl;
-          const V3 ca = v3(LMEM(LMm::kBS + ka * 3), LMEM(LMm::kBS + ka * 3 + 1), LMEM(LMm::kBS + ka * 3 + 2));
-          const V3 cbp = v3(PEER(dls, LMm::kBS + kbs * 3), PEER(dls, LMm::kBS + kbs * 3 + 1), PEER(dls, LMm::kBS + kbs * 3 + 2));
+          const V3 ca = bs_centre(0, c, ka);
+          const V3 cbp = bs_centre(dls, (kb == 7) ? c : lb, kbs);
           const V3 cb = (kb == 7) ? rootc : cbp;
           const V3 dc = cb - ca;
           const float d2c = dot(dc, dc);
@@ -2382,21 +2406,28 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           gmy = note ? fminf(gmy, gp_) : gmy;
 #pragma unroll
           for (int k = 0; k < 4; k++) gpart[k] = (notep && k == lb) ? fminf(gpart[k], gp_) : gpart[k];
-          reach_r |= (mine && inr) ? (1ull << (i / Q::kRep)) : 0ull;
+          const int bit_ = i / Q::kRep;
+          if (kWide && bit_ >= 64) reach_r2 |= (mine && inr) ? (1ull << (bit_ - 64)) : 0ull;
+          else reach_r |= (mine && inr) ? (1ull << bit_) : 0ull;
         }
         gap_note(c, gmy);
 #pragma unroll
         for (int k = 0; k < 4; k++) gap_of[k] = fminf(gap_of[k], gpart[k]);
       }
       // every replica's mask -> ONE mask of my chain's entries in reach, bit = entry (exact as floats: 16 bits with four replicas)
-      unsigned long long reach_all = reach_r;
+      unsigned long long reach_all = reach_r, reach_all2 = reach_r2;
       if (Q::kRep > 1) {
-        reach_all = 0ull;
+        reach_all = 0ull; reach_all2 = 0ull;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          unsigned m_ = (unsigned)Q::rep_bcast((float)(unsigned)reach_r, r);
+          unsigned m_ = (unsigned)Q::rep_bcast((float)((unsigned)reach_r & 0xffffu), r);
+          if (kWide) m_ |= (unsigned)Q::rep_bcast((float)(((unsigned)reach_r >> 16) & 0xffffu), r) << 16;      // entries 64 .. 127: bits 16 .. 31 of a replica's mask
 #pragma nounroll
-          while (m_) { const int b_ = __builtin_ctz(m_); reach_all |= 1ull << (4 * b_ + r); m_ &= m_ - 1u; }
+          while (m_) {
+            const int b_ = __builtin_ctz(m_), e_ = 4 * b_ + r;
+            if (kWide && e_ >= 64) reach_all2 |= 1ull << (e_ - 64); else reach_all |= 1ull << e_;
+            m_ &= m_ - 1u;
+          }
         }
       }
       LM_PHASE(15);
@@ -2406,12 +2437,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         // ---- 1b. the next chunk of my chain's entries in reach (every replica builds the same list)
         int nw = 0, nunits = 0;
 #pragma nounroll
-        while (reach_all != 0ull && nw < kWcap) {
-          const int i = __builtin_ctzll(reach_all);
-          const int nbp = (int)cm[oz + off_lpair_c + i * LM_LP_SIZE + 1] >> 16;
+        while ((reach_all != 0ull || (kWide && reach_all2 != 0ull)) && nw < kWcap) {
+          const bool lo_ = reach_all != 0ull;
+          const int i = lo_ ? __builtin_ctzll(reach_all) : 64 + __builtin_ctzll(reach_all2);
+          const int nbp = (int)LPE(off_lpair_c, i, 1) >> 16;
           if (nunits + nbp > kScap) break;                   // its body pairs would not fit S: next chunk (an entry alone always fits)
-          reach_all &= reach_all - 1ull;
-          LMEM(kW1 + nw) = (float)(i + 64 * nbp);
+          if (lo_) reach_all &= reach_all - 1ull; else reach_all2 &= reach_all2 - 1ull;
+          LMEM(kW1 + nw) = (float)(i + kEB * nbp);
           nw++; nunits += nbp;
         }
         if (!(Q::sum((nw > 0) ? 1.0f : 0.0f) > 0.0f)) break;          // no chain of the environment has entries in reach left (quad-uniform)
@@ -2439,14 +2471,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               int u = g - base[cs], i = 0, jb = 0;
 #pragma nounroll
               for (int t = 0; t < nw_of[cs]; t++) {
-                const int w = (int)PEER(cs - c, kW1 + t), nb = w >> 6;
-                if (u < nb) { i = w & 63; jb = u; break; }
+                const int w = (int)PEER(cs - c, kW1 + t), nb = w / kEB;
+                if (u < nb) { i = w & (kEB - 1); jb = u; break; }
                 u -= nb;
               }
               EntryCtx E;
               entry_ctx_of(cs, i, E);
               entry_frames(E);
-              const int bfirst = (int)cm[oz + off_lpair_of(cs) + i * LM_LP_SIZE + 1] & 65535;
+              const int bfirst = (int)LPE(off_lpair_of(cs), i, 1) & 65535;
               const float* br = P.bpt + (bfirst + jb) * LM_BP_SIZE;
               const float* bo = br + (E.own_q ? LM_BP_P2 : LM_BP_P1); const float* bq = br + (E.own_q ? LM_BP_P1 : LM_BP_P2);
               const V3 co = E.po + mul(E.Ro, v3(bo[0], bo[1], bo[2])), ao = mul(E.Ro, v3(bo[3], bo[4], bo[5]));
@@ -2533,6 +2565,16 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 }
                 gap_note(cs, clearance);
                 if (is_cross) gap_note(E.lb, clearance);
+                if constexpr (DETECT_ONLY) {
+                  // this kernel has no contact machinery for geom pairs: a CONTACT hands the control step to the replay kernel
+                  // (lm_step.h). Hull pairs of neighbouring links sit inside each other's bounding capsules for good: they go
+                  // through the colliders like everywhere else, and only what those find counts (flush_queue)
+                  if (in_reach) {
+                    if (kind == 3) is_prox = true;
+                    else if (kind == 0) cnt.need_full = 1;
+                    else { want_q = true; code = (float)(i * 65536 + first + v); }
+                  }
+                } else
                 if (in_reach && kind == 3) is_prox = true;              // a pair without a collider (a mesh that came without a hull): counted
                 else if (!kCapBox && in_reach && kind == 1 && (int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_CAPSULE) cnt.need_full = 1;     // capsule against a box: the replay kernel's
                 else if (in_reach && kind != 0) {
@@ -2578,7 +2620,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       flush_queue();            // every lane of the wave arrives here together: the queued pairs of all of them run side by side
       LM_TICK(15);              // self-collisions: convex pairs (MPR)
       LM_PHASE(13);
-      emit_results();
+      if constexpr (PAIRS) emit_results();
       // contacts beyond what the queue / the result list of my chain hold: dropped, counted
       if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
       if (nres_of[c] > kRcap) n_over += nres_of[c] - kRcap;
@@ -2793,7 +2835,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // factorisation eliminates the lanes in order and carries the cross blocks along (arrow_factor_g): exact for any pattern.
   bool any_pair = false;
   int adj0 = 0;
-  constexpr int NX = PAIRS ? ((MC <= 3) ? 3 : 2) : 1;         // cross blocks a lane may hold: chains above it (quadruped 4 chains, humanoids 3)
+  constexpr int NX = PAIRS ? ((MC <= 3 || MC == 6) ? 3 : 2) : 1;         // cross blocks a lane may hold: chains above it (quadruped and six-link robots 4 chains, humanoids 3)
   if (PAIRS) {
     adj0 = (int)(Q::sum((float)(pair_mask_out << (4 * c))) + 0.5f);
     // symmetric closure (a lane that ran out of slots may lack its mirror of a contact its partner holds)
@@ -2804,7 +2846,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       for (int j = 0; j < 4; j++) if ((adj0 >> (4 * i + j)) & 1) sym |= 1 << (4 * j + i);
     adj0 = sym;
     any_pair = adj0 != 0;
-    if (MC > 3 && (adj0 >> 12) != 0) any_pair = false;         // (a fourth humanoid chain has no cross-block storage: never lowered with pairs)
+    if (NX < 3 && (adj0 >> 12) != 0) any_pair = false;         // (a fourth chain of a five-link humanoid has no cross-block storage: never lowered with pairs)
   }
   auto ldS = [&](int base) -> Sp {       // twist from lane memory
     Sp S; S.w = v3(LMEM(base), LMEM(base + 1), LMEM(base + 2)); S.v = v3(LMEM(base + 3), LMEM(base + 4), LMEM(base + 5)); return S;
@@ -3336,6 +3378,23 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               int adj = adj0;
               arrow_factor_g<Q, MC, NX>(Hcc, Hcr, Hrep, Hpart, Lr, Xc, c, adj);
               arrow_solve_g<Q, MC, NX>(Hcc, Hcr, Lr, Xc, c, adj, sc, sr);
+              if (anydup) {
+                // the two copies of a shared first link's dof stay ONE coordinate (tie_shared_dof), with the coupled factors
+                float zc[MC], zr[6];
+#pragma unroll
+                for (int k = 0; k < MC; k++) zc[k] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) zr[i] = 0.0f;
+                zc[0] = (float)duprole;
+                arrow_solve_g<Q, MC, NX>(Hcc, Hcr, Lr, Xc, c, adj, zc, zr);
+                const float lam = Q::sum((float)duprole * sc[0]) / Q::sum((float)duprole * zc[0]);
+#pragma unroll
+                for (int k = 0; k < MC; k++) sc[k] = fmaf(-lam, zc[k], sc[k]);
+#pragma unroll
+                for (int i = 0; i < 6; i++) sr[i] = fmaf(-lam, zr[i], sr[i]);
+                const float xa = Q::sum(duprole > 0 ? sc[0] : 0.0f);
+                if (duprole < 0) sc[0] = xa;
+              }
             }
           }
           if (!coupled) {
@@ -3670,6 +3729,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #undef CU
 #undef SL
 #undef PEER
+#undef LPE
 #undef LMEM
 }
 

@@ -30,8 +30,15 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
   return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
 #elif LM_FAMILY == 5    // muscle humanoid
   return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART>(L, a, kind);
-#elif LM_FAMILY == 7    // UnitreeG1 with the torso joint welded: two 6-link legs (four 1 mm spheres per foot), two 5-link arms
-  return launch_family<6, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
+#elif LM_FAMILY == 7    // UnitreeG1 (two 6-link legs: four 1 mm spheres per foot, two arms that share the torso link), UnitreeH1 with its arms.
+#ifndef LM_SIX_PAIRS
+// 1: the whole pair pass in the regular kernels (lane memory 32.8 KB + 9.4 KB of constants: THREE workgroups per CU — a batch of 4096
+// runs its last quarter of workgroups behind the first finishers). 3: detection only (39.2 KB, four per CU; a self-contact hands the
+// control step to the replay kernel): right for gaits — but robots that stumble under a random policy touch themselves in a quarter of
+// their control steps, and 1100 replays per launch at one environment per workgroup cost 129 ms per step (measured, round 4).
+#define LM_SIX_PAIRS 1
+#endif
+  return launch_family<6, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART, LM_SIX_PAIRS>(L, a, kind);
 #elif LM_FAMILY == 8    // HumanoidTorque with its bone hulls colliding (RK4): floor + self-contacts in eight slots
   return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART, 1>(L, a, kind);
 #elif LM_FAMILY == 9    // UnitreeH1: hip-yaw cylinders and link meshes colliding (Euler)

@@ -81,7 +81,7 @@ static int family_of(const lm_batch* b) {
   const bool big = T.max_links > 3, six = T.max_links > 5, rk4 = b->m->P.integrator == LM_INT_RK4, few = T.max_contacts <= 4;
   static const bool generic = LM_PROBE_ENV("LM_GENERIC_KERNELS") != nullptr;      // A/B: run-time cone for the humanoids
   const bool pyr3 = T.all_pyr3 && !generic;
-  if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;
+  if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;      // (with or without self-collision tables: its regular kernels detect, its replay kernel collides)
   // five-link humanoids whose lowering carries self-collision tables (bone hulls, link meshes, cylinders): the pair families
   if (big && T.npair > 0 && pyr3) return rk4 ? (T.na == 0 ? 8 : 6) : (T.na == 0 ? 9 : 10);
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return 0;
@@ -94,7 +94,7 @@ static int family_of(const lm_batch* b) {
 }
 
 static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
-static bool family_has_pairs(int fam) { return fam == 0 || fam == 8 || fam == 9 || fam == 10; }
+static bool family_has_pairs(int fam) { return fam == 0 || fam == 7 || fam == 8 || fam == 9 || fam == 10; }
 
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
@@ -253,6 +253,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   P.scale = 1.0f / ((float)cmod[LM_H_MEANINERTIA] * (float)T.nv);
   P.off_runsup = (int)cmod[LM_H_OFF_RUNSUP];
   P.gt = m->d_gt;
+  P.cmg = m->d_cm;
   {
     const size_t ngp = (size_t)cmod[LM_H_NGPAIR], off = (size_t)cmod[LM_H_OFF_GPT];
     if (ngp > 0 && n < off + ngp * LM_GPAIR_SIZE) return fail("chain model lacks the geom-pair table");

@@ -77,7 +77,7 @@ CM_CHAINS = ROOT_SIZE
 # ---- self-collisions (kernels compiled with PAIRS): per lane a list of link pairs (LP_SIZE floats each, chain by chain
 # [entry][field] in the tail): code = own link + 8 * partner link (7 = root body) + 64 * partner lane (the own link is the pair's FIRST
 # link: a cross-chain pair is listed in that lane only; + 256 would mark the second link's view, which the device still decodes), range = first body pair + 65536 * number of body pairs (<= 24), squared reach of the two bounding spheres
-MAXLP = 64
+MAXLP = 128        # link-pair entries per lane (64 for the three- and five-link families: one mask word on the device)
 PAIR_PAD = 0.03   # metres: link pairs closer than touching + PAIR_PAD go through the narrow phase (csrc/lm_core.h LM_PAIR_PAD)
 LP_SIZE = 3
 # geom-pair records (global memory): kind (0 sphere/capsule pair with a collider, 1 counted only: bounding capsules of a pair the
@@ -768,9 +768,13 @@ def lower(m, task):
     # (pyramids) have kernels with the pair path; a model without a candidate pair (Atlas, Talos: contype 0) keeps the plain ones
     pairs_on = (task.get("self_collisions", True) and _count_self_pairs(m) > 0
                 and ((m.cone == mjcf.CONE_ELLIPTIC and max_links <= 3 and m.integrator == mjcf.INT_EULER and not muscles)
-                     or (m.cone == mjcf.CONE_PYRAMIDAL and 3 < max_links <= 5 and not shared_first)))
+                     or (m.cone == mjcf.CONE_PYRAMIDAL and 3 < max_links <= 5 and not shared_first)
+                     # six-link chains (UnitreeG1, UnitreeH1 with its arms): the regular kernels only DETECT (a geom pair within reach
+                     # hands the control step to the family's replay kernel, which has the pair pass: csrc/lm_family.hip)
+                     or (m.cone == mjcf.CONE_PYRAMIDAL and max_links == 6 and m.integrator == mjcf.INT_EULER and not muscles)))
     pair_tab = _self_collision_tables(m, root, chains, kin, register_hull, hull_block) if pairs_on else None
     h[H_OFF_LPAIR] = off
+    off_before_lp = off
     gpt, bpt = np.zeros(0), np.zeros(0)
     if pair_tab is not None:
         lanes_lp, gpt, spheres, kinds, bpt = pair_tab
@@ -788,7 +792,9 @@ def lower(m, task):
             max_contacts = 8                  # the pair families are compiled with eight slots per chain (floor + self-contacts)
             h[H_MAXCONTACTS] = max_contacts
     assert off <= CM_SIZE
-    h[H_CM_USED] = off
+    # what a workgroup copies into its LDS: everything — but the six-link kernels read their link-pair lists (3 KB for UnitreeG1)
+    # from the table's copy in global memory, they do not fit beside that family's lane memory at four workgroups per CU
+    h[H_CM_USED] = off_before_lp if max_links > 5 else off
     h[H_GT_SIZE] = GT_SIZE
     h[H_NGRF] = n_grf
     if max_groups_seen > 2 and max_links < MAXC:
@@ -919,7 +925,8 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
         li = -1
         for b in chain:
             li += m.body_jntnum[b]
-            where[b] = (c, li)
+            if b not in where:              # (a first link shared by two chains belongs to the first of them: its owner)
+                where[b] = (c, li)
 
     def rel_pose(b):
         w = m.body_weldid[b]
@@ -995,6 +1002,14 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
         if wp not in where or wq not in where:
             raise UnsupportedModel("self-collision pair outside the root+chains structure")
         (lp, kp), (lq, kq) = where[wp], where[wq]
+        # a first link SHARED by two chains (a torso with an arm on either side) against a link of the chain that carries its
+        # massless COPY: both are links of that chain — the relative motion does not depend on the shared dof, and as a pair of ONE
+        # lane its rows hold that chain's own joints only (between the owner's lane and the copy's it would couple the two copies)
+        if lp >= 0 and lq >= 0 and lp != lq:
+            if kp == 0 and chains[lq][0] == wp:
+                lp = lq
+            elif kq == 0 and chains[lp][0] == wq:
+                lq = lp
         if lp < 0:                                                   # the root body is always the PARTNER of an entry
             (wp, wq), (lp, kp), (lq, kq) = (wq, wp), (lq, kq), (lp, kp)
         margin_max = 0.0
@@ -1083,11 +1098,13 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
             else:
                 lanes_lp[lp].append([kp + 8 * kq + 64 * max(lq, 0), first + 65536 * n, reach2])
         spheres_r[where[wp]], spheres_r[where[wq]] = sphere[wp], sphere[wq]
-    if max(len(x) for x in lanes_lp) > MAXLP:
+        spheres_r[(lp, kp)], spheres_r[(lq, kq)] = sphere[wp], sphere[wq]          # (a shared first link seen as the copy lane's link 0)
+    six = max(len(ch) for ch in chains) > 5            # (six-link chains: two mask words on the device, lists read from global memory)
+    if max(len(x) for x in lanes_lp) > (MAXLP if six else 64):
         raise UnsupportedModel("too many self-collision link pairs (%s)" % [len(x) for x in lanes_lp])
     # what the device packs into one float32 (csrc/lm_core.h: the pair pass): a work item = entry * 65536 + geom-pair record; a body
     # pair in reach = entry * 32 + body pair of the entry + 4096 * its geom pairs; an entry in reach = entry + 64 * its body pairs
-    if len(records) >= 65536 or len(bodypairs) >= 65536 or max(len(x) for x in lanes_lp) > 64:
+    if len(records) >= 65536 or len(bodypairs) >= 65536 or max(len(x) for x in lanes_lp) > (MAXLP if six else 64):
         raise UnsupportedModel("self-collision tables beyond the device's packing (%d geom pairs, %d body pairs, %s link pairs per lane)"
                                % (len(records), len(bodypairs), [len(x) for x in lanes_lp]))
     assert all(int(bp[BP_N]) <= 24 for bp in bodypairs) and all((int(e[1]) >> 16) <= 24 for x in lanes_lp for e in x)

@@ -16,6 +16,9 @@
 #define LM_POW01(x, p) exp2f((p) * log2f(x))
 #include "../../loco_mujoco_amd/csrc/lm_core.h"
 
+#ifndef EMU_SIX_PAIRS
+#define EMU_SIX_PAIRS 1
+#endif
 #ifndef EMU_LS_POINTS
 #define EMU_LS_POINTS 1
 #endif
@@ -142,7 +145,7 @@ template <int MC, int NS, bool RK4, int NM = 0, int PM = 0>
 static int emu_run_t(const double* chain_model, int n, double* qpos, double* qvel, double* warm, const double* action,
                      int nsub, int debug_env, float* dbgM, float* dbg5, int* counters, double* act = nullptr,
                      int* leave = nullptr, const int* only = nullptr) {
-  constexpr bool PAIRS = PM != 0;
+  constexpr bool PAIRS = PM == 1 || PM == 2;      // (3: detection only — the lane memory of a kernel without the pair pass)
   const double* H = chain_model;
   const int nv = (int)H[LM_H_NV], nu = (int)H[LM_H_NU];
   std::vector<float> cm(LM_CM_SIZE);
@@ -160,7 +163,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
-  P.off_runsup = (int)H[LM_H_OFF_RUNSUP]; P.gt = gt.data();
+  P.off_runsup = (int)H[LM_H_OFF_RUNSUP]; P.gt = gt.data(); P.cmg = cm.data();
   std::vector<float> gpt((size_t)H[LM_H_NGPAIR] * LM_GPAIR_SIZE + 1);
   for (size_t i = 0; i + 1 < gpt.size(); i++) gpt[i] = (float)H[(size_t)H[LM_H_OFF_GPT] + i];
   P.gpt = gpt.data();
@@ -325,7 +328,7 @@ static int emu_dispatch(const double* chain_model, int n, double* qpos, double* 
   const bool rk4 = (int)chain_model[LM_H_INTEGRATOR] == LM_INT_RK4;
   const bool big = (int)chain_model[LM_H_MAXLINKS] > 3, few = (int)chain_model[LM_H_MAXCONTACTS] <= 4;
   if ((int)chain_model[LM_H_MAXLINKS] > 5)
-    return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, N8, false>(EMU_ARGS, nullptr, leave, only) : -1;
+    return (!rk4 && (int)chain_model[LM_H_NMUSCLE] == 0) ? emu_run_t<6, N8, false, 0, BIGK ? 1 : EMU_SIX_PAIRS>(EMU_ARGS, nullptr, leave, only) : -1;      // (lm_family.hip LM_SIX_PAIRS: 1 the whole pair pass, 3 detection only | the replay kernel's pair pass)
   // the five-link humanoids with self-collision tables (bone hulls, UnitreeH1's cylinders and meshes): the pair families, 8 slots
   if ((int)chain_model[LM_H_NGPAIR] > 0 && big) {
     if ((int)chain_model[LM_H_NMUSCLE] > 0) return (act && !rk4) ? emu_run_t<5, N8, false, LM_MAXMUS, 1>(EMU_ARGS, act, leave, only) : -1;

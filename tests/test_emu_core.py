@@ -673,3 +673,44 @@ def test_core_native_box_and_cylinder_pairs_vs_oracle(robot):
         replayed += cnt["replayed"]; selfcon += cnt["selfcon"]
         assert np.abs(q[0] - qo).max() < 1e-4 and np.abs(v[0] - vo).max() < 1e-2, (robot, i, np.abs(q[0] - qo).max(), np.abs(v[0] - vo).max())
     print("native pairs (%s): %d states, qpos max %.2e qvel max %.2e, self-contacts %d, replayed %d" % (robot, len(pick), worst_q, worst_v, selfcon, replayed))
+
+
+@pytest.mark.parametrize("robot", ["g1", "h1arms"])
+def test_core_six_link_self_collisions_detect_and_replay(robot):
+    """self-collisions of the six-link family (UnitreeG1 default, UnitreeH1 with its arms; reference
+    humanoids/unitreeG1.py:246, unitreeH1.py:235): the whole pair pass for six-link chains - link-pair lists of up to 128 entries per
+    lane read from global memory, cross blocks between all four chains, the shared torso link tied in the coupled solves, a pair of the
+    torso with the arm that carries its copy as a pair of ONE lane. (A detection-only variant of the regular kernels, a contact handing
+    the control step to the replay kernel, is kept as the switch LM_SIX_PAIRS = 3 of lm_family.hip / EMU_SIX_PAIRS here.)
+    States of tests/golden/six_link_self_contact_states.npz (oracle rollouts of
+    stumbling robots, arm-on-arm poses: tools/make_six_link_fixtures.py) vs the fp64 oracle; the well-conditioned ones at the stated
+    tolerance, the others (the oracle itself moves under float32-sized input noise) at three times the oracle's own spread."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "six_link_self_contact_states.npz"))
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeG1.walk", debug=True) if robot == "g1" else LocoEnv.make("UnitreeH1.walk", debug=True, disable_arms=False)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["max_links"] == 6 and info["self_collision_tables"]["convex"] > 100 and int(cmod[lowering.H_NGPAIR]) > 0
+    assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_LPAIR])          # the link-pair lists stay out of the LDS copy
+    o = Oracle(pack_model(m))
+    q0, v0, a0, spread = d[robot + "_qpos"], d[robot + "_qvel"], d[robot + "_action"], d[robot + "_oracle_spread"]
+    pick = list(range(0, len(q0), 2)) + ([len(q0) - 1, len(q0) - 3] if robot == "g1" else [])       # (the GPU test runs all of them; the last four of g1: arm on arm)
+    q, v, _, cnt, _ = pyemu.run(cmod, q0[pick], v0[pick], a0[pick], nsub=10, rep=4)
+    assert cnt["overflow"] == 0 and cnt["selfcon"] > 0, cnt      # (LM_SIX_PAIRS 1: the regular instantiation has the pair pass; 3: every one of them replayed)
+    held = 0
+    for j, i in enumerate(pick):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a0[i])
+        qo, vo, _, st = o.step(q0[i], v0[i], ctrl, 10)
+        assert st["convex_contacts"] > 0
+        eq, ev = np.abs(q[j] - qo).max(), np.abs(v[j] - vo).max()
+        well = spread[i, 0] < 1e-5 and spread[i, 1] < 1e-3
+        held += well
+        assert (eq < 1e-4 and ev < 1e-2) if well else (eq < 3 * spread[i, 0] + 1e-4 and ev < 3 * spread[i, 1] + 1e-2), (robot, i, eq, ev, spread[i])
+    assert held >= 2
+    # an upright gait does not leave the regular instantiation: the hulls of neighbouring links sit inside each other's bounding
+    # capsules for good, the colliders say "no contact"
+    tab = env._reset_table()
+    rows = tab[np.random.RandomState(0).randint(0, len(tab), 4)]
+    _, _, _, cnt, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], np.zeros((4, len(env._action_indices))), nsub=10, rep=4)
+    assert cnt["replayed"] == 0 and cnt["selfcon"] == 0, cnt

@@ -585,9 +585,9 @@ def _h1_kat_inputs(env, task):
 
 
 # rows k -> k + 1 reproduced to qpos 1e-8 / qvel 5e-6 (28 of 58); the others: within 1e-3 (5 more) or listed with their error in
-# profiles/r3_notes.md §2 — 25 carry an MPR contact between two curved shapes (hip-yaw capsule on hip-pitch cylinder; libccd stops by
-# tolerance, the contact point depends on its iteration path), 5 have a foot lying nearly flat, where the engine's further plane-hull
-# contacts depend on its own hull graph of the sole
+# profiles/r3_notes.md §2 — 26 carry an MPR contact of a hip-yaw link's cylinder (its flat cap) against the hull of the hip-pitch link's mesh
+# and are ill-conditioned in float64 (test_h1_unreproduced_rows_are_ill_conditioned_in_float64 below), 4 have a foot lying nearly flat,
+# where the engine's further plane-hull contacts depend on its own hull graph of the sole
 H1_EXACT = {"run": [0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 25, 26, 27, 29], "walk": [0, 1, 2, 13, 15, 16, 17, 18, 19, 20, 21, 25, 26]}
 H1_WITHIN_1E3 = {"run": 17, "walk": 16}
 
@@ -615,6 +615,45 @@ def test_h1_environment_rows_with_the_packaged_hulls(task):
             exact.append(k)
     assert exact == H1_EXACT[task]
     assert sum(e < 1e-3 for e in errs) == H1_WITHIN_1E3[task] and max(errs) < 0.2
+
+
+# the golden rows of UnitreeH1 that are NOT reproduced, and why (round 4). Rows listed here have a foot lying nearly flat: further
+# plane-hull contacts that depend on the engine's own hull graph of the sole (profiles/r3_notes.md §2). Every other unreproduced
+# row carries ONE convex contact — the cylinder of a hip-yaw link against the hull of the hip-pitch link's mesh, MPR on the flat cap
+# of a cylinder — and is ILL-CONDITIONED IN FLOAT64: the oracle's own result moves by as much as it is off the golden row when its
+# input moves by 1e-13 relative. No restatement that is not bit-identical to the reference's binary can reproduce those rows.
+H1_HULL_GRAPH_ROWS = {"run": [28], "walk": [22, 23, 24]}
+
+
+@pytest.mark.parametrize("task", ["run", "walk"])
+def test_h1_unreproduced_rows_are_ill_conditioned_in_float64(task):
+    np.random.seed(0)
+    env = attach(LocoEnv.make("UnitreeH1." + task, debug=True))
+    m = env._model
+    env.reset()
+    g, qidx, rows = _h1_kat_inputs(env, task)
+    o = env._backend.oracle
+    rs = np.random.RandomState(1)
+    chaotic, stable = [], []
+    for k, (qpos, qvel, a) in enumerate(rows):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        q, v, w, st = o.step(qpos, qvel, ctrl, nsub=10)
+        err = np.abs(v[qidx] - g[k + 1, 15:32]).max()
+        if err < 5e-6:
+            continue
+        spread = 0.0
+        for _ in range(6):
+            q2, v2, _, _ = o.step(qpos * (1 + 1e-13 * rs.randn(len(qpos))), qvel, ctrl, nsub=10)
+            spread = max(spread, np.abs(v2 - v).max())
+        # the convex contact of the row: a cylinder (hip-yaw link) against a mesh hull
+        cons = [c for c in o.forward(qpos, qvel, ctrl)["contacts"] if c["geom1"] != 0]
+        (chaotic if spread > 0.1 * err else stable).append(k)
+        if spread > 0.1 * err:      # (the contact may only begin during the control step)
+            assert st["convex_contacts"] > 0 and all(sorted((int(m.geom_type[c["geom1"]]), int(m.geom_type[c["geom2"]]))) == [3, 5] for c in cons), (k, cons)
+    print("UnitreeH1.%s: unreproduced rows that are ill-conditioned in float64 %s; others %s" % (task, chaotic, stable))
+    assert stable == H1_HULL_GRAPH_ROWS[task]
+    assert len(chaotic) == {"run": 15, "walk": 11}[task]
 
 
 # ---------------------------------------------------------------------------------------------------------------
