@@ -2856,6 +2856,28 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // ================= unit constraint rows: friction loss, joint limits =================
   float fl_aref_r[6], fl_aref_c[MC];     // friction-loss reference accelerations
   float lim_s_c[MC], lim_D_c[MC], lim_aref_c[MC];   // active limit: sign (+1 lower, -1 upper, 0 none)
+  // limit rows of the ROOT dofs (replicated in the four lanes, counted once like the root's friction-loss rows): compiled into the
+  // muscle families and the run-time-cone kernels — HumanoidMuscle's pelvis joints are `limited` (humanoid_muscle.xml), no other
+  // robot of the path has a limited root joint, and six more rows' state in every kernel's Newton loop is not free
+  constexpr bool ROOT_LIM = NM > 0 || CONE < 0;
+  constexpr int NRL = ROOT_LIM ? 6 : 1;
+  float lim_s_r[NRL], lim_D_r[NRL], lim_aref_r[NRL];
+#pragma unroll
+  for (int i = 0; i < NRL; i++) { lim_s_r[i] = 0; lim_D_r[i] = 0; lim_aref_r[i] = 0; }
+  if constexpr (ROOT_LIM) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) if (RD(i, LM_D_LIMITED) != 0.0f) {
+      const float dlo = qr[i] - RD(i, LM_D_LO), dhi = RD(i, LM_D_HI) - qr[i];
+      const float sgn = (dlo < 0.0f) ? 1.0f : ((dhi < 0.0f) ? -1.0f : 0.0f);
+      if (sgn != 0.0f) {
+        const float dist = (sgn > 0) ? dlo : dhi;
+        const float imp = impedance(&RD(i, LM_D_LIM_S0), 1, dist, 0.0f);
+        const float Rl = fmaxf(kMinVal, (1.0f - imp) * RDV(i, 1, LM_D_INVW) / imp);
+        lim_s_r[i] = sgn; lim_D_r[i] = 1.0f / Rl;
+        lim_aref_r[i] = -RD(i, LM_D_LIM_B) * (sgn * vr[i]) - RD(i, LM_D_LIM_K) * imp * dist;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 6; i++) fl_aref_r[i] = -RD(i, LM_D_FLOSS_B) * vr[i];
 #pragma unroll
@@ -2963,6 +2985,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     if (Q::rep() == 0) {
 #pragma unroll
       for (int i = 0; i < 6; i++) cr += friction_cost(xr[i] - fl_aref_r[i], FLOSS_R(i), (inr_on ? dp->rfl_r[i] : RD(i, LM_D_FLOSS_R)));
+      if constexpr (ROOT_LIM) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { const float x = lim_s_r[i] * xr[i] - lim_aref_r[i]; if (lim_s_r[i] != 0.0f && x < 0.0f) cr += 0.5f * lim_D_r[i] * x * x; }
+      }
       cost = w0 * cr;
 #pragma unroll
       for (int k = 0; k < MC; k++) if (k < nl) {
@@ -3029,7 +3055,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   for (int k = 0; k < MC; k++) qf_c[k] = 0;
   bool has_rows = false;
 #pragma unroll
-  for (int i = 0; i < 6; i++) has_rows = has_rows || (FLOSS_R(i) > 0.0f);
+  for (int i = 0; i < 6; i++) has_rows = has_rows || (FLOSS_R(i) > 0.0f) || (ROOT_LIM && lim_s_r[ROOT_LIM ? i : 0] != 0.0f);
 #pragma unroll
   for (int k = 0; k < MC; k++) has_rows = has_rows || (k < nl && (FLOSS_C(k) > 0.0f || lim_s_c[k] != 0.0f));
   has_rows = has_rows || nslot > 0;
@@ -3053,7 +3079,8 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       float fu_r[6];
       // friction-loss rows: force = -clamp(x/R, -f, f); quadratic zone (Hessian 1/R) iff |x| < R f
       float ff_r[6], iR_r[6], ff_c[MC], iR_c[MC];
-      unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0;   // rows in their quadratic zone (Hessian)
+      unsigned act_fr_r = 0, act_fr_c = 0, act_lim = 0, act_lim_r = 0;   // rows in their quadratic zone (Hessian)
+      float jlim_r[NRL];
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         ff_r[i] = FLOSS_R(i); const float Rr = (inr_on ? dp->rfl_r[i] : RD(i, LM_D_FLOSS_R));
@@ -3062,6 +3089,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         jfr_r[i] = x;
         fu_r[i] = -fminf(fmaxf(x * iR_r[i], -ff_r[i]), ff_r[i]);
         if (fabsf(x) < Rr * ff_r[i]) act_fr_r |= 1u << i;
+        if constexpr (ROOT_LIM) {
+          jlim_r[i] = lim_s_r[i] * ar[i] - lim_aref_r[i];
+          if (jlim_r[i] < 0.0f && lim_s_r[i] != 0.0f) { fu_r[i] -= lim_s_r[i] * lim_D_r[i] * jlim_r[i]; act_lim_r |= 1u << i; }
+        }
       }
 #pragma unroll
       for (int k = 0; k < MC; k++) {
@@ -3207,6 +3238,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int i = 0; i < 21; i++) Hpart[i] = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (act_fr_r & (1u << i)) Hrep[tri(i, i)] += iR_r[i];
+        if constexpr (ROOT_LIM) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) if (act_lim_r & (1u << i)) Hrep[tri(i, i)] += lim_D_r[i];
+        }
         auto hess_slot = [&](int s, auto is_pair) {
           constexpr bool IP = decltype(is_pair)::value;
           oz = LM_OPAQUE_ZERO();
@@ -3464,6 +3499,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               const float t = jv_r[i] * fminf(fmaxf(x * iR_r[i], -ff_r[i]), ff_r[i]);
               r1 += t; rm += fabsf(t);
               r2 = fmaf((fabsf(x) * iR_r[i] < ff_r[i]) ? iR_r[i] : 0.0f, jv_r[i] * jv_r[i], r2);
+              if constexpr (ROOT_LIM) {
+                const float jvl = lim_s_r[i] * jv_r[i];
+                const float xl = fminf(fmaf(alpha, jvl, jlim_r[i]), 0.0f);       // lim_D_r = 0 when no limit is active
+                const float tl = lim_D_r[i] * xl * jvl;
+                r1 += tl; rm += fabsf(tl);
+                r2 = fmaf((xl < 0.0f) ? lim_D_r[i] : 0.0f, jvl * jvl, r2);
+              }
             }
 #pragma unroll
             for (int k = 0; k < MC; k++) {

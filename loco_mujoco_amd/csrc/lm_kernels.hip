@@ -192,7 +192,8 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   if (LM_PROBE_ENV("LM_NO_PAIRS")) for (int c = 0; c < LM_NCHAIN; c++) cm[LM_CM_CHAINS + LM_C_NLPAIR * LM_NCHAIN + c] = 0.0f;      // A/B: self-collision broad phase off
   for (int i = 0; i < 6; i++) {
     const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
-    if (blk[LM_D_LIMITED] != 0.0f) { return fail("limited root joints are not supported"); }
+    // limit rows on the root dofs are compiled into the muscle families (and the run-time-cone kernels) only: lm_core.h ROOT_LIM
+    if (blk[LM_D_LIMITED] != 0.0f && (int)cmod[LM_H_NMUSCLE] == 0) { return fail("limited root joints are supported for models with muscles only (the muscle kernel families carry the root limit rows)"); }
   }
   HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
   HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));

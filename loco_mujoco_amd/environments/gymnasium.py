@@ -50,8 +50,10 @@ class GymnasiumWrapper(_Env):
         return obs, reward, absorbing, False, info
 
     def reset(self, *, seed=None, options=None):
+        # like the reference (environments/gymnasium.py:73-77): a passed seed initialises the wrapper's OWN generator (gymnasium's
+        # `np_random`); the environment draws from the global `np.random`, which this call does not touch
         if seed is not None:
-            np.random.seed(seed)
+            self._np_random = np.random.default_rng(seed)
         return self._env.reset(), {}
 
     def render(self):

@@ -352,8 +352,10 @@ def lower(m, task):
             block[D_FLOSS_R] = max(MINVAL, (1 - d0) * m.dof_invweight0[d] / d0)
             block[D_FLOSS_B] = _kb(m.dof_solref[d], m.dof_solimp[d], m.timestep)[1]
         limited = bool(m.jnt_limited[d])
-        if limited and is_root:
-            # the device has no limit rows for the (replicated) root dofs. A root limit that cannot become active is
+        if limited and is_root and getattr(m, "na", 0) > 0:
+            pass        # the muscle families carry limit rows for the root dofs (csrc/lm_core.h ROOT_LIM): HumanoidMuscle's pelvis joints
+        elif limited and is_root:
+            # the other families have no limit rows for the (replicated) root dofs. A root limit that cannot become active is
             # dropped: translation ranges of tens of metres, or angles whose termination band (evaluated every
             # control step) lies strictly inside the joint range.
             lo, hi = m.jnt_range[d]

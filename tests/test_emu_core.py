@@ -714,3 +714,41 @@ def test_core_six_link_self_collisions_detect_and_replay(robot):
     rows = tab[np.random.RandomState(0).randint(0, len(tab), 4)]
     _, _, _, cnt, _ = pyemu.run(cmod, rows[:, :m.nv], rows[:, m.nv:2 * m.nv], np.zeros((4, len(env._action_indices))), nsub=10, rep=4)
     assert cnt["replayed"] == 0 and cnt["selfcon"] == 0, cnt
+
+
+def _root_limit_states(env):
+    """HumanoidMuscle in the air (no contacts) with pelvis rotations beyond their joint limits (humanoid_muscle.xml: the pelvis joints
+    are `limited`, +-pi/2): limit rows on the replicated root dofs."""
+    m = env._model
+    tab = env._reset_table()
+    rs = np.random.RandomState(0)
+    rows = tab[rs.randint(0, len(tab), 4)].copy()
+    q, v = rows[:, :m.nv].copy(), rows[:, m.nv:2 * m.nv].copy()
+    q[:, 1] += 1.0                         # pelvis_ty
+    q[0, 3], v[0, 3] = 1.62, 0.5           # pelvis_tilt beyond its upper limit, still moving out
+    q[1, 5], v[1, 5] = -1.60, -1.0         # pelvis_rotation beyond its lower limit
+    q[2, 3], v[2, 3] = -1.60, -2.0         # pelvis_tilt, the other side
+    q[3, 3], q[3, 5] = -1.65, 1.63         # two at once
+    return q, v, rs.uniform(-1, 1, (4, len(env._action_indices)))
+
+
+def test_core_root_dof_limit_rows():
+    """VERDICT r3 item 9: limit rows on the (replicated) root dofs — compiled into the muscle families (lm_core.h ROOT_LIM);
+    HumanoidMuscle's pelvis joints are limited (reference data/humanoid/humanoid_muscle.xml), the lowering used to drop them after
+    proving that they cannot become active. States with the pelvis beyond its limits, one control step vs the oracle; the rows act
+    (the tilt velocity is reversed) and every state is inside the stated tolerance, plain and replicated layout."""
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle.run", debug=True)
+    m = env._model
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["dropped_root_limits"] == []
+    o = Oracle(pack_model(m))
+    q, v, acts = _root_limit_states(env)
+    for rep in (1, 4):
+        qe, ve, _, cnt, _ = pyemu.run(cmod, q, v, acts, nsub=10, rep=rep)
+        for i in range(4):
+            ctrl = np.zeros(m.nu)
+            ctrl[env._action_indices] = env._preprocess_action(acts[i])
+            qo, vo, _, _, _ = o.step_act(q[i], v[i], np.zeros(m.na), ctrl, 10)
+            assert np.abs(qe[i] - qo).max() < 1e-5 and np.abs(ve[i] - vo).max() < 1e-3, (rep, i)
+        assert ve[0, 3] < -0.3 and v[0, 3] > 0       # the limit row turned the tilt around

@@ -2132,3 +2132,37 @@ def test_six_link_self_collisions_on_the_device(robot):
           % (robot, st["kernel_ms"] / 60, st["self_contacts"], st["replayed_env_steps"], st["overflow_contacts"], st["self_proximity"], st["episodes"]))
     assert np.isfinite(q).all() and np.isfinite(v).all() and st["nan_resets"] == 0
     assert st["overflow_contacts"] == 0 and st["self_proximity"] == 0 and st["self_contacts"] > 0
+
+
+def test_root_dof_limit_rows_on_the_device():
+    """VERDICT r3 item 9 on the GPU: HumanoidMuscle with its pelvis beyond the joint limits of the (replicated) root dofs — the
+    states of tests/test_emu_core.py::_root_limit_states, one control step vs the fp64 oracle (family 10: muscles + self-collisions)."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+
+    def _root_limit_states(env):          # (as in tests/test_emu_core.py)
+        m = env._model
+        tab = env._reset_table()
+        rs = np.random.RandomState(0)
+        rows = tab[rs.randint(0, len(tab), 4)].copy()
+        q, v = rows[:, :m.nv].copy(), rows[:, m.nv:2 * m.nv].copy()
+        q[:, 1] += 1.0                         # pelvis_ty: in the air
+        q[0, 3], v[0, 3] = 1.62, 0.5           # pelvis_tilt beyond its upper limit, still moving out
+        q[1, 5], v[1, 5] = -1.60, -1.0         # pelvis_rotation beyond its lower limit
+        q[2, 3], v[2, 3] = -1.60, -2.0         # pelvis_tilt, the other side
+        q[3, 3], q[3, 5] = -1.65, 1.63         # two at once
+        return q, v, rs.uniform(-1, 1, (4, len(env._action_indices)))
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidMuscle.run", debug=True)
+    m = env._model
+    oracle = Oracle(pack_model(m))
+    q0, v0, acts = _root_limit_states(env)
+    b = HipBatch(HipModel(env._chain_model()), len(q0))
+    b.set_state(q0, v0)
+    b.step(acts)
+    q1, v1 = b.get_state()
+    eq = ev = 0.0
+    for i in range(len(q0)):
+        qo, vo, _, _ = _oracle_step(env, oracle, q0[i].astype(np.float32).astype(np.float64), v0[i].astype(np.float32).astype(np.float64), acts[i], np.zeros(m.na))
+        eq, ev = max(eq, np.abs(q1[i] - qo).max()), max(ev, np.abs(v1[i] - vo).max())
+    print("root-dof limit rows on the device: qpos %.2e qvel %.2e; tilt velocity %.3f -> %.3f" % (eq, ev, v0[0, 3], v1[0, 3]))
+    assert eq < QTOL and ev < VTOL and v1[0, 3] < -0.3
