@@ -48,7 +48,7 @@ def parity_sample(env, hm, table, random_policy, n=64):
     """Second half of the metric: qpos / qvel L-infinity of the device against the fp64 oracle port after one control step
     from n dataset states under the workload's policy (checker only, outside the timed region)."""
     from loco_mujoco_amd.backend import HipBatch
-    from loco_mujoco_amd.model_blob import pack_model
+    from oracle.model_blob import pack_model
     from oracle.pyoracle import Oracle
     m = env._model
     nv, na = m.nv, getattr(m, "na", 0)
@@ -124,7 +124,7 @@ def cpu_baseline_all_cores(task, random_policy, make_kw, budget_s=8.0):
 
 def cpu_baseline(env, table, task, random_policy, budget_s=12.0, seed=0):
     """fp64 oracle restatement, one thread, same policy and initial-state distribution; bounded sample."""
-    from loco_mujoco_amd.model_blob import pack_model
+    from oracle.model_blob import pack_model
     from oracle.pyoracle import Oracle
     m = env._model
     oracle = Oracle(pack_model(m))

@@ -67,7 +67,8 @@ typedef struct {
   double kernel_ms;        /* HIP-event time of the step kernels of this call (rollout only) */
   double self_proximity;   /* forward passes x geom pairs WITHOUT a collider (a box / cylinder against another geom of the robot)
                               within the contact margin: the state was outside the validated collision domain */
-  double self_contacts;    /* self-contacts (sphere / capsule pairs, convex pairs of two links) simulated, summed over the forward passes */
+  double self_contacts;    /* self-contacts simulated (sphere / capsule pairs in closed form, the engine's native box / cylinder colliders,
+                              convex pairs of two links through MPR), summed over the forward passes */
   double replayed_env_steps; /* env-steps that left the regular kernel's capacity (contact slots, pair lists, convex collider) and were
                               run by the family's replay kernel instead (lm_batch_set_replay); part of env_steps */
 } lm_stats;

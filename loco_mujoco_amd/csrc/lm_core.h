@@ -983,9 +983,10 @@ LM_DEV void segment_closest(V3 p1, V3 d1, float h1, V3 p2, V3 d2, float h2, floa
 // One support call site: the phases of the algorithm are a small state machine around it. Both shapes are inflated by
 // margin / 2 along the search direction; result: normal from geom 1 to geom 2, contact point (relative to O) midway between the
 // two witness points, distance = margin - depth. The support search of a hull climbs its vertex graph (adjacency blocks).
-// OUT OF LINE on the device (LM_DEV_COLD = noinline): float64 arithmetic, a private portal array and ~100 live values of its own —
-// inlined into the step kernel they cost every launch 500 B of scratch per lane (the quadruped's bench rollout, which never
-// calls it, ran 17 % slower); as a function the kernel's own registers are saved once around the rare call.
+// INLINED into the step kernel (LM_DEV_COLD = forceinline, lm_step.h): float64 arithmetic, a private portal array and ~100 live values
+// of its own cost every kernel that contains it 500-1000 B of scratch per lane — but as a real function (noinline: -1.5 % on the
+// quadruped's bench rollout) kernels that CALL it at the register ceiling came out wrong under one build setting or another
+// (profiles/r3_notes.md §4; -DLM_MPR_CALL reproduces it).
 struct MprOut { float nx, ny, nz, px, py, pz, dist; int found; };
 #ifdef LM_TIMERS
 #define LM_MPR_COUNT(i, n) (mc[i] += (n))

@@ -61,7 +61,7 @@ struct lm_batch {
   // the replay kernel's pollers run beside the regular launch on `stream2`, forked from / joined into the launch stream with the two
   // events; `h_hint` (pinned) receives the number of abandoned control steps of a completed launch: how many pollers the next one gets
   int stat_pre_off, nstat; int* h_hint; int hint, hint_seen; int epoch;
-  hipStream_t stream2; hipEvent_t ev_fork, ev_join;
+  hipStream_t stream2; hipEvent_t ev_fork, ev_join, ev_done[2];
   float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
@@ -143,6 +143,10 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
     if (want > 0) {
       KArgs p = r;
       p.drain = 0; p.stats_off = b->stat_pre_off;
+      // not further ahead than one launch: the pollers start once the launch BEFORE the previous one is complete (they are then resident
+      // while the previous launch tails off and wait for its drain pass on the device). Without this a host that queues hundreds of
+      // launches ahead of the device would start them long before their launch: they would wait out their time-out and leave
+      if (b->epoch >= 2 && hipStreamWaitEvent(b->stream2, b->ev_done[b->epoch & 1], 0) != hipSuccess) { g_launch_err = "stream wait failed"; return; }
       const LaunchCtx L2 = {b->stream2, b->N, want};
       if (!table[fam][0](L2, p, big) && !table[fam][1](L2, p, big) && !table[fam][2](L2, p, big)) { g_launch_err = "no replay kernel in the family"; return; }
       if (hipEventRecord(b->ev_join, b->stream2) != hipSuccess) { g_launch_err = "stream join failed"; return; }
@@ -157,6 +161,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
     r.drain = 1; r.stats_off = 0;
     const LaunchCtx L3 = {b->stream, b->N, lmk::kReplayGrid};
     if (!table[fam][0](L3, r, big) && !table[fam][1](L3, r, big) && !table[fam][2](L3, r, big)) { g_launch_err = "no replay kernel in the family"; return; }
+    if (hipEventRecord(b->ev_done[b->epoch & 1], b->stream) != hipSuccess) { g_launch_err = "event record failed"; return; }
     b->epoch++;
   }
 }
@@ -358,6 +363,7 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks)));
   HIPCHK(hipStreamCreate(&b->stream)); HIPCHK(hipStreamCreate(&b->stream2));
   HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&b->ev_done[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_done[1], hipEventDisableTiming));
   HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); HIPCHK(hipEventCreateWithFlags(&b->ev_ext, hipEventDisableTiming));
   return 0;
 }
@@ -431,6 +437,8 @@ void lm_batch_destroy(lm_batch* b) {
   if (b->ev_ext) (void)hipEventDestroy(b->ev_ext);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+  if (b->ev_done[0]) (void)hipEventDestroy(b->ev_done[0]);
+  if (b->ev_done[1]) (void)hipEventDestroy(b->ev_done[1]);
   if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
   if (b->h_hint) (void)hipHostFree(b->h_hint);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -858,6 +866,7 @@ int lm_get_stats(lm_batch* b, lm_stats* out, int reset) {
   return 0;
 }
 
+#ifdef LM_TIMERS      // (the shipped library exports nothing that include/locohip.h does not declare: tests/test_abi_exports.py)
 /* profiling builds (-DLM_TIMERS): cycles spent per solver region, summed over workgroups (not part of the ABI header) */
 int lm_debug_timers(lm_batch* b, unsigned long long* out16) {
   HIPCHK(hipSetDevice(b->m->device));
@@ -894,6 +903,8 @@ int lm_debug_mpr_counters(lm_batch* b, unsigned long long* out8 /* 16 values */)
   HIPCHK(hipMemset(b->timers + 16 + 32 * (size_t)b->nblocks, 0, sizeof(unsigned long long) * 16));
   return 0;
 }
+
+#endif
 
 int lm_sync(lm_batch* b) {
   HIPCHK(hipSetDevice(b->m->device));

@@ -9,10 +9,10 @@ configuration of BASELINE config 3: box feet (``base_humanoid.py:435-470``), arm
 The skeleton's bones are collidable MESH geoms in the reference model. Their convex hulls collide with the floor on the device
 (plane vs hull: a contact at the support vertex and up to three at its hull-graph neighbours, the rules found on the UnitreeH1 golden
 rows); bone against
-bone is the engine's convex-convex path (libccd), which is not restated: such pairs are counted by the oracle when their hulls
-come within the contact margin (``unhandled_pairs``). The box feet — the only geoms that touch the floor while the model is
-upright — are simulated; the reference's golden rollouts of this environment (tests/test_datasets/HumanoidTorque.*.npy) are
-reproduced to 1e-13 up to the first bone-against-bone contact.
+bone is the engine's convex-convex path (libccd's MPR), restated in the oracle and on the device (692 hull pairs); one foot box on the
+other is the engine's native box-box collider, restated too. The reference's golden rollouts of this environment
+(tests/test_datasets/HumanoidTorque.*.npy) are reproduced row by row, the ten rows of HumanoidTorque.walk with bone-on-bone contacts
+included.
 """
 
 import os

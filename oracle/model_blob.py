@@ -1,5 +1,5 @@
 """
-Pack a :class:`loco_mujoco_amd.mjcf.CompiledModel` into the flat float64 "general model" array
+TEST INFRASTRUCTURE (lives with the oracle, not in the product package). Pack a :class:`loco_mujoco_amd.mjcf.CompiledModel` into the flat float64 "general model" array
 (``include/lm_model_blob.h``) that the fp64 test oracle consumes. The product path uses
 ``loco_mujoco_amd.lowering.lower`` instead.
 """

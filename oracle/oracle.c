@@ -19,9 +19,11 @@
  * (affine actuators with a force range), plane vs convex mesh (one contact at the hull's support vertex), mass and
  * inertia of bodies defined by their geoms (in loco_mujoco_amd/mjcf.py).
  * Pinned / unpinned: every golden file of UnitreeA1 (.simple, .hard rows), Atlas (.walk, .carry), Talos (.walk, .carry),
- * HumanoidTorque / HumanoidMuscle (+ the 4Ages variants) is reproduced row by row except rows with convex-convex (bone
- * mesh) contacts, which the proximity counter flags; plane-mesh is pinned on the UnitreeH1 rows without hull-hull contact.
- * UNPINNED (no golden row exercises them): sphere/capsule self-collisions, plane-cylinder, position servos, the muscle
+ * HumanoidTorque / HumanoidMuscle (+ the 4Ages variants) is reproduced row by row, the rows with convex-convex (bone mesh)
+ * contacts through the restated general convex collider (MPR, below), the box-on-box rows of the 4Ages "all" file through the
+ * restated native box collider; plane-mesh is pinned on the UnitreeH1 rows without hull-hull contact; 26 UnitreeH1 rows with a
+ * cylinder-cap-on-hull MPR contact are ill-conditioned in float64 and reproduced by nothing (tests/test_oracle_golden.py).
+ * UNPINNED (no golden row exercises them): sphere/capsule self-collisions, sphere-box / sphere-cylinder / capsule-box, plane-cylinder, position servos, the muscle
  * curve beyond lmax, the reward values, per-environment joint parameters, foot-force observations.
  *
  * Deliberately simple and dense (O(nbody*nv^2) mass matrix from body Jacobians, dense Cholesky):

@@ -7,7 +7,7 @@ Never imported by the product.
 
 import numpy as np
 
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 
 

@@ -19,6 +19,10 @@ def test_library_exports_all_declared_symbols():
         assert hasattr(lib, name), name
     from loco_mujoco_amd import backend
     assert set(backend.EXPORTS) == declared
+    # ... and nothing of its own beyond them (the lm_debug_* entry points of the profiling builds exist under -DLM_TIMERS only)
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "loco_mujoco_amd", "csrc", "liblocohip.so")], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (lm_[a-z_0-9]+)$", syms, flags=re.M))
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_shipped_library_reads_no_environment_variable():

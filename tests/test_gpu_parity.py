@@ -15,7 +15,7 @@ import pytest
 
 import loco_mujoco_amd
 from loco_mujoco_amd import LocoEnv, lowering
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 
 pytestmark = pytest.mark.gpu

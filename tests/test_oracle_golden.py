@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from loco_mujoco_amd import LocoEnv, mjcf
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 from oracle_backend import attach
 

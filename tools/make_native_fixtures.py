@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from loco_mujoco_amd import LocoEnv, mjcf
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 
 NAMES = {mjcf.GEOM_SPHERE: "sphere", mjcf.GEOM_CAPSULE: "capsule", mjcf.GEOM_CYLINDER: "cylinder", mjcf.GEOM_BOX: "box", mjcf.GEOM_MESH: "mesh"}

@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from loco_mujoco_amd import LocoEnv, lowering            # noqa: E402
-from loco_mujoco_amd.model_blob import pack_model        # noqa: E402
+from oracle.model_blob import pack_model        # noqa: E402
 from oracle.pyoracle import Oracle                       # noqa: E402
 
 

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from loco_mujoco_amd import LocoEnv
 from loco_mujoco_amd.backend import HipBatch, HipModel
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 np.random.seed(0)
 env = LocoEnv.make("Talos.walk", debug=True); m = env._model

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from loco_mujoco_amd import LocoEnv
 from loco_mujoco_amd.backend import HipBatch, HipModel
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 
 task, mode = sys.argv[1], sys.argv[2]

@@ -1,7 +1,7 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 from loco_mujoco_amd import LocoEnv
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 y = "/tmp/dr.yaml"

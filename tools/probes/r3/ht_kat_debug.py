@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT)
 from loco_mujoco_amd import LocoEnv
 from loco_mujoco_amd.backend import HipBatch, HipModel
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 task = sys.argv[1] if len(sys.argv) > 1 else "HumanoidTorque.run"
 np.random.seed(0)

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from loco_mujoco_amd import LocoEnv
 from loco_mujoco_amd.backend import HipBatch, HipModel
-from loco_mujoco_amd.model_blob import pack_model
+from oracle.model_blob import pack_model
 from oracle.pyoracle import Oracle
 
 def rollout(task, n=4096, steps=60, warm=30, kw={}, random_a1=False):

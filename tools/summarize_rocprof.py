@@ -30,7 +30,12 @@ with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w", newline="") as 
 # replay kernel (launched behind every step, empty most of the time: lm_step.h) are summarised separately
 rows_k = db.execute("select name, count(*) c, sum(duration) d from kernels where name like '%step_kernel%' group by name").fetchall()
 cmax = max(r[1] for r in rows_k)
-names = [r[0] for r in sorted(rows_k, key=lambda r: (r[1] * 2 < cmax, -r[2]))]
+def is_replay(name):          # step_kernel<MC, NS, ...>: the replay kernels are the instantiations with NS > 8 (128 slots per chain)
+    try:
+        return int(name.split("step_kernel<")[1].split(",")[1]) > 8
+    except Exception:
+        return False
+names = [r[0] for r in sorted(rows_k, key=lambda r: (is_replay(r[0]), r[1] * 2 < cmax, -r[2]))]
 kname = names[0]
 def kernel_row(name):
     return db.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, min(duration), "
