@@ -13,11 +13,13 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
 #define LM_A1_NS 6
 #endif
 #ifndef LM_A1_PAIRS
-// 1: the pair pass with the convex collider inlined. 2 (without it: a control step that brings a box / cylinder pair within reach is
-// abandoned and replayed by the family's replay kernel, lm_step.h) was measured in round 4: the regular kernel's scratch falls from
-// 608 to 44 bytes per lane, the bench rollout stays where it is (1.575 vs 1.585 ms, same box: what the pair pass costs is the
-// detection, not the collider), and under a random policy two environments per launch wait for their replay. Kept as a switch.
-#define LM_A1_PAIRS 1
+// 2: the pair pass WITHOUT the inlined convex collider in the regular kernels: a control step that brings a box / cylinder pair within
+// reach is abandoned and run by the family's replay kernel (lm_step.h). Measured at the end of round 4, same box, two runs each
+// (tools/probes/r4/ab_a1_variants.sh): 1.558 ms per control step of the bench rollout against 1.629 ms with the collider inlined (1):
+// -4.4 % — the native box / cylinder colliders had taken the kernel's scratch from 608 to 896 bytes per lane. The bench rollout
+// abandons no control step, a random policy two environments per launch (taken over by the pollers beside the launch). Other
+// variants of the same A/B: max-ILP scheduler +3.0 %, iterative-minreg +9.0 %, -O2 +2.0 %, five slots +1.0 %.
+#define LM_A1_PAIRS 2
 #endif
   return launch_family<3, LM_A1_NS, false, LM_CONE_ELLIPTIC, 0, LM_PART, LM_A1_PAIRS>(L, a, kind);
 #elif LM_FAMILY == 1    // humanoid, RK4, one box foot per leg (HumanoidTorque)

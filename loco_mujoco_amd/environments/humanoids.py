@@ -49,8 +49,12 @@ class BaseHumanoid(LocoEnv):
     def __init__(self, use_muscles=False, use_box_feet=True, disable_arms=True, alpha_box_feet=0.5, xml_path=None,
                  timestep=0.001, **kwargs):
         if not use_box_feet or not disable_arms:
-            raise NotImplementedError("only the default humanoid configuration (box feet, arms disabled) is built: "
-                                      "mesh feet need a convex-hull collider (SURVEY.md §8f)")
+            # use_box_feet=False keeps the subtalar / mtp joints (seven-joint legs) AND their joint equality constraints
+            # (humanoid_torque.xml `<equality>`: *_constraint), disable_arms=False adds two seven-joint arms that branch off the torso
+            # behind the three lumbar joints, with wrist equality constraints: chains of seven links, equality rows and a branch behind a
+            # three-dof chain are not built
+            raise NotImplementedError("only the default humanoid configuration (box feet, arms disabled) is built: mesh feet / free arms "
+                                      "need seven-link chains, joint equality constraints and a branch behind the lumbar chain")
         self._use_muscles, self._use_box_feet, self._disable_arms = use_muscles, use_box_feet, disable_arms
         joints_to_remove, motors_to_remove, equ_constr_to_remove, collision_groups = self._get_xml_modifications()
         drop = ["q_" + j for j in joints_to_remove] + ["dq_" + j for j in joints_to_remove]

@@ -30,7 +30,7 @@ from . import mjcf
 MAXC = 6          # links per chain the table has room for (5 for every robot but UnitreeG1's legs)
 NCHAIN = 4
 NROOT = 6
-MAXG = 40         # floor-collidable geoms per chain (with / without a device collider, each)
+MAXG = 68         # floor-collidable geoms per chain (with / without a device collider, each); the humanoid's trunk chain with its welded arms has 65 (every hand bone)
 MAXRG = 80        # geoms welded to the root (no device collider: proximity is counted)
 
 # ---- per-dof parameter block (used for root dofs and chain links)

@@ -336,8 +336,8 @@ static int emu_dispatch(const double* chain_model, int n, double* qpos, double* 
   }
   if ((int)chain_model[LM_H_NMUSCLE] > 0)
     return (act && big && !rk4 && few) ? emu_run_t<5, N4, false, LM_MAXMUS>(EMU_ARGS, act, leave, only) : -1;
-  // the quadruped (LM_A1_PAIRS = 1 in lm_family.hip: the convex collider in the regular kernels too)
-  if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, N6, false, 0, 1>(EMU_ARGS, nullptr, leave, only);
+  // the quadruped (LM_A1_PAIRS = 2 in lm_family.hip: the regular kernels leave the convex collider to the replay kernel)
+  if (!big && !rk4 && (int)chain_model[LM_H_CONE] == LM_CONE_ELLIPTIC) return emu_run_t<3, N6, false, 0, BIGK ? 1 : 2>(EMU_ARGS, nullptr, leave, only);
   if (!big && !rk4) return emu_run_t<3, 5, false>(EMU_ARGS, nullptr, BIGK ? nullptr : leave, only);          // (generic family: no replay kernel)
   if (!big && rk4) return emu_run_t<3, 4, true>(EMU_ARGS, nullptr, BIGK ? nullptr : leave, only);
   if (!rk4 && few) return emu_run_t<5, N4, false>(EMU_ARGS, nullptr, leave, only);
