@@ -2858,9 +2858,16 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   float fl_aref_r[6], fl_aref_c[MC];     // friction-loss reference accelerations
   float lim_s_c[MC], lim_D_c[MC], lim_aref_c[MC];   // active limit: sign (+1 lower, -1 upper, 0 none)
   // limit rows of the ROOT dofs (replicated in the four lanes, counted once like the root's friction-loss rows): compiled into the
-  // muscle families and the run-time-cone kernels — HumanoidMuscle's pelvis joints are `limited` (humanoid_muscle.xml), no other
-  // robot of the path has a limited root joint, and six more rows' state in every kernel's Newton loop is not free
-  constexpr bool ROOT_LIM = NM > 0 || CONE < 0;
+  // REPLAY kernels of the muscle families and the run-time-cone kernels — HumanoidMuscle's pelvis joints are `limited`
+  // (humanoid_muscle.xml), no other robot of the path has a limited root joint, and the regular kernels sit at the register ceiling:
+  // six more rows' state stays out of their Newton loop. The regular muscle kernels only LOOK: a root dof
+  // beyond its limit hands the control step to the replay kernel (lm_step.h), from the untouched state — the rows would have been
+  // inactive in every pass before that one, so the replay follows the same trajectory up to it
+  constexpr bool ROOT_LIM = (NM > 0 && NS > 8) || CONE < 0;
+  if constexpr (NM > 0 && !ROOT_LIM) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) if (RD(i, LM_D_LIMITED) != 0.0f && (qr[i] < RD(i, LM_D_LO) || qr[i] > RD(i, LM_D_HI))) cnt.need_full = 1;
+  }
   constexpr int NRL = ROOT_LIM ? 6 : 1;
   float lim_s_r[NRL], lim_D_r[NRL], lim_aref_r[NRL];
 #pragma unroll
