@@ -105,7 +105,9 @@ int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup);
    contact slots per chain; a control step that needs more is abandoned unstored and run by the family's replay kernel (a slot for
    every contact, long pair lists, the convex collider): as a few polling workgroups beside the regular launch (second stream; only
    when recent launches abandoned steps) and as a pass behind it. enabled = 1 (default); 0 = regular kernels only: contacts beyond
-   the slots are dropped and counted in overflow_contacts (A/B measurements); 2 = every control step through the replay kernel
+   the slots are dropped and counted in overflow_contacts, and what the regular kernels leave to the replay kernel altogether (the
+   quadruped's convex pairs and capsule-box pairs, root-joint limits of the muscle humanoid) is not simulated: flag bit 2 and
+   self_proximity say when (A/B measurements); 2 = every control step through the replay kernel
    (tests); 3 / 4 = 1 / 2 without the pollers (for profilers that run one kernel at a time: pollers would wait out their 0.5 s). */
 int lm_batch_set_replay(lm_batch* b, int enabled);
 /* one byte per environment: 1 = the replay kernel ran at least one control step of this environment since the marks were last

@@ -439,8 +439,14 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 
   // ---- validity flags of this control step: where the device left its collision model (tests and statistics)
+  bool need_unsim = false;
   {
-    const float f_over = QuadDpp::sum((float)cnt.overflow), f_prox = QuadDpp::sum((float)cnt.selfprox), f_unh = QuadDpp::sum((float)cnt.unhandled);
+    // (with the replay switched off — lm_batch_set_replay(b, 0), an A/B mode — what the regular kernel leaves to the replay kernel is not
+    // simulated at all: a convex pair of the quadruped within reach, a root dof of the muscle humanoid beyond its limit. Flagged and
+    // counted like a pair without a collider)
+    const float f_need = (!REPLAY && !a.replay_list && QuadDpp::env_ballot(cnt.need_full > 0) != 0u) ? 1.0f : 0.0f;      // (any replica may have seen it)
+    const float f_over = QuadDpp::sum((float)cnt.overflow), f_prox = QuadDpp::sum((float)cnt.selfprox) + f_need, f_unh = QuadDpp::sum((float)cnt.unhandled);
+    need_unsim = f_need > 0.0f;
     if (a.flags && c == 0 && valid) a.flags[e] = (unsigned char)((f_over > 0.0f ? 1 : 0) | (f_prox > 0.0f ? 2 : 0) | (f_unh > 0.0f ? 4 : 0));
   }
 
@@ -580,10 +586,12 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
         atomicAdd(&blk_stats[3], nonfinite ? 1.0f : 0.0f); atomicAdd(&blk_stats[4], (float)cnt.solver_iters);
         atomicAdd(&blk_stats[7], (float)cnt.ls_evals); atomicAdd(&blk_stats[8], (float)cnt.ls_capped);
         atomicAdd(&blk_stats[9], cnt.it_max >= 8 ? 1.0f : 0.0f);
+        if (need_unsim) atomicAdd(&blk_stats[10], 1.0f);
       }
       if (cnt.overflow) atomicAdd(&blk_stats[5], (float)cnt.overflow);
       if (cnt.unhandled) atomicAdd(&blk_stats[6], (float)cnt.unhandled);
       if (PAIRS && cnt.selfprox) atomicAdd(&blk_stats[10], (float)cnt.selfprox);
+
       if (PAIRS && cnt.selfcon) atomicAdd(&blk_stats[11], (float)cnt.selfcon);
       if (REPLAY && c == 0) { atomicAdd(&blk_stats[12], 1.0f); if (a.replay_mark) a.replay_mark[e] = 1; }
     }

@@ -2166,3 +2166,10 @@ def test_root_dof_limit_rows_on_the_device():
         eq, ev = max(eq, np.abs(q1[i] - qo).max()), max(ev, np.abs(v1[i] - vo).max())
     print("root-dof limit rows on the device: qpos %.2e qvel %.2e; tilt velocity %.3f -> %.3f" % (eq, ev, v0[0, 3], v1[0, 3]))
     assert eq < QTOL and ev < VTOL and v1[0, 3] < -0.3
+    assert (b.flags() == 0).all() and b.stats()["replayed_env_steps"] == len(q0)       # the rows live in the replay kernel
+    # the replay switched off (an A/B mode): the regular muscle kernels have no root limit rows — the step says so (flag bit 2)
+    b0 = HipBatch(HipModel(env._chain_model()), len(q0))
+    b0.set_replay(0)
+    b0.set_state(q0, v0)
+    b0.step(acts)
+    assert ((b0.flags() & 2) != 0).all() and b0.stats()["self_proximity"] >= len(q0)
