@@ -761,3 +761,26 @@ def test_model_rule_randomisation_with_several_models(tmp_path):
         assert changed == [0, 1] and list(b._pending_variants[b._model_envs(i)]) == [0, 1]
     # the four sizes differ in their inertial numbers: so do their pools
     assert not np.array_equal(b._variant_pools[0]["tables"][2][0], b._variant_pools[3]["tables"][2][0])
+
+
+def test_lowering_keeps_every_collider_and_builds_the_six_link_pair_tables():
+    """Round 4: no floor-collidable geom is demoted to a proximity sphere any more (MAXG covers the humanoid's trunk chain with its 65
+    geoms — the hand and finger bones used to be counted only), and the six-link robots get their self-collision tables: link-pair
+    lists of up to 128 entries per lane that stay out of the workgroup's LDS copy of the constant table (H_CM_USED ends before them)."""
+    from loco_mujoco_amd import lowering
+    np.random.seed(0)
+    for task, kw in (("HumanoidTorque.run", {}), ("HumanoidMuscle.walk", {}), ("HumanoidTorque4Ages.walk.1", {}), ("UnitreeA1.simple", {}),
+                     ("Atlas.walk", {}), ("Talos.walk", {}), ("UnitreeH1.run", {}), ("UnitreeG1.walk", {}), ("UnitreeH1.walk", dict(disable_arms=False))):
+        env = LocoEnv.make(task, debug=True, **kw)
+        cmod, info = lowering.lower(env._model, env._device_task())
+        assert not info.get("demoted_geoms"), (task, info.get("demoted_geoms"))
+        assert int(cmod[lowering.H_CM_USED]) * 4 <= 13 * 1024          # the constant table of every robot fits its LDS share
+        if info["max_links"] == 6:
+            t = info["self_collision_tables"]
+            assert t["convex"] > 100 and max(t["link_pairs"]) <= lowering.MAXLP and int(cmod[lowering.H_NGPAIR]) == t["closed_form"] + t["native"] + t["convex"]
+            assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_LPAIR])
+        elif info.get("self_collision_tables"):
+            assert max(info["self_collision_tables"]["link_pairs"]) <= 64 and int(cmod[lowering.H_CM_USED]) > int(cmod[lowering.H_OFF_LPAIR])
+    # five-link humanoids without muscles run in the eight-slot families (a fifth contact on a leg must not abandon the control step)
+    talos = LocoEnv.make("Talos.walk", debug=True)
+    assert lowering.lower(talos._model, talos._device_task())[1]["max_contacts"] == 8
