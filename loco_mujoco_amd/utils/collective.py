@@ -201,6 +201,15 @@ class Collective:
     def barrier(self):
         self.all_reduce(np.zeros(1))
 
+    def comm_count(self):
+        """Ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); None when the reduction does not run on RCCL."""
+        if self._comm is None:
+            return None
+        n = C.c_int(0)
+        self._nccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._check(self._nccl.ncclCommCount(self._comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
+
     def close(self):
         if self._comm is not None:
             self._nccl.ncclCommDestroy.argtypes = [C.c_void_p]

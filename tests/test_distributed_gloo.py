@@ -123,7 +123,28 @@ def test_require_rccl_fails_loudly_without_gpus(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=300)
-    assert out.returncode != 0 and "RAISED RCCL was required" in out.stdout + out.stderr
+    # (the two ranks' prints interleave on the shared pipe: match the message, not the prefix before it)
+    assert out.returncode != 0 and "RCCL was required" in out.stdout + out.stderr
+
+
+def test_bench_gpus_flag_makes_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher starts two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+    127.0.0.1) and reports n_gpus = 2 (`--plumbing-only`: ranks, rendezvous and the reduction, no GPU work); under a launcher whose
+    WORLD_SIZE disagrees with --gpus it refuses; and on a node without a GPU per rank it fails loudly instead of reporting one rank."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-only"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_counted"] == 2 and res["rank_sum"] == 1.0
+    out = subprocess.run([sys.executable, bench, "--gpus", "4", "--plumbing-only"], capture_output=True, text=True, timeout=300,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
 
 
 @pytest.mark.gpu
@@ -144,6 +165,7 @@ def test_rccl_binding_single_rank_communicator_on_the_gpu():
     c._init_rccl(uid)
     v = np.array([1.5, -2.0, 800.0, 0.25])
     assert np.array_equal(c._reduce_rccl(v, SUM), v) and np.array_equal(c._reduce_rccl(v, MAX), v)
+    assert c.comm_count() == 1                       # what bench.py reports as config.ranks_seen_by_rccl
     c.close()
     assert c._comm is None
 

@@ -1293,18 +1293,21 @@ def _worker_oracle_steps(args):
     return out
 
 
-# measured in round 4 (gpurun_out/r4b): comparable 4096 / 4096 / 4034 / 3953 / 4096 / 4091 / 4096 / 4096 / 3821, failing 0 / 0 / 0 / 1 / 0 / 0 / 0 / 1 / 0
-_R4_4096_CASES = [("UnitreeA1.simple", {}, "zero", 12, 1.0, 0.0), ("UnitreeA1.simple", {}, "random", 12, 0.99, 0.0005),
-                  ("HumanoidTorque.run", {}, "random", 12, 0.97, 0.001), ("HumanoidTorque.run", {}, "random", 3, 0.95, 0.001),
-                  ("Atlas.walk", {}, "random", 12, 0.99, 0.0005), ("HumanoidMuscle.run", {}, "random", 12, 0.99, 0.0005),
-                  ("Talos.walk", {}, "random", 12, 0.99, 0.0005), ("UnitreeH1.walk", {}, "random", 3, 0.99, 0.001),
-                  ("UnitreeG1.walk", {}, "random", 3, 0.97, 0.001)]        # (round 4: the six-link family simulates its self-collisions — no 'no_device_pairs' branch any more)
+# (task, kwargs, policy, control steps of the roll-in, max_fail, max_illcond). Measured in round 4, over 4096 states:
+# failing 0 / 0 / 1 / 1 / 0 / 1 / 0 / 4 / 0, ill-conditioned 0 / 0 / 1 / 0 / 0 / 1 / 1 / 324 / 14.
+#   max_fail: states beyond the tolerance although comparable and the oracle stable under one-ulp input noise — an EXACT upper bound
+#             (0 where none was measured: there the maximum over every comparable, well-conditioned state is asserted <= tolerance);
+#   max_illcond: states beyond the tolerance whose fp64 oracle itself jumps under one-ulp input noise — the measured count plus a small
+#             margin, so that the excused class cannot grow silently (a kernel defect confined to near-switching contacts would show here).
+_R5_4096_CASES = [("UnitreeA1.simple", {}, "zero", 12, 0, 0), ("UnitreeA1.simple", {}, "random", 12, 0, 0),
+                  ("HumanoidTorque.run", {}, "random", 12, 1, 3), ("HumanoidTorque.run", {}, "random", 3, 1, 2),
+                  ("Atlas.walk", {}, "random", 12, 0, 0), ("HumanoidMuscle.run", {}, "random", 12, 1, 3),
+                  ("Talos.walk", {}, "random", 12, 0, 3), ("UnitreeH1.walk", {}, "random", 3, 4, 360),
+                  ("UnitreeG1.walk", {}, "random", 3, 0, 20)]
 
 
-# min_ok: comparable states (the oracle has a collider for every pair in reach) / 4096; max_fail: states beyond the tolerance that the
-# STRICT conditioning rule does not explain, as a fraction of 4096 (the number DESIGN.md §2 quotes per configuration)
-@pytest.mark.parametrize("task,kw,policy,nroll,min_ok,max_fail", _R4_4096_CASES)
-def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, min_ok, max_fail):
+@pytest.mark.parametrize("task,kw,policy,nroll,max_fail,max_illcond", _R5_4096_CASES)
+def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nroll, max_fail, max_illcond):
     """the error distribution over 4096 REACHABLE states per configuration. The states come from a device
     rollout (dataset states, then `nroll` control steps under the configuration's policy, no restarts: walking, stumbling and
     collapsing robots, self-contacts of the quadruped), then ONE control step with a fresh action on the device and in the
@@ -1315,7 +1318,8 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
     state beyond the tolerance, 1.2e-7 relative = one float32 ulp; round 3 probed up to 3e-6 and also excused a state whose oracle
     moved by half of the device's error — both gone). No state is left out for a dropped contact any more: the replay kernel
     (lm_step.h) runs what the regular kernels cannot hold, `overflow_contacts` must be 0. What is still beyond the tolerance after
-    (i) and (ii) is counted as FAILING and bounded per configuration by `max_fail` — a number, quoted in DESIGN.md.
+    (i) and (ii) is counted as FAILING and bounded per configuration by `max_fail` — a COUNT (0 for most configurations: then the
+    maximum over every comparable, well-conditioned state is asserted); the ill-conditioned class (ii) is bounded by `max_illcond`.
     Knife edge: a contact or a joint limit that switches on within a hair of a substep boundary — the engine's contact damping acts at full strength from the first pass in which dist < margin,
     so a foot arriving at 2 m/s gains or loses ~0.05 m/s with the pass in which it is first seen, in float64 as in float32. The humanoid's bone meshes, the box feet against them and UnitreeH1's cylinders and link meshes collide through the engine's convex collider (MPR) on both sides now; what the oracle still only counts is box against box (one foot on the other)."""
     from multiprocessing.pool import ThreadPool
@@ -1400,11 +1404,21 @@ def test_4096_reachable_states_one_control_step_vs_oracle(task, kw, policy, nrol
         np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r3_outliers", "%s_%s_%d.npz" % (task, policy, nroll)),
                  q0=q0[worst], v0=v0[worst], act=actions[worst], q1=q1[worst], v1=v1[worst], qo=np.array([res[i][0] for i in worst]), vo=np.array([res[i][1] for i in worst]),
                  eq=eq[worst], ev=ev[worst], flags=flags[worst], depth=depth[worst])
-    assert (~unhandled).sum() >= min_ok * n and failing.sum() <= max_fail * n, (int((~unhandled).sum()), int(failing.sum()))
+    # THE GATES. Every state is comparable (`unhandled` is asserted empty above for every robot with device pair tables); the excused
+    # class (ill-conditioned) and the failing class are both bounded by counts per configuration
+    comparable = ~unhandled & ~illcond
+    assert unhandled.sum() == 0 or no_device_pairs, int(unhandled.sum())
+    assert illcond.sum() <= max_illcond, ("ill-conditioned states", int(illcond.sum()), max_illcond)
+    assert failing.sum() <= max_fail, ("failing states", int(failing.sum()), max_fail, float(eq[comparable].max()), float(ev[comparable].max()))
+    if max_fail == 0:
+        # evaluated BEFORE anything beyond the tolerance is set aside: the maximum over every comparable, well-conditioned state
+        assert eq[comparable].max() <= QTOL and ev[comparable].max() <= VTOL, (float(eq[comparable].max()), float(ev[comparable].max()))
+    else:
+        # the few failing states are not wildly off either (a defect would be O(1))
+        assert eq[comparable].max() <= 100 * QTOL and ev[comparable].max() <= 100 * VTOL, (float(eq[comparable].max()), float(ev[comparable].max()))
     # the device says when it leaves its collision model, and not more often than the oracle finds a pair without a collider
     prox = (flags & 2) != 0
     assert no_device_pairs or (prox.sum() <= 1.1 * unhandled.sum() + 8 and (unhandled.sum() < 20 or (prox & unhandled).sum() >= 0.9 * unhandled.sum()))
-    assert eq[ok].max() <= QTOL and ev[ok].max() <= VTOL
 
 
 def test_bench_two_ranks_on_one_gpu_shard_invariance(tmp_path):
@@ -1446,18 +1460,46 @@ def test_bench_line_rates_are_their_own_legs():
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--sustained", "200", "--no-cpu-baseline"],
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--sustained", "200", "--no-cpu-baseline", "--configs", "off"],
                          capture_output=True, text=True, timeout=500, cwd=root)
     assert run.returncode == 0, run.stderr[-3000:]
     line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
     n = line["config"]["global_envs"]
     assert n == 4096 and line["steps"] == 20 and line["warmup"] == 5
-    for leg in (line, line["rollout_fused"], line["sustained"]):
+    for leg in (line, line["rollout_fused"], line["sustained"], line["burst"]):
         assert abs(leg["value"] * leg["ms_per_step"] * 1e-3 / n - 1.0) < 1e-9, leg
-    assert line["sustained"]["steps"] == 200
+    # `value` IS the sustained block (200 per-step launches) when the driver's --steps is shorter: the conservative headline; the
+    # 20-step block is reported as `burst`
+    assert line["sustained"]["steps"] == 200 and line["timed_steps"] == 200 and line["burst"]["steps"] == 20
+    assert line["value"] == line["sustained"]["value"] and line["ms_per_step"] == line["sustained"]["ms_per_step"]
     # per-step launches in both: the sustained block cannot be much faster than the 20-step block of the same state mixture
-    assert 0.5 * line["value"] < line["sustained"]["value"] < 1.5 * line["value"]
+    assert 0.5 * line["burst"]["value"] < line["value"] < 1.5 * line["burst"]["value"]
+    assert abs(line["roofline"]["kernel_ms_per_launch"] - line["ms_per_step"]) < 0.1 * line["ms_per_step"]
     assert line["stats"]["overflow_contacts"] == 0 and line["stats"]["nan_resets"] == 0
+    assert line["config"]["ranks_seen_by_rccl"] is None                     # one rank: no communicator
+
+
+def test_bench_line_carries_the_other_baseline_configs():
+    """The default command line (one rank, UnitreeA1.simple, 4096) also runs short legs of BASELINE configs 3-5 — HumanoidTorque.run 4096,
+    Atlas.walk with back joints + joint-damping randomisation 2048, HumanoidMuscle.run 2048 — under `configs`, each with its own kernel
+    time, roofline, parity sample against the fp64 oracle and the replay kernel's share; nothing dropped anywhere."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--sustained", "0", "--fuse", "0",
+                          "--no-cpu-baseline", "--config-steps", "10", "--config-warmup", "5"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert sorted(line["configs"]) == ["Atlas.walk.dr", "HumanoidMuscle.run", "HumanoidTorque.run"]
+    for key, envs, cfg_no, bytes_per in (("HumanoidTorque.run", 4096, 3, 660), ("Atlas.walk.dr", 2048, 4, 660), ("HumanoidMuscle.run", 2048, 5, 1712)):
+        c = line["configs"][key]
+        assert "error" not in c, c
+        assert c["envs"] == envs and c["baseline_config"] == cfg_no and c["steps"] == 10
+        assert abs(c["value"] * c["ms_per_step"] * 1e-3 / envs - 1.0) < 1e-9
+        assert 0.0 < c["kernel_ms"] <= c["ms_per_step"] * 1.02
+        assert c["roofline"]["algorithmic_bytes_per_env_step"] == bytes_per and c["roofline"]["algorithmic_bytes_per_launch"] == bytes_per * envs
+        assert c["parity"]["within_tolerance"] and c["parity"]["states"] >= 56
+        assert c["stats"]["overflow_contacts"] == 0 and c["stats"]["nan_resets"] == 0 and c["stats"]["replayed_env_steps"] >= 0
 
 
 @pytest.mark.parametrize("task", ["run", "walk"])
