@@ -234,7 +234,7 @@ def make_env(task, dr):
 class Workload:
     """One task on this rank's GPU: environment, model, batch with the bench's initial states and device-side restarts."""
 
-    def __init__(self, task, n, dr, rank, world, device, no_pollers=False):
+    def __init__(self, task, n, dr, rank, world, device, no_pollers=False, handoff=None):
         from loco_mujoco_amd.backend import HipBatch, HipModel
         self.task, self.n, self.dr, self.world = task, n, dr, world
         self.default_task = task == "UnitreeA1.simple"
@@ -245,6 +245,8 @@ class Workload:
         self.b = b = HipBatch(self.hm, n)
         if no_pollers:
             b.set_replay(3)
+        if handoff is not None:
+            b.set_handoff(*handoff)
         self.offset = offset = rank * n
         self.nv = nv = env._model.nv
         rs = np.random.RandomState(0)
@@ -456,6 +458,8 @@ def main():
                     "`value` is ITS rate (the conservative one) and the --steps block is reported as `burst`")
     ap.add_argument("--no-pollers", action="store_true", help="profiling runs (rocprofv3 runs one kernel at a time): the replay kernel only as the "
                     "pass behind the regular launch, no polling workgroups beside it (lm_batch_set_replay(3))")
+    ap.add_argument("--handoff", default=None, help="slots,queue,iters: thresholds of the hand-off of hard control steps to the replay kernel "
+                    "(lm_batch_set_handoff; 0 = off, -1 = the family's default) — tuning runs")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="short legs of the other BASELINE configs "
                     "(HumanoidTorque.run, Atlas.walk --dr 2048, HumanoidMuscle.run 2048) under the `configs` key; auto = one rank, default task")
@@ -504,7 +508,8 @@ def main():
     ranks_rccl = coll.comm_count()
 
     n = args.envs_per_gpu
-    W = Workload(args.task, n, args.dr, rank, world, local_rank, no_pollers=args.no_pollers)
+    handoff = tuple(int(x) for x in args.handoff.split(",")) if args.handoff else None
+    W = Workload(args.task, n, args.dr, rank, world, local_rank, no_pollers=args.no_pollers, handoff=handoff)
     b, env = W.b, W.env
 
     b.rollout(args.warmup, action_mode=W.action_mode, seed=11)

@@ -156,6 +156,11 @@ struct Params {
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
   const float* cmg;   // the constant table in GLOBAL memory: the six-link kernels read their link-pair lists from there (they do not fit
                       // beside the lane memory in the workgroup's LDS share: lowering.py ends H_CM_USED before them)
+  // hand-off of HARD control steps (lm_step.h): a regular kernel whose environment holds more than `hard_slots` contact slots in a
+  // chain, queues more than `hard_queue` convex / native pairs for a chain, or needs more than `hard_iters` Newton iterations in one
+  // forward pass sets Counters::hard — the control step goes to the family's replay kernel, which gives the environment a whole wave
+  // (sixteen replicas instead of four). 0 = that criterion is off. The results do not depend on the route beyond float32 rounding.
+  int hard_slots, hard_queue, hard_iters;
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
@@ -164,6 +169,7 @@ struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int l
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
   int need_full;     // a convex pair came within reach in a kernel compiled WITHOUT the convex collider (PM == 2): the control step is
                      // abandoned and replayed by the full kernel (lm_step.h)
+  int hard;          // the control step is one of the batch's hardest (Params::hard_*): handed to the replay kernel when there is one
   int peak_slots, peak_q, peak_res;   // largest number of contact slots / queued convex pairs / pair results of this lane's chain in a pass (the
                      // replay kernel decides with them whether the environment fits the regular kernel again, lm_step.h)
   float grf[4][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's foot-force groups (2; 4 in the six-link kernels)
@@ -2131,10 +2137,14 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       auto set_bases = [&](const int* n) { base[0] = 0; for (int cs = 0; cs < 4; cs++) base[cs + 1] = base[cs] + n[cs]; };
       auto chain_of = [&](int g) -> int { return (g >= base[1] ? 1 : 0) + (g >= base[2] ? 1 : 0) + (g >= base[3] ? 1 : 0); };
       // bits [lo, hi) of a ballot: the lanes that work on chain cs's units in this round
-      auto chain_bits = [&](int cs, int round) -> unsigned {
+      using mask_t = typename Q::mask_t;                              // one bit per lane of the environment (kW <= 16: 32 bits; the whole wave: 64)
+      constexpr int kMaskBits = 8 * (int)sizeof(mask_t);
+      auto mbelow = [&](int i) -> mask_t { return (i >= kMaskBits) ? ~(mask_t)0 : (((mask_t)1 << i) - (mask_t)1); };      // bits [0, i)
+      auto mcount = [&](mask_t m) -> int { return (sizeof(mask_t) == 8) ? __builtin_popcountll((unsigned long long)m) : __builtin_popcount((unsigned)m); };
+      auto chain_bits = [&](int cs, int round) -> mask_t {
         int lo = base[cs] - round * kW, hi = base[cs + 1] - round * kW;
         lo = (lo < 0) ? 0 : lo; hi = (hi > kW) ? kW : hi;
-        return (hi > lo) ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+        return (hi > lo) ? (mbelow(hi) & ~mbelow(lo)) : (mask_t)0;
       };
       auto share4 = [&](int x, int* out) {
 #pragma unroll
@@ -2270,9 +2280,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 }
               }
               const bool found = mo.found != 0;
-              const unsigned fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
+              const mask_t fm = Q::env_ballot(found);          // (also the point between this round's reads of the queue and its writes)
               if (found) {
-                const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + __builtin_popcount(fm & chain_bits(cs, round) & ((1u << me) - 1u));
+                const int k = ((stage == 0) ? kept[cs] : nres_of[cs] + kept[cs]) + mcount(fm & chain_bits(cs, round) & mbelow(me));
                 if (stage == 0) Q::peer_write(lmem, ls, kQItem + k, cs - c, raw);       // survivor: compacted in place (k <= t)
                 else if (DETECT_ONLY) cnt.need_full = 1;      // a contact: the replay kernel's business
                 else if (k < kRcap) {
@@ -2283,7 +2293,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 }
               }
 #pragma unroll
-              for (int c2 = 0; c2 < 4; c2++) kept[c2] += __builtin_popcount(fm & chain_bits(c2, round));
+              for (int c2 = 0; c2 < 4; c2++) kept[c2] += mcount(fm & chain_bits(c2, round));
               Q::fence(); Q::quad_sync();
               if (!Q::any(stage == 1 && g < T && kind == 1 && sub + 1 < ncon_item)) break;
             }
@@ -2420,12 +2430,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (Q::kRep > 1) {
         reach_all = 0ull; reach_all2 = 0ull;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < Q::kRep; r++) {
           unsigned m_ = (unsigned)Q::rep_bcast((float)((unsigned)reach_r & 0xffffu), r);
           if (kWide) m_ |= (unsigned)Q::rep_bcast((float)(((unsigned)reach_r >> 16) & 0xffffu), r) << 16;      // entries 64 .. 127: bits 16 .. 31 of a replica's mask
 #pragma nounroll
           while (m_) {
-            const int b_ = __builtin_ctz(m_), e_ = 4 * b_ + r;
+            const int b_ = __builtin_ctz(m_), e_ = Q::kRep * b_ + r;
             if (kWide && e_ >= 64) reach_all2 |= 1ull << (e_ - 64); else reach_all |= 1ull << e_;
             m_ &= m_ - 1u;
           }
@@ -2491,13 +2501,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               if (bgap < 0.0f) { hitb = true; s0 = (float)(i * 32 + jb + 4096 * (int)br[LM_BP_N]); s1 = br[LM_BP_FIRST]; }
               else { gap_note(cs, bgap); if (E.kb != 7 && !E.same_lane) gap_note(E.lb, bgap); }
             }
-            const unsigned sm = Q::env_ballot(hitb);
+            const mask_t sm = Q::env_ballot(hitb);
             if (hitb) {
-              const int k = ns_of[cs] + __builtin_popcount(sm & chain_bits(cs, round) & ((1u << me) - 1u));
+              const int k = ns_of[cs] + mcount(sm & chain_bits(cs, round) & mbelow(me));
               Q::peer_write(lmem, ls, kS1 + 2 * k, cs - c, s0); Q::peer_write(lmem, ls, kS1 + 2 * k + 1, cs - c, s1);
             }
 #pragma unroll
-            for (int c2 = 0; c2 < 4; c2++) ns_of[c2] += __builtin_popcount(sm & chain_bits(c2, round));
+            for (int c2 = 0; c2 < 4; c2++) ns_of[c2] += mcount(sm & chain_bits(c2, round));
           }
         }
         Q::fence(); Q::quad_sync();
@@ -2590,10 +2600,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 }
               }
             }
-            const unsigned rm = Q::env_ballot(has_res), qm = Q::env_ballot(want_q), pm = Q::env_ballot(is_prox);
-            const unsigned below = chain_bits(cs, round) & ((1u << me) - 1u);
+            const mask_t rm = Q::env_ballot(has_res), qm = Q::env_ballot(want_q), pm = Q::env_ballot(is_prox);
+            const mask_t below = chain_bits(cs, round) & mbelow(me);
             if (has_res) {
-              const int k = nres_of[cs] + __builtin_popcount(rm & below);
+              const int k = nres_of[cs] + mcount(rm & below);
               if (k < kRcap) {
                 const int rb_ = kRes + 8 * k, dlw = cs - c;
                 Q::peer_write(lmem, ls, rb_, dlw, code); Q::peer_write(lmem, ls, rb_ + 1, dlw, rdist);
@@ -2602,12 +2612,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               }
             }
             if (want_q) {
-              const int k = nq_of[cs] + __builtin_popcount(qm & below);
+              const int k = nq_of[cs] + mcount(qm & below);
               if (k < kQueue) Q::peer_write(lmem, ls, kQItem + k, cs - c, code);
             }
 #pragma unroll
-            for (int c2 = 0; c2 < 4; c2++) { const unsigned cb_ = chain_bits(c2, round); nres_of[c2] += __builtin_popcount(rm & cb_); nq_of[c2] += __builtin_popcount(qm & cb_); }
-            n_prox += __builtin_popcount(pm);
+            for (int c2 = 0; c2 < 4; c2++) { const mask_t cb_ = chain_bits(c2, round); nres_of[c2] += mcount(rm & cb_); nq_of[c2] += mcount(qm & cb_); }
+            n_prox += mcount(pm);
           }
         }
         Q::fence(); Q::quad_sync();
@@ -2626,6 +2636,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
       if (nres_of[c] > kRcap) n_over += nres_of[c] - kRcap;
       cnt.peak_q = (nq_of[c] > cnt.peak_q) ? nq_of[c] : cnt.peak_q; cnt.peak_res = (nres_of[c] > cnt.peak_res) ? nres_of[c] : cnt.peak_res;
+      if (!LMm::kBig && P.hard_queue > 0 && nq_of[c] > P.hard_queue) cnt.hard = 1;
       // the smallest clearance of any pair of my chain, whichever lane of the environment looked at it
       {
         float gmine = 3.0e38f;
@@ -2633,7 +2644,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
         for (int cs = 0; cs < 4; cs++) {
           float gq = gap_of[cs];
           gq = fminf(fminf(Q::quad_read(gq, 0), Q::quad_read(gq, 1)), fminf(Q::quad_read(gq, 2), Q::quad_read(gq, 3)));
-          if (Q::kRep > 1) gq = fminf(fminf(Q::rep_bcast(gq, 0), Q::rep_bcast(gq, 1)), fminf(Q::rep_bcast(gq, 2), Q::rep_bcast(gq, 3)));
+          if (Q::kRep > 1) {
+            float gm_ = gq;
+#pragma unroll
+            for (int r = 0; r < Q::kRep; r++) gm_ = fminf(gm_, Q::rep_bcast(gq, r));
+            gq = gm_;
+          }
           if (cs == c) gmine = gq;
         }
         gap_min = gmine;
@@ -2645,6 +2661,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
     cnt.ncon += nslot;
     cnt.peak_slots = (nslot > cnt.peak_slots) ? nslot : cnt.peak_slots;
+    if (!LMm::kBig && P.hard_slots > 0 && nslot > P.hard_slots) cnt.hard = 1;
     LM_TICK(0);
     pair_mask_out = pair_mask;
     for (int s2 = 0; s2 < nslot; s2++) { if ((int)SL(s2, SL_LINK) < 0) nrootslot++; if (PAIRS && SL(s2, SL_PART) != 0.0f) npairslot++; }
@@ -2858,13 +2875,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   float fl_aref_r[6], fl_aref_c[MC];     // friction-loss reference accelerations
   float lim_s_c[MC], lim_D_c[MC], lim_aref_c[MC];   // active limit: sign (+1 lower, -1 upper, 0 none)
   // limit rows of the ROOT dofs (replicated in the four lanes, counted once like the root's friction-loss rows): compiled into the
-  // REPLAY kernels of the muscle families and the run-time-cone kernels — HumanoidMuscle's pelvis joints are `limited`
-  // (humanoid_muscle.xml), no other robot of the path has a limited root joint, and the regular kernels sit at the register ceiling:
-  // six more rows' state stays out of their Newton loop. The regular muscle kernels only LOOK: a root dof
-  // beyond its limit hands the control step to the replay kernel (lm_step.h), from the untouched state — the rows would have been
-  // inactive in every pass before that one, so the replay follows the same trajectory up to it
-  constexpr bool ROOT_LIM = (NM > 0 && NS > 8) || CONE < 0;
-  if constexpr (NM > 0 && !ROOT_LIM) {
+  // muscle families (HumanoidMuscle's pelvis joints are `limited`, humanoid_muscle.xml: measured free there), into EVERY family's
+  // replay kernel and into the run-time-cone kernels. The regular kernels of the other families sit at the register ceiling and no
+  // robot of the path needs the rows there (lowering.py keeps a root limit only when it can become active): they only LOOK — a
+  // limited root dof beyond its range hands the control step to the family's replay kernel (lm_step.h), from the untouched state; the
+  // rows would have been inactive in every pass before that one, so the replay follows the same trajectory up to it.
+  constexpr bool ROOT_LIM = NM > 0 || NS > 8 || CONE < 0;
+  if constexpr (!ROOT_LIM) {
 #pragma unroll
     for (int i = 0; i < 6; i++) if (RD(i, LM_D_LIMITED) != 0.0f && (qr[i] < RD(i, LM_D_LO) || qr[i] > RD(i, LM_D_HI))) cnt.need_full = 1;
   }
@@ -3585,7 +3602,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
                   for (int j = 0; j < 4; j++) line(cand[j], cd1[j], cd2[j], cmg[j]);
                 } else {
-                  const int r = Q::rep();
+                  const int r = Q::rep() & 3;       // (sixteen replicas: four groups evaluate the same four points)
                   const float mine = (r == 0) ? cand[0] : ((r == 1) ? cand[1] : ((r == 2) ? cand[2] : cand[3]));
                   float x1, x2, xm;
                   line(mine, x1, x2, xm);
@@ -3702,6 +3719,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
   cnt.solver_iters += (c == 0) ? iters : 0;
+  if (!LMm::kBig && P.hard_iters > 0 && iters > P.hard_iters) cnt.hard = 1;
   if (c == 0 && iters > cnt.it_max) cnt.it_max = iters;
 
   if (dbg) {

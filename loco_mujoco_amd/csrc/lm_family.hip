@@ -1,5 +1,5 @@
 // lm_family.hip — one kernel family (LM_FAMILY) and part (LM_PART) of the step kernels; see lm_step.h.
-// The library links one object per family and part (parts 0..2 of the families 0..5 and 7..10, parts 0..1 of the generic family 6) so that `make -j`
+// The library links one object per family and part (parts 0..2 of the families 0, 2, 4, 5 and 7..10, parts 0..1 of the generic family 6) so that `make -j`
 // builds them in parallel.
 #include "lm_step.h"
 
@@ -22,13 +22,9 @@ bool LM_CAT(launch_f, LM_FAMILY, p, LM_PART)(const LaunchCtx& L, const KArgs& a,
 #define LM_A1_PAIRS 2
 #endif
   return launch_family<3, LM_A1_NS, false, LM_CONE_ELLIPTIC, 0, LM_PART, LM_A1_PAIRS>(L, a, kind);
-#elif LM_FAMILY == 1    // humanoid, RK4, one box foot per leg (HumanoidTorque)
-  return launch_family<5, 4, true, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
-#elif LM_FAMILY == 2    // Atlas: two boxes per foot
+#elif LM_FAMILY == 2    // five-link humanoids, RK4 (Atlas: two boxes per foot)
   return launch_family<5, 8, true, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
-#elif LM_FAMILY == 3    // Talos (Euler)
-  return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
-#elif LM_FAMILY == 4    // Talos carrying a box
+#elif LM_FAMILY == 4    // five-link humanoids, Euler (Talos, the carry tasks)
   return launch_family<5, 8, false, LM_CONE_PYRAMIDAL, 0, LM_PART>(L, a, kind);
 #elif LM_FAMILY == 5    // muscle humanoid
   return launch_family<5, 4, false, LM_CONE_PYRAMIDAL, LM_MAXMUS, LM_PART>(L, a, kind);

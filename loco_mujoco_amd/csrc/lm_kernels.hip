@@ -32,6 +32,7 @@ struct lm_model {
   lm::Params P; Task T;
   int nroot;
   std::vector<int> root_dofs;
+  bool root_limited;         // a root dof with an active-able limit (lm_batch_set_replay)
 };
 
 struct lm_batch {
@@ -63,6 +64,7 @@ struct lm_batch {
   int stat_pre_off, nstat; int* h_hint; int hint, hint_seen; int epoch;
   hipStream_t stream2; hipEvent_t ev_fork, ev_join, ev_done[2];
   float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
+  int hard_slots, hard_queue, hard_iters;      // hand-off of hard control steps to the replay kernel (lm_batch_set_handoff; lm_core.h Params::hard_*)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
@@ -85,23 +87,29 @@ static int family_of(const lm_batch* b) {
   // five-link humanoids whose lowering carries self-collision tables (bone hulls, link meshes, cylinders): the pair families
   if (big && T.npair > 0 && pyr3) return rk4 ? (T.na == 0 ? 8 : 6) : (T.na == 0 ? 9 : 10);
   if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return 0;
-  if (big && rk4 && T.na == 0 && few && pyr3) return 1;
+  // (families 1 / 3 — four contact slots per chain — are gone: since round 4 every five-link humanoid without muscles runs in the
+  // eight-slot families, where a fifth contact on a leg does not abandon the control step)
   if (big && rk4 && T.na == 0 && pyr3) return 2;
-  if (big && !rk4 && T.na == 0 && few && pyr3) return 3;
   if (big && !rk4 && T.na == 0 && pyr3) return 4;
   if (big && !rk4 && T.na > 0 && few && pyr3) return 5;
   return 6;
 }
 
 static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
+// The family's default thresholds of the hand-off of hard control steps (lm_batch_set_handoff). Measured in round 5
+// (profiles/r5_notes.md): 0 = off.
+static void default_handoff(lm_batch* b) {
+  b->hard_slots = 0; b->hard_queue = 0; b->hard_iters = 0;
+  if (const char* v = LM_PROBE_ENV("LM_HANDOFF")) sscanf(v, "%d,%d,%d", &b->hard_slots, &b->hard_queue, &b->hard_iters);   // A/B knob of the probe builds
+}
 static bool family_has_pairs(int fam) { return fam == 0 || fam == 7 || fam == 8 || fam == 9 || fam == 10; }
 
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   static const bool no_replicas = LM_PROBE_ENV("LM_NO_REPLICAS") != nullptr;                  // A/B switch
   static const lmk::family_fn table[lmk::LMK_NFAMILY][3] = {
-      {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {lmk::launch_f1p0, lmk::launch_f1p1, lmk::launch_f1p2},
-      {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {lmk::launch_f3p0, lmk::launch_f3p1, lmk::launch_f3p2},
+      {lmk::launch_f0p0, lmk::launch_f0p1, lmk::launch_f0p2}, {nullptr, nullptr, nullptr},
+      {lmk::launch_f2p0, lmk::launch_f2p1, lmk::launch_f2p2}, {nullptr, nullptr, nullptr},
       {lmk::launch_f4p0, lmk::launch_f4p1, lmk::launch_f4p2}, {lmk::launch_f5p0, lmk::launch_f5p1, lmk::launch_f5p2},
       {lmk::launch_f6p0, lmk::launch_f6p1, lmk::launch_f6p2}, {lmk::launch_f7p0, lmk::launch_f7p1, lmk::launch_f7p2},
       {lmk::launch_f8p0, lmk::launch_f8p1, lmk::launch_f8p2}, {lmk::launch_f9p0, lmk::launch_f9p1, lmk::launch_f9p2},
@@ -195,11 +203,10 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   std::vector<float> cm(LM_CM_SIZE);
   for (int i = 0; i < LM_CM_SIZE; i++) cm[i] = (float)cmod[LM_HEADER_SIZE + i];
   if (LM_PROBE_ENV("LM_NO_PAIRS")) for (int c = 0; c < LM_NCHAIN; c++) cm[LM_CM_CHAINS + LM_C_NLPAIR * LM_NCHAIN + c] = 0.0f;      // A/B: self-collision broad phase off
-  for (int i = 0; i < 6; i++) {
-    const float* blk = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
-    // limit rows on the root dofs are compiled into the muscle families (and the run-time-cone kernels) only: lm_core.h ROOT_LIM
-    if (blk[LM_D_LIMITED] != 0.0f && (int)cmod[LM_H_NMUSCLE] == 0) { return fail("limited root joints are supported for models with muscles only (the muscle kernel families carry the root limit rows)"); }
-  }
+  // (limited root joints: limit rows in the muscle families, the run-time-cone kernels and every family's replay kernel; the other
+  // regular kernels hand a control step with a root dof beyond its range to the replay kernel — lm_core.h ROOT_LIM)
+  m->root_limited = false;
+  for (int i = 0; i < 6; i++) if (cm[LM_R_DOFS + i * LM_D_SIZE + LM_D_LIMITED] != 0.0f) m->root_limited = true;
   HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
   HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));
   {
@@ -307,6 +314,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     P.meshadj = m->d_meshadj;
   }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.hard_slots = P.hard_queue = P.hard_iters = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = LM_PROBE_ENV("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   if (const char* v = LM_PROBE_ENV("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
@@ -385,6 +393,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
   b->replay = 1;
+  default_handoff(b);
   {
     // a model with self-collision tables needs a kernel family with the pair pass: anything else would silently not simulate them
     const int fam = family_of(b);
@@ -398,6 +407,15 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   return 0;
 }
 
+/* hand-off of hard control steps (include/locohip.h): thresholds per batch; negative = the family's default */
+int lm_batch_set_handoff(lm_batch* b, int slots, int queue, int iters) {
+  if (!b) return fail("null batch");
+  lm_batch d = *b;
+  default_handoff(&d);
+  b->hard_slots = slots >= 0 ? slots : d.hard_slots; b->hard_queue = queue >= 0 ? queue : d.hard_queue; b->hard_iters = iters >= 0 ? iters : d.hard_iters;
+  return 0;
+}
+
 /* speculate / replay (lm_step.h): on (default) = a control step that needs more contact slots, longer pair lists or — the
    quadruped — the convex collider is replayed by the family's big kernel instead of dropping contacts; off = the regular kernels
    alone (contacts beyond the slots are dropped and counted: the behaviour of rounds 1-3, kept for A/B measurements). */
@@ -405,6 +423,11 @@ int lm_batch_set_replay(lm_batch* b, int enabled) {
   if (!b) return fail("null batch");
   // 2 (tests): every control step goes through the replay kernel; 3 / 4 = 1 / 2 without pollers: the replay kernel only as the pass
   // behind the regular launch (profilers that run one kernel at a time would leave the pollers waiting for their time-out)
+  if (!enabled && b->m->T.na == 0 && family_of(b) >= 0 && family_of(b) != 6) {
+    // the regular kernels of the families without muscles have no limit rows for the root dofs: without the replay kernel a root dof
+    // beyond its range would run without its row (flagged per step, but wrong physics) — refuse rather than offer that
+    if (b->m->root_limited) return fail("this model has a limited root joint whose limit rows live in the replay kernel: replay cannot be switched off");
+  }
   b->replay = (enabled >= 2 && enabled <= 4) ? enabled : (enabled ? 1 : 0);
   return 0;
 }
@@ -694,6 +717,7 @@ static KArgs make_args(lm_batch* b) {
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
+  a.P.hard_slots = b->hard_slots; a.P.hard_queue = b->hard_queue; a.P.hard_iters = b->hard_iters;
   a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
   // speculate / replay: every family but the generic one has a replay kernel
   if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; a.replay_all = b->replay == 2 || b->replay == 4; }
@@ -851,10 +875,13 @@ int lm_get_flags(lm_batch* b, uint8_t* out) {
 }
 
 int lm_get_replay_marks(lm_batch* b, uint8_t* out, int reset) {
+  if (!b) return fail("null batch");
   HIPCHK(hipSetDevice(b->m->device));
+  // copy and clear ON the library's stream: it is ordered behind every launch (also one on a caller's stream: ev_ext) and behind the
+  // replay kernel's pollers (ev_join), which write the marks
+  if (out) HIPCHK(hipMemcpyAsync(out, b->replay_mark, b->N, hipMemcpyDeviceToHost, b->stream));
+  if (reset) HIPCHK(hipMemsetAsync(b->replay_mark, 0, b->N, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (out) HIPCHK(hipMemcpy(out, b->replay_mark, b->N, hipMemcpyDeviceToHost));
-  if (reset) HIPCHK(hipMemset(b->replay_mark, 0, b->N));
   return 0;
 }
 

@@ -20,6 +20,7 @@
 #include <math.h>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #define LM_DEV __device__ __forceinline__
 // The convex-pair collider is INLINED into the step kernel. As a real function (noinline) it kept its float64 registers and its private
@@ -48,19 +49,27 @@ namespace lmk {
 // the replicas run the same instruction stream and split the four step lengths of a line-search round between them.
 template <int REP>
 struct QuadDppT {
-  static constexpr int kRep = REP, kPoints = (REP == 4) ? 4 : 1;
+  static constexpr int kRep = REP, kPoints = (REP >= 4) ? 4 : 1;
+  // one bit per lane of an environment (bit 4 * replica + chain): 16 lanes with four replicas, the whole wave with sixteen
+  using mask_t = typename std::conditional<(REP > 8), unsigned long long, unsigned>::type;
   static __device__ __forceinline__ int rep() { return (threadIdx.x >> 2) & (REP - 1); }
   static __device__ __forceinline__ float rep_bcast(float x, int r) {
     if (REP == 1) return x;
-    const int src = (int)((__lane_id() & ~12u) | ((unsigned)r << 2));
+    const int src = (int)((__lane_id() & ~(unsigned)(4 * (REP - 1))) | ((unsigned)r << 2));
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x)));
   }
-  // sum over the replicas: butterfly over lane^4 and lane^8, the same association in every replica
+  // sum over the replicas: butterfly over lane^4 and lane^8 (and lane^16, lane^32 with sixteen replicas), the same association in
+  // every replica
   static __device__ __forceinline__ float rep_sum(float x) {
     if (REP == 1) return x;
     const unsigned l = __lane_id();
     float y = x + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 4u) << 2), __float_as_int(x)));
-    return y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 8u) << 2), __float_as_int(y)));
+    y = y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 8u) << 2), __float_as_int(y)));
+    if (REP > 4) {
+      y = y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 16u) << 2), __float_as_int(y)));
+      y = y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 32u) << 2), __float_as_int(y)));
+    }
+    return y;
   }
   static __device__ __forceinline__ float sum(float x) {
     // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
@@ -79,9 +88,10 @@ struct QuadDppT {
   static __device__ __forceinline__ float peer(const LM_LMEM_T* lmem, int ls, int i, int dl) { return lmem[i * ls + dl]; }
   static __device__ __forceinline__ void peer_write(LM_LMEM_T* lmem, int ls, int i, int dl, float v) { lmem[i * ls + dl] = v; }
   // one bit per lane of my environment (bit 4 * replica + chain): the wave's ballot, my environment's part of it
-  static __device__ __forceinline__ unsigned env_ballot(bool b) {
+  static __device__ __forceinline__ mask_t env_ballot(bool b) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(b);
-    return (REP == 4) ? (unsigned)((m >> (__lane_id() & 48u)) & 0xffffull) : (unsigned)((m >> (__lane_id() & 60u)) & 0xfull);
+    if (REP == 16) return (mask_t)m;                     // the wave is ONE environment
+    return (REP == 4) ? (mask_t)((m >> (__lane_id() & 48u)) & 0xffffull) : (mask_t)((m >> (__lane_id() & 60u)) & 0xfull);
   }
   static __device__ __forceinline__ float quad_read(float x, int src) {
     const int lane = (int)((__lane_id() & ~3u) | (unsigned)src);
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   // Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
   for (int s = 0; s < a.T.nsub; s++) {
     if (!REPLAY && a.replay_list && !gone) {
-      const bool leave = (a.replay_all && s == 0) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+      const bool leave = (a.replay_all && s == 0) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
       if (leave) {
         if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // what this wave stored in the launch's earlier control steps
         if (valid && c == 0) {
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- the last substep's verdict (see the loop above)
   if (!REPLAY && a.replay_list && !gone) {
-    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
+    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
     if (leave) {
       if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (valid && c == 0) {
@@ -644,8 +654,9 @@ struct LaunchCtx { hipStream_t stream; int N, epb; };
 // kernel kinds of one family (picked by the host, lm_kernels.hip::launch_variant)
 enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK_FUSED_DR, LMK_DRV_REP4, LMK_DRV_REP1, LMK_FUSED_DRV,
        LMK_BIG, LMK_BIG_DR, LMK_BIG_DRV /* the replay kernels, one per part */, LMK_NKINDS };
-constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 1 humanoid RK4 4 slots, 2 humanoid RK4 8 slots, 3 Euler 4 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots),
+constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 2 humanoid RK4 8 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots), (1 / 3: the four-slot humanoid families, dropped in round 5)
                                     // 8 / 9 / 10 = five-link humanoids WITH self-collisions (8 slots): RK4 | Euler | Euler + muscles
+constexpr int kReplayRep = 16;      // replicas of the replay kernels' ONE environment per workgroup (a full wave)
 constexpr int kReplayGrid = 64;     // workgroups of the replay kernel's drain pass (each walks the list with this stride), and the most pollers
 
 template <class K>
@@ -675,7 +686,9 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
     // L.epb carries the number of workgroups asked for here (pollers: a few; the drain pass: kReplayGrid). The statistics slots are
     // one per workgroup of the REGULAR launch (+ kReplayGrid for the pollers): not more workgroups than that
     const int ngroups = (int)((L.N + a.epb - 1) / a.epb), want = L.epb;
-    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, 4, true, PMB>, dim3(ngroups < want ? ngroups : want), dim3(16), (size_t)LMb::kPadded * 4, L, b);
+    // SIXTEEN replicas: the whole wave for one environment (contact slots, geoms, hull vertices, muscles and the pair pass's work
+    // lists dealt to 64 lanes instead of 16) — the environments that come here are the batch's hardest, and the launch ends with them
+    launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, kReplayRep, true, PMB>, dim3(ngroups < want ? ngroups : want), dim3(4 * kReplayRep), (size_t)LMb::kPadded * 4, L, b);
     return true;
   }
   if constexpr (PART == 0) {
@@ -704,9 +717,7 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
 // defined in the lm_family.hip objects; false = this family/part has no kernel of that kind
 typedef bool (*family_fn)(const LaunchCtx&, const KArgs&, int kind);
 bool launch_f0p0(const LaunchCtx&, const KArgs&, int); bool launch_f0p1(const LaunchCtx&, const KArgs&, int); bool launch_f0p2(const LaunchCtx&, const KArgs&, int);
-bool launch_f1p0(const LaunchCtx&, const KArgs&, int); bool launch_f1p1(const LaunchCtx&, const KArgs&, int); bool launch_f1p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f2p0(const LaunchCtx&, const KArgs&, int); bool launch_f2p1(const LaunchCtx&, const KArgs&, int); bool launch_f2p2(const LaunchCtx&, const KArgs&, int);
-bool launch_f3p0(const LaunchCtx&, const KArgs&, int); bool launch_f3p1(const LaunchCtx&, const KArgs&, int); bool launch_f3p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f4p0(const LaunchCtx&, const KArgs&, int); bool launch_f4p1(const LaunchCtx&, const KArgs&, int); bool launch_f4p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f5p0(const LaunchCtx&, const KArgs&, int); bool launch_f5p1(const LaunchCtx&, const KArgs&, int); bool launch_f5p2(const LaunchCtx&, const KArgs&, int);
 bool launch_f6p0(const LaunchCtx&, const KArgs&, int); bool launch_f6p1(const LaunchCtx&, const KArgs&, int); bool launch_f6p2(const LaunchCtx&, const KArgs&, int);

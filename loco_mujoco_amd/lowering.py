@@ -355,16 +355,15 @@ def lower(m, task):
         if limited and is_root and getattr(m, "na", 0) > 0:
             pass        # the muscle families carry limit rows for the root dofs (csrc/lm_core.h ROOT_LIM): HumanoidMuscle's pelvis joints
         elif limited and is_root:
-            # the other families have no limit rows for the (replicated) root dofs. A root limit that cannot become active is
-            # dropped: translation ranges of tens of metres, or angles whose termination band (evaluated every
-            # control step) lies strictly inside the joint range.
+            # the regular kernels of the other families have no limit rows for the (replicated) root dofs: a root dof beyond its range
+            # hands the control step to the family's replay kernel, which has them (csrc/lm_core.h ROOT_LIM). A root limit that cannot
+            # become active is dropped, so that the robots of the path never take that detour: translation ranges of tens of metres, or
+            # angles whose termination band (evaluated every control step) lies strictly inside the joint range.
             lo, hi = m.jnt_range[d]
             tlo, thi = term_q.get(int(d), (-np.inf, np.inf))
             if (m.jnt_type[d] == 0 and min(-lo, hi) >= 50.0) or (tlo > lo and thi < hi):
                 limited = False
                 dropped_root_limits.append(int(d))
-            else:
-                raise UnsupportedModel("root joint %s has a reachable limit" % m.jnt_names[d])
         block[D_LIMITED] = limited
         block[D_LO], block[D_HI] = m.jnt_range[d]
         if limited:

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdint>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #define LM_DEV inline
 #define LM_OPAQUE_ZERO() 0
@@ -36,7 +37,8 @@ constexpr int kThreads = 4 * EMU_REP;
 std::barrier<> g_bar(kThreads);      // everybody: any(), fence(), start / end of an environment
 // the device's cross-lane operations have different participants: a quad sum joins the 4 chain lanes of ONE replica, the
 // replica operations join the EMU_REP replicas of ONE chain lane (lanes with fewer geoms / links skip them altogether)
-std::barrier<> g_bar_rep[4] = {std::barrier<>(4), std::barrier<>(4), std::barrier<>(4), std::barrier<>(4)};
+struct QuadBarrier { std::barrier<> b{4}; void arrive_and_wait() { b.arrive_and_wait(); } };
+QuadBarrier g_bar_rep[EMU_REP];      // one per replica (quad)
 std::barrier<> g_bar_lane[4] = {std::barrier<>(EMU_REP), std::barrier<>(EMU_REP), std::barrier<>(EMU_REP), std::barrier<>(EMU_REP)};
 float g_buf[EMU_REP][4], g_rbuf[EMU_REP][4];
 int g_ibuf[kThreads];
@@ -44,11 +46,12 @@ float* g_lmem[EMU_REP][4];          // private lane memory of (replica, chain)
 std::vector<float> g_snap[4];       // per chain: lane memory as of the last fence
 int g_lmem_size = 0, g_conflicts = 0;
 thread_local int t_lane = 0, t_rep = 0;
-int g_ops[16][5];                   // per thread: calls of sum, any, rep_bcast, rep_sum, fence (EMU_WATCHDOG diagnostics)
+int g_ops[64][5];                   // per thread: calls of sum, any, rep_bcast, rep_sum, fence (EMU_WATCHDOG diagnostics)
 #define OPC(k) (g_ops[t_rep * 4 + t_lane][k]++)
 template <int POINTS, int REP>
 struct QuadThreadsT {
-  static constexpr int kRep = REP, kPoints = (REP == 4) ? 4 : POINTS;
+  static constexpr int kRep = REP, kPoints = (REP >= 4) ? 4 : POINTS;
+  using mask_t = std::conditional_t<(REP > 8), unsigned long long, unsigned>;       // one bit per thread of the environment (lm_step.h QuadDppT)
   static int rep() { return t_rep; }
   static float rep_bcast(float x, int r) {
     if (REP == 1) return x;
@@ -57,15 +60,17 @@ struct QuadThreadsT {
     float y = g_rbuf[r][t_lane];
     g_bar_lane[t_lane].arrive_and_wait(); return y;
   }
-  static float rep_sum(float x) {       // the device's butterfly: lane^4 then lane^8, i.e. replica^1 then replica^2
+  static float rep_sum(float x) {       // the device's butterfly: lane^4 then lane^8 (^16, ^32 with sixteen replicas), i.e. replica^1, ^2 (^4, ^8)
     if (REP == 1) return x;
     OPC(3);
-    g_rbuf[t_rep][t_lane] = x; g_bar_lane[t_lane].arrive_and_wait();
-    float y = x + g_rbuf[t_rep ^ 1][t_lane];
-    g_bar_lane[t_lane].arrive_and_wait();
-    g_rbuf[t_rep][t_lane] = y; g_bar_lane[t_lane].arrive_and_wait();
-    float z = y + g_rbuf[t_rep ^ 2][t_lane];
-    g_bar_lane[t_lane].arrive_and_wait(); return z;
+    float y = x;
+    for (int bit = 1; bit < REP; bit <<= 1) {
+      g_rbuf[t_rep][t_lane] = y; g_bar_lane[t_lane].arrive_and_wait();
+      const float o = g_rbuf[t_rep ^ bit][t_lane];
+      g_bar_lane[t_lane].arrive_and_wait();
+      y = y + o;
+    }
+    return y;
   }
   static void fence() {
     if (REP == 1) return;
@@ -96,10 +101,10 @@ struct QuadThreadsT {
   static void quad_sync() { g_bar_rep[t_rep].arrive_and_wait(); }
   static float peer(const float* /*lmem*/, int /*ls*/, int i, int dl) { return g_lmem[t_rep][t_lane + dl][i]; }
   static void peer_write(float* /*lmem*/, int /*ls*/, int i, int dl, float v) { g_lmem[t_rep][t_lane + dl][i] = v; }
-  static unsigned env_ballot(bool b) {      // bit 4 * replica + chain of every thread of the environment
+  static mask_t env_ballot(bool b) {      // bit 4 * replica + chain of every thread of the environment
     g_ibuf[t_rep * 4 + t_lane] = b; g_bar.arrive_and_wait();
-    unsigned r = 0;
-    for (int i = 0; i < kThreads; i++) r |= (g_ibuf[i] ? 1u : 0u) << i;
+    mask_t r = 0;
+    for (int i = 0; i < kThreads; i++) r |= (mask_t)(g_ibuf[i] ? 1 : 0) << i;
     g_bar.arrive_and_wait(); return r;
   }
   static float quad_read(float x, int src) {
@@ -160,6 +165,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.hard_slots = P.hard_queue = P.hard_iters = 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];
@@ -266,7 +272,7 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
         lm::substep<QuadThreads, MC, NS, RK4, (PAIRS && MC <= 3) ? 1 : kEmuCone<MC>, NM, kEmuDR, PM>(cm.data(), c, P, qr, vr, qc, vc, war, wac, actr, actc, lmem, 1, cnt,
                                                       (e == debug_env && s == 0 && dbgM && t_rep == 0) ? &dbg : nullptr, mt.data(), &dofp, false, pair_slack);
       QuadThreads::fence();          // like the kernel before it stores: the activations were updated by their owner replicas
-      static int acc[16][9];
+      static int acc[64][9];
       {
         int* A = acc[t_rep * 4 + c];
         A[0] = cnt.solver_iters; A[1] = cnt.overflow; A[2] = cnt.unhandled; A[3] = cnt.ncon; A[4] = cnt.ls_evals; A[5] = cnt.ls_capped; A[6] = cnt.selfprox; A[7] = cnt.selfcon;

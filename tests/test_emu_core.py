@@ -752,3 +752,80 @@ def test_core_root_dof_limit_rows():
             qo, vo, _, _, _ = o.step_act(q[i], v[i], np.zeros(m.na), ctrl, 10)
             assert np.abs(qe[i] - qo).max() < 1e-5 and np.abs(ve[i] - vo).max() < 1e-3, (rep, i)
         assert ve[0, 3] < -0.3 and v[0, 3] > 0       # the limit row turned the tilt around
+
+
+def _a1_with_limited_root_tz():
+    """A synthetic quadruped whose root joint trunk_tz is `limited` to [-0.5, -0.18] (the reference's file has it unlimited,
+    unitree_a1_torque.xml:80-85): the dataset states stand at -0.168, i.e. BEYOND the upper limit — the limit row pushes the trunk down.
+    The termination band of trunk_tz (> -0.24) does not lie inside the range, so the lowering must keep the limit."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    m = env._model
+    m.jnt_limited[2] = 1
+    m.jnt_range[2] = (-0.5, -0.18)
+    cmod, info = lowering.lower(m, env._device_task())
+    assert info["dropped_root_limits"] == [] and cmod[lowering.HEADER_SIZE + lowering.R_DOFS + 2 * lowering.D_SIZE + lowering.D_LIMITED] == 1.0
+    tab = env._reset_table()
+    rs = np.random.RandomState(1)
+    rows = tab[rs.randint(0, len(tab), 4)].copy()
+    q, v = rows[:, :m.nv].copy(), rows[:, m.nv:2 * m.nv].copy()
+    q[3, 2] = -0.21                      # one state INSIDE the range: no row, no hand-over
+    return env, m, cmod, q, v, rs.uniform(-0.3, 0.3, (4, 12))
+
+
+def test_core_root_limit_rows_in_every_family_through_the_replay_instantiation():
+    """a limited root joint is accepted for EVERY kernel family. The regular instantiations of the families without
+    muscles only look (lm_core.h ROOT_LIM): a root dof beyond its range hands the control step to the replay instantiation, which
+    carries the limit rows — device code vs the fp64 oracle compiled from the same model, regular + replay like the library."""
+    env, m, cmod, q, v, acts = _a1_with_limited_root_tz()
+    o = Oracle(pack_model(m))
+    qe, ve, _, cnt, _ = pyemu.run(cmod, q, v, acts, nsub=10, rep=4)
+    assert cnt["replayed"] == 3 and cnt["overflow"] == 0, cnt          # the three states beyond the limit; the fourth stays in the regular instantiation
+    for i in range(4):
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        qo, vo, _, _ = o.step(q[i], v[i], ctrl, 10)
+        # (the fourth state was pushed 4 cm into the floor to get inside the range: stiff contacts, the stated tolerance)
+        tq, tv = (1e-5, 1e-3) if i < 3 else (1e-4, 1e-2)
+        assert np.abs(qe[i] - qo).max() < tq and np.abs(ve[i] - vo).max() < tv, (i, np.abs(qe[i] - qo).max(), np.abs(ve[i] - vo).max())
+    # the row acts: without it (the unlimited model) the trunk ends higher
+    np.random.seed(0)
+    env0 = LocoEnv.make("UnitreeA1.simple", debug=True)
+    q0, _, _, cnt0, _ = pyemu.run(env0._chain_model(), q, v, acts, nsub=10, rep=4)
+    assert cnt0["replayed"] == 0 and (qe[:3, 2] < q0[:3, 2] - 2e-4).all() and abs(qe[3, 2] - q0[3, 2]) < 1e-6
+
+
+def test_core_wide_replay_instantiation_sixteen_replicas():
+    """Round 5: the replay kernels run ONE environment per wave on SIXTEEN replicas (lm_step.h kReplayRep; 64 emulator threads here):
+    contact slots, floor geoms, hull vertices and the work lists of the pair pass are dealt to 64 lanes, ballots are 64 bits wide,
+    replica sums are four-stage butterflies. Tangled quadrupeds (more self-contacts than the regular kernel's slots) and humanoid states
+    with box / hull pairs in contact, every control step through the big instantiation: within the stated tolerance of the fp64 oracle,
+    within rounding of the four-replica run of the same instantiation, and no lane-memory word written differently by two replicas."""
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True)
+    m, cmod = env._model, env._chain_model()
+    o = Oracle(pack_model(m))
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_tangled_states.npz"))
+    for i in range(len(d["q"])):
+        q0, v0, a = d["q"][i].astype(np.float64), d["v"][i].astype(np.float64), d["a"][i]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        qo, vo = o.step(q0, v0, ctrl, 10)[:2]
+        q4, v4, _, c4, _ = pyemu.run(cmod, q0, v0, a, nsub=10, rep=4, replay=2)
+        q16, v16, _, c16, _ = pyemu.run(cmod, q0, v0, a, nsub=10, rep=16, replay=2)
+        assert c16["overflow"] == 0 and c16["ncon"] == c4["ncon"] and c16["selfcon"] == c4["selfcon"], (c4, c16)
+        assert np.abs(q16[0] - qo).max() < 1e-4 and np.abs(v16[0] - vo).max() < 1e-2
+        assert np.abs(q16 - q4).max() < 2e-5 and np.abs(v16 - v4).max() < 2e-3
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque.run", debug=True)
+    m, cmod = env._model, env._chain_model()
+    o = Oracle(pack_model(m))
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "native_pair_states.npz"))
+    for i in (9, 18):
+        q0, v0, a = d["ht_q"][i], d["ht_v"][i], d["ht_a"][i]
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(a)
+        qo, vo, _, st = o.step(q0, v0, ctrl, 10)
+        q16, v16, _, c16, _ = pyemu.run(cmod, q0, v0, a, nsub=10, rep=16, replay=2)
+        assert st["convex_contacts"] > 100 and c16["selfcon"] > 100 and c16["overflow"] == 0 and c16["selfprox"] == 0
+        assert np.abs(q16[0] - qo).max() < 1e-4 and np.abs(v16[0] - vo).max() < 1e-2

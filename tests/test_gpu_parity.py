@@ -1937,12 +1937,13 @@ def test_done_byte_bit_layout_and_episode_restarted_key(setup):
 @pytest.mark.parametrize("task,kw", [("UnitreeA1.simple", {}), ("HumanoidTorque.run", {}), ("HumanoidTorque.run", dict(nopairs=True)), ("Atlas.walk", {}),
                                      ("Atlas.walk", dict(dr=True)), ("Talos.walk", {}), ("Talos.carry", {}), ("HumanoidMuscle.run", {}),
                                      ("HumanoidMuscle.run", dict(nopairs=True)), ("UnitreeH1.run", {}), ("UnitreeG1.walk", {}), ("UnitreeH1.walk", dict(arms=True))])
-def test_replay_kernel_is_bitwise_the_regular_kernel(task, kw):
-    """Every family's REPLAY kernel (128 contact slots per chain, long pair lists, one environment per workgroup: lm_step.h) against its
-    regular kernel: 128 dataset states, three control steps under random actions with `set_replay(2)` — every control step abandoned and
-    run by the replay kernel — and with the default. Where no environment needed the replay kernel in the default run, the states
-    must be BITWISE equal: the replay kernel is the same arithmetic with more room (it is compiled from the same source as another
-    template instance; the tests that exceed the regular kernels' capacity only ever see a few of its code paths)."""
+def test_replay_kernel_agrees_with_the_regular_kernel(task, kw):
+    """Every family's REPLAY kernel (128 contact slots per chain, long pair lists, ONE environment per wave on sixteen replicas: lm_step.h)
+    against its regular kernel (four environments per wave on four replicas each): 128 dataset states, three control steps under random
+    actions with `set_replay(2)` — every control step abandoned and run by the replay kernel — and with the default. Same source, another
+    template instance; since round 5 the sums over contact slots are split sixteen ways instead of four, so the two agree within float32
+    rounding (amplified over three control steps of contact dynamics), not bitwise: asserted at a tenth of the stated tolerance for 99 % of
+    the environments that never needed the replay kernel in the default run, and at the stated tolerance for all of them."""
     from loco_mujoco_amd.backend import HipBatch, HipModel
     np.random.seed(0)
     mk = {}
@@ -1981,8 +1982,11 @@ def test_replay_kernel_is_bitwise_the_regular_kernel(task, kw):
     print("%s %s: replay kernel vs regular kernel, %d of %d environments never needed it in the default run: max |dq| %.3g |dv| %.3g"
           % (task, kw, same.sum(), n, np.abs(q1 - q2)[same].max(), np.abs(v1 - v2)[same].max()))
     assert same.sum() >= 0.8 * n
-    assert np.array_equal(q1[same], q2[same]) and np.array_equal(v1[same], v2[same]) and np.array_equal(o1[same], o2[same])
-    assert a1 is None or np.array_equal(a1[same], a2[same])
+    dq, dv = np.abs(q1 - q2)[same].max(axis=1), np.abs(v1 - v2)[same].max(axis=1)
+    print("   p50 |dq| %.3g |dv| %.3g, p99 |dq| %.3g |dv| %.3g" % (np.median(dq), np.median(dv), np.percentile(dq, 99), np.percentile(dv, 99)))
+    assert np.percentile(dq, 99) < 0.1 * QTOL and np.percentile(dv, 99) < 0.1 * VTOL
+    assert dq.max() < QTOL and dv.max() < VTOL and np.abs(o1 - o2)[same].max() < VTOL
+    assert a1 is None or np.abs(a1 - a2)[same].max() < 1e-4
     assert np.isfinite(q2).all() and np.isfinite(v2).all()
 
 
@@ -2208,10 +2212,70 @@ def test_root_dof_limit_rows_on_the_device():
         eq, ev = max(eq, np.abs(q1[i] - qo).max()), max(ev, np.abs(v1[i] - vo).max())
     print("root-dof limit rows on the device: qpos %.2e qvel %.2e; tilt velocity %.3f -> %.3f" % (eq, ev, v0[0, 3], v1[0, 3]))
     assert eq < QTOL and ev < VTOL and v1[0, 3] < -0.3
-    assert (b.flags() == 0).all() and b.stats()["replayed_env_steps"] == len(q0)       # the rows live in the replay kernel
-    # the replay switched off (an A/B mode): the regular muscle kernels have no root limit rows — the step says so (flag bit 2)
+    assert (b.flags() == 0).all() and b.stats()["replayed_env_steps"] == 0       # round 5: the muscle families carry the rows in their regular kernels
+    # ... so the replay switched off (an A/B mode) changes nothing for them
     b0 = HipBatch(HipModel(env._chain_model()), len(q0))
     b0.set_replay(0)
     b0.set_state(q0, v0)
     b0.step(acts)
-    assert ((b0.flags() & 2) != 0).all() and b0.stats()["self_proximity"] >= len(q0)
+    q2, v2 = b0.get_state()
+    assert (b0.flags() == 0).all() and np.array_equal(q1, q2) and np.array_equal(v1, v2)
+
+
+def test_root_dof_limit_rows_of_a_family_without_muscles_on_the_device():
+    """a limited root joint in a family WITHOUT muscles — a synthetic quadruped whose trunk_tz is limited to
+    [-0.5, -0.18] (tests/test_emu_core.py::_a1_with_limited_root_tz). `lm_model_create` accepts it; the regular kernel only looks: the
+    three states beyond the limit are handed to the replay kernel, which carries the rows, the fourth stays; all four match the fp64
+    oracle compiled from the same model. Switching the replay kernel off is refused for such a model (it would drop the rows)."""
+    from loco_mujoco_amd.backend import BackendError, HipBatch, HipModel
+    from test_emu_core import _a1_with_limited_root_tz
+    env, m, cmod, q0, v0, acts = _a1_with_limited_root_tz()
+    oracle = Oracle(pack_model(m))
+    b = HipBatch(HipModel(cmod), len(q0))
+    b.set_state(q0, v0)
+    b.step(acts)
+    q1, v1 = b.get_state()
+    assert (b.flags() == 0).all() and b.stats()["replayed_env_steps"] == 3 and list(b.replay_marks()) == [True, True, True, False]
+    for i in range(len(q0)):
+        qo, vo, _, _ = _oracle_step(env, oracle, q0[i].astype(np.float32).astype(np.float64), v0[i].astype(np.float32).astype(np.float64), acts[i])
+        assert np.abs(q1[i] - qo).max() < QTOL and np.abs(v1[i] - vo).max() < VTOL, (i, np.abs(q1[i] - qo).max(), np.abs(v1[i] - vo).max())
+    with pytest.raises(BackendError, match="limited root joint"):
+        b.set_replay(0)
+
+
+def test_hand_off_of_hard_control_steps_to_the_replay_kernel():
+    """Round 5 (`lm_batch_set_handoff`): a control step whose environment holds many contacts / queues many convex pairs / needs many Newton
+    iterations is handed to the replay kernel, which gives it a whole wave (sixteen replicas) — the launch ends with its hardest
+    environment. HumanoidTorque.run, 512 robots stumbling under the random policy: with thresholds the replay kernel runs many more
+    control steps than with the criteria off, nothing is dropped either way, and the states agree within float32 rounding."""
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    np.random.seed(0)
+    env = LocoEnv.make("HumanoidTorque.run", debug=True)
+    m = env._model
+    hm = HipModel(env._chain_model())
+    tab = env._reset_table()
+    n = 512
+    rs = np.random.RandomState(7)
+    rows = tab[rs.randint(0, len(tab), n)]
+    acts = rs.uniform(-1, 1, (10, n, len(env._action_indices)))
+    out = []
+    for thr in ((0, 0, 0), (5, 6, 6)):
+        b = HipBatch(hm, n)
+        b.set_handoff(*thr)
+        b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+        for a in acts[:9]:
+            b.step(a)
+        q0, v0 = b.get_state()
+        b.stats(reset=True)
+        b.step(acts[9])
+        st = b.stats()
+        out.append((q0, v0) + b.get_state() + (st,))
+    (qa0, va0, qa, va, sa), (qb0, vb0, qb, vb, sb) = out
+    assert sa["overflow_contacts"] == 0 and sb["overflow_contacts"] == 0 and sa["nan_resets"] == 0 and sb["nan_resets"] == 0
+    assert sb["replayed_env_steps"] > sa["replayed_env_steps"] + 10, (sa["replayed_env_steps"], sb["replayed_env_steps"])
+    # the LAST control step from states that agree: one step of rounding-level difference between the two routes
+    close = (np.abs(qa0 - qb0).max(axis=1) < 1e-5) & (np.abs(va0 - vb0).max(axis=1) < 1e-3)
+    dq, dv = np.abs(qa - qb)[close].max(axis=1), np.abs(va - vb)[close].max(axis=1)
+    print("hand-off: replayed %d -> %d control steps of %d; %d environments entered the last step in agreeing states: |dq| p99 %.2e max %.2e, |dv| p99 %.2e max %.2e"
+          % (sa["replayed_env_steps"], sb["replayed_env_steps"], n, close.sum(), np.percentile(dq, 99), dq.max(), np.percentile(dv, 99), dv.max()))
+    assert close.sum() > 0.8 * n and np.percentile(dq, 99) < 0.1 * QTOL and np.percentile(dv, 99) < 0.1 * VTOL and dq.max() < QTOL and dv.max() < VTOL
