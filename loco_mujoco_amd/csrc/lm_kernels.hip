@@ -49,6 +49,7 @@ struct lm_batch {
   int table_rows; unsigned long long seed; long long env_offset; int auto_reset, horizon; unsigned step_index;
   int epb, nblocks;
   unsigned long long* timers;
+  unsigned long long* tline;     // LM_TIMERS builds: time line of the last launch (lm_step.h KArgs::tline)
   hipStream_t stream;
   lm_stats acc;            // host-side accumulation (double)
   hipEvent_t ev0, ev1;
@@ -58,6 +59,8 @@ struct lm_batch {
   // speculate / replay (lm_step.h): list of the environments whose control step left the regular kernel's capacity, its control
   // words, the fused step at which each left; `replay` = 0 switches the mechanism off (contacts beyond the slots are then dropped)
   int *replay_list, *replay_ctl, *stall; int replay;
+  int* premark;                              // prediction (lm_step.h KArgs::premark): environments that start their next control step in the replay kernel
+  float *hq, *hv, *hw; int* hsub;            // resume (lm_step.h KArgs::hq): substep-start states of the control steps that leave the regular kernel
   unsigned char* replay_mark;
   // the replay kernel's pollers run beside the regular launch on `stream2`, forked from / joined into the launch stream with the two
   // events; `h_hint` (pinned) receives the number of abandoned control steps of a completed launch: how many pollers the next one gets
@@ -104,6 +107,12 @@ static void default_handoff(lm_batch* b) {
 }
 static bool family_has_pairs(int fam) { return fam == 0 || fam == 7 || fam == 8 || fam == 9 || fam == 10; }
 
+// (Round 5, tried and dropped: a one-workgroup GATE kernel in front of the regular launch that waits until the launch's pollers are
+// resident, and a higher priority for their stream. Launched first on their own stream the pollers lose the race for the chip in 7
+// launches of 10 and start when the first regular workgroups retire, 4.4 ms into a HumanoidTorque launch; with the gate they are
+// resident at once — and every poller then keeps one regular workgroup waiting for those 4.4 ms instead (the kernels' 512 registers
+// allow one wave per SIMD, and 4096 environments are exactly one wave per SIMD): the step time is the same, 16.0 ms either way.
+// profiles/r5_notes.md §4.)
 template <bool FWD>
 static void launch_variant(lm_batch* b, const KArgs& a) {
   static const bool no_replicas = LM_PROBE_ENV("LM_NO_REPLICAS") != nullptr;                  // A/B switch
@@ -145,9 +154,17 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
     // (a rollout queues hundreds of launches before the first has run: no news = no change; news = the latest count, decaying slowly)
     const int last = b->h_hint[0], seen = b->h_hint[1];
     if (seen != b->hint_seen) { b->hint_seen = seen; b->hint = last > b->hint ? last : (b->hint > 0 ? b->hint - 1 : 0); }
-    int want = a.replay_all ? lmk::kReplayGrid : (b->hint > 0 ? b->hint + 2 : 0);
-    if (want > lmk::kReplayGrid / 2 && !a.replay_all) want = lmk::kReplayGrid / 2;
+    // how many: the abandoned steps of a launch scatter around the recent count like a Poisson variable (HumanoidTorque.run: 12.6 +- 3.5
+    // per launch) — an entry without a poller of its own waits for one to finish a whole hard control step. pollers = kPollMul x
+    // recent count + kPollAdd, at most kPollCap (round 5: profiles/r5_notes.md §4)
+    static int poll_mul = lmk::kPollMul, poll_add = lmk::kPollAdd, poll_cap = lmk::kPollCap;
+    static const bool poll_env = [] { if (const char* v = LM_PROBE_ENV("LM_POLLERS")) sscanf(v, "%d,%d,%d", &poll_mul, &poll_add, &poll_cap); return true; }();
+    (void)poll_env;
+    int want = a.replay_all ? lmk::kReplayGrid : (b->hint > 0 ? (poll_mul * b->hint) / 2 + poll_add : 0);
+    if (want > poll_cap && !a.replay_all) want = poll_cap;
+    if (want > lmk::kReplayGrid) want = lmk::kReplayGrid;
     if (b->replay >= 3) want = 0;
+    if (b->h_hint[2] > 0) want = 0;        // a poller timed out once: they do not overlap with the regular kernel here (serialised kernels) — drain pass only from now on
     if (want > 0) {
       KArgs p = r;
       p.drain = 0; p.stats_off = b->stat_pre_off;
@@ -159,6 +176,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
       if (!table[fam][0](L2, p, big) && !table[fam][1](L2, p, big) && !table[fam][2](L2, p, big)) { g_launch_err = "no replay kernel in the family"; return; }
       if (hipEventRecord(b->ev_join, b->stream2) != hipSuccess) { g_launch_err = "stream join failed"; return; }
       pollers = true;
+
     }
   }
   if (!table[fam][0](L, r, kind) && !table[fam][1](L, r, kind) && !table[fam][2](L, r, kind)) { g_launch_err = "no kernel of this kind in the family"; return; }
@@ -359,16 +377,22 @@ static int batch_alloc(lm_batch* b) {
   if (m->T.na > 0) { HIPCHK(hipMalloc(&b->act, sizeof(float) * m->T.na * N)); HIPCHK(hipMemset(b->act, 0, sizeof(float) * m->T.na * N)); }
   b->stat_pre_off = b->nblocks; b->nstat = b->nblocks + lmk::kReplayGrid;      // the concurrent replay kernel adds into slots of its own
   HIPCHK(hipMalloc(&b->stats, sizeof(DevStats) * b->nstat));
-  HIPCHK(hipHostMalloc((void**)&b->h_hint, sizeof(int) * 2, hipHostMallocDefault)); b->h_hint[0] = 0; b->h_hint[1] = 0;
+  HIPCHK(hipHostMalloc((void**)&b->h_hint, sizeof(int) * 4, hipHostMallocDefault)); b->h_hint[0] = 0; b->h_hint[1] = 0; b->h_hint[2] = 0; b->h_hint[3] = 0;
   HIPCHK(hipMalloc(&b->replay_list, sizeof(int) * N)); HIPCHK(hipMalloc(&b->stall, sizeof(int) * N)); HIPCHK(hipMalloc(&b->replay_ctl, sizeof(int) * 8));
   HIPCHK(hipMemset(b->replay_list, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->stall, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->replay_ctl, 0, sizeof(int) * 8));
   HIPCHK(hipMalloc(&b->replay_mark, N)); HIPCHK(hipMemset(b->replay_mark, 0, N));
+  HIPCHK(hipMalloc(&b->hq, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->hv, sizeof(float) * nv * N)); HIPCHK(hipMalloc(&b->hw, sizeof(float) * nv * N));
+  HIPCHK(hipMalloc(&b->hsub, sizeof(int) * N)); HIPCHK(hipMemset(b->hsub, 0, sizeof(int) * N));
+  HIPCHK(hipMalloc(&b->premark, sizeof(int) * N)); HIPCHK(hipMemset(b->premark, 0, sizeof(int) * N));
   HIPCHK(hipMalloc(&b->slack, sizeof(float) * 12 * N)); HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * N));
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
   HIPCHK(hipMemset(b->stats, 0, sizeof(DevStats) * b->nstat));
   HIPCHK(hipMalloc(&b->timers, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->timers, 0, sizeof(unsigned long long) * (32 + 32 * (size_t)b->nblocks)));
+#ifdef LM_TIMERS
+  HIPCHK(hipMalloc(&b->tline, sizeof(unsigned long long) * (4 * (size_t)N + 2 * (size_t)b->nblocks))); HIPCHK(hipMemset(b->tline, 0, sizeof(unsigned long long) * (4 * (size_t)N + 2 * (size_t)b->nblocks)));
+#endif
   HIPCHK(hipStreamCreate(&b->stream)); HIPCHK(hipStreamCreate(&b->stream2));
   HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&b->ev_done[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_done[1], hipEventDisableTiming));
@@ -452,7 +476,7 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
                   b->vrec, b->vgt, b->vgpt, b->var};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -547,6 +571,7 @@ int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_
     if (!idx.empty()) {
       const int n = (int)idx.size();
       hipLaunchKernelGGL(zero_ints, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->ep_step, b->scr_idx, n);
+      hipLaunchKernelGGL(zero_ints, dim3((n + 255) / 256), dim3(256), 0, b->stream, b->premark, b->scr_idx, n);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(b->stream));
     }
@@ -557,6 +582,7 @@ int lm_set_state(lm_batch* b, const float* qpos, const float* qvel, const uint8_
   if (b->act) HIPCHK(hipMemsetAsync(b->act, 0, sizeof(float) * na * N, b->stream));
   HIPCHK(hipMemsetAsync(b->warm, 0, sizeof(float) * nv * N, b->stream));
   HIPCHK(hipMemsetAsync(b->ep_step, 0, sizeof(int) * N, b->stream));
+  HIPCHK(hipMemsetAsync(b->premark, 0, sizeof(int) * N, b->stream));
   HIPCHK(hipMemsetAsync(b->slack, 0, sizeof(float) * 12 * N, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
@@ -718,9 +744,20 @@ static KArgs make_args(lm_batch* b) {
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
   a.P.hard_slots = b->hard_slots; a.P.hard_queue = b->hard_queue; a.P.hard_iters = b->hard_iters;
-  a.epb = b->epb; a.timers = b->timers; a.nfused = 1;
+  a.epb = b->epb; a.timers = b->timers; a.tline = b->tline; a.nfused = 1;
   // speculate / replay: every family but the generic one has a replay kernel
-  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark; a.replay_all = b->replay == 2 || b->replay == 4; }
+  if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark;
+    static const bool no_resume = LM_PROBE_ENV("LM_NO_RESUME") != nullptr;       // A/B: restart abandoned control steps from their own state (round 4)
+    if (!no_resume) { a.hq = b->hq; a.hv = b->hv; a.hw = b->hw; }
+    a.hsub = b->hsub;
+    static const bool no_premark = LM_PROBE_ENV("LM_NO_PREMARK") != nullptr;       // A/B: every control step starts in the regular kernel (round 4)
+    if (!no_premark) {
+      a.premark = b->premark;
+      // the regular kernels' capacity per chain (lm_family.hip / lm_core.h LaneMem: contact slots, queued convex pairs, pair results)
+      const Task& T = b->m->T;
+      const int fam = family_of(b);
+      a.reg_ns = fam == 0 ? 6 : (fam == 5 ? 4 : 8); a.reg_q = T.max_links >= 5 ? 24 : 8; a.reg_r = a.reg_ns < 8 ? a.reg_ns : 8;
+    } a.replay_all = b->replay == 2 || b->replay == 4; }
   static const bool no_xcd_map = LM_PROBE_ENV("LM_NO_XCD_MAP") != nullptr;
   a.xcd_map = no_xcd_map ? 0 : 1;
   return a;
@@ -919,6 +956,16 @@ int lm_debug_wg_regions(lm_batch* b, unsigned long long* out, int nblocks) {
   HIPCHK(hipStreamSynchronize(b->stream));
   if (nblocks != b->nblocks) return fail("nblocks mismatch");
   HIPCHK(hipMemcpy(out, b->timers + 16 + 16 * (size_t)nblocks, sizeof(unsigned long long) * 16 * (size_t)nblocks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* profiling builds: wall-clock time line of the last launch(es) since the last call: [N][4] + [nblocks][2] (lm_step.h KArgs::tline), cleared */
+int lm_debug_timeline(lm_batch* b, unsigned long long* out) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t n = 4 * (size_t)b->N + 2 * (size_t)b->nblocks;
+  HIPCHK(hipMemcpy(out, b->tline, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->tline, 0, sizeof(unsigned long long) * n));
   return 0;
 }
 

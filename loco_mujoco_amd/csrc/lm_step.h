@@ -140,11 +140,24 @@ struct KArgs {
   lm::Params P; Task T;
   DevStats* stats;
   unsigned long long* timers;   // LM_TIMERS builds: cycle counters per solver region (lane 0 of each workgroup)
+  unsigned long long* tline;    // LM_TIMERS builds: wall-clock (100 MHz) time line of the LAST launch: per environment [4] = listed for the replay
+                                // kernel | taken by a replay workgroup | done there | substep it resumes at; then per regular workgroup [2] = start | end
   // speculate / replay (see step_kernel): environments whose control step left the regular kernel's capacity
   int* replay_list;             // [N] environment id + 1 per entry (0 = empty / taken), appended by the regular kernel (null: no replay, drops are final)
   int* replay_ctl;              // [0] entries appended, [1] tickets handed out (pollers), [2] regular workgroups that are through, [3] workgroups of the
-                                // drain pass that are through (the last one resets [0..3]), [5] the epoch: launches whose drain pass is complete
+                                // drain pass that are through (the last one resets [0..3]), [5] the epoch: launches whose drain pass is complete,
+                                // [7] pollers that left by their time-out, ever (-> host_hint[2]: the host stops launching pollers)
   int* stall;                   // [N] the fused control step at which the environment left the regular kernel (0 for single-step launches)
+  // RESUME (round 5): the state at the START of the substep in which the control step left the regular kernel's capacity, SoA [nv][N]
+  // each (positions, velocities, warm start), and that substep's number [N] (0: from the control step's own state). The replay kernel
+  // continues from there instead of running the whole control step again: a robot that runs out of contact slots in substep 8 of 10
+  // used to cost 0.8 + 1.0 control steps, and the launch ends with it (profiles/r5_notes.md §3-4)
+  float* hq; float* hv; float* hw; int* hsub;
+  // PREDICTION (round 5): a robot folded on the floor stays beyond the regular kernel's capacity for a few control steps. The replay
+  // kernel leaves a mark [N] when the control step it just ran needed more than the regular kernel holds (reg_ns slots / reg_q queued
+  // pairs / reg_r pair results per chain) and the episode goes on; the regular kernel hands a marked environment over BEFORE its first
+  // substep instead of finding out again at the end of it (1.5 ms into the launch, and the launch ends with these robots)
+  int* premark; int reg_ns, reg_q, reg_r;
   int replay_all;               // tests (lm_batch_set_replay(b, 2)): EVERY control step is abandoned and run by the replay kernel
   unsigned char* replay_mark;   // [N] sticky: the replay kernel ran (part of) this environment's control steps since the marks were last cleared
   int reg_grid;                 // workgroups of the regular launch (the pollers leave when all of them are through)
@@ -201,7 +214,7 @@ __device__ __forceinline__ int replay_next(const KArgs& a, int& cursor) {
   // kernel had taken every SIMD): they are resident early, and wait here until the previous launch's drain pass has reset the
   // control words (epoch)
   while (__hip_atomic_load(&a.replay_ctl[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-    if ((long long)wall_clock64() - t0 > 50000000ll) return 0;
+    if ((long long)wall_clock64() - t0 > 50000000ll) { atomicAdd(&a.replay_ctl[7], 1); return 0; }
     __builtin_amdgcn_s_sleep(64);
   }
   const int ticket = atomicAdd(&a.replay_ctl[1], 1);
@@ -213,7 +226,9 @@ __device__ __forceinline__ int replay_next(const KArgs& a, int& cursor) {
     // every regular workgroup is through and my ticket is beyond the last entry: nothing will come any more
     if (__hip_atomic_load(&a.replay_ctl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= a.reg_grid &&
         ticket >= __hip_atomic_load(&a.replay_ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) return 0;
-    if ((long long)wall_clock64() - t0 > 50000000ll) return 0;      // (0.5 s: never wait for ever — the drain pass takes what is left)
+    // (0.5 s: never wait for ever — the drain pass takes what is left; counted: the host stops launching pollers after the first
+    // time-out, which means that they do not run beside the regular kernel here — a profiler or a runtime that serialises kernels)
+    if ((long long)wall_clock64() - t0 > 50000000ll) { atomicAdd(&a.replay_ctl[7], 1); return 0; }
     __builtin_amdgcn_s_sleep(64);
   }
 }
@@ -232,11 +247,14 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     if (!work) {
       if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; a.host_hint[2] = a.replay_ctl[7]; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
       }
       return;
     }
   }
+#ifdef LM_TIMERS
+  if (!REPLAY && !FORWARD_ONLY && a.tline && threadIdx.x == 0) a.tline[4 * (long long)a.N + 2 * blockIdx.x] = wall_clock64();
+#endif
   extern __shared__ float dyn_lds[];                       // [constant model table (used part)] [lane memory]
   float* cm = dyn_lds;
   __shared__ float mt[NM > 0 ? LM_MT_SIZE : 1];            // muscle records + tendon paths (muscle variant only)
@@ -257,6 +275,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     entry = __shfl(entry, 0, 64);
     if (entry <= 0) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the state the regular kernel stored before it listed the environment
+#ifdef LM_TIMERS
+    if (a.tline && threadIdx.x == 0) a.tline[4 * (entry - 1) + 1] = wall_clock64();
+#endif
   }
   // XCD-aware workgroup -> environment mapping. The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (own
   // L2 each), while neighbouring environments share 64-byte lines of the SoA state arrays ([dof][N]: 4 environments of a
@@ -413,18 +434,49 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   // stored, its lanes sit the rest out (the wave's other environments are no longer held up by the robot that needs the big kernel,
   // usually the slowest of them) and the environment is listed for the replay kernel at once: a poller may already be waiting.
   // Any lane of the environment may have seen it (the pair pass deals its tests to all replicas): an environment-wide vote.
-  for (int s = 0; s < a.T.nsub; s++) {
+  // RESUME: the families whose control steps are long and do run out of capacity under a random policy (the humanoids). Not with
+  // muscles (their activation states advance in lane memory) and not with foot-force observations (running sums over the substeps):
+  // those restart from the control step's own state as before, and so does the quadruped (rare, and its kernel is the bench line's)
+  constexpr bool RESUME = MC >= 5 && NM == 0 && !FORWARD_ONLY;
+  const bool resume_on = RESUME && a.hq != nullptr && a.T.ngrf == 0;
+  int s0 = 0;                       // REPLAY: the substep at which this control step is taken over
+  if (REPLAY && RESUME && resume_on && fused == first_step && in_range) {
+    s0 = a.hsub[e];
+    if (s0 > 0) {
+      // the state at the start of that substep, as the regular kernel left it (reward, actuation and the episode bookkeeping above
+      // and below belong to the control step and use its own state / counters)
+#pragma unroll
+      for (int i = 0; i < 6; i++) { qr[i] = a.hq[dr[i] * N + e]; vr[i] = a.hv[dr[i] * N + e]; war[i] = a.hw[dr[i] * N + e]; }
+#pragma unroll
+      for (int k = 0; k < MC; k++) if (k < nl) { qc[k] = a.hq[dc[k] * N + e]; vc[k] = a.hv[dc[k] * N + e]; wac[k] = a.hw[dc[k] * N + e]; }
+      pair_slack[0] = pair_slack[1] = pair_slack[2] = 0.0f;       // "detect now": the slack of the control step's start says nothing here
+    }
+  }
+  for (int s = s0; s < a.T.nsub; s++) {
     if (!REPLAY && a.replay_list && !gone) {
-      const bool leave = (a.replay_all && s == 0) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
+      const bool leave = (s == 0 && (a.replay_all || (a.premark && a.premark[e] != 0))) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
       if (leave) {
         if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // what this wave stored in the launch's earlier control steps
         if (valid && c == 0) {
           a.stall[e] = fused;
+          // substep s - 1 is the one that did not fit: its start state was stored at the top of that iteration (below)
+          if (a.hsub) a.hsub[e] = (resume_on && s >= 2) ? s - 1 : 0;
+#ifdef LM_TIMERS
+          if (a.tline) { a.tline[4 * e] = wall_clock64(); a.tline[4 * e + 3] = (resume_on && s >= 2) ? s - 1 : 0; }
+#endif
           __threadfence();
           const int k = atomicAdd(&a.replay_ctl[0], 1);
           atomicExch(&a.replay_list[k], e + 1);
         }
         gone = true; valid = false;
+      } else if (RESUME && resume_on && s >= 1 && valid) {
+        // the start state of substep s, for a replay kernel that may have to take the control step over from here
+        if (c == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) { a.hq[dr[i] * N + e] = qr[i]; a.hv[dr[i] * N + e] = vr[i]; a.hw[dr[i] * N + e] = war[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < MC; k++) if (k < nl) { a.hq[dc[k] * N + e] = qc[k]; a.hv[dc[k] * N + e] = vc[k]; a.hw[dc[k] * N + e] = wac[k]; }
       }
     }
     if (REPLAY ? fused >= first_step : !gone)        // (the replay kernel: the control steps before the one it takes over are the regular kernel's)
@@ -440,6 +492,10 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (valid && c == 0) {
         a.stall[e] = fused;
+        if (a.hsub) a.hsub[e] = (resume_on && a.T.nsub >= 2) ? a.T.nsub - 1 : 0;      // the LAST substep did not fit
+#ifdef LM_TIMERS
+        if (a.tline) { a.tline[4 * e] = wall_clock64(); a.tline[4 * e + 3] = (resume_on && a.T.nsub >= 2) ? a.T.nsub - 1 : 0; }
+#endif
         __threadfence();
         const int k = atomicAdd(&a.replay_ctl[0], 1);
         atomicExch(&a.replay_list[k], e + 1);
@@ -588,6 +644,12 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
   }
 
+  // ---- REPLAY: will the next control step of this environment need this kernel again? (see KArgs::premark)
+  if (REPLAY && a.premark) {
+    const bool big = QuadDpp::env_ballot(cnt.peak_slots > a.reg_ns || cnt.peak_q > a.reg_q || cnt.peak_res > a.reg_r) != 0u;
+    if (valid && c == 0) a.premark[e] = (big && step_no != 0 && !nonfinite) ? 1 : 0;
+  }
+
   // ---- statistics: LDS adds inside the workgroup, one plain read-modify-write per workgroup slot (no global atomics)
   if (a.stats) {
     if (valid) {
@@ -621,6 +683,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #endif
   }
   }  // fused control steps
+#ifdef LM_TIMERS
+  if (REPLAY && a.tline && threadIdx.x == 0) a.tline[4 * e_raw + 2] = wall_clock64();
+#endif
   }  // REPLAY: list entries of this workgroup
   if (a.stats) {
     __syncthreads();
@@ -629,6 +694,9 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       *dst += blk_stats[i];
     }
   }
+#ifdef LM_TIMERS
+  if (!REPLAY && !FORWARD_ONLY && a.tline && threadIdx.x == 0) a.tline[4 * (long long)a.N + 2 * blockIdx.x + 1] = wall_clock64();
+#endif
   if (!REPLAY && !FORWARD_ONLY && a.replay_list) {
     // this regular workgroup is through: the pollers leave when all are (replay_next)
     __syncthreads();
@@ -641,7 +709,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     if (threadIdx.x == 0) {
       __threadfence();
       const int tail = a.replay_ctl[0];
-      if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+      if (atomicAdd(&a.replay_ctl[3], 1) == (int)gridDim.x - 1) { if (a.host_hint) { a.host_hint[0] = tail; a.host_hint[1] = a.epoch + 1; a.host_hint[2] = a.replay_ctl[7]; } a.replay_ctl[0] = 0; a.replay_ctl[1] = 0; a.replay_ctl[2] = 0; a.replay_ctl[3] = 0; __threadfence(); __hip_atomic_store(&a.replay_ctl[5], a.epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
     }
   }
 #undef RD
@@ -656,8 +724,16 @@ enum { LMK_FWD = 0, LMK_REP4, LMK_REP1, LMK_DR_REP4, LMK_DR_REP1, LMK_FUSED, LMK
        LMK_BIG, LMK_BIG_DR, LMK_BIG_DRV /* the replay kernels, one per part */, LMK_NKINDS };
 constexpr int LMK_NFAMILY = 11;     // 0 quadruped, 2 humanoid RK4 8 slots, 4 Euler 8 slots, 5 muscles, 6 generic, 7 six-link chains (Euler, 8 slots), (1 / 3: the four-slot humanoid families, dropped in round 5)
                                     // 8 / 9 / 10 = five-link humanoids WITH self-collisions (8 slots): RK4 | Euler | Euler + muscles
-constexpr int kReplayRep = 16;      // replicas of the replay kernels' ONE environment per workgroup (a full wave)
-constexpr int kReplayGrid = 64;     // workgroups of the replay kernel's drain pass (each walks the list with this stride), and the most pollers
+// Replicas of the replay kernels' ONE environment per workgroup. 4 (shipped): the regular kernels' arithmetic exactly — a control step
+// comes out bitwise the same from either kernel. 16 (-DLM_REPLAY_REP=16): the whole wave for the environment, everything that is dealt
+// over replicas / lanes dealt four times wider. Measured in round 5 (profiles/r5_notes.md §3): a hard HumanoidTorque costs 10.4 ms with
+// sixteen replicas and 10.2 ms with four — what it waits for is the latency of single convex pairs and of spilled registers, not lanes.
+#ifndef LM_REPLAY_REP
+#define LM_REPLAY_REP 4
+#endif
+constexpr int kReplayRep = LM_REPLAY_REP;
+constexpr int kReplayGrid = 128;    // workgroups of the replay kernel's drain pass (each walks the list with this stride), and the most pollers
+constexpr int kPollMul = 2, kPollAdd = 2, kPollCap = 32;      // pollers of a launch = kPollMul / 2 x (recently abandoned steps) + kPollAdd, at most kPollCap (lm_kernels.hip)
 
 template <class K>
 static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, const LaunchCtx& L, const KArgs& a) {
@@ -686,8 +762,6 @@ static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
     // L.epb carries the number of workgroups asked for here (pollers: a few; the drain pass: kReplayGrid). The statistics slots are
     // one per workgroup of the REGULAR launch (+ kReplayGrid for the pollers): not more workgroups than that
     const int ngroups = (int)((L.N + a.epb - 1) / a.epb), want = L.epb;
-    // SIXTEEN replicas: the whole wave for one environment (contact slots, geoms, hull vertices, muscles and the pair pass's work
-    // lists dealt to 64 lanes instead of 16) — the environments that come here are the batch's hardest, and the launch ends with them
     launch_one(step_kernel<MC, NSB, RK4, false, CONE, NM, PART, kReplayRep, true, PMB>, dim3(ngroups < want ? ngroups : want), dim3(4 * kReplayRep), (size_t)LMb::kPadded * 4, L, b);
     return true;
   }
