@@ -24,11 +24,11 @@
 
 #define LM_DEV __device__ __forceinline__
 // The convex-pair collider is INLINED into the step kernel. As a real function (noinline) it kept its float64 registers and its private
-// portal array out of the quadruped's kernel (-1.5 % on the bench rollout, which never calls it), but kernels that contain the CALL
-// and sit at the register ceiling came out wrong under one build setting or another — every environment off by O(1): <5,8,RK4,PAIRS>
-// at -Os with the default scheduler, the fused <5,8,Euler,muscles,PAIRS> with the max-ILP scheduler, <5,8,Euler,muscles,PAIRS> at
-// -O2 without the machine scheduler; the same builds WITHOUT the call (-DLM_NO_MPR) are right, and so is the same source with a
-// printf next to the call (profiles/r3_notes.md §4, tools/probes/r3/sched_repro.sh reproduces it with -DLM_MPR_CALL).
+// portal array out of the quadruped's kernel (-1.5 % on the bench rollout, which never calls it), but in round 3 kernels that contained
+// the CALL and sat at the register ceiling came out wrong under one build setting or another (profiles/r3_notes.md §4). Round 5
+// (profiles/r5_notes.md §5): on the current source -DLM_MPR_CALL is right with all three scheduler settings, and no faster for the
+// humanoids either (HumanoidTorque.run 15.9 / 16.2 / 16.5 ms against 16.0 inlined: the kernels spill MORE with the call, 668-742 VGPRs
+// against 578) — the defect behind those failures is a code-generation one that comes and goes with the source (see csrc/Makefile).
 #ifdef LM_MPR_CALL
 #define LM_DEV_COLD __device__ __attribute__((noinline))
 #else
