@@ -234,7 +234,7 @@ def make_env(task, dr):
 class Workload:
     """One task on this rank's GPU: environment, model, batch with the bench's initial states and device-side restarts."""
 
-    def __init__(self, task, n, dr, rank, world, device, no_pollers=False, handoff=None):
+    def __init__(self, task, n, dr, rank, world, device, no_pollers=False):
         from loco_mujoco_amd.backend import HipBatch, HipModel
         self.task, self.n, self.dr, self.world = task, n, dr, world
         self.default_task = task == "UnitreeA1.simple"
@@ -245,8 +245,6 @@ class Workload:
         self.b = b = HipBatch(self.hm, n)
         if no_pollers:
             b.set_replay(3)
-        if handoff is not None:
-            b.set_handoff(*handoff)
         self.offset = offset = rank * n
         self.nv = nv = env._model.nv
         rs = np.random.RandomState(0)
@@ -393,6 +391,7 @@ def side_config(cfg, rank, device, steps, warmup, lib_sha, with_cpu):
            "roofline": roofline_block(W, st["kernel_ms"] / steps, lib_sha),
            "stats": {"overflow_contacts": st["overflow_contacts"], "unhandled_geom_substeps": st["unhandled_geoms"],
                      "self_proximity": st["self_proximity"], "self_contacts": st["self_contacts"],
+                     "own_manifold_contacts": st.get("own_manifold_contacts", 0.0),
                      "replayed_env_steps": st.get("replayed_env_steps", 0.0), "episodes": st["episodes"], "nan_resets": st["nan_resets"],
                      "newton_iters_per_forward_pass": st["solver_iters"] / max(st["env_steps"] * W.forwards_per_env_step(), 1)}}
     out["parity"] = parity_sample(W.env, W.hm, W.table, True)
@@ -458,8 +457,6 @@ def main():
                     "`value` is ITS rate (the conservative one) and the --steps block is reported as `burst`")
     ap.add_argument("--no-pollers", action="store_true", help="profiling runs (rocprofv3 runs one kernel at a time): the replay kernel only as the "
                     "pass behind the regular launch, no polling workgroups beside it (lm_batch_set_replay(3))")
-    ap.add_argument("--handoff", default=None, help="slots,queue,iters: thresholds of the hand-off of hard control steps to the replay kernel "
-                    "(lm_batch_set_handoff; 0 = off, -1 = the family's default) — tuning runs")
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="short legs of the other BASELINE configs "
                     "(HumanoidTorque.run, Atlas.walk --dr 2048, HumanoidMuscle.run 2048) under the `configs` key; auto = one rank, default task")
@@ -508,8 +505,7 @@ def main():
     ranks_rccl = coll.comm_count()
 
     n = args.envs_per_gpu
-    handoff = tuple(int(x) for x in args.handoff.split(",")) if args.handoff else None
-    W = Workload(args.task, n, args.dr, rank, world, local_rank, no_pollers=args.no_pollers, handoff=handoff)
+    W = Workload(args.task, n, args.dr, rank, world, local_rank, no_pollers=args.no_pollers)
     b, env = W.b, W.env
 
     b.rollout(args.warmup, action_mode=W.action_mode, seed=11)
@@ -535,7 +531,8 @@ def main():
                      st["overflow_contacts"], st["unhandled_geoms"], st["solver_iters"], st["kernel_ms"],
                      fused[0] if fused is not None else 0.0, st["self_proximity"], st["self_contacts"],
                      sustained[0] if sustained is not None else 0.0, sustained[1] if sustained is not None else 0.0,
-                     st.get("replayed_env_steps", 0.0), sustained[2] if sustained is not None else 0.0], dtype=np.float64)
+                     st.get("replayed_env_steps", 0.0), sustained[2] if sustained is not None else 0.0,
+                     st.get("own_manifold_contacts", 0.0)], dtype=np.float64)
     tmax = coll.all_reduce(vals, MAX)
     vals = coll.all_reduce(vals, SUM)
     elapsed, kernel_ms, fused_elapsed = float(tmax[0]), float(tmax[8]), float(tmax[9])
@@ -571,8 +568,8 @@ def main():
                                "(horizon 1000), 10 physics substeps per env-step"
                                % (W.label(), n, "zero-action" if W.default_task else "random-policy"),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 16 doubles at report time",
-                                  "tcp": "socket reduction of 16 doubles at report time (RCCL not used)"}[coll.backend],
+                   "collective": {"none": "none (one rank)", "rccl": "ncclAllReduce (RCCL) of 17 doubles at report time",
+                                  "tcp": "socket reduction of 17 doubles at report time (RCCL not used)"}[coll.backend],
                    "ranks_seen_by_rccl": ranks_rccl,
                    "value_is": ("the sustained block: %d per-step launches after the --steps block (same policy, same state mixture); the --steps "
                                 "block is `burst`" % args.sustained) if main_steps != args.steps else "the --steps block (it covers --sustained)"},
@@ -582,6 +579,8 @@ def main():
                   # where the device left its validated collision model (all ranks): forward passes x geom pairs of the robot
                   # without a pair collider (box / cylinder) within the margin, and self-contacts it did simulate
                   "self_proximity": vals[10], "self_contacts": vals[11],
+                  # of those: contacts of box-box / capsule-box pairs, whose manifold construction is the library's own (lm_core.h nat_*)
+                  "own_manifold_contacts": vals[16],
                   # control steps that left the regular kernel's capacity (contact slots, pair lists) and were run by the replay kernel
                   "replayed_env_steps": vals[14],
                   "newton_iters_per_forward_pass": vals[7] / max(env_steps * W.forwards_per_env_step(), 1),

@@ -71,6 +71,9 @@ typedef struct {
                               convex pairs of two links through MPR), summed over the forward passes */
   double replayed_env_steps; /* env-steps that left the regular kernel's capacity (contact slots, pair lists, convex collider) and were
                               run by the family's replay kernel instead (lm_batch_set_replay); part of env_steps */
+  double own_manifold_contacts; /* of self_contacts: contacts of box-box and capsule-box pairs. Their manifold construction is this
+                              library's own (the engine's mjc_BoxBox / mjc_CapsuleBox case analysis is not restated: csrc/lm_core.h nat_*):
+                              exact where the geometry leaves no choice (pinned edge-edge case), approximate for face contacts */
 } lm_stats;
 
 typedef struct {
@@ -110,14 +113,6 @@ int lm_batch_set_layout(lm_batch* b, int envs_per_workgroup);
    self_proximity say when (A/B measurements); 2 = every control step through the replay kernel
    (tests); 3 / 4 = 1 / 2 without the pollers (for profilers that run one kernel at a time: pollers would wait out their 0.5 s). */
 int lm_batch_set_replay(lm_batch* b, int enabled);
-/* Hand-off of HARD control steps (no counterpart in the reference, which steps one MjData at a time: base.py:185). A launch ends with
-   its slowest environment; the regular kernels run four environments per wave in lock step, the replay kernels one per workgroup.
-   A control step whose environment holds more than `slots` contacts in a chain, queues more than `queue` convex / native pairs for a
-   chain, or needs more than `iters` Newton iterations in one forward pass is handed to the replay kernel like one that left the
-   regular kernel's capacity (counted in replayed_env_steps). 0 switches a criterion off (the default of every family: measured in
-   round 5, profiles/r5_notes.md §3 — no configuration gains from it); negative = the family's default. Results do not depend on the
-   route (tests/test_gpu_parity.py::test_replay_kernel_is_bitwise_the_regular_kernel). */
-int lm_batch_set_handoff(lm_batch* b, int slots, int queue, int iters);
 /* one byte per environment: 1 = the replay kernel ran at least one control step of this environment since the marks were last
    cleared (reset = 1 clears them after the copy; out may be NULL). Diagnostics of THIS path, like lm_get_flags. */
 int lm_get_replay_marks(lm_batch* b, uint8_t* out, int reset);

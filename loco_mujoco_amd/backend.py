@@ -23,7 +23,7 @@ class Dims(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("env_steps", "episodes", "reward_sum", "nan_resets", "solver_iters",
                                           "overflow_contacts", "unhandled_geoms", "linesearch_evals", "linesearch_capped", "steps_with_8plus_iters", "kernel_ms",
-                                          "self_proximity", "self_contacts", "replayed_env_steps")]
+                                          "self_proximity", "self_contacts", "replayed_env_steps", "own_manifold_contacts")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
-           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_batch_set_handoff", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
+           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
            "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows"]
@@ -65,7 +65,6 @@ def load_library():
     lib.lm_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.lm_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.lm_batch_set_replay.argtypes = [C.c_void_p, C.c_int]
-    lib.lm_batch_set_handoff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.lm_get_replay_marks.argtypes = [C.c_void_p, _U8, C.c_int]
     lib.lm_batch_destroy.argtypes = [C.c_void_p]
     lib.lm_batch_destroy.restype = None
@@ -169,12 +168,6 @@ class HipBatch:
         are dropped and counted (A/B measurements)."""
         # 2 (tests): everything through the replay kernel; 3 / 4: like 1 / 2 without the concurrent pollers (profilers)
         _check(self._lib.lm_batch_set_replay(self._h, int(enabled) if enabled in (2, 3, 4) else int(bool(enabled))))
-
-    def set_handoff(self, slots=-1, queue=-1, iters=-1):
-        """Hand-off of hard control steps to the replay kernel (``lm_batch_set_handoff``): contact slots per chain, queued convex /
-        native pairs per chain, Newton iterations per forward pass above which a control step is run by the replay kernel (one
-        environment per wave on sixteen replicas); 0 = criterion off, -1 = the family's default."""
-        _check(self._lib.lm_batch_set_handoff(self._h, int(slots), int(queue), int(iters)))
 
     def replay_marks(self, reset=False):
         """Per environment: did the replay kernel run one of its control steps since the marks were last cleared?"""

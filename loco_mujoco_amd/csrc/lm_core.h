@@ -156,20 +156,18 @@ struct Params {
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
   const float* cmg;   // the constant table in GLOBAL memory: the six-link kernels read their link-pair lists from there (they do not fit
                       // beside the lane memory in the workgroup's LDS share: lowering.py ends H_CM_USED before them)
-  // hand-off of HARD control steps (lm_step.h): a regular kernel whose environment holds more than `hard_slots` contact slots in a
-  // chain, queues more than `hard_queue` convex / native pairs for a chain, or needs more than `hard_iters` Newton iterations in one
-  // forward pass sets Counters::hard — the control step goes to the family's replay kernel, which gives the environment a whole wave
-  // (sixteen replicas instead of four). 0 = that criterion is off. The results do not depend on the route beyond float32 rounding.
-  int hard_slots, hard_queue, hard_iters;
+  int root_limited;   // some root dof is `limited` (lowering.py keeps a root limit only when it can become active): the regular kernels of
+                      // the families without root limit rows look at the root positions every pass (forward: ROOT_LIM)
 };
 
 struct Counters { int solver_iters; int overflow; int unhandled; int ncon; int ls_evals; int ls_capped; int it_max;
   int selfprox;      // forward passes x geom pairs without a collider (box / cylinder against something) within the margin
   int selfcon;       // self-contacts simulated, summed over the forward passes
+  int natown;        // of those: contacts of box-box and capsule-box pairs — this code's OWN manifold construction, not the engine's case
+                     // analysis (nat_box_box / nat_capsule_box below): counted so that a rollout says how much of it rests on them
   int pair_passes;   // forward passes in which the self-collision detection ran (diagnostics)
   int need_full;     // a convex pair came within reach in a kernel compiled WITHOUT the convex collider (PM == 2): the control step is
                      // abandoned and replayed by the full kernel (lm_step.h)
-  int hard;          // the control step is one of the batch's hardest (Params::hard_*): handed to the replay kernel when there is one
   int peak_slots, peak_q, peak_res;   // largest number of contact slots / queued convex pairs / pair results of this lane's chain in a pass (the
                      // replay kernel decides with them whether the environment fits the regular kernel again, lm_step.h)
   float grf[4][3];   // sums of the contact-frame force (normal, t1, t2) of the chain's foot-force groups (2; 4 in the six-link kernels)
@@ -1379,10 +1377,18 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
   return out;
 }
 
-// ---- native pairs (geom-pair kind 1): the engine's own colliders for a box or a cylinder against a sphere / capsule / box
-// (mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, mjc_BoxBox of the third-party mujoco==2.3.7). oracle/oracle.c nat_* is the
-// float64 restatement these follow step by step (same constructions, same order of the contacts); the box-box edge case is
-// pinned on the reference's golden rollout HumanoidTorque4Ages.run.all (tests/test_oracle_golden.py). A pair can have several
+// ---- native pairs (geom-pair kind 1): pairs the engine sends to its own colliders for a box or a cylinder against a sphere / capsule /
+// box (mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, mjc_BoxBox of the third-party mujoco==2.3.7). Sphere-box and sphere-cylinder
+// are determined by the geometry (closest feature) and are restatements. CAPSULE-BOX and BOX-BOX are NOT the engine's case analysis:
+// the engine's source is not available here, and these two are this code's own constructions with the engine's contact conventions
+// (normal from geom 1 to geom 2, point midway, dist = signed gap, at most 2 / 8 contacts) — capsule-box: the closest point of the axis
+// segment (bisection) as a sphere against the box, a second contact at the far end of the axis when that end is within the margin;
+// box-box: a 15-axis separation test, an edge-edge contact when an edge axis separates best by more than 5 % + 1e-6, else the incident
+// face clipped against the reference face (Sutherland-Hodgman). Exactly the engine's result where the geometry leaves no choice: the
+// box-box EDGE case is pinned to 1e-14 by the reference's golden rollout HumanoidTorque4Ages.run.all rows 9-10; the FACE case is off by
+// 5.7e-3 at HumanoidMuscle4Ages.run.all row 33 (tests/test_oracle_golden.py holds it to 1e-2): approximate. oracle/oracle.c nat_* carries
+// the same constructions in float64, so device-vs-oracle agreement says nothing about these two against the engine; their contacts are
+// counted (Counters::natown -> lm_stats.own_manifold_contacts). A pair can have several
 // contacts (capsule-box 2, box-box 8): `sub` selects one, `ncon` says how many there are — the caller runs the collider once per
 // contact instead of keeping eight results alive in a kernel that has no registers to spare.
 struct NatGeom { int type; V3 c, ax; float half, rad; V3 ex, ey, ez, hs; };
@@ -2218,7 +2224,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #pragma unroll
           for (int j2 = 0; j2 < 6; j2++) SL(slot, SL_AREF + j2) = -Bp * vel[j2] - ((j2 == 0) ? Kr : 0.0f);
         }
-        if (Q::rep() == 0 && (g1own || E.kb == 7 || E.same_lane)) cnt.selfcon++;
+        if (Q::rep() == 0 && (g1own || E.kb == 7 || E.same_lane)) {
+          cnt.selfcon++;
+          if ((int)rec[LM_GP_KIND] == 1 && (int)rec[LM_GP_X2 + LM_GX_TYPE] == LM_GEOM_BOX &&
+              ((int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_BOX || (int)rec[LM_GP_X1 + LM_GX_TYPE] == LM_GEOM_CAPSULE)) cnt.natown++;
+        }
       };
       // ---- 4. the convex pairs of the queues
       auto flush_queue = [&]() {
@@ -2636,7 +2646,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       if (nq_of[c] > kQueue) n_over += nq_of[c] - kQueue;
       if (nres_of[c] > kRcap) n_over += nres_of[c] - kRcap;
       cnt.peak_q = (nq_of[c] > cnt.peak_q) ? nq_of[c] : cnt.peak_q; cnt.peak_res = (nres_of[c] > cnt.peak_res) ? nres_of[c] : cnt.peak_res;
-      if (!LMm::kBig && P.hard_queue > 0 && nq_of[c] > P.hard_queue) cnt.hard = 1;
       // the smallest clearance of any pair of my chain, whichever lane of the environment looked at it
       {
         float gmine = 3.0e38f;
@@ -2661,7 +2670,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
     cnt.ncon += nslot;
     cnt.peak_slots = (nslot > cnt.peak_slots) ? nslot : cnt.peak_slots;
-    if (!LMm::kBig && P.hard_slots > 0 && nslot > P.hard_slots) cnt.hard = 1;
     LM_TICK(0);
     pair_mask_out = pair_mask;
     for (int s2 = 0; s2 < nslot; s2++) { if ((int)SL(s2, SL_LINK) < 0) nrootslot++; if (PAIRS && SL(s2, SL_PART) != 0.0f) npairslot++; }
@@ -2882,8 +2890,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // rows would have been inactive in every pass before that one, so the replay follows the same trajectory up to it.
   constexpr bool ROOT_LIM = NM > 0 || NS > 8 || CONE < 0;
   if constexpr (!ROOT_LIM) {
+    if (P.root_limited) {        // (a scalar branch: no robot of the path takes it)
 #pragma unroll
-    for (int i = 0; i < 6; i++) if (RD(i, LM_D_LIMITED) != 0.0f && (qr[i] < RD(i, LM_D_LO) || qr[i] > RD(i, LM_D_HI))) cnt.need_full = 1;
+      for (int i = 0; i < 6; i++) if (RD(i, LM_D_LIMITED) != 0.0f && (qr[i] < RD(i, LM_D_LO) || qr[i] > RD(i, LM_D_HI))) cnt.need_full = 1;
+    }
   }
   constexpr int NRL = ROOT_LIM ? 6 : 1;
   float lim_s_r[NRL], lim_D_r[NRL], lim_aref_r[NRL];
@@ -3719,7 +3729,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     }
   }
   cnt.solver_iters += (c == 0) ? iters : 0;
-  if (!LMm::kBig && P.hard_iters > 0 && iters > P.hard_iters) cnt.hard = 1;
   if (c == 0 && iters > cnt.it_max) cnt.it_max = iters;
 
   if (dbg) {

@@ -67,7 +67,6 @@ struct lm_batch {
   int stat_pre_off, nstat; int* h_hint; int hint, hint_seen; int epoch;
   hipStream_t stream2; hipEvent_t ev_fork, ev_join, ev_done[2];
   float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
-  int hard_slots, hard_queue, hard_iters;      // hand-off of hard control steps to the replay kernel (lm_batch_set_handoff; lm_core.h Params::hard_*)
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
@@ -99,12 +98,6 @@ static int family_of(const lm_batch* b) {
 }
 
 static bool family_has_replicas(const lm_batch* b) { return family_of(b) != 6; }
-// The family's default thresholds of the hand-off of hard control steps (lm_batch_set_handoff). Measured in round 5
-// (profiles/r5_notes.md): 0 = off.
-static void default_handoff(lm_batch* b) {
-  b->hard_slots = 0; b->hard_queue = 0; b->hard_iters = 0;
-  if (const char* v = LM_PROBE_ENV("LM_HANDOFF")) sscanf(v, "%d,%d,%d", &b->hard_slots, &b->hard_queue, &b->hard_iters);   // A/B knob of the probe builds
-}
 static bool family_has_pairs(int fam) { return fam == 0 || fam == 7 || fam == 8 || fam == 9 || fam == 10; }
 
 // (Round 5, tried and dropped: a one-workgroup GATE kernel in front of the regular launch that waits until the launch's pollers are
@@ -179,15 +172,26 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
 
     }
   }
-  if (!table[fam][0](L, r, kind) && !table[fam][1](L, r, kind) && !table[fam][2](L, r, kind)) { g_launch_err = "no kernel of this kind in the family"; return; }
+  // A failure from here on leaves pollers in flight that wait for a regular launch which will not come: they give up after their
+  // time-out. Wait for them, and put the control words back to "no launch in progress" (the epoch did not advance: nothing drained),
+  // so that the batch can be launched again or destroyed safely.
+  auto bail = [&](const char* msg) {
+    g_launch_err = msg;
+    if (pollers) {
+      (void)hipStreamSynchronize(b->stream2);
+      (void)hipStreamSynchronize(b->stream);
+      (void)hipMemset(b->replay_ctl, 0, sizeof(int) * 4);
+    }
+  };
+  if (!table[fam][0](L, r, kind) && !table[fam][1](L, r, kind) && !table[fam][2](L, r, kind)) { bail("no kernel of this kind in the family"); return; }
   if (replay) {
     // the drain pass, behind the regular launch AND the pollers: whatever is still listed; resets the control words. An empty
-    // list costs a few microseconds (64 workgroups read a word and leave)
-    if (pollers && hipStreamWaitEvent(b->stream, b->ev_join, 0) != hipSuccess) { g_launch_err = "stream join failed"; return; }
+    // list costs a few microseconds (its workgroups read a word and leave)
+    if (pollers && hipStreamWaitEvent(b->stream, b->ev_join, 0) != hipSuccess) { bail("stream join failed"); return; }
     r.drain = 1; r.stats_off = 0;
     const LaunchCtx L3 = {b->stream, b->N, lmk::kReplayGrid};
-    if (!table[fam][0](L3, r, big) && !table[fam][1](L3, r, big) && !table[fam][2](L3, r, big)) { g_launch_err = "no replay kernel in the family"; return; }
-    if (hipEventRecord(b->ev_done[b->epoch & 1], b->stream) != hipSuccess) { g_launch_err = "event record failed"; return; }
+    if (!table[fam][0](L3, r, big) && !table[fam][1](L3, r, big) && !table[fam][2](L3, r, big)) { bail("no replay kernel in the family"); return; }
+    if (hipEventRecord(b->ev_done[b->epoch & 1], b->stream) != hipSuccess) { bail("event record failed"); return; }
     b->epoch++;
   }
 }
@@ -332,7 +336,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
     P.meshadj = m->d_meshadj;
   }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
-  P.hard_slots = P.hard_queue = P.hard_iters = 0;
+  P.root_limited = m->root_limited ? 1 : 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = LM_PROBE_ENV("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   if (const char* v = LM_PROBE_ENV("LM_LS_NOISE")) P.ls_noise = (float)atof(v);
@@ -417,7 +421,6 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   }
   b->nblocks = (n_envs + b->epb - 1) / b->epb;
   b->replay = 1;
-  default_handoff(b);
   {
     // a model with self-collision tables needs a kernel family with the pair pass: anything else would silently not simulate them
     const int fam = family_of(b);
@@ -428,15 +431,6 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   }
   if (batch_alloc(b)) { lm_batch_destroy(b); return 1; }     // g_err holds the failed call; nothing leaks
   *out = b;
-  return 0;
-}
-
-/* hand-off of hard control steps (include/locohip.h): thresholds per batch; negative = the family's default */
-int lm_batch_set_handoff(lm_batch* b, int slots, int queue, int iters) {
-  if (!b) return fail("null batch");
-  lm_batch d = *b;
-  default_handoff(&d);
-  b->hard_slots = slots >= 0 ? slots : d.hard_slots; b->hard_queue = queue >= 0 ? queue : d.hard_queue; b->hard_iters = iters >= 0 ? iters : d.hard_iters;
   return 0;
 }
 
@@ -743,7 +737,6 @@ static KArgs make_args(lm_batch* b) {
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
-  a.P.hard_slots = b->hard_slots; a.P.hard_queue = b->hard_queue; a.P.hard_iters = b->hard_iters;
   a.epb = b->epb; a.timers = b->timers; a.tline = b->tline; a.nfused = 1;
   // speculate / replay: every family but the generic one has a replay kernel
   if (b->replay && family_of(b) >= 0 && family_of(b) != 6) { a.replay_list = b->replay_list; a.replay_ctl = b->replay_ctl; a.stall = b->stall; a.replay_mark = b->replay_mark;
@@ -780,7 +773,7 @@ static int drain_stats(lm_batch* b) {
     b->acc.env_steps += x.env_steps; b->acc.episodes += x.episodes; b->acc.reward_sum += x.reward_sum;
     b->acc.nan_resets += x.nan_resets; b->acc.solver_iters += x.solver_iters; b->acc.overflow_contacts += x.overflow;
     b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals; b->acc.linesearch_capped += x.ls_capped; b->acc.steps_with_8plus_iters += x.it_ge8;
-    b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon; b->acc.replayed_env_steps += x.replayed;
+    b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon; b->acc.replayed_env_steps += x.replayed; b->acc.own_manifold_contacts += x.natown;
   }
   return 0;
 }

@@ -112,8 +112,8 @@ struct Task {
   float rp[8];
 };
 
-struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, selfprox, selfcon, replayed, pad_[3]; };
-constexpr int kNStats = 13;
+struct DevStats { float env_steps, episodes, reward_sum, nan_resets, solver_iters, overflow, unhandled, ls_evals, ls_capped, it_ge8, selfprox, selfcon, replayed, natown, pad_[2]; };
+constexpr int kNStats = 14;
 
 struct KArgs {
   const float* cm;          // constant table [LM_CM_SIZE]
@@ -438,6 +438,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   // muscles (their activation states advance in lane memory) and not with foot-force observations (running sums over the substeps):
   // those restart from the control step's own state as before, and so does the quadruped (rare, and its kernel is the bench line's)
   constexpr bool RESUME = MC >= 5 && NM == 0 && !FORWARD_ONLY;
+  constexpr bool PREDICT = MC >= 5;      // (KArgs::premark: the humanoids' folded robots; the quadruped's kernel stays as it was)
   const bool resume_on = RESUME && a.hq != nullptr && a.T.ngrf == 0;
   int s0 = 0;                       // REPLAY: the substep at which this control step is taken over
   if (REPLAY && RESUME && resume_on && fused == first_step && in_range) {
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
   for (int s = s0; s < a.T.nsub; s++) {
     if (!REPLAY && a.replay_list && !gone) {
-      const bool leave = (s == 0 && (a.replay_all || (a.premark && a.premark[e] != 0))) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
+      const bool leave = (s == 0 && (a.replay_all || (PREDICT && a.premark && a.premark[e] != 0))) || QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
       if (leave) {
         if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // what this wave stored in the launch's earlier control steps
         if (valid && c == 0) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- the last substep's verdict (see the loop above)
   if (!REPLAY && a.replay_list && !gone) {
-    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0 || cnt.hard > 0) != 0u;
+    const bool leave = QuadDpp::env_ballot(cnt.overflow > 0 || cnt.need_full > 0) != 0u;
     if (leave) {
       if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (valid && c == 0) {
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
   }
 
   // ---- REPLAY: will the next control step of this environment need this kernel again? (see KArgs::premark)
-  if (REPLAY && a.premark) {
+  if (REPLAY && MC >= 5 && a.premark) {
     const bool big = QuadDpp::env_ballot(cnt.peak_slots > a.reg_ns || cnt.peak_q > a.reg_q || cnt.peak_res > a.reg_r) != 0u;
     if (valid && c == 0) a.premark[e] = (big && step_no != 0 && !nonfinite) ? 1 : 0;
   }
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (PAIRS && cnt.selfprox) atomicAdd(&blk_stats[10], (float)cnt.selfprox);
 
       if (PAIRS && cnt.selfcon) atomicAdd(&blk_stats[11], (float)cnt.selfcon);
+      if (PAIRS && cnt.natown) atomicAdd(&blk_stats[13], (float)cnt.natown);
       if (REPLAY && c == 0) { atomicAdd(&blk_stats[12], 1.0f); if (a.replay_mark) a.replay_mark[e] = 1; }
     }
 #ifdef LM_TIMERS

@@ -10,7 +10,8 @@ The skeleton's bones are collidable MESH geoms in the reference model. Their con
 (plane vs hull: a contact at the support vertex and up to three at its hull-graph neighbours, the rules found on the UnitreeH1 golden
 rows); bone against
 bone is the engine's convex-convex path (libccd's MPR), restated in the oracle and on the device (692 hull pairs); one foot box on the
-other is the engine's native box-box collider, restated too. The reference's golden rollouts of this environment
+other goes to the engine's native box-box collider, for which the device and the oracle carry a construction of their own (exact
+for the edge-edge case the reference's golden rollout pins, approximate for face contacts: csrc/lm_core.h nat_box_box). The reference's golden rollouts of this environment
 (tests/test_datasets/HumanoidTorque.*.npy) are reproduced row by row, the ten rows of HumanoidTorque.walk with bone-on-bone contacts
 included.
 """

@@ -521,8 +521,11 @@ static double box_box_gap(const double* p1, const double* R1, const double* s1,
 /* engine_collision_primitive.c: mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, mjc_BoxBox) —   */
 /* third party, not under /root/reference, not installed. Sphere-box and sphere-cylinder are fully    */
 /* determined by the geometry (closest feature, midpoint, signed distance) and restated as such.     */
-/* Capsule-box and box-box are the engine's own constructions (which contacts of a manifold are      */
-/* kept); they are restated from their published behaviour — capsule: the closest point of the axis  */
+/* Capsule-box and box-box are NOT restatements of the engine's case analysis (mjc_CapsuleBox /     */
+/* mjc_BoxBox decide which contacts of a manifold are kept; their source is not available here):      */
+/* they are this repository's own constructions with the engine's contact conventions, the same ones  */
+/* the device carries (csrc/lm_core.h nat_*), so device-vs-oracle agreement is circular for these two */
+/* pair types and only the golden rows speak — capsule: the closest point of the axis                */
 /* segment as a sphere against the box + a second contact at the far end when that is within the     */
 /* margin too; boxes: separating-axis search over the 15 axes, then either the incident face clipped  */
 /* against the reference face (<= 8 contacts) or the closest points of the two edges — NOT pinned by  */

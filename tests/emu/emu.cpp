@@ -165,7 +165,8 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
-  P.hard_slots = P.hard_queue = P.hard_iters = 0;
+  P.root_limited = 0;
+  for (int i = 0; i < 6; i++) if (cm[LM_R_DOFS + i * LM_D_SIZE + LM_D_LIMITED] != 0.0f) P.root_limited = 1;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = getenv("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   P.integrator = (int)H[LM_H_INTEGRATOR]; P.cone = (int)H[LM_H_CONE]; P.act_position = (int)H[LM_H_ACTMODE];

@@ -2238,38 +2238,3 @@ def test_root_dof_limit_rows_of_a_family_without_muscles_on_the_device():
         assert np.abs(q1[i] - qo).max() < QTOL and np.abs(v1[i] - vo).max() < VTOL, (i, np.abs(q1[i] - qo).max(), np.abs(v1[i] - vo).max())
     with pytest.raises(BackendError, match="limited root joint"):
         b.set_replay(0)
-
-
-def test_hand_off_of_hard_control_steps_to_the_replay_kernel():
-    """Round 5 (`lm_batch_set_handoff`): a control step whose environment holds many contacts / queues many convex pairs / needs many Newton
-    iterations is handed to the replay kernel (its wave mates stop waiting for it; profiles/r5_notes.md §3 for what that buys). HumanoidTorque.run, 512 robots stumbling under the random policy: with thresholds the replay kernel runs many more
-    control steps than with the criteria off, nothing is dropped either way, and — the shipped replay kernels run on four replicas like
-    the regular ones — the states do not depend on the route by a single bit."""
-    from loco_mujoco_amd.backend import HipBatch, HipModel
-    np.random.seed(0)
-    env = LocoEnv.make("HumanoidTorque.run", debug=True)
-    m = env._model
-    hm = HipModel(env._chain_model())
-    tab = env._reset_table()
-    n = 512
-    rs = np.random.RandomState(7)
-    rows = tab[rs.randint(0, len(tab), n)]
-    acts = rs.uniform(-1, 1, (10, n, len(env._action_indices)))
-    out = []
-    for thr in ((0, 0, 0), (5, 6, 6)):
-        b = HipBatch(hm, n)
-        b.set_handoff(*thr)
-        b.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
-        for a in acts[:9]:
-            b.step(a)
-        q0, v0 = b.get_state()
-        b.stats(reset=True)
-        b.step(acts[9])
-        st = b.stats()
-        out.append((q0, v0) + b.get_state() + (st,))
-    (qa0, va0, qa, va, sa), (qb0, vb0, qb, vb, sb) = out
-    assert sa["overflow_contacts"] == 0 and sb["overflow_contacts"] == 0 and sa["nan_resets"] == 0 and sb["nan_resets"] == 0
-    assert sb["replayed_env_steps"] > sa["replayed_env_steps"] + 10, (sa["replayed_env_steps"], sb["replayed_env_steps"])
-    # four replicas in either kernel: the route does not change a bit
-    assert np.array_equal(qa, qb) and np.array_equal(va, vb)
-    print("hand-off: replayed %d -> %d control steps of %d, states bitwise equal" % (sa["replayed_env_steps"], sb["replayed_env_steps"], n))
