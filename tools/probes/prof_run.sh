@@ -6,7 +6,7 @@ EXTRA=${3:-}            # e.g. "--task HumanoidTorque.run" or "--task Atlas.walk
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --configs off --sustained 0 $EXTRA"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --configs off --sustained 0 --fuse 0 $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc1 -o pmc1 -- $CMD > /dev/null 2> $OUT/pmc1.err
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_FLAT SQ_IFETCH SQ_WAIT_INST_LDS -d $OUT/pmc2 -o pmc2 -- $CMD > /dev/null 2> $OUT/pmc2.err
