@@ -3013,7 +3013,10 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     return 0.5f * x * x / Rr;
   };
   // lane-partial constraint cost at acceleration (xr, xc) (root rows weighted so that the quad sum counts them once)
-  auto cost_at = [&](const float* xr, const float* xc) -> float {
+  // `dst`: where the row residuals J x - aref of the contact slots are left (SL_JAR | SL_JV as scratch): the Newton loop starts from
+  // the residuals of the point the warm start picks instead of building them a third time
+  auto cost_at = [&](const float* xr, const float* xc, auto dst) -> float {
+    constexpr int DST = decltype(dst)::value;
     // with replicas: the unit rows are counted by replica 0, the contact slots are dealt round-robin (callers add
     // the parts up with Q::rep_sum)
     float cost = 0, cr = 0;
@@ -3044,12 +3047,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           float x[4], f3[3], cs = 0.0f;
           pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
-          for (int r = 0; r < 4; r++) x[r] -= SL(s, SL_AREF + r);
+          for (int r = 0; r < 4; r++) { x[r] -= SL(s, SL_AREF + r); SL(s, DST + r) = x[r]; }
           pyr_force(x, SL(s, SL_D), SL(s, SL_MU), f3, cs);
           cost += (IP ? slot_weight(s) : 1.0f) * cs;
         } else {
 #pragma unroll
-          for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); Dj[j] = SL(s, SL_D + j); }
+          for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, DST + j) = jar[j]; Dj[j] = SL(s, SL_D + j); }
 #pragma unroll
           for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
           cost += (IP ? slot_weight(s) : 1.0f) * cone_eval<false>(jar, Dj, fr, SL(s, SL_MU), dim).cost;
@@ -3067,15 +3070,27 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   float ar[6], ac[MC];
   {
     // warm start: the better of (previous qacc, qacc_smooth)
-    float cost_smooth = Q::rep_sum(Q::sum(cost_at(a0r, a0c)));
+    float cost_smooth = Q::rep_sum(Q::sum(cost_at(a0r, a0c, std::integral_constant<int, (int)SL_JAR>{})));
     float yr[6], yc[MC], gauss = 0, gr = 0;
     mulM(war, wac, yr, yc);
 #pragma unroll
     for (int k = 0; k < MC; k++) gauss += 0.5f * (yc[k] - sm_c[k]) * (wac[k] - a0c[k]);
 #pragma unroll
     for (int i = 0; i < 6; i++) gr += 0.5f * (yr[i] - sm_r[i]) * (war[i] - a0r[i]);
-    float cost_warm = Q::rep_sum(Q::sum(cost_at(war, wac))) + Q::sum(gauss + w0 * gr);
+    float cost_warm = Q::rep_sum(Q::sum(cost_at(war, wac, std::integral_constant<int, (int)SL_JV>{}))) + Q::sum(gauss + w0 * gr);
     bool use_warm = cost_warm < cost_smooth;
+    if (use_warm) {
+      // the row residuals of the chosen point into SL_JAR (every replica those of the slots it was dealt above)
+      for (int s = Q::rep(); s < nslot; s += Q::kRep) {
+        if (PYR3((int)SL(s, SL_DIM))) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) SL(s, SL_JAR + r) = SL(s, SL_JV + r);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; j++) SL(s, SL_JAR + j) = SL(s, SL_JV + j);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) ar[i] = use_warm ? war[i] : a0r[i];
 #pragma unroll
@@ -3083,6 +3098,20 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   }
 
   LM_TICK(3);
+  // Newton bookkeeping (round 5; the engine's own solver keeps Jaref and Ma the same way): the row residuals J a - aref of the contact
+  // slots and M a are MOVED by alpha x (J s, M s) after a line search instead of being rebuilt from the link images in every iteration,
+  // the first iteration starts from the residuals the warm-start comparison left behind, and the line search does not evaluate alpha = 0
+  // (phi'(0) = g . s, phi''(0) = s . H s = -g . s along the Newton direction). Same iteration counts, same parity; quadruped bench
+  // rollout -9.6 %, Atlas + DR -12 %, Talos -8 %, HumanoidMuscle -7 %, HumanoidTorque -6 % (profiles/r5_notes.md §7). Carrying M a costs
+  // the six-link kernels more in spills than it saves (UnitreeG1 +5 %): they recompute it. LM_JAR_RECOMPUTE / LM_MA_RECOMPUTE /
+  // LM_LS_EVAL0: the bookkeeping of rounds 1-4, for A/B builds.
+#ifdef LM_JAR_RECOMPUTE
+  constexpr bool kJarIncr = false, kMaIncr = false;
+#elif defined(LM_MA_RECOMPUTE)
+  constexpr bool kJarIncr = true, kMaIncr = false;
+#else
+  constexpr bool kJarIncr = true, kMaIncr = MC < 6;
+#endif
   float qf_r[6], qf_c[MC];      // constraint forces in joint space
 #pragma unroll
   for (int i = 0; i < 6; i++) qf_r[i] = 0;
@@ -3097,14 +3126,15 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   bool done = !(Q::sum(has_rows ? 1.0f : 0.0f) > 0.0f);   // quad-uniform: nothing to solve in this environment
   int iters = 0;
 
+  float Mar[6], Mac[MC];          // M a, moved by alpha x M s after a line search like the row residuals
   for (int it = 0; it <= P.iterations; it++) {
     if (!Q::any(!done)) break;
     oz = LM_OPAQUE_ZERO();
     if (!done) {
       // ---- gradient at the current point
       float jfr_r[6], jfr_c[MC], jlim_c[MC];     // jar of the unit rows
-      float Mar[6], Mac[MC];
-      if (!(P.ablate & 16)) mulM(ar, ac, Mar, Mac);
+      if (kMaIncr && it > 0) {}
+      else if (!(P.ablate & 16)) mulM(ar, ac, Mar, Mac);
       else {
 #pragma unroll
         for (int i = 0; i < 6; i++) Mar[i] = ar[i];
@@ -3155,28 +3185,44 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       Sp Fp[PAIRS ? MC : 1];       // wrenches of the self-contacts per link: they act on the chain dofs only (the opposite
 #pragma unroll                     // wrench on the other body cancels them on the root)
       for (int k = 0; k < (PAIRS ? MC : 1); k++) Fp[k] = sp0();
+      // The row residuals J a - aref of the contact slots are built from the link images of a in the FIRST iteration only; after a line
+      // search they move by alpha x (J s), which the line search has in SL_JV (below) — the engine's own Newton does the same
+      // (Jaref += alpha Jv). LM_JAR_RECOMPUTE: rounds 1-4 (rebuilt in every iteration), for A/B builds.
+
+      const bool fresh_rows = !kJarIncr;          // (the first iteration starts from the residuals the warm start left: cost_at)
       if ((nslot > 0 || any_pair) && !(P.ablate & 32)) {
-        link_images(ar, ac);
+        if (fresh_rows) link_images(ar, ac);
         auto grad_slot = [&](int s, auto is_pair) {
           constexpr bool IP = decltype(is_pair)::value;
           float Dj[6], fr[5], jar[6];
           const int link = (int)SL(s, SL_LINK);
           const V3 rc = v3(SL(s, SL_RX), SL(s, SL_RY), SL(s, SL_RZ));
-          if constexpr (IP) slot_rows_of_images(s, jar);
-          else contact_rows(pick(link), rc, jar);
+          if (fresh_rows) {
+            if constexpr (IP) slot_rows_of_images(s, jar);
+            else contact_rows(pick(link), rc, jar);
+          }
           const int dim = (int)SL(s, SL_DIM);
           float fc[6];
           int zone;
           if (PYR3(dim)) {
             float x[4], dummy = 0;
-            pyr_rows(jar, SL(s, SL_MU), x);
+            if (fresh_rows) {
+              pyr_rows(jar, SL(s, SL_MU), x);
 #pragma unroll
-            for (int r = 0; r < 4; r++) { x[r] -= SL(s, SL_AREF + r); SL(s, SL_JAR + r) = x[r]; }
+              for (int r = 0; r < 4; r++) { x[r] -= SL(s, SL_AREF + r); SL(s, SL_JAR + r) = x[r]; }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; r++) x[r] = SL(s, SL_JAR + r);
+            }
             zone = (int)pyr_force(x, SL(s, SL_D), SL(s, SL_MU), fc, dummy);
             fc[3] = fc[4] = fc[5] = 0.0f;
           } else {
 #pragma unroll
-            for (int j = 0; j < 6; j++) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; Dj[j] = SL(s, SL_D + j); }
+            for (int j = 0; j < 6; j++) {
+              if (fresh_rows) { jar[j] -= SL(s, SL_AREF + j); SL(s, SL_JAR + j) = jar[j]; }
+              else jar[j] = SL(s, SL_JAR + j);
+              Dj[j] = SL(s, SL_D + j);
+            }
 #pragma unroll
             for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
             ConeEval e = cone_eval<true>(jar, Dj, fr, SL(s, SL_MU), dim);
@@ -3586,7 +3632,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           // Root of the increasing phi'. It is piecewise smooth with very different slopes: saturating friction
           // rows give S-shapes, a stiff contact crossing its sticking sliver gives a near-jump.
           float d1, d2, mag, alpha = 0, lo = 0, hi = -1.0f, dlo, dhi = 0.0f;
+          // phi'(0) = g . s = -dec and, along the Newton direction H s = -g, phi''(0) = s . H s = dec: no evaluation at 0
+          // (LM_LS_EVAL0: rounds 1-4 evaluated the line at alpha = 0, for A/B builds)
+#ifdef LM_LS_EVAL0
           line(0.0f, d1, d2, mag);
+#else
+          d1 = -dec; d2 = dec; mag = 0.0f; (void)mag;
+#endif
 #ifdef LM_LS_TRACE
           if (getenv("LM_SCAN")) { for (float aa = 1e-7f; aa < 2.0f; aa *= 3.0f) { float x1, x2, xm; line(aa, x1, x2, xm); if (c == 0) printf("    scan alpha %.3g d1 %.6g d2 %.6g\n", aa, x1, x2); } line(0.0f, d1, d2, mag); }
 #endif
@@ -3685,6 +3737,24 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           }
           if (c == 0 && !ls_done) cnt.ls_capped++;
           LM_TICK(8);
+          if (kMaIncr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) Mar[i] = fmaf(alpha, Mvr[i], Mar[i]);
+#pragma unroll
+            for (int k = 0; k < MC; k++) Mac[k] = fmaf(alpha, Mvc[k], Mac[k]);
+          }
+          if (kJarIncr && nslot > 0) {
+            // every replica moves the rows of the slots it owns in the gradient (the same words whoever writes them)
+            for (int s = s_first; s < nslot; s += s_step) {
+              if (PYR3((int)SL(s, SL_DIM))) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) SL(s, SL_JAR + r) = fmaf(alpha, SL(s, SL_JV + r), SL(s, SL_JAR + r));
+              } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) SL(s, SL_JAR + j) = fmaf(alpha, SL(s, SL_JV + j), SL(s, SL_JAR + j));
+              }
+            }
+          }
 #pragma unroll
           for (int i = 0; i < 6; i++) ar[i] = fmaf(alpha, sr[i], ar[i]);
 #pragma unroll
