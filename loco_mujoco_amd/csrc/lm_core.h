@@ -212,7 +212,11 @@ LM_DEV float impedance(const float* s /*clipped solimp[5]*/, int stride, float p
 // On the GPU this is an LDS array indexed [field][lane] (stride = lanes per workgroup, conflict-free); slots are
 // walked with ordinary loops so that only one contact's working set is in registers at a time.
 enum { SL_LINK = 0, SL_DIM, SL_MU, SL_RX, SL_RY, SL_RZ, SL_D, SL_FR = SL_D + 6, SL_AREF = SL_FR + 5, SL_JAR = SL_AREF + 6,
-       SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_GRF /* force group of the chain (0/1) or -1 */, SL_SIZE };
+       SL_JV = SL_JAR + 6, SL_ZONE = SL_JV + 6, SL_GRF /* force group of the chain (0/1) or -1 */,
+       // line-search coefficients of an elliptic contact, prepared once per Newton iteration (the engine's PrimalPrepare): with
+       // x(alpha) = jar + alpha jv the cone's normal part N = N0 + alpha Np and tangential norm T^2 = UU + 2 alpha UV + alpha^2 VV are
+       // polynomials in alpha, the quadratic ("bottom") zone's derivative is A + alpha B: [N0, Np, UU, UV, VV, A, B, Dm, mu]
+       SL_PREP, SL_SIZE = SL_PREP + 9 };
 // pair extension of a slot record (kernels with self-collisions, PAIRS): SL_PART = 0 for a floor contact, else
 // sign * (1 + partner lane * 8 + partner link), partner link 7 = the root body; sign = +1 when this lane's body carries the
 // contact's SECOND geom (the normal points from geom 1 to geom 2). Then the unit normal, world axes.
@@ -1785,6 +1789,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   constexpr int SL_AREF = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_AREF, SL_JAR = kCompactSlots ? (int)SLC_JAR : (int)lm::SL_JAR;
   constexpr int SL_JV = kCompactSlots ? (int)SLC_JV : (int)lm::SL_JV, SL_ZONE = kCompactSlots ? (int)SLC_ZONE : (int)lm::SL_ZONE;
   constexpr int SL_GRF = kCompactSlots ? (int)SLC_GRF : (int)lm::SL_GRF;
+  constexpr int SL_PREP = kCompactSlots ? 0 : (int)lm::SL_PREP;          // (no elliptic contacts in the kernels with compact slot records)
   constexpr int SL_PART = kCompactSlots ? (int)SLC_SIZE : (int)lm::SL_PART;
   constexpr int SL_NX = SL_PART + 1, SL_NY = SL_PART + 2, SL_NZ = SL_PART + 3;
   (void)SL_FR;
@@ -3560,6 +3565,24 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             for (int s = 0; s < nfloor; s++) jv_slot(s, std::false_type{});
             if constexpr (PAIRS) for (int s = nfloor; s < nslot; s++) jv_slot(s, std::true_type{});
             if (PAIRS && any_pair) Q::quad_sync();
+            if constexpr (CONE != 0) {
+              // elliptic contacts: the line search's polynomials, prepared by the replica that owns the slot in the gradient
+              for (int s = s_first; s < nslot; s += s_step) {
+                const int dim = (int)SL(s, SL_DIM);
+                if (PYR3(dim)) continue;
+                const float mu = SL(s, SL_MU), x0 = SL(s, SL_JAR), v0 = SL(s, SL_JV), D0 = SL(s, SL_D);
+                float UU = 0, UV = 0, VV = 0, A = D0 * x0 * v0, B = D0 * v0 * v0;
+#pragma unroll
+                for (int j = 1; j < 6; j++) if (j < dim) {
+                  const float xj = SL(s, SL_JAR + j), vj = SL(s, SL_JV + j), fj = SL(s, SL_FR + j - 1), Dj_ = SL(s, SL_D + j);
+                  const float u = xj * fj, v = vj * fj;
+                  UU = fmaf(u, u, UU); UV = fmaf(u, v, UV); VV = fmaf(v, v, VV);
+                  A = fmaf(Dj_ * xj, vj, A); B = fmaf(Dj_ * vj, vj, B);
+                }
+                SL(s, SL_PREP + 0) = x0 * mu; SL(s, SL_PREP + 1) = v0 * mu; SL(s, SL_PREP + 2) = UU; SL(s, SL_PREP + 3) = UV; SL(s, SL_PREP + 4) = VV;
+                SL(s, SL_PREP + 5) = A; SL(s, SL_PREP + 6) = B; SL(s, SL_PREP + 7) = D0 / fmaxf(kMinVal, mu * mu * (1.0f + mu * mu)); SL(s, SL_PREP + 8) = mu;
+              }
+            }
           }
           Q::fence();
           float Mvr[6], Mvc[MC];
@@ -3613,11 +3636,29 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   c1 = fmaf(D * x, xv, c1); c2 = fmaf((x < 0.0f) ? D : 0.0f, xv * xv, c2);
                 }
               } else {
+#ifdef LM_LS_CONE_DIRECT
 #pragma unroll
                 for (int j = 0; j < 6; j++) { jar[j] = SL(s, SL_JAR + j); jv[j] = SL(s, SL_JV + j); Dj[j] = SL(s, SL_D + j); }
 #pragma unroll
                 for (int j = 0; j < 5; j++) fr[j] = SL(s, SL_FR + j);
                 cone_line(jar, jv, alpha, Dj, fr, SL(s, SL_MU), dim, c1, c2);
+#else
+                // from the prepared polynomials (cone_line is the same arithmetic on the rows themselves)
+                (void)Dj; (void)fr; (void)jar; (void)jv;
+                const float N0 = SL(s, SL_PREP + 0), Np = SL(s, SL_PREP + 1), UU0 = SL(s, SL_PREP + 2), UV0 = SL(s, SL_PREP + 3), VV = SL(s, SL_PREP + 4);
+                const float mu = SL(s, SL_PREP + 8);
+                const float N = fmaf(alpha, Np, N0), uv = fmaf(alpha, VV, UV0);
+                const float T = sqrtf(fmaxf(fmaf(alpha, UV0 + uv, UU0), 0.0f));
+                if (N >= mu * T || (T <= 0 && N >= 0)) {}
+                else if (mu * N + T <= 0 || (T <= 0 && N < 0)) { const float B = SL(s, SL_PREP + 6); c1 = fmaf(alpha, B, SL(s, SL_PREP + 5)); c2 = B; }
+                else {
+                  const float Dm = SL(s, SL_PREP + 7);
+                  const float Tp = uv / T, Tpp = VV / T - uv * uv / (T * T * T);
+                  const float NmT = N - mu * T, NmTp = Np - mu * Tp;
+                  c1 = Dm * NmT * NmTp;
+                  c2 = Dm * (NmTp * NmTp - NmT * mu * Tpp);
+                }
+#endif
               }
 #ifdef LM_LS_TRACE
               if (getenv("LM_ROWS")) printf("      lane %d slot %d alpha %.6g c1 %.6g c2 %.6g\n", c, s, alpha, c1, c2);
