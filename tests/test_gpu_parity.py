@@ -1987,6 +1987,10 @@ def test_replay_kernel_is_bitwise_the_regular_kernel(task, kw):
     assert same.sum() >= 0.8 * n
     assert np.array_equal(q1[same], q2[same]) and np.array_equal(v1[same], v2[same]) and np.array_equal(o1[same], o2[same])
     assert a1 is None or np.array_equal(a1[same], a2[same])
+    # round 5 (RESUME): an environment that DID need the replay kernel in the default run ran substeps 0..s-1 of that control step in the
+    # regular kernel and s..9 in the replay kernel — the same arithmetic as all ten in the replay kernel: bitwise equal too
+    assert np.array_equal(q1, q2) and np.array_equal(v1, v2) and np.array_equal(o1, o2), ("resumed control steps differ", int(m1.sum()))
+    assert a1 is None or np.array_equal(a1, a2)
     assert np.isfinite(q2).all() and np.isfinite(v2).all()
 
 
