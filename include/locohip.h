@@ -147,6 +147,23 @@ int lm_get_variant_index(lm_batch* b, int32_t* index);
    reset table holds n_variants blocks of rows_per_variant rows (each block with its model's constants in the goal columns);
    a device-side restart from row i then puts the environment on variant i / rows_per_variant. 0 = independent uniform redraw. */
 int lm_set_variant_rows(lm_batch* b, int rows_per_variant);
+/* the model compiler on the device: a FRESHLY randomised model per environment and episode, like the reference's re-compile at
+   every reset() (base.py:183-185, utils/domain_randomization.py:219-227,386-514). `index` / `data` = the program of
+   lowering.model_compiler_tables (the draws of the randomisation rules, the model's Jacobians at qpos0, where every derived
+   value lands); `record` / `geom_table` / `pair_table` = the nominal model's tables (lm_set_model_variants' layout, ONE set).
+   The batch then holds one slot per environment; this call and lm_compile_models (the host-side reset; mask NULL = everyone)
+   draw and compile on the device, and so does every device-side restart (lm_set_auto_reset) before the episode's first step:
+   armature / mass / diaginertia / fullinertia / geom friction drawn with a counter-based generator keyed by (seed, global
+   environment id, models this environment has had), M(qpos0) -> dof_invweight0 / body_invweight0 / meaninertia in float64.
+   Fused launches fall back to one control step per launch. lm_set_model_variants replaces the compiler by a pool again. */
+int lm_set_model_compiler(lm_batch* b, const int32_t* index, long long n_index, const double* data, long long n_data,
+                          const float* record, const float* geom_table, const float* pair_table, int pair_floats, uint64_t seed);
+int lm_compile_models(lm_batch* b, const uint8_t* mask);
+/* what the compiler drew for the CURRENT model of every environment, [N][n_draw] in the order of the program's draws, and how
+   many models each environment has had (either may be NULL): the host (and the oracle) rebuild that model from these */
+int lm_get_model_draws(lm_batch* b, double* draws, uint32_t* generation);
+/* the tables environment `env` runs on (its variant's slot; any of the three may be NULL) */
+int lm_get_model_tables(lm_batch* b, int env, float* record, float* geom_table, float* pair_table);
 int lm_set_activation(lm_batch* b, const float* act, const uint8_t* mask);
 int lm_get_activation(lm_batch* b, float* act);
 

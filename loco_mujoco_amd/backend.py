@@ -38,7 +38,8 @@ EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_dest
            "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
-           "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows"]
+           "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows",
+           "lm_set_model_compiler", "lm_compile_models", "lm_get_model_draws", "lm_get_model_tables"]
 
 _lib = None
 
@@ -90,6 +91,11 @@ def load_library():
     lib.lm_set_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32), _U8]
     lib.lm_get_variant_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.lm_set_variant_rows.argtypes = [C.c_void_p, C.c_int]
+    lib.lm_set_model_compiler.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_longlong, C.POINTER(C.c_double), C.c_longlong, _F, _F, _F,
+                                          C.c_int, C.c_uint64]
+    lib.lm_compile_models.argtypes = [C.c_void_p, _U8]
+    lib.lm_get_model_draws.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    lib.lm_get_model_tables.argtypes = [C.c_void_p, C.c_int, _F, _F, _F]
     _lib = lib
     return lib
 
@@ -234,6 +240,40 @@ class HipBatch:
         gpt = np.ascontiguousarray(np.stack([t[2] for t in tables]), dtype=np.float32) if npair else None
         _check(self._lib.lm_set_model_variants(self._h, _fp(rec), _fp(gt), _fp(gpt) if gpt is not None else None, npair, len(tables)))
         self.n_variants = len(tables)
+
+    def set_model_compiler(self, program, nominal_tables, seed=0):
+        """The model compiler on the device: ``program`` = (int32, float64) of ``lowering.model_compiler_tables``, ``nominal_tables`` =
+        ``lowering.variant_tables(nominal, nominal)``. Every environment gets a slot and a freshly drawn model of its own, now and at
+        every device-side restart; :meth:`compile_models` is the host-side reset."""
+        ib = np.ascontiguousarray(program[0], dtype=np.int32)
+        db = np.ascontiguousarray(program[1], dtype=np.float64)
+        rec, gt = _f32(nominal_tables[0], (len(nominal_tables[0]),)), _f32(nominal_tables[1], (len(nominal_tables[1]),))
+        npair = len(nominal_tables[2])
+        gpt = _f32(nominal_tables[2], (npair,)) if npair else None
+        _check(self._lib.lm_set_model_compiler(self._h, ib.ctypes.data_as(C.POINTER(C.c_int32)), len(ib), db.ctypes.data_as(C.POINTER(C.c_double)),
+                                               len(db), _fp(rec), _fp(gt), _fp(gpt) if gpt is not None else None, npair, int(seed) & (2 ** 64 - 1)))
+        self.n_variants = self.n
+        self.n_model_draws = int(ib[4])
+        self._table_sizes = (len(rec), len(gt), npair)
+
+    def compile_models(self, mask=None):
+        """A fresh model for the masked environments (None: all), drawn and compiled on the device."""
+        keep, mp = _mask(mask, self.n)
+        _check(self._lib.lm_compile_models(self._h, mp))
+
+    def get_model_draws(self):
+        """(draws [n, n_draw] float64 of every environment's CURRENT model, models each environment has had [n])."""
+        d = np.empty((self.n, self.n_model_draws), dtype=np.float64)
+        g = np.empty(self.n, dtype=np.uint32)
+        _check(self._lib.lm_get_model_draws(self._h, d.ctypes.data_as(C.POINTER(C.c_double)), g.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return d, g
+
+    def get_model_tables(self, env, sizes=None):
+        """(record, geom table, geom-pair table) environment ``env`` runs on."""
+        nr, ng, npair = sizes if sizes is not None else self._table_sizes
+        rec, gt, gpt = np.empty(nr, dtype=np.float32), np.empty(ng, dtype=np.float32), np.empty(npair, dtype=np.float32)
+        _check(self._lib.lm_get_model_tables(self._h, int(env), _fp(rec), _fp(gt), _fp(gpt) if npair else None))
+        return rec, gt, gpt
 
     def set_variant_index(self, index, mask=None):
         idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int32), (self.n,)))

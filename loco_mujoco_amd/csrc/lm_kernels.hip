@@ -2,6 +2,7 @@
 // launches of the step kernels. The kernels themselves live in lm_step.h / lm_core.h and are compiled per family in
 // lm_family.hip (one object per family and part, so the library builds in parallel).
 #include "lm_step.h"
+#include "lm_compile.h"
 #include <memory>
 
 using lmk::KArgs; using lmk::Task; using lmk::DevStats; using lmk::LaunchCtx;
@@ -55,6 +56,9 @@ struct lm_batch {
   hipEvent_t ev0, ev1;
   hipEvent_t ev_ext;       // orders the library's stream behind a launch on a caller's stream (lm_step_device)
   float *vrec, *vgt, *vgpt; int* var; int nvar, gpt_floats, var_rows; bool dofprm_of_variants;   // model variants (lm_set_model_variants, lm_set_variant_rows)
+  // the model compiler on the device (lm_set_model_compiler, lm_compile.hip): its program, per environment the restart flag, the draw
+  // counter and the values drawn; the variant tables above then hold ONE slot per environment
+  int* mc_ib; double* mc_db; int mc_ndraw; unsigned char *vdirty, *mc_mask; unsigned* vgen; double* vdraws; unsigned long long mc_seed;
   float* scr; int* scr_idx; size_t scr_cap;   // staging for masked uploads (rows of the masked environments only)
   // speculate / replay (lm_step.h): list of the environments whose control step left the regular kernel's capacity, its control
   // words, the fused step at which each left; `replay` = 0 switches the mechanism off (contacts beyond the slots are then dropped)
@@ -471,7 +475,7 @@ void lm_batch_destroy(lm_batch* b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
                   b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
-                  b->vrec, b->vgt, b->vgpt, b->var};
+                  b->vrec, b->vgt, b->vgpt, b->var, b->mc_ib, b->mc_db, b->vdirty, b->mc_mask, b->vgen, b->vdraws};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -644,12 +648,15 @@ int lm_set_dof_randomization(lm_batch* b, const float* spec) {
   return 0;
 }
 
+static void compile_models(lm_batch* b, const unsigned char* mask, int all);
+
 int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_tables, const float* pair_tables,
                           int pair_floats, int n_variants) {
   HIPCHK(hipSetDevice(b->m->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   for (float** p : {&b->vrec, &b->vgt, &b->vgpt}) if (*p) { (void)hipFree(*p); *p = nullptr; }
   b->nvar = 0; b->gpt_floats = 0;
+  if (b->mc_ib) { (void)hipFree(b->mc_ib); (void)hipFree(b->mc_db); b->mc_ib = nullptr; b->mc_db = nullptr; }      // a pool replaces the compiler
   if (n_variants <= 0) {       // pool removed: the joint-parameter rows go with it when this call had created them
     if (b->dofprm_of_variants && b->dofprm && !b->drspec) { (void)hipFree(b->dofprm); b->dofprm = nullptr; }
     b->dofprm_of_variants = false;
@@ -676,6 +683,7 @@ int lm_set_model_variants(lm_batch* b, const float* records, const float* geom_t
 int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->m->device));
   if (b->nvar <= 0) return fail("the batch has no model variants");
+  if (b->mc_ib) return fail("the model compiler is on: every environment owns its slot (lm_compile_models draws a new model)");
   std::vector<int> cur(b->N);
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(cur.data(), b->var, sizeof(int) * b->N, hipMemcpyDeviceToHost));
@@ -691,6 +699,7 @@ int lm_set_variant_index(lm_batch* b, const int32_t* index, const uint8_t* mask)
 
 int lm_set_variant_rows(lm_batch* b, int rows_per_variant) {
   if (rows_per_variant < 0) return fail("rows_per_variant must be >= 0");
+  if (rows_per_variant > 0 && b->mc_ib) return fail("the model compiler is on: the model does not follow the reset-table row");
   if (rows_per_variant > 0 && (b->nvar <= 0 || b->table_rows != b->nvar * rows_per_variant))
     return fail("the reset table must hold n_variants blocks of rows_per_variant rows (set the variants and the table first)");
   b->var_rows = rows_per_variant;
@@ -702,6 +711,101 @@ int lm_get_variant_index(lm_batch* b, int32_t* index) {
   HIPCHK(hipStreamSynchronize(b->stream));
   if (b->nvar <= 0) { for (int e = 0; e < b->N; e++) index[e] = 0; return 0; }
   HIPCHK(hipMemcpy(index, b->var, sizeof(int) * b->N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lm_set_model_compiler(lm_batch* b, const int32_t* index, long long n_index, const double* data, long long n_data,
+                          const float* record, const float* geom_table, const float* pair_table, int pair_floats, uint64_t seed) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (!index || !data || n_index < lmc::kIntHead || n_data < lmc::kDblHead) return fail("the model compiler needs its program");
+  if ((unsigned)index[0] != lmc::kMagic) return fail("not a model-compiler program (lowering.model_compiler_tables)");
+  const int nv = index[1], nrb = index[2], ngs = index[3], nd = index[4], nslot = index[5], nrec = index[6], ncon = index[7], nbody = index[8];
+  if (nv != b->m->T.nv) return fail("the model-compiler program is of another model (nv)");
+  if (nv > lmc::kMaxNv || nrb > lmc::kMaxRbody || ngs > lmc::kMaxGslot || nd > lmc::kMaxDraw || nslot > lmc::kMaxSlot || nbody > lmc::kMaxBody || nd < 1)
+    return fail("the model-compiler program is beyond the device compiler's tables (lm_compile.h)");
+  const long long want_i = lmc::kIntHead + (long long)nd * lmc::kDrawInts + (long long)nrb * lmc::kRbInts + 2ll * nrec + (long long)ncon * lmc::kConInts;
+  const long long want_d = lmc::kDblHead + (long long)nd * lmc::kDrawDbls + (long long)nrb * lmc::kRbDbls + (long long)nbody * 6 * nv + (long long)nv * nv + 2ll * nv +
+                           (long long)nslot * 10 + 3ll * ngs;
+  if (want_i != n_index || want_d != n_data) return fail("the model-compiler program has the wrong size");
+  const int* recops = index + lmc::kIntHead + nd * lmc::kDrawInts + nrb * lmc::kRbInts;
+  for (int i = 0; i < nrec; i++)
+    if (recops[2 * i] < 0 || recops[2 * i] >= LM_IR_SIZE * LM_NCHAIN || recops[2 * i + 1] < 0 || recops[2 * i + 1] >= 3 * nv + 1 + nslot * 10)
+      return fail("the model-compiler program writes outside the inertial record");
+  const int* conops = recops + 2 * nrec;
+  for (int i = 0; i < ncon; i++) {
+    const int* op = conops + i * lmc::kConInts;
+    const long long last = (long long)op[1] + 12ll * op[2], cap = op[0] == 0 ? (long long)LM_GT_SIZE : (long long)pair_floats;
+    if (op[0] < 0 || op[0] > 1 || op[1] < 0 || op[2] < 1 || last >= cap || op[4] < 0 || op[4] >= ngs || op[5] < 0 || op[5] >= ngs ||
+        op[6] < 0 || op[6] >= nbody || op[7] < 0 || op[7] >= nbody)
+      return fail("the model-compiler program writes outside the contact tables");
+  }
+  // the tables: one slot per environment, every slot starts as the nominal model
+  if (lm_set_model_variants(b, nullptr, nullptr, nullptr, 0, 0)) return 1;
+  if (!record || !geom_table) return fail("the model compiler needs the nominal inertial record and geom table");
+  if ((pair_table != nullptr) != (b->m->n_gpt_floats > 0) || (pair_table && pair_floats != b->m->n_gpt_floats))
+    return fail("the geom-pair table does not match the model's");
+  if (!b->dofprm) {
+    if (lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;
+    b->dofprm_of_variants = true;
+  }
+  const int N = b->N;
+  const size_t nr = (size_t)LM_IR_SIZE * LM_NCHAIN, ng = (size_t)LM_GT_SIZE, np_ = (size_t)(pair_table ? pair_floats : 0);
+  float* nominal = nullptr;
+  HIPCHK(hipMalloc(&nominal, sizeof(float) * (nr + ng + np_)));
+  HIPCHK(hipMemcpy(nominal, record, sizeof(float) * nr, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(nominal + nr, geom_table, sizeof(float) * ng, hipMemcpyHostToDevice));
+  if (np_) HIPCHK(hipMemcpy(nominal + nr + ng, pair_table, sizeof(float) * np_, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->vrec, sizeof(float) * nr * N)); HIPCHK(hipMalloc(&b->vgt, sizeof(float) * ng * N));
+  if (np_) HIPCHK(hipMalloc(&b->vgpt, sizeof(float) * np_ * N));
+  lmc::replicate(b->vrec, nominal, (long long)nr, N, b->stream);
+  lmc::replicate(b->vgt, nominal + nr, (long long)ng, N, b->stream);
+  if (np_) lmc::replicate(b->vgpt, nominal + nr + ng, (long long)np_, N, b->stream);
+  if (!b->var) HIPCHK(hipMalloc(&b->var, sizeof(int) * N));
+  lmc::iota(b->var, N, b->stream);
+  HIPCHK(hipMalloc(&b->mc_ib, sizeof(int) * n_index)); HIPCHK(hipMemcpy(b->mc_ib, index, sizeof(int) * n_index, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->mc_db, sizeof(double) * n_data)); HIPCHK(hipMemcpy(b->mc_db, data, sizeof(double) * n_data, hipMemcpyHostToDevice));
+  for (void** p : {(void**)&b->vdirty, (void**)&b->mc_mask, (void**)&b->vgen, (void**)&b->vdraws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIPCHK(hipMalloc(&b->vdirty, N)); HIPCHK(hipMemset(b->vdirty, 0, N));
+  HIPCHK(hipMalloc(&b->mc_mask, N));
+  HIPCHK(hipMalloc(&b->vgen, sizeof(unsigned) * N)); HIPCHK(hipMemset(b->vgen, 0, sizeof(unsigned) * N));
+  HIPCHK(hipMalloc(&b->vdraws, sizeof(double) * (size_t)N * nd));
+  b->mc_ndraw = nd; b->mc_seed = seed; b->nvar = N; b->gpt_floats = (int)np_; b->var_rows = 0;
+  compile_models(b, nullptr, 1);                       // every environment starts on a model of its own
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipFree(nominal));
+  return 0;
+}
+
+int lm_compile_models(lm_batch* b, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (!b->mc_ib) return fail("the batch has no model compiler (lm_set_model_compiler)");
+  if (mask) HIPCHK(hipMemcpyAsync(b->mc_mask, mask, b->N, hipMemcpyHostToDevice, b->stream));
+  compile_models(b, mask ? b->mc_mask : nullptr, mask ? 0 : 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int lm_get_model_draws(lm_batch* b, double* draws, uint32_t* generation) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (!b->mc_ib) return fail("the batch has no model compiler (lm_set_model_compiler)");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (draws) HIPCHK(hipMemcpy(draws, b->vdraws, sizeof(double) * (size_t)b->N * b->mc_ndraw, hipMemcpyDeviceToHost));
+  if (generation) HIPCHK(hipMemcpy(generation, b->vgen, sizeof(unsigned) * b->N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lm_get_model_tables(lm_batch* b, int env, float* record, float* geom_table, float* pair_table) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (b->nvar <= 0) return fail("the batch has no model variants");
+  if (env < 0 || env >= b->N) return fail("environment out of range");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  int var = 0;
+  HIPCHK(hipMemcpy(&var, b->var + env, sizeof(int), hipMemcpyDeviceToHost));
+  if (record) HIPCHK(hipMemcpy(record, b->vrec + (size_t)var * LM_IR_SIZE * LM_NCHAIN, sizeof(float) * LM_IR_SIZE * LM_NCHAIN, hipMemcpyDeviceToHost));
+  if (geom_table) HIPCHK(hipMemcpy(geom_table, b->vgt + (size_t)var * LM_GT_SIZE, sizeof(float) * LM_GT_SIZE, hipMemcpyDeviceToHost));
+  if (pair_table && b->vgpt) HIPCHK(hipMemcpy(pair_table, b->vgpt + (size_t)var * b->gpt_floats, sizeof(float) * b->gpt_floats, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -732,7 +836,7 @@ static KArgs make_args(lm_batch* b) {
   KArgs a;
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
-  a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
+  a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.vdirty = b->mc_ib ? b->vdirty : nullptr; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
   a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
@@ -756,12 +860,21 @@ static KArgs make_args(lm_batch* b) {
   return a;
 }
 
+static void compile_models(lm_batch* b, const unsigned char* mask, int all) {
+  lmc::Args c;
+  c.ib = b->mc_ib; c.db = b->mc_db; c.N = b->N; c.seed = b->mc_seed; c.env_offset = b->env_offset; c.dirty = b->vdirty; c.mask = mask; c.all = all;
+  c.gen = b->vgen; c.vrec = b->vrec; c.vgt = b->vgt; c.vgpt = b->vgpt; c.gpt_floats = b->gpt_floats; c.slack = b->slack; c.draws = b->vdraws;
+  lmc::launch(c, b->stream);
+}
+
 static void launch_step(lm_batch* b, const KArgs& a) {
   // the per-thread HIP error state is shared with whoever else uses HIP in this process (PyTorch probes peers, pointer
   // attributes ...): drop what they left behind so that the check after the launch reports OUR launch
   (void)hipGetLastError();
   g_launch_err = nullptr;
   launch_variant<false>(b, a);
+  // the environments that restarted an episode in this launch get their fresh model before the next one (stream order)
+  if (b->mc_ib && b->auto_reset && b->table_rows > 0) compile_models(b, nullptr, 0);
 }
 
 static int drain_stats(lm_batch* b) {
@@ -843,6 +956,7 @@ int lm_rollout_fused(lm_batch* b, int n_steps, int steps_per_launch, int action_
   if (steps_per_launch < 1) return fail("steps_per_launch must be >= 1");
   static const bool no_replicas = LM_PROBE_ENV("LM_NO_REPLICAS") != nullptr;
   if (b->epb > 4 || no_replicas || !family_has_replicas(b)) steps_per_launch = 1;     // no fused kernels for the full-wave layout
+  if (b->mc_ib) steps_per_launch = 1;       // a restart inside a launch needs its fresh model before the episode's first step
   KArgs a = make_args(b);
   a.action = nullptr; a.action_mode = action_mode == 0 ? 1 : 2;   // kernel: 1 = zero action, 2 = random
   a.seed = b->seed ^ (seed * 0x9E3779B97F4A7C15ull);

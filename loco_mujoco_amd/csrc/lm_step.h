@@ -125,6 +125,8 @@ struct KArgs {
   // tables [nvar][gpt_floats] (or null), and the variant of every environment [N] (redrawn at a device-side restart)
   const float* vrec; const float* vgt; const float* vgpt; int* var; int nvar, gpt_floats;
   int var_rows;             // > 0: the reset table is nvar blocks of var_rows rows, the variant follows the row (lm_set_variant_rows)
+  unsigned char* vdirty;    // [N] or null: the model compiler is on (lm_set_model_compiler: slot e belongs to environment e) — a device-side
+                            // restart asks for a FRESH model here instead of drawing an index; lm_compile.hip writes it after the launch
   float* qpos; float* qvel; float* warm; float* goal;   // SoA [dim][N]
   int* ep_step; unsigned* ep_count;
   const float* action;      // [N][nu] or null
@@ -563,7 +565,8 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       if (DR == 2 && a.nvar > 1 && c == 0 && valid) {
         // new episode, new model variant (reference base.py:183-185: a freshly randomised model per reset)
         const unsigned long long rv = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ 0xA24BAED4963EE407ull);
-        a.var[e] = (a.var_rows > 0) ? (int)((r % (unsigned long long)a.table_rows) / (unsigned long long)a.var_rows)      // the model of the row drawn above
+        if (a.vdirty) a.vdirty[e] = 1;
+        else a.var[e] = (a.var_rows > 0) ? (int)((r % (unsigned long long)a.table_rows) / (unsigned long long)a.var_rows)      // the model of the row drawn above
                                     : (int)(rv % (unsigned long long)a.nvar);
       }
       if (DR && a.drspec && valid) {

@@ -48,7 +48,7 @@ class LocoEnv:
                  n_substeps=10, reward_type=None, reward_params=None, traj_params=None, random_start=True,
                  init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
                  use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
-                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=32, model_variants_per_reset=4,
+                 N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=None, model_variants_per_reset=4,
                  **viewer_params):
         self._model = model
         # models compiled per batch for the randomisation rules that change compile-time constants (inertial, armature, geom
@@ -57,6 +57,12 @@ class LocoEnv:
         # models, of which every reset() REPLACES `model_variants_per_reset` (round-robin; 0 = fixed pool), so that a long training
         # is not limited to the first pool; a batch of at most that many environments runs one brand-new model per environment
         # and episode — the reference's behaviour exactly. Device-side restarts (auto-reset inside a rollout) draw from the pool.
+        # Round 5: `n_model_variants=None` (the default) takes the MODEL COMPILER ON THE DEVICE instead (csrc/lm_compile.hip): every
+        # environment draws and compiles a model of its own at reset() and at every device-side restart — the reference's behaviour,
+        # at any batch size. An explicit `n_model_variants` keeps the host-compiled pool (and several models in one batch always do).
+        self._compiler_wanted = n_model_variants is None
+        self._pending_compile = False
+        n_model_variants = 32 if n_model_variants is None else n_model_variants
         self._n_model_variants = int(n_model_variants)
         self._variants_per_reset = int(model_variants_per_reset)
         self._variant_models = {}          # model index -> [CompiledModel] (kept for inspection and the parity tests)
@@ -173,11 +179,30 @@ class LocoEnv:
             if self._pooled:
                 from ..lowering import variant_tables
                 self._backend.set_model_variants([variant_tables(nominal, self._chain_model(m)) for m in self._models])
+            elif self._use_model_compiler:
+                from ..lowering import model_compiler_tables, variant_tables
+                ops, svd = self._domain_rand.model_draw_ops()
+                ib, db, self._compiler_info = model_compiler_tables(self._model, self._device_task(), ops, svd)
+                self._backend.set_model_compiler((ib, db), variant_tables(nominal, nominal), seed=int(self._domain_rand_rs.randint(0, 2 ** 31 - 1)))
             elif self._domain_rand is not None and self._domain_rand.has_model_rules:
                 self._ensure_variant_pool()
                 self._backend.set_model_variants(self._variant_tables)
                 self._variant_dirty = False
         return self._backend
+
+    @property
+    def _use_model_compiler(self):
+        """True if the randomisation rules that change compile-time constants run through the model compiler on the device."""
+        return bool(self._compiler_wanted and self._domain_rand is not None and self._domain_rand.has_model_rules
+                    and not self._blocks and not self._pooled and self._n_models == 1)
+
+    def model_of_env(self, e):
+        """The compiled model environment ``e`` currently runs on when the device compiles the models: rebuilt on the host from the
+        draws the device reports (``lm_get_model_draws``) — for inspection, the parity tests and the oracle."""
+        if not self._use_model_compiler:
+            raise ValueError("the environments of this batch do not compile their models on the device")
+        draws, _ = self.backend.get_model_draws()
+        return self._domain_rand.variant_from_draws(draws[int(e)])
 
     # the current model's pool (see __init__)
     def _pool(self):
@@ -237,7 +262,11 @@ class LocoEnv:
     def refresh_model_variants(self, count=None):
         """Replace `count` models of the pool (default: all of them) by fresh draws, round-robin. Returns the pool indices that
         were replaced. Takes effect on the device at the next upload of a reset (environments in mid-episode on a replaced index
-        would change model: call it where every environment restarts, as reset() does)."""
+        would change model: call it where every environment restarts, as reset() does). With the model compiler on the device: a
+        fresh model for EVERY environment, at once."""
+        if self._use_model_compiler:
+            self.backend.compile_models()
+            return np.arange(self.n_envs)
         self._ensure_variant_pool()
         k = self._n_model_variants if count is None else min(int(count), self._n_model_variants)
         if k <= 0:
@@ -410,7 +439,9 @@ class LocoEnv:
             fresh = {}
             # the models whose environments restart: every block's model, or the one this episode drew
             idxs = list(range(self._n_models)) if self._blocks else [self._current_model_idx]
-            if self._domain_rand.has_model_rules:
+            if self._use_model_compiler:
+                self._pending_compile = True            # drawn and compiled on the device when the state goes up
+            elif self._domain_rand.has_model_rules:
                 for idx in idxs:
                     if self._blocks:
                         self._select_model(idx)
@@ -424,7 +455,7 @@ class LocoEnv:
             state = np.random.get_state()
             np.random.set_state(self._domain_rand_rs.get_state())
             self._pending_dof_params = self._domain_rand.sample(self.n_envs)
-            if self._domain_rand.has_model_rules:
+            if self._domain_rand.has_model_rules and not self._use_model_compiler:
                 self._pending_variants = np.zeros(self.n_envs, dtype=np.int64)
                 for idx in idxs:
                     envs = self._model_envs(idx) if self._blocks else np.arange(self.n_envs)
@@ -594,11 +625,14 @@ class LocoEnv:
                 self._variant_dirty = False
             if getattr(self, "_pending_variants", None) is not None:
                 b.set_variant_index(self._pending_variants[envs])
+            if self._pending_compile:
+                b.compile_models()               # reset(): a freshly drawn model per environment (reference base.py:183-185)
             goal = self._goal_rows()
             if goal is not None:
                 b.set_goal(goal[:len(envs)])
         self._pending_dof_params = None
         self._pending_variants = None
+        self._pending_compile = False
         self._pending_state = False
 
     def _goal_rows(self):

@@ -404,6 +404,8 @@ def lower(m, task):
     n_grf = 3 * len(grf_groups)
     grf_obs_base = task["nobs"] - n_grf
 
+    blk_geom = {}                      # id(geom block) -> model geom (the blocks live until the table is written)
+
     def geom_blocks(w, link_index):
         """floor-collidable geoms of weld group w: (supported blocks, unsupported blocks)."""
         sup, unsup = [], []
@@ -440,6 +442,7 @@ def lower(m, task):
                 blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
                 blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
                 _fill_contact_params(blk, m, b, dim, fr)
+                blk_geom[id(blk)] = g
                 sup.append(blk)
                 continue
             if t == mjcf.GEOM_MESH:
@@ -464,10 +467,15 @@ def lower(m, task):
             blk[G_K], blk[G_B] = _kb(solref, solimp, m.timestep)
             blk[G_S0:G_S0 + 5] = _clip_solimp(solimp)
             _fill_contact_params(blk, m, b, dim, fr)
+            blk_geom[id(blk)] = g
             sup.append(blk)
         return sup, unsup
 
     info = dict(root=root, chains=chains, shared_first=shared_first)
+    # provenance of everything a model VARIANT changes (model_compiler_tables): record rows of the dofs [(lane or -1, link or root dof
+    # index, dof, copy)], weld group behind every inertial slot [(lane or -1, link, body)], model geom behind every geom-table record
+    # [(slot, lane, geom)], geoms behind every geom-pair record [(geom a, geom b)]
+    prov = info["variant_provenance"] = dict(dofs=[], links=[(-1, -1, root)], geoms=[], pairs=[])
     mesh_verts = []                    # hull vertices of the mesh colliders, link frame (device table, global memory)
     mesh_nbr_first, mesh_nbr = [], []  # per vertex: start of its neighbour list in the neighbour table (hull-local indices, -1 ends)
     hull_slot = {}                     # geom -> (first vertex in the table, vertices in the link frame)
@@ -513,6 +521,7 @@ def lower(m, task):
         d = m.body_jntadr[root] + k
         fill_dof(rb[R_DOFS + k * D_SIZE:R_DOFS + (k + 1) * D_SIZE], d, qobs, vobs, is_root=True)
         dof_to_lane[d] = -2
+        prov["dofs"].append((-1, k, int(d), False))
     sup, unsup = geom_blocks(root, 0)
     if any(sb[G_GRF] >= 0 for sb in sup):
         raise UnsupportedModel("foot-force group on the root body")
@@ -549,6 +558,7 @@ def lower(m, task):
             lb = blk[C_LINKS + li * LINK_SIZE:C_LINKS + (li + 1) * LINK_SIZE]
             copy = c in shared_first and li == 0
             fill_dof(lb[:D_SIZE], d, qobs, vobs)
+            prov["dofs"].append((c, li, int(d), bool(copy)))
             if copy:
                 # the massless copy of the shared link: same joint and dof index (both lanes load the same q, v), but everything
                 # that acts ON the dof — damping, stiffness, armature, friction loss, limit, motor, observation, termination —
@@ -571,6 +581,7 @@ def lower(m, task):
                 ex[L_R0:L_R0 + 9] = np.eye(3).reshape(9)
             if last and not copy:
                 mass, com, inertia = merged_inertial(b)
+                prov["links"].append((c, li, int(b)))
                 ex[L_MASS], ex[L_CX:L_CX + 3] = mass, com
                 ex[L_IXX:L_IXX + 6] = [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1], inertia[0, 2],
                                        inertia[1, 2]]
@@ -617,6 +628,7 @@ def lower(m, task):
             standing.append((c, bottom, cap))
         for i, gblk in enumerate(geoms):
             gt[(i * G_SIZE + np.arange(G_SIZE)) * NCHAIN + c] = gblk
+            prov["geoms"].append((i, c, blk_geom[id(gblk)]))
             chain_prune[c].append([gblk[G_LINK], gblk[G_PX], gblk[G_PY], gblk[G_PZ], gblk[G_RBOUND], gblk[G_TYPE]])
         # the geoms of one link form a group with a bounding sphere: a link far above the floor costs one test per pass
         i = 0
@@ -773,7 +785,7 @@ def lower(m, task):
                      # six-link chains (UnitreeG1, UnitreeH1 with its arms): the regular kernels only DETECT (a geom pair within reach
                      # hands the control step to the family's replay kernel, which has the pair pass: csrc/lm_family.hip)
                      or (m.cone == mjcf.CONE_PYRAMIDAL and max_links == 6 and m.integrator == mjcf.INT_EULER and not muscles)))
-    pair_tab = _self_collision_tables(m, root, chains, kin, register_hull, hull_block) if pairs_on else None
+    pair_tab = _self_collision_tables(m, root, chains, kin, register_hull, hull_block, prov["pairs"]) if pairs_on else None
     h[H_OFF_LPAIR] = off
     off_before_lp = off
     gpt, bpt = np.zeros(0), np.zeros(0)
@@ -907,7 +919,7 @@ def _engine_uses_ccd(t1, t2):
     return t1 == mjcf.GEOM_CYLINDER and t2 in (mjcf.GEOM_CYLINDER, mjcf.GEOM_BOX)
 
 
-def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
+def _self_collision_tables(m, root, chains, kin, register_hull, hull_block, pair_prov=None):
     """
     Tables of the self-collision path (kernels compiled with PAIRS): candidate geom pairs after the engine's filters (different
     weld groups, not parent and child, contype / conaffinity — the floor is handled elsewhere), grouped by link pair.
@@ -1081,6 +1093,8 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block):
                     rec[GP_RR1], rec[GP_RR2] = rr1, rr1 * fr[0] * fr[0] / (fr[1] * fr[1])
                     rec[GP_RR3:GP_RR3 + 3] = [rr1 * fr[0] * fr[0] / (fr[k] * fr[k]) for k in (2, 3, 4)]
                 records.append(rec)
+                if pair_prov is not None:
+                    pair_prov.append((int(a), int(b)))
                 margin_max = max(margin_max, margin)
                 bp_margin = max(bp_margin, margin)
             bp[BP_MARGIN] = bp_margin
@@ -1127,3 +1141,157 @@ def _count_self_pairs(m):
             if (m.geom_contype[g1] & m.geom_conaffinity[g2]) or (m.geom_contype[g2] & m.geom_conaffinity[g1]):
                 n += 1
     return n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The model compiler on the device (csrc/lm_compile.hip): a fresh model per device-side restart
+# ---------------------------------------------------------------------------------------------------------------
+# The reference re-compiles its model at every reset (base.py:183-185, utils/domain_randomization.py:219-227). What a re-compile
+# changes on this path is the data of `variant_tables`; the device writes it per environment from that environment's own draws:
+# the draws (`JointRandomization.model_draw_ops`), the inertial numbers of the drawn bodies (mjcf.inertia_from_spec), the mass matrix
+# at qpos0 (mjcf.mass_matrix: a sum over bodies of J^T I J, linear in the drawn masses / inertia tensors, so the bodies without a
+# rule are summed here once), its inverse -> dof_invweight0 / body_invweight0 / meaninertia (mjcf._set_const), and from those the
+# record fields and the contact constants exactly as `lower` writes them. This function prepares the constants of that program.
+MC_MAGIC = 0x4C4D4D43  # "LMMC"
+MC_IH_SIZE, MC_DH_SIZE = 16, 8
+MC_RB_INTS, MC_RB_DBLS = 4, 55
+MC_DRAW_INTS, MC_DRAW_DBLS = 4, 2
+MC_CON_INTS = 8
+MC_NSLOT = 1 + NCHAIN * MAXC
+
+
+def model_compiler_tables(m, task, draw_ops, svd):
+    """
+    ``(int32 blob, float64 blob, info)`` for ``lm_set_model_compiler``: the constants of the device-side model compiler for model
+    ``m`` lowered with ``task`` and the draws ``draw_ops`` / ``svd`` of ``JointRandomization.model_draw_ops``.
+
+    int32:  header [magic, nv, n_rbody, n_gslot, n_draw, n_slot, n_recop, n_conop, n_body, pyramidal, balanceinertia, 0...]
+            draws   [n_draw][kind, target, index, component]      (index: dof | drawn-body index | friction slot)
+            rbodies [n_rbody][body, inertial kind, inertial slot, has singular values]
+            recops  [n_recop][destination in the record (row * NCHAIN + lane), source value]
+            conops  [n_conop][table (0 geom table, 1 pair table), index of the TRAN entry, stride between fields, dim + 16 * mix
+                              (0 max, 1 first, 2 second) + 256 * pair, friction slot a, friction slot b, body a, body b]
+    float64: header [impratio, boundmass, boundinertia, MINVAL, nv as float, 0...]
+            draws [n_draw][a, b]; rbodies [n_rbody][mass, vals 6, R(quat) 9, U 9, Vt 9, com in the slot frame 3, R in the slot
+            frame 9, R in the world at qpos0 9]; jac [n_body][6][nv] at the bodies' centres of mass (qpos0); mbase [nv][nv] (bodies
+            without a rule, no armature); armature [nv]; friction-loss factor (1-d0)/d0 [nv] (< 0: no row); slot base [n_slot][mass,
+            mass*com 3, inertia about the slot origin 6]; friction [n_gslot][3]
+    Values the device gathers the record from: ARM[nv] INVW[nv] RFL[nv] SCALE LINK[n_slot][10].
+    """
+    from .utils.domain_randomization import JointRandomization as JR
+    chain, info = lower(m, task)
+    prov = info["variant_provenance"]
+    nv, nb = m.nv, m.nbody
+    kin = mjcf.forward_kinematics(m, m.qpos0)
+    jac = mjcf.body_jacobians(m, kin, kin["xipos"])            # [nbody][6][nv]: rows 0-2 translation at the COM, 3-5 rotation
+    rbodies = sorted(set(op[4] for op in draw_ops if op[3] in (JR.TARGET_MASS, JR.TARGET_DIAGINERTIA, JR.TARGET_SINGULAR)))
+    rb_index = {b: j for j, b in enumerate(rbodies)}
+    gslots = {}                                                 # model geom -> friction slot
+
+    def gslot(g):
+        return gslots.setdefault(int(g), len(gslots))
+
+    # inertial slots: 0 = root body, 1 + lane * MAXC + link
+    slot_of_weld = {}
+    for c, li, w in prov["links"]:
+        slot_of_weld[int(w)] = 0 if c < 0 else 1 + c * MAXC + li
+
+    def rel_pose(b):
+        w = m.body_weldid[b]
+        rw = kin["xmat"][w]
+        return rw.T @ (kin["xpos"][b] - kin["xpos"][w]), rw.T @ kin["xmat"][b]
+
+    slot_base = np.zeros((MC_NSLOT, 10))
+    mbase = np.zeros((nv, nv))
+    for b in range(1, nb):
+        w = int(m.body_weldid[b])
+        if b in rb_index:
+            continue
+        jp, jr = jac[b, 0:3], jac[b, 3:6]
+        iw = kin["xmat"][b] @ m.body_inertia[b] @ kin["xmat"][b].T
+        mbase += m.body_mass[b] * jp.T @ jp + jr.T @ iw @ jr
+        if w == 0:
+            continue
+        if w not in slot_of_weld:
+            raise UnsupportedModel("body %s outside the inertial slots" % m.body_names[b])
+        p, r = rel_pose(b)
+        cb = p + r @ m.body_ipos[b]
+        io = r @ m.body_inertia[b] @ r.T + m.body_mass[b] * (cb @ cb * np.eye(3) - np.outer(cb, cb))
+        slot_base[slot_of_weld[w]] += np.concatenate([[m.body_mass[b]], m.body_mass[b] * cb,
+                                                       [io[0, 0], io[1, 1], io[2, 2], io[0, 1], io[0, 2], io[1, 2]]])
+    ints = [np.zeros(MC_IH_SIZE, dtype=np.int64)]
+    dbls = [np.zeros(MC_DH_SIZE)]
+    # draws
+    di, dd = np.zeros((len(draw_ops), MC_DRAW_INTS), dtype=np.int64), np.zeros((len(draw_ops), MC_DRAW_DBLS))
+    for i, (kind, a, b, target, index, comp) in enumerate(draw_ops):
+        idx = index if target == JR.TARGET_ARMATURE else (gslot(index) if target == JR.TARGET_FRICTION else rb_index[index])
+        di[i], dd[i] = (kind, target, idx, comp), (a, b)
+    # drawn bodies
+    ri, rd = np.zeros((len(rbodies), MC_RB_INTS), dtype=np.int64), np.zeros((len(rbodies), MC_RB_DBLS))
+    for j, b in enumerate(rbodies):
+        kind = int(m.body_inertial_kind[b])
+        if kind == 0:
+            raise ValueError("body %s has no <inertial> element" % m.body_names[b])
+        w = int(m.body_weldid[b])
+        if w not in slot_of_weld:
+            raise UnsupportedModel("body %s outside the inertial slots" % m.body_names[b])
+        ri[j] = (b, kind, slot_of_weld[w], 1 if b in svd else 0)
+        p, r = rel_pose(b)
+        u, vt = svd.get(b, (np.eye(3), np.eye(3)))
+        rd[j] = np.concatenate([[m.body_xml_mass[b]], m.body_inertial_vals[b], mjcf.quat_to_mat(m.body_inertial_quat[b]).ravel(),
+                                np.asarray(u).ravel(), np.asarray(vt).ravel(), p + r @ m.body_ipos[b], r.ravel(), kin["xmat"][b].ravel()])
+    # record gather: which value lands where
+    V_ARM, V_INVW, V_RFL, V_SCALE, V_LINK = 0, nv, 2 * nv, 3 * nv, 3 * nv + 1
+    recops = []
+    fd = -np.ones(nv)
+    for c, li, d, copy in prov["dofs"]:
+        fl = m.dof_frictionloss[d]
+        if fl > 0 or m.dof_invweight0[d] > 0:
+            si = _clip_solimp(m.dof_solimp[d])
+            d0 = si[0] if not (si[0] == si[1] or si[2] <= MINVAL) else 0.5 * (si[0] + si[1])
+            fd[d] = (1 - d0) / d0
+        row = (IR_ROOT_DOF + 3 * li) if c < 0 else (li * IR_LINK + 10)
+        for lane in (range(NCHAIN) if c < 0 else [c]):
+            if not copy:
+                recops.append((row * NCHAIN + lane, V_ARM + d))
+            recops.append(((row + 1) * NCHAIN + lane, V_INVW + d))
+            if fd[d] >= 0:
+                recops.append(((row + 2) * NCHAIN + lane, V_RFL + d))
+    for c, li, w in prov["links"]:
+        s = slot_of_weld[int(w)]
+        row = IR_ROOT if c < 0 else li * IR_LINK
+        for lane in (range(NCHAIN) if c < 0 else [c]):
+            recops += [((row + f) * NCHAIN + lane, V_LINK + s * 10 + f) for f in range(10)]
+    recops += [(IR_SCALE * NCHAIN + lane, V_SCALE) for lane in range(NCHAIN)]
+    # contact constants
+    floor = [g for g in range(m.ngeom) if m.geom_type[g] == mjcf.GEOM_PLANE][0]
+
+    def mix_mode(a, b):
+        pa, pb = m.geom_priority[a], m.geom_priority[b]
+        return 0 if pa == pb else (1 if pa > pb else 2)
+
+    conops = []
+    for i, c, g in prov["geoms"]:
+        dim = _mix_with_floor(m, g, floor)[0]
+        conops.append((0, (i * G_SIZE + G_TRAN) * NCHAIN + c, NCHAIN, dim + 16 * mix_mode(g, floor), gslot(g), gslot(floor),
+                       int(m.geom_body[g]), 0))
+    for k, (a, b) in enumerate(prov["pairs"]):
+        dim = _mix_with_floor(m, a, b)[0]
+        conops.append((1, k * GPAIR_SIZE + GP_TRAN, 1, dim + 16 * mix_mode(a, b) + 256, gslot(a), gslot(b),
+                       int(m.geom_body[a]), int(m.geom_body[b])))
+    assert G_MU - G_TRAN == GP_MU - GP_TRAN == 2 and G_F0 - G_TRAN == GP_F0 - GP_TRAN == 3 and G_RR1 - G_TRAN == GP_RR1 - GP_TRAN == 8
+    fric = np.zeros((len(gslots), 3))
+    for g, s in gslots.items():
+        fric[s] = m.geom_friction[g]
+    pyramidal = m.cone != mjcf.CONE_ELLIPTIC
+    head_i, head_d = ints[0], dbls[0]
+    head_i[:11] = (MC_MAGIC, nv, len(rbodies), len(gslots), len(draw_ops), MC_NSLOT, len(recops), len(conops), nb, int(pyramidal),
+                   int(bool(m.compiler_bounds[2])))
+    head_d[:5] = (m.impratio, m.compiler_bounds[0], m.compiler_bounds[1], MINVAL, nv)
+    ints += [di.ravel(), ri.ravel(), np.asarray(recops, dtype=np.int64).reshape(-1, 2).ravel(),
+             np.asarray(conops, dtype=np.int64).reshape(-1, MC_CON_INTS).ravel()]
+    dbls += [dd.ravel(), rd.ravel(), np.asarray(jac, dtype=np.float64)[:, :6].ravel(), mbase.ravel(), np.asarray(m.dof_armature, dtype=np.float64),
+             fd, slot_base.ravel(), fric.ravel()]
+    out_info = dict(n_draw=len(draw_ops), n_rbody=len(rbodies), n_gslot=len(gslots), n_recop=len(recops), n_conop=len(conops),
+                    rbodies=rbodies, gslots=dict(gslots))
+    return np.concatenate(ints).astype(np.int32), np.concatenate(dbls).astype(np.float64), out_info

@@ -212,6 +212,109 @@ class JointRandomization:
                     # compiler prefers over geom masses — the rule changes nothing
         return mjcf.model_variant(m, body_mass=mass, body_inertial=inertial, dof_armature=armature, geom_friction=friction)
 
+    # ---- the same rules as a flat list of scalar draws: what the device-side model compiler executes per restart
+    TARGET_ARMATURE, TARGET_MASS, TARGET_DIAGINERTIA, TARGET_SINGULAR, TARGET_FRICTION = 0, 1, 2, 3, 4
+
+    def model_draw_ops(self, model=None):
+        """
+        The rules of :meth:`sample_model_variant` as scalar draws in the SAME order (``np.random`` draws a vector as consecutive
+        scalars): ``[(kind, a, b, target, index, component)]`` with ``kind`` KIND_CLIPPED_NORMAL / KIND_UNIFORM / KIND_NORMAL (both
+        normals are clipped at 0), ``target`` TARGET_*: armature of dof ``index``; mass / diaginertia component / singular value
+        (of the upper-triangular fullinertia matrix) of body ``index``; friction component of geom ``index``. Second result:
+        ``{body: (U, Vt)}`` of the fullinertia rules. Raises what the sampler asserts.
+        """
+        m = self._model if model is None else model
+        ops, svd = [], {}
+        for d, kind, a, b in self.armature_rules:
+            ops.append((kind, a, b, self.TARGET_ARMATURE, d, 0))
+
+        def scalar(value, rule, what, name):
+            if "sigma" in rule:
+                return (KIND_CLIPPED_NORMAL, float(value), float(rule["sigma"]))
+            if "uniform_range" in rule:
+                low, high = rule["uniform_range"]
+                assert high > low, "uniform_range for body %s wrongly specified, because high < low" % name
+                assert low >= 0.0, "uniform_range for body %s wrongly specified, because low < 0.0" % name
+                return (KIND_UNIFORM, float(low), float(high))
+            delta = rule["uniform_range_delta"]
+            assert type(delta) == float, "uniform_range_delta parameter for %s should be a float, but found %s." % (name, type(delta))
+            assert value - delta > 0.0, "uniform_range_delta param (%g) for body %s is bigger than %s (%g)." % (delta, name, what, value)
+            return (KIND_UNIFORM, float(value - delta), float(value + delta))
+
+        for b, irules, grules in self.body_rules:
+            name = m.body_names[b]
+            for param, rule in irules:
+                if param == "mass":
+                    ops.append(scalar(float(m.body_xml_mass[b]), rule, "mass", name) + (self.TARGET_MASS, b, 0))
+                    continue
+                assert "uniform_range_delta" in rule, ("domain randomization of inertia only allowed using uniform_range_delta, "
+                                                       "but found %s." % list(rule.keys()))
+                delta = rule["uniform_range_delta"]
+                assert type(delta) == float, "uniform_range_delta parameter for %s should be a float, but found %s." % (name, type(delta))
+                kind = int(m.body_inertial_kind[b])
+                if param == "diaginertia":
+                    assert kind == 1, "Randomizing diaginertia not allowed if not specified in the xml."
+                    d0 = m.body_inertial_vals[b, :3]
+                    assert np.all(d0 - delta > 0.0), "Error for body %s. uniform_range_delta param (%g) is bigger than the smallest singular values (%g)." % (name, delta, d0.min())
+                    ops += [(KIND_UNIFORM, float(d0[k] - delta), float(d0[k] + delta), self.TARGET_DIAGINERTIA, b, k) for k in range(3)]
+                elif param == "fullinertia":
+                    assert kind == 2, "Randomizing fullinertia not allowed if not specified in the xml."
+                    fi = m.body_inertial_vals[b]
+                    triu = np.array([[fi[0], fi[3], fi[4]], [0.0, fi[1], fi[5]], [0.0, 0.0, fi[2]]])
+                    u, sv, vh = np.linalg.svd(triu, compute_uv=True)
+                    assert np.all(sv - delta > 0.0), "Error for body %s. uniform_range_delta param (%g) is bigger than the smallest singular values (%g)." % (name, delta, sv.min())
+                    svd[b] = (u, vh)
+                    ops += [(KIND_UNIFORM, float(sv[k] - delta), float(sv[k] + delta), self.TARGET_SINGULAR, b, k) for k in range(3)]
+            for g, prs in grules:
+                for param, rule in prs:
+                    if param != "friction":
+                        continue
+                    fr = np.asarray(m.geom_friction[g], dtype=np.float64)
+                    if "sigma" in rule:
+                        assert len(rule["sigma"]) == 3, "sigma for randomizing friction in geom of body %s needs to be 3-dimensional" % name
+                        ops += [(KIND_CLIPPED_NORMAL, float(fr[k]), float(rule["sigma"][k]), self.TARGET_FRICTION, g, k) for k in range(3)]
+                    elif "uniform_range_delta" in rule:
+                        delta = np.asarray(rule["uniform_range_delta"], dtype=np.float64)
+                        assert len(delta) == 3, "uniform_range_delta for randomizing friction in geom of body %s needs to be 3-dimensional" % name
+                        assert np.all(fr >= delta), "uniform_delta range is bigger than friction coefficient. Error occurred in body %s." % name
+                        ops += [(KIND_UNIFORM, float(fr[k] - delta[k]), float(fr[k] + delta[k]), self.TARGET_FRICTION, g, k) for k in range(3)]
+        return ops, svd
+
+    def variant_from_draws(self, values, model=None):
+        """The compiled model of ONE set of draws (``values[i]`` = the value op ``i`` of :meth:`model_draw_ops` drew): what
+        :meth:`sample_model_variant` returns when ``np.random`` draws these numbers. The device-side model compiler reports its draws
+        (``lm_get_model_draws``); this is the host's (and the oracle's) model of that environment."""
+        from .. import mjcf
+        m = self._model if model is None else model
+        ops, svd = self.model_draw_ops(m)
+        assert len(values) == len(ops)
+        armature, mass, diag, sing, friction = {}, {}, {}, {}, {}
+        for (kind, a, b, target, index, comp), v in zip(ops, values):
+            v = float(v)
+            if target == self.TARGET_ARMATURE:
+                armature[index] = v
+            elif target == self.TARGET_MASS:
+                mass[index] = v
+            elif target == self.TARGET_DIAGINERTIA:
+                diag.setdefault(index, m.body_inertial_vals[index, :3].copy())[comp] = v
+            elif target == self.TARGET_SINGULAR:
+                sing.setdefault(index, np.zeros(3))[comp] = v
+            else:
+                friction.setdefault(index, np.asarray(m.geom_friction[index], dtype=np.float64).copy())[comp] = v
+        inertial = {b: np.concatenate([d, np.zeros(3)]) for b, d in diag.items()}
+        for b, sv in sing.items():
+            t = svd[b][0] @ np.diag(sv) @ svd[b][1]
+            inertial[b] = np.array([t[0, 0], t[1, 1], t[2, 2], t[0, 1], t[0, 2], t[1, 2]])
+        return mjcf.model_variant(m, body_mass=mass, body_inertial=inertial, dof_armature=armature, geom_friction=friction)
+
+    @staticmethod
+    def draw_op(op):
+        """One scalar draw of an op with ``np.random`` (the reference's generator)."""
+        kind, a, b = op[:3]
+        if kind == KIND_UNIFORM:
+            return float(np.random.uniform(a, b))
+        return float(np.clip(np.random.normal(a, b), 0.0, np.inf))
+
     def sample(self, n=1):
         """(3, n, nv) damping / stiffness / frictionloss drawn with ``np.random`` (the reference's generator)."""
         out = np.repeat(self.nominal[:, None, :], n, axis=1)

@@ -1714,6 +1714,130 @@ def test_model_variants_redrawn_at_device_side_restarts():
     assert np.array_equal(ia, np.concatenate([ib0, ib1])) and np.array_equal(qa, np.concatenate([qb0, qb1]))
 
 
+_COMPILER_RULES = {
+    "UnitreeA1.simple": "Inertial:\n  trunk:\n    mass: {sigma: 1.0}\n    fullinertia:\n      uniform_range_delta: 0.002\n"
+                        "Geoms:\n  FR_calf:\n    friction:\n      sigma: [0.1, 0.001, 0.00001]\n"
+                        "Joints:\n  FR_hip_joint:\n    armature:\n      uniform_range: [0.01, 0.02]\n",
+    "HumanoidTorque.walk": "Default:\n  Inertial:\n    mass:\n      sigma: 0.3\n  Geoms:\n    friction:\n      sigma: [0.1, 0.001, 0.00001]\n",
+}
+
+
+@pytest.mark.parametrize("task", ["Talos.walk", "UnitreeA1.simple", "HumanoidTorque.walk"])
+def test_device_model_compiler_writes_the_host_compilers_tables(task, tmp_path):
+    """The model compiler on the device (csrc/lm_compile.hip; the default for randomisation rules that change compile-time constants):
+    every environment draws its own armature / mass / diaginertia / fullinertia / friction and compiles its own tables. The tables
+    each environment RUNS ON (read back) against the host path for the SAME draws — mjcf.model_variant (M(qpos0), its inverse,
+    dof_invweight0 / body_invweight0 / meaninertia in float64), lowering.lower, lowering.variant_tables — to float32 rounding.
+    Talos: the golden rule file; the quadruped: fullinertia through its singular values, elliptic cones, the geom-pair table;
+    the humanoid: every body and every geom drawn, the compiler's boundinertia / balanceinertia, pyramids."""
+    from loco_mujoco_amd import lowering
+    if task in _COMPILER_RULES:
+        cfg = tmp_path / "dr.yaml"
+        cfg.write_text(_COMPILER_RULES[task])
+        cfg = str(cfg)
+    else:
+        cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    n = 12
+    env = LocoEnv.make(task, debug=True, n_envs=n, domain_randomization_config=cfg)
+    assert env._use_model_compiler
+    env.reset()
+    nu = len(env._action_indices)
+    env.step(np.zeros((n, nu)))
+    b = env.backend
+    draws, gen = b.get_model_draws()
+    assert b.n_variants == n and (gen == 2).all()            # one model when the compiler was set up, one at reset()
+    assert len(np.unique(draws.round(12), axis=0)) == n        # nobody shares a model
+    nominal = env._chain_model()
+    nom_tabs = lowering.variant_tables(nominal, nominal)
+    worst = 0.0
+    for e in (0, 5, n - 1):
+        want = lowering.variant_tables(nominal, env._chain_model(env.model_of_env(e)))
+        got = b.get_model_tables(e)
+        for name, w, g, w0 in zip(("record", "geom table", "pair table"), want, got, nom_tabs):
+            w32 = w.astype(np.float32)
+            assert w32.shape == g.shape
+            err = np.abs(w32.astype(np.float64) - g) / np.maximum(np.abs(w32), 1e-30)
+            assert err.max(initial=0.0) < 3e-6, (task, e, name, np.nonzero(err > 3e-6)[0][:8])
+            worst = max(worst, float(err.max(initial=0.0)))
+        assert (want[0].astype(np.float32) != nom_tabs[0].astype(np.float32)).any()
+    print("%s: device-compiled tables vs the host compiler on the same draws: max relative difference %.1e" % (task, worst))
+
+
+def test_fresh_model_per_device_side_restart():
+    """The reference compiles a freshly randomised model at EVERY reset (base.py:183-185). 4096 Talos environments with restarts
+    every 4 control steps: after 13 steps every environment is on its fifth model at least (one at set-up, one at reset(), one per
+    restart), all 4096 current parameter sets are distinct and so are the ones before the last restart; 16 environments then take
+    one control step against the oracle compiled from THEIR draw (and their own joint damping) — and differ from the nominal robot.
+    Keyed by (seed, global environment id, models had): independent of how the environments are split over batches."""
+    n = 4096
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True, n_envs=n, domain_randomization_config=cfg)
+    m = env._model
+    env.reset()
+    env.enable_auto_reset(seed=3, horizon=4)
+    env.step(np.zeros((n, 12)))
+    b = env.backend
+    b.rollout(7, action_mode=1, seed=11)
+    before, gen0 = b.get_model_draws()
+    st = b.rollout(5, action_mode=1, seed=12)
+    draws, gen = b.get_model_draws()
+    assert st["overflow_contacts"] == 0 and st["nan_resets"] == 0
+    restarts = int(gen.sum()) - 2 * n
+    assert (gen >= 5).all() and (gen > gen0).all() and restarts >= 3 * n
+    assert len(np.unique(draws.round(12), axis=0)) == n and len(np.unique(np.concatenate([before, draws]).round(12), axis=0)) == 2 * n
+    ops, _ = env._domain_rand.model_draw_ops()
+    lo = np.array([a if k == 2 else 0.0 for k, a, bb, *_ in ops]); hi = np.array([bb if k == 2 else np.inf for k, a, bb, *_ in ops])
+    assert (draws >= lo).all() and (draws <= hi).all()
+    uni = [i for i, op in enumerate(ops) if op[0] == 2]
+    mid = np.array([(ops[i][1] + ops[i][2]) / 2 for i in uni]); half = np.array([(ops[i][2] - ops[i][1]) / 2 for i in uni])
+    assert np.abs((draws[:, uni].mean(0) - mid) / half).max() < 0.06 and np.abs(draws[:, uni].std(0) / half - 1 / np.sqrt(3)).max() < 0.03
+    # one control step of 16 environments vs the oracle of THEIR model
+    b.set_auto_reset(False, horizon=1000)
+    q0, v0 = b.get_state()
+    prm = b.get_dof_params()
+    acts = np.random.RandomState(2).uniform(-0.3, 0.3, (n, 12))
+    b.step(acts)
+    q, v = b.get_state()
+    eq, ev, enom = [], [], []
+    for i in range(0, n, n // 16):
+        mv = env._domain_rand.variant_from_draws(draws[i])
+        ctrl = np.zeros(m.nu)
+        ctrl[env._action_indices] = env._preprocess_action(acts[i])
+        d, s_, f = prm["damping"][i], prm["stiffness"][i], prm["frictionloss"][i]
+        qo, vo = Oracle(pack_model(_with_dof_params(mv, d, s_, f))).step(q0[i].astype(np.float64), v0[i].astype(np.float64), ctrl, nsub=10)[:2]
+        qn, vn = Oracle(pack_model(_with_dof_params(m, d, s_, f))).step(q0[i].astype(np.float64), v0[i].astype(np.float64), ctrl, nsub=10)[:2]
+        eq.append(np.abs(q[i] - qo).max()); ev.append(np.abs(v[i] - vo).max()); enom.append(np.abs(v[i] - vn).max())
+    print("fresh model per restart: %d device-side restarts in 13 control steps of %d environments, each with a model of its own; 16 environments "
+          "vs the oracle of their own draw: qpos %.2e qvel %.2e (vs the nominal robot: qvel %.2e)" % (restarts, n, max(eq), max(ev), max(enom)))
+    assert max(eq) < QTOL and max(ev) < VTOL and max(enom) > 10 * VTOL
+    # sharding: 48 environments in one batch = 24 + 24 with global offsets, bitwise, models included
+    from loco_mujoco_amd import lowering
+    from loco_mujoco_amd.backend import HipBatch
+    ops, svd = env._domain_rand.model_draw_ops()
+    prog = lowering.model_compiler_tables(m, env._device_task(), ops, svd)[:2]
+    nominal = env._chain_model()
+    tabs = lowering.variant_tables(nominal, nominal)
+    tab = env._reset_table()
+
+    def run(nenv, offset):
+        bb = HipBatch(env._hip_model, nenv)
+        rows = tab[(np.arange(offset, offset + nenv) * 7) % len(tab)]
+        bb.set_state(rows[:, :m.nv], rows[:, m.nv:2 * m.nv])
+        bb.set_reset_table(tab, seed=9, global_env_offset=offset)
+        bb.set_auto_reset(True, horizon=3)
+        bb.set_model_compiler(prog, tabs, seed=5)
+        bb.compile_models()
+        bb.rollout(10, action_mode=1, seed=4)
+        return bb.get_model_draws()[0], bb.get_state()
+
+    da, (qa, va) = run(48, 0)
+    d0, (qb0, vb0) = run(24, 0)
+    d1, (qb1, vb1) = run(24, 24)
+    assert np.array_equal(da, np.concatenate([d0, d1])) and np.array_equal(qa, np.concatenate([qb0, qb1])) and np.array_equal(va, np.concatenate([vb0, vb1]))
+
+
 def test_model_variants_with_self_collision_pairs_vs_oracle(tmp_path):
     """UnitreeA1: the variant brings its own geom-pair table (body_invweight0 of both bodies enters a self-contact's
     regulariser). Trunk mass + fullinertia (the reference's singular-value rule) + foot friction."""

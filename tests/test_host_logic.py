@@ -784,3 +784,152 @@ def test_lowering_keeps_every_collider_and_builds_the_six_link_pair_tables():
     # five-link humanoids without muscles run in the eight-slot families (a fifth contact on a leg must not abandon the control step)
     talos = LocoEnv.make("Talos.walk", debug=True)
     assert lowering.lower(talos._model, talos._device_task())[1]["max_contacts"] == 8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The model compiler on the device (csrc/lm_compile.hip): its program, executed here in numpy
+# ---------------------------------------------------------------------------------------------------------------
+
+def _run_model_compiler_program(ib, db, values, nominal_tables):
+    """numpy restatement of csrc/lm_compile.hip's kernel for ONE environment: the tables it writes from the draws ``values``."""
+    from loco_mujoco_amd import lowering as L
+    nv, nrb, ngs, nd, nslot, nrec, ncon, nbody, pyramidal, balance = [int(x) for x in ib[1:11]]
+    impratio, boundmass, boundinertia, minval = db[0:4]
+    io, do = L.MC_IH_SIZE, L.MC_DH_SIZE
+    i_draw = ib[io:io + nd * 4].reshape(nd, 4); io += nd * 4
+    i_rb = ib[io:io + nrb * 4].reshape(nrb, 4); io += nrb * 4
+    i_rec = ib[io:io + nrec * 2].reshape(nrec, 2); io += nrec * 2
+    i_con = ib[io:io + ncon * 8].reshape(ncon, 8); io += ncon * 8
+    assert io == len(ib)
+    do += nd * 2
+    d_rb = db[do:do + nrb * 55].reshape(nrb, 55); do += nrb * 55
+    jac = db[do:do + nbody * 6 * nv].reshape(nbody, 6, nv); do += nbody * 6 * nv
+    mbase = db[do:do + nv * nv].reshape(nv, nv); do += nv * nv
+    arm = db[do:do + nv].copy(); do += nv
+    fd = db[do:do + nv]; do += nv
+    slot = db[do:do + nslot * 10].reshape(nslot, 10).copy(); do += nslot * 10
+    fric = db[do:do + ngs * 3].reshape(ngs, 3).copy(); do += ngs * 3
+    assert do == len(db)
+    mass, vals, sv = d_rb[:, 0].copy(), d_rb[:, 1:7].copy(), np.zeros((nrb, 3))
+    for (kind, target, idx, comp), v in zip(i_draw, values):
+        if target == 0:
+            arm[idx] = v
+        elif target == 1:
+            mass[idx] = v
+        elif target == 2:
+            vals[idx, comp] = v
+        elif target == 3:
+            sv[idx, comp] = v
+        else:
+            fric[idx, comp] = v
+    sym = lambda a: np.array([[a[0], a[3], a[4]], [a[3], a[1], a[5]], [a[4], a[5], a[2]]])
+    M = mbase + np.diag(arm)
+    for j in range(nrb):
+        rd = d_rb[j]
+        if i_rb[j, 3]:
+            t = rd[16:25].reshape(3, 3) @ np.diag(sv[j]) @ rd[25:34].reshape(3, 3)
+            vals[j] = [t[0, 0], t[1, 1], t[2, 2], t[0, 1], t[0, 2], t[1, 2]]
+        if i_rb[j, 1] == 2:
+            inr = sym(vals[j])
+        else:
+            r = rd[7:16].reshape(3, 3)
+            inr = r @ np.diag(vals[j, :3]) @ r.T
+        if boundinertia > 0 or balance:
+            ev, evec = np.linalg.eigh(inr)
+            if boundinertia > 0:
+                ev = np.maximum(ev, boundinertia)
+            if balance and ev[0] + ev[1] < ev[2]:
+                ev[:] = ev.mean()
+            inr = evec @ np.diag(ev) @ evec.T
+        if boundmass > 0:
+            mass[j] = max(mass[j], boundmass)
+        x = rd[46:55].reshape(3, 3)
+        J = jac[i_rb[j, 0]]
+        M += mass[j] * J[:3].T @ J[:3] + J[3:].T @ (x @ inr @ x.T) @ J[3:]
+        c, r = rd[34:37], rd[37:46].reshape(3, 3)
+        o = r @ inr @ r.T + mass[j] * (c @ c * np.eye(3) - np.outer(c, c))
+        slot[i_rb[j, 2]] += np.concatenate([[mass[j]], mass[j] * c, [o[0, 0], o[1, 1], o[2, 2], o[0, 1], o[0, 2], o[1, 2]]])
+    minv = np.linalg.inv(M)
+    V = np.zeros(3 * nv + 1 + nslot * 10)
+    V[0:nv], V[nv:2 * nv] = arm, np.diag(minv)
+    V[2 * nv:3 * nv] = np.where(fd >= 0, np.maximum(minval, fd * np.diag(minv)), 0.0)
+    V[3 * nv] = 1.0 / ((np.trace(M) / nv) * nv)
+    for s in range(nslot):
+        a = slot[s]
+        if a[0] <= 0:
+            continue
+        m_, c = a[0], a[1:4] / a[0]
+        o = sym(a[4:10]) - m_ * (c @ c * np.eye(3) - np.outer(c, c))
+        V[3 * nv + 1 + s * 10:3 * nv + 11 + s * 10] = [m_, c[0], c[1], c[2], o[0, 0], o[1, 1], o[2, 2], o[0, 1], o[0, 2], o[1, 2]]
+    biw = np.array([np.trace(jac[b, :3] @ minv @ jac[b, :3].T) / 3.0 for b in range(nbody)])
+    rec, gt, gpt = [np.array(t, dtype=np.float64) for t in nominal_tables]
+    for dst, src in i_rec:
+        rec[dst] = V[src]
+    for tab_i, at, st, code, ga, gb, ba, bb in i_con:
+        tab = gt if tab_i == 0 else gpt
+        dim, mix, pair = code & 15, (code >> 4) & 15, (code >> 8) & 1
+        f3 = np.maximum(fric[ga], fric[gb]) if mix == 0 else (fric[ga] if mix == 1 else fric[gb])
+        fr = np.array([f3[0], f3[0], f3[1], f3[2], f3[2]])
+        tran = biw[ba] + biw[bb]
+        if pyramidal:
+            mu = 0.0 if (pair and dim != 3) else fr[0]
+            vt = 2 * mu * mu * (1 + mu * mu) * tran if dim == 3 else (4.0 * tran if pair else tran)
+            vmu, rr = mu, np.ones(5)
+        else:
+            vt, vmu, rr1 = tran, fr[0] / np.sqrt(max(minval, impratio)), 1.0 / max(minval, impratio)
+            rr = np.array([rr1, rr1 * fr[0] ** 2 / fr[1] ** 2] + [rr1 * fr[0] ** 2 / fr[k] ** 2 for k in (2, 3, 4)])
+        tab[at], tab[at + 2 * st] = vt, vmu
+        tab[at + 3 * st:at + 8 * st:st], tab[at + 8 * st:at + 13 * st:st] = fr, rr
+    return rec, gt, gpt
+
+
+_DR_ALL_RULES = {
+    "Talos.walk": "golden/dr_talos_inertial.yaml",
+}
+
+
+@pytest.mark.parametrize("task, rules", [
+    ("Talos.walk", None),
+    ("UnitreeA1.simple", "Inertial:\n  trunk:\n    mass: {sigma: 1.0}\n    fullinertia:\n      uniform_range_delta: 0.002\n"
+                         "Geoms:\n  FR_calf:\n    friction:\n      sigma: [0.1, 0.001, 0.00001]\n"
+                         "Joints:\n  FR_hip_joint:\n    armature:\n      uniform_range: [0.01, 0.02]\n"),
+    ("HumanoidTorque.walk", "Default:\n  Inertial:\n    mass:\n      sigma: 0.3\n  Geoms:\n    friction:\n      sigma: [0.1, 0.001, 0.00001]\n"),
+])
+def test_model_compiler_program_reproduces_the_host_compiler(task, rules, tmp_path):
+    """The program the device-side model compiler runs (lowering.model_compiler_tables), executed in numpy from a set of draws,
+    gives the tables of the host path for the same draws: ``variant_tables(lower(mjcf.model_variant(...)))`` — inertial record
+    (link inertias, armature, dof_invweight0, friction-loss regulariser, solver scale), geom table and geom-pair table. Talos: the
+    golden configuration (mass, diaginertia, friction, armature); the quadruped: fullinertia through the singular values, elliptic
+    cones, self-collision pairs; the humanoid: EVERY body and geom drawn, the compiler's inertia bounds, pyramids."""
+    from loco_mujoco_amd import lowering
+    from loco_mujoco_amd.utils.domain_randomization import JointRandomization
+    if rules is None:
+        cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    else:
+        cfg = tmp_path / "dr.yaml"
+        cfg.write_text(rules)
+        cfg = str(cfg)
+    env = LocoEnv.make(task, debug=True)
+    m = env._model
+    jr = JointRandomization(m, cfg)
+    ops, svd = jr.model_draw_ops()
+    assert len(ops) > 0
+    # the ops ARE the sampler: drawn in sequence with the reference's generator they give sample_model_variant's model
+    np.random.seed(11)
+    values = [jr.draw_op(op) for op in ops]
+    np.random.seed(11)
+    ref = jr.sample_model_variant()
+    v = jr.variant_from_draws(values)
+    assert np.array_equal(v.body_mass, ref.body_mass) and np.array_equal(v.body_inertia, ref.body_inertia)
+    assert np.array_equal(v.dof_armature, ref.dof_armature) and np.array_equal(v.geom_friction, ref.geom_friction)
+    assert np.array_equal(v.dof_invweight0, ref.dof_invweight0)
+    ib, db, info = lowering.model_compiler_tables(m, env._device_task(), ops, svd)
+    assert ib.dtype == np.int32 and db.dtype == np.float64 and info["n_draw"] == len(ops)
+    nominal = env._chain_model()
+    want = lowering.variant_tables(nominal, env._chain_model(v))
+    got = _run_model_compiler_program(ib, db, values, lowering.variant_tables(nominal, nominal))
+    for name, w, g in zip(("record", "geom table", "pair table"), want, got):
+        assert w.shape == g.shape
+        err = np.abs(w - g) / np.maximum(np.abs(w), 1e-30)
+        assert err[w != g].max(initial=0.0) < 1e-9, (name, np.nonzero(err > 1e-9)[0][:8], w[err > 1e-9][:4], g[err > 1e-9][:4])
+    assert (want[0] != lowering.variant_tables(nominal, nominal)[0]).any()
