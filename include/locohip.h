@@ -15,6 +15,9 @@
  *   lm_get_state        <- data.qpos / data.qvel reads (ObservationHelper._build_obs, base.py:202)
  *   lm_set_dof_params / lm_set_dof_randomization / lm_set_model_variants <- DomainRandomizationHandler.get_randomized_model
  *                          (utils/domain_randomization.py:219-227): joint damping/stiffness/frictionloss per environment
+ *   lm_set_model_compiler / lm_compile_models / lm_get_model_draws / lm_get_model_tables <- the reference's re-compile of a
+ *                          randomised XML at every reset (base.py:183-185, utils/domain_randomization.py:219-227,386-514: armature,
+ *                          Inertial mass / diaginertia / fullinertia, Geoms friction), drawn and compiled on the device
  *   lm_set/get_activation <- data.act (muscle activation state, humanoids.py:320 HumanoidMuscle; integrated by mj_step)
  *   lm_set_goal         <- per-episode goal written into the observation
  *                          (unitreeA1.py:288-291 set_goal, :454-476 _create_observation)
