@@ -156,6 +156,7 @@ struct Params {
   const float* gt;    // geom table (global memory): full geom records [geom][field][chain], read when a geom is within reach of the floor
   const float* cmg;   // the constant table in GLOBAL memory: the six-link kernels read their link-pair lists from there (they do not fit
                       // beside the lane memory in the workgroup's LDS share: lowering.py ends H_CM_USED before them)
+  int root_xyz;       // the root's translations are slides along +x, +y, +z in a root frame that is the world's (solve(): ROOT_XYZ)
   int root_limited;   // some root dof is `limited` (lowering.py keeps a root limit only when it can become active): the regular kernels of
                       // the families without root limit rows look at the root positions every pass (forward: ROOT_LIM)
 };
@@ -2894,6 +2895,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // limited root dof beyond its range hands the control step to the family's replay kernel (lm_step.h), from the untouched state; the
   // rows would have been inactive in every pass before that one, so the replay follows the same trajectory up to it.
   constexpr bool ROOT_LIM = NM > 0 || NS > 8 || CONE < 0;
+  // the quadruped family (three links per chain, elliptic cones compiled in): its models have the root's translations as slides along
+  // +x, +y, +z in this order, in a root frame that is the world's (checked when a model is given that family: lm_kernels.hip family_of)
+  constexpr bool ROOT_XYZ = MC == 3 && CONE == 1;
   if constexpr (!ROOT_LIM) {
     if (P.root_limited) {        // (a scalar branch: no robot of the path takes it)
 #pragma unroll
@@ -3357,10 +3361,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const float sg = (part > 0.0f) ? 1.0f : -1.0f;
             V3 n, t1, t2;
             slot_frame(s, n, t1, t2);
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-              for (int j = 0; j < 6; j++) Jc[r][j] = 0;
             const bool own_pair = pl != 7 && pc == c;          // both bodies in my chain: the joints up to the nearer one cancel
 #pragma unroll
             for (int k = 0; k < MC; k++) {
@@ -3385,7 +3385,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 6; r++) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
+            for (int r = ROOT_XYZ ? 3 : 0; r < 6; r++) if (r >= 3 || !(MC >= 5 && P.root_xyz)) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
 #pragma unroll
             for (int k = 0; k < MC; k++) {
               if (k <= link) contact_rows(ldS(LMm::kSc + k * 6), rc, Jc[6 + k]);
@@ -3395,22 +3395,45 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
               }
             }
           }
-          if (CONE != 0 && dim > 3) {
+          // J^T Hc J over the columns [root 6 | chain MC]. Two shortcuts (round 5): a SELF-contact has no root columns (the loop starts at
+          // the chain's), and in the quadruped family (ROOT_XYZ) the root's three translation columns of a floor contact are the unit
+          // rows -e2, +e1, +e0 of the contact frame (contact_rows of the slides along x, y, z): their products are picked out of Hc
+          // and out of Hc J instead of multiplied — 342 instead of 594 multiply-adds per condim-6 slot
+          auto accumulate = [&](auto nr_tag, auto unit_tag) {
+            constexpr int NR = decltype(nr_tag)::value;
+            constexpr bool UNIT = !IP && decltype(unit_tag)::value;
+            constexpr int A0 = IP ? 6 : (UNIT ? 3 : 0);
+            constexpr int ui[3] = {2, 1, 0};
+            constexpr float us[3] = {-1.0f, 1.0f, 1.0f};
+            if constexpr (UNIT) {
 #pragma unroll
-            for (int a = 0; a < 6 + MC; a++) {
-              float t[6];
+              for (int a = 0; a < 3; a++)
 #pragma unroll
-              for (int i = 0; i < 6; i++) {
+                for (int b = 0; b <= a; b++) Hpart[tri(a, b)] += (us[a] * us[b]) * Hc[(ui[a] <= ui[b]) ? tri(ui[b], ui[a]) : tri(ui[a], ui[b])];
+            }
+#pragma unroll
+            for (int a = A0; a < 6 + MC; a++) {
+              float t[NR];
+#pragma unroll
+              for (int i = 0; i < NR; i++) {
                 float acc = 0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) acc = fmaf(Hc[(j <= i) ? tri(i, j) : tri(j, i)], Jc[a][j], acc);
+                for (int j = 0; j < NR; j++) acc = fmaf(Hc[(j <= i) ? tri(i, j) : tri(j, i)], Jc[a][j], acc);
                 t[i] = acc;
               }
+              if constexpr (UNIT) {
 #pragma unroll
-              for (int b = 0; b <= a; b++) {
+                for (int b = 0; b < 3; b++) {
+                  const float d = us[b] * t[ui[b]];
+                  if (a < 6) Hpart[tri(a, b)] += d;
+                  else Hcr[a - 6][b] += d;
+                }
+              }
+#pragma unroll
+              for (int b = A0; b <= a; b++) {
                 float d = 0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) d = fmaf(t[j], Jc[b][j], d);
+                for (int j = 0; j < NR; j++) d = fmaf(t[j], Jc[b][j], d);
                 if (a < 6) Hpart[tri(a, b)] += d;
                 else if (b < 6) Hcr[a - 6][b] += d;
                 else Hcc[tri(a - 6, b - 6)] += d;
@@ -3420,42 +3443,25 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 for (int b = 0; b < MC; b++) {
                   float d = 0;
 #pragma unroll
-                  for (int j = 0; j < 6; j++) d = fmaf(t[j], Jp[b][j], d);
+                  for (int j = 0; j < NR; j++) d = fmaf(t[j], Jp[b][j], d);
 #pragma unroll
                   for (int xs = 0; xs < NX; xs++) if (xs == xslot) Xc[xs][a - 6][b] += d;
                 }
               }
             }
+          };
+          if constexpr (IP || ROOT_XYZ || MC < 5) {
+            if (CONE != 0 && dim > 3) accumulate(std::integral_constant<int, 6>{}, std::integral_constant<bool, ROOT_XYZ>{});
+            else accumulate(std::integral_constant<int, 3>{}, std::integral_constant<bool, ROOT_XYZ>{});
           } else {
-#pragma unroll
-            for (int a = 0; a < 6 + MC; a++) {
-              float t[3];
-#pragma unroll
-              for (int i = 0; i < 3; i++) {
-                float acc = 0;
-#pragma unroll
-                for (int j = 0; j < 3; j++) acc = fmaf(Hc[(j <= i) ? tri(i, j) : tri(j, i)], Jc[a][j], acc);
-                t[i] = acc;
-              }
-#pragma unroll
-              for (int b = 0; b <= a; b++) {
-                float d = 0;
-#pragma unroll
-                for (int j = 0; j < 3; j++) d = fmaf(t[j], Jc[b][j], d);
-                if (a < 6) Hpart[tri(a, b)] += d;
-                else if (b < 6) Hcr[a - 6][b] += d;
-                else Hcc[tri(a - 6, b - 6)] += d;
-              }
-              if constexpr (IP) if (cross && a >= 6) {
-#pragma unroll
-                for (int b = 0; b < MC; b++) {
-                  float d = 0;
-#pragma unroll
-                  for (int j = 0; j < 3; j++) d = fmaf(t[j], Jp[b][j], d);
-#pragma unroll
-                  for (int xs = 0; xs < NX; xs++) if (xs == xslot) Xc[xs][a - 6][b] += d;
-                }
-              }
+            // the humanoid families serve robots with either kind of root (Atlas, Talos, UnitreeH1 / G1: slides along x, y, z in a root
+            // frame that is the world's; the two humanoids: a turned pelvis frame): a uniform branch on the model's flag
+            if (P.root_xyz) {
+              if (CONE != 0 && dim > 3) accumulate(std::integral_constant<int, 6>{}, std::true_type{});
+              else accumulate(std::integral_constant<int, 3>{}, std::true_type{});
+            } else {
+              if (CONE != 0 && dim > 3) accumulate(std::integral_constant<int, 6>{}, std::false_type{});
+              else accumulate(std::integral_constant<int, 3>{}, std::false_type{});
             }
           }
         };
@@ -3562,8 +3568,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 for (int j = 0; j < 6; j++) SL(s, SL_JV + j) = jv[j];
               }
             };
-            for (int s = 0; s < nfloor; s++) jv_slot(s, std::false_type{});
-            if constexpr (PAIRS) for (int s = nfloor; s < nslot; s++) jv_slot(s, std::true_type{});
+            // (by the replica that owns the slot in the gradient — rounds 1-4: every replica wrote every slot's rows; the line search
+            // reads them behind the fence below)
+            for (int s = s_first; s < nfloor; s += s_step) jv_slot(s, std::false_type{});
+            if constexpr (PAIRS) {
+              if (nslot > nfloor) for (int s = aligned_from(nfloor, s_first, s_step); s < nslot; s += s_step) jv_slot(s, std::true_type{});
+            }
             if (PAIRS && any_pair) Q::quad_sync();
             if constexpr (CONE != 0) {
               // elliptic contacts: the line search's polynomials, prepared by the replica that owns the slot in the gradient

@@ -34,6 +34,7 @@ struct lm_model {
   int nroot;
   std::vector<int> root_dofs;
   bool root_limited;         // a root dof with an active-able limit (lm_batch_set_replay)
+  bool root_xyz;             // the root's first three dofs are slides along +x, +y, +z in a root frame that is the world's (lm_core.h ROOT_XYZ)
 };
 
 struct lm_batch {
@@ -92,7 +93,8 @@ static int family_of(const lm_batch* b) {
   if (six) return (!rk4 && T.na == 0 && pyr3) ? 7 : -1;      // (with or without self-collision tables: its regular kernels detect, its replay kernel collides)
   // five-link humanoids whose lowering carries self-collision tables (bone hulls, link meshes, cylinders): the pair families
   if (big && T.npair > 0 && pyr3) return rk4 ? (T.na == 0 ? 8 : 6) : (T.na == 0 ? 9 : 10);
-  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC) return 0;
+  // (the quadruped family's Hessian takes the root's translation columns as unit rows: lm_core.h ROOT_XYZ; another root -> generic kernels)
+  if (!big && !rk4 && T.na == 0 && b->m->P.cone == LM_CONE_ELLIPTIC && b->m->root_xyz) return 0;
   // (families 1 / 3 — four contact slots per chain — are gone: since round 4 every five-link humanoid without muscles runs in the
   // eight-slot families, where a fifth contact on a leg does not abandon the control step)
   if (big && rk4 && T.na == 0 && pyr3) return 2;
@@ -233,6 +235,13 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   // regular kernels hand a control step with a root dof beyond its range to the replay kernel — lm_core.h ROOT_LIM)
   m->root_limited = false;
   for (int i = 0; i < 6; i++) if (cm[LM_R_DOFS + i * LM_D_SIZE + LM_D_LIMITED] != 0.0f) m->root_limited = true;
+  m->root_xyz = cm[LM_R_NDOF] == 6.0f;
+  for (int i = 0; i < 9; i++) if (cm[LM_R_R0 + i] != ((i % 4 == 0) ? 1.0f : 0.0f)) m->root_xyz = false;
+  for (int i = 0; i < 3; i++) {
+    const float* d = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
+    if (d[LM_D_TYPE] != 0.0f) m->root_xyz = false;                       // (0 = slide: mjcf.JNT_SLIDE)
+    for (int k = 0; k < 3; k++) if (d[LM_D_AX + k] != ((k == i) ? 1.0f : 0.0f)) m->root_xyz = false;
+  }
   HIPCHK(hipMalloc(&m->d_cm, sizeof(float) * LM_CM_SIZE));
   HIPCHK(hipMemcpy(m->d_cm, cm.data(), sizeof(float) * LM_CM_SIZE, hipMemcpyHostToDevice));
   {
@@ -341,6 +350,7 @@ int lm_model_create(const double* cmod, size_t n, int device, lm_model** out) {
   }
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
   P.root_limited = m->root_limited ? 1 : 0;
+  P.root_xyz = m->root_xyz ? 1 : 0;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
   if (const char* v = LM_PROBE_ENV("LM_LS_GRID")) sscanf(v, "%f,%f,%f", &P.ls_grid[0], &P.ls_grid[1], &P.ls_grid[2]);   // A/B knob
   if (const char* v = LM_PROBE_ENV("LM_LS_NOISE")) P.ls_noise = (float)atof(v);

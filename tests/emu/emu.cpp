@@ -165,6 +165,13 @@ static int emu_run_t(const double* chain_model, int n, double* qpos, double* qve
   P.iterations = (int)H[LM_H_ITERATIONS]; P.tolerance = 1e-6f; P.nv = nv;
   P.scale = 1.0f / ((float)H[LM_H_MEANINERTIA] * nv);
   P.ls_tol = 1e-2f; P.ls_iters = 12; P.ls_noise = 2e-6f; P.ablate = 0;
+  P.root_xyz = cm[LM_R_NDOF] == 6.0f;        // as lm_kernels.hip lm_model_create
+  for (int i = 0; i < 9; i++) if (cm[LM_R_R0 + i] != ((i % 4 == 0) ? 1.0f : 0.0f)) P.root_xyz = 0;
+  for (int i = 0; i < 3; i++) {
+    const float* d = cm.data() + LM_R_DOFS + i * LM_D_SIZE;
+    if (d[LM_D_TYPE] != 0.0f) P.root_xyz = 0;
+    for (int k = 0; k < 3; k++) if (d[LM_D_AX + k] != ((k == i) ? 1.0f : 0.0f)) P.root_xyz = 0;
+  }
   P.root_limited = 0;
   for (int i = 0; i < 6; i++) if (cm[LM_R_DOFS + i * LM_D_SIZE + LM_D_LIMITED] != 0.0f) P.root_limited = 1;
   P.ls_grid[0] = 0.25f; P.ls_grid[1] = 0.0625f; P.ls_grid[2] = 0.015625f;
