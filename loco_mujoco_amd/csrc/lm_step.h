@@ -58,10 +58,18 @@ struct QuadDppT {
     const int src = (int)((__lane_id() & ~(unsigned)(4 * (REP - 1))) | ((unsigned)r << 2));
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x)));
   }
-  // sum over the replicas: butterfly over lane^4 and lane^8 (and lane^16, lane^32 with sixteen replicas), the same association in
-  // every replica
+  // sum over the replicas, the same association in every replica. Four replicas: the row rotations of DPP — x + ror8(x), then
+  // y + ror4(y): every replica adds the same two pair sums (a + b = b + a bit for bit), one VALU instruction per stage (rounds 1-4
+  // and the sixteen-replica layout: ds_bpermute butterflies over lane^4, lane^8 (, lane^16, lane^32) through the LDS crossbar)
   static __device__ __forceinline__ float rep_sum(float x) {
     if (REP == 1) return x;
+#ifndef LM_REP_SUM_BPERMUTE
+    if (REP == 4) {
+      // row_ror:8 = 0x128, row_ror:4 = 0x124 (rotation within the 16-lane row = within the environment)
+      const float y4 = x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x128, 0xF, 0xF, true));
+      return y4 + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(y4), 0x124, 0xF, 0xF, true));
+    }
+#endif
     const unsigned l = __lane_id();
     float y = x + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 4u) << 2), __float_as_int(x)));
     y = y + __int_as_float(__builtin_amdgcn_ds_bpermute((int)((l ^ 8u) << 2), __float_as_int(y)));

@@ -60,11 +60,13 @@ struct QuadThreadsT {
     float y = g_rbuf[r][t_lane];
     g_bar_lane[t_lane].arrive_and_wait(); return y;
   }
-  static float rep_sum(float x) {       // the device's butterfly: lane^4 then lane^8 (^16, ^32 with sixteen replicas), i.e. replica^1, ^2 (^4, ^8)
-    if (REP == 1) return x;
+  static float rep_sum(float x) {       // the device's association: four replicas (DPP row rotations) replica^2 then replica^1; sixteen: the
+    if (REP == 1) return x;             // ds_bpermute butterfly replica^1, ^2, ^4, ^8
     OPC(3);
     float y = x;
-    for (int bit = 1; bit < REP; bit <<= 1) {
+    constexpr int kStages = (REP >= 16) ? 4 : (REP >= 8 ? 3 : (REP >= 4 ? 2 : 1));
+    for (int k = 0; k < kStages; k++) {
+      const int bit = (REP == 4) ? (2 >> k) : (1 << k);
       g_rbuf[t_rep][t_lane] = y; g_bar_lane[t_lane].arrive_and_wait();
       const float o = g_rbuf[t_rep ^ bit][t_lane];
       g_bar_lane[t_lane].arrive_and_wait();
