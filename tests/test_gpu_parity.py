@@ -1297,7 +1297,8 @@ def _worker_oracle_steps(args):
 # failing 0 / 0 / 1 / 1 / 0 / 1 / 0 / 4 / 0, ill-conditioned 0 / 0 / 1 / 0 / 0 / 1 / 1 / 324 / 14. UnitreeH1.walk after round 5's Newton bookkeeping
 # (other rounding): failing 8, ill-conditioned 317 — its failing states sit right beside the ill-conditioned class (the hip cylinder's cap on
 # a mesh hull: 1.4 x / 2.4 x the tolerance at worst, the oracle's own jump just under it), so their count moves with the rounding: bound 12.
-# UnitreeG1.walk: one state moved from 0.99 x to 1.06 x the qvel tolerance with the same change: failing 1.
+# UnitreeG1.walk: one state moved from 0.99 x to 1.06 x the qvel tolerance with the same change: failing 1. With the replica sums through
+# DPP row rotations (another association of the same four-term sums): failing 0, ill-conditioned 14 -> 22 (of 4096; bound 30).
 #   max_fail: states beyond the tolerance although comparable and the oracle stable under one-ulp input noise — an EXACT upper bound
 #             (0 where none was measured: there the maximum over every comparable, well-conditioned state is asserted <= tolerance);
 #   max_illcond: states beyond the tolerance whose fp64 oracle itself jumps under one-ulp input noise — the measured count plus a small
@@ -1306,7 +1307,7 @@ _R5_4096_CASES = [("UnitreeA1.simple", {}, "zero", 12, 0, 0), ("UnitreeA1.simple
                   ("HumanoidTorque.run", {}, "random", 12, 1, 3), ("HumanoidTorque.run", {}, "random", 3, 1, 2),
                   ("Atlas.walk", {}, "random", 12, 0, 0), ("HumanoidMuscle.run", {}, "random", 12, 1, 3),
                   ("Talos.walk", {}, "random", 12, 0, 3), ("UnitreeH1.walk", {}, "random", 3, 12, 360),
-                  ("UnitreeG1.walk", {}, "random", 3, 1, 20)]
+                  ("UnitreeG1.walk", {}, "random", 3, 1, 30)]
 
 
 @pytest.mark.parametrize("task,kw,policy,nroll,max_fail,max_illcond", _R5_4096_CASES)
