@@ -933,3 +933,16 @@ def test_model_compiler_program_reproduces_the_host_compiler(task, rules, tmp_pa
         err = np.abs(w - g) / np.maximum(np.abs(w), 1e-30)
         assert err[w != g].max(initial=0.0) < 1e-9, (name, np.nonzero(err > 1e-9)[0][:8], w[err > 1e-9][:4], g[err > 1e-9][:4])
     assert (want[0] != lowering.variant_tables(nominal, nominal)[0]).any()
+
+
+def test_model_compiler_is_the_default_and_the_pool_an_option():
+    """Rules that change compile-time constants: `n_model_variants` unset -> the model compiler on the device (one model per
+    environment and episode, like the reference); an explicit pool size keeps the host-compiled pool; several models in one batch
+    (the carried weights) use the variant tables for the MODELS and keep the pool; rules without compile-time constants need neither."""
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    assert LocoEnv.make("Talos.walk", debug=True, n_envs=4, domain_randomization_config=cfg)._use_model_compiler
+    assert not LocoEnv.make("Talos.walk", debug=True, n_envs=4, domain_randomization_config=cfg, n_model_variants=8)._use_model_compiler
+    assert not LocoEnv.make("Talos.carry", debug=True, n_envs=4, domain_randomization_config=cfg)._use_model_compiler
+    assert not LocoEnv.make("Talos.walk", debug=True, n_envs=4)._use_model_compiler
+    with pytest.raises(ValueError, match="do not compile their models on the device"):
+        LocoEnv.make("Talos.walk", debug=True, n_envs=4).model_of_env(0)
