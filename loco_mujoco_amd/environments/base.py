@@ -180,15 +180,25 @@ class LocoEnv:
                 from ..lowering import variant_tables
                 self._backend.set_model_variants([variant_tables(nominal, self._chain_model(m)) for m in self._models])
             elif self._use_model_compiler:
-                from ..lowering import model_compiler_tables, variant_tables
-                ops, svd = self._domain_rand.model_draw_ops()
-                ib, db, self._compiler_info = model_compiler_tables(self._model, self._device_task(), ops, svd)
-                self._backend.set_model_compiler((ib, db), variant_tables(nominal, nominal), seed=int(self._domain_rand_rs.randint(0, 2 ** 31 - 1)))
+                self._install_model_compiler(nominal)
             elif self._domain_rand is not None and self._domain_rand.has_model_rules:
                 self._ensure_variant_pool()
                 self._backend.set_model_variants(self._variant_tables)
                 self._variant_dirty = False
         return self._backend
+
+    def _install_model_compiler(self, nominal=None):
+        """(Re-)install the model compiler on the device: its program and a seed from the randomisation's own generator — after
+        ``seed()`` the models of the following episodes are a function of that seed again."""
+        from ..lowering import model_compiler_tables, variant_tables
+        nominal = self._chain_model() if nominal is None else nominal
+        if getattr(self, "_compiler_program", None) is None:
+            ops, svd = self._domain_rand.model_draw_ops()
+            ib, db, self._compiler_info = model_compiler_tables(self._model, self._device_task(), ops, svd)
+            self._compiler_program = (ib, db, variant_tables(nominal, nominal))
+        ib, db, tabs = self._compiler_program
+        self._backend.set_model_compiler((ib, db), tabs, seed=int(self._domain_rand_rs.randint(0, 2 ** 31 - 1)))
+        self._compiler_reseed = False
 
     @property
     def _use_model_compiler(self):
@@ -626,6 +636,8 @@ class LocoEnv:
             if getattr(self, "_pending_variants", None) is not None:
                 b.set_variant_index(self._pending_variants[envs])
             if self._pending_compile:
+                if getattr(self, "_compiler_reseed", False):
+                    self._install_model_compiler()          # seed() since the last episode: the draws follow the new seed
                 b.compile_models()               # reset(): a freshly drawn model per environment (reference base.py:183-185)
             goal = self._goal_rows()
             if goal is not None:
@@ -831,6 +843,7 @@ class LocoEnv:
         if self._domain_rand is not None:
             self._domain_rand_rs = np.random.RandomState(seed)
             self._variant_tables = None          # the pool is a function of the seed: rebuilt at the next reset()
+            self._compiler_reseed = self._backend is not None      # ... and so is the device compiler's draw sequence
 
     def play_trajectory(self, n_episodes=None, n_steps_per_episode=None, render=False, **kwargs):
         """Kinematic replay of the loaded trajectory (reference ``base.py:314-386``): yields the observation

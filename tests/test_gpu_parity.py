@@ -1765,6 +1765,22 @@ def test_device_model_compiler_writes_the_host_compilers_tables(task, tmp_path):
     print("%s: device-compiled tables vs the host compiler on the same draws: max relative difference %.1e" % (task, worst))
 
 
+def test_device_model_compiler_follows_the_seed():
+    """``env.seed(s)`` re-seeds the randomisation (reference: np.random.seed in the worker processes): the models the device draws
+    at the following resets are a function of that seed again — same seed, same draws; another seed, other draws."""
+    cfg = os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml")
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True, n_envs=8, domain_randomization_config=cfg)
+    out = []
+    for seed in (5, 6, 5):
+        env.seed(seed)
+        env.reset()
+        env.step(np.zeros((8, 12)))
+        out.append(env.backend.get_model_draws()[0].copy())
+    assert np.array_equal(out[0], out[2]) and not np.array_equal(out[0], out[1])
+    assert len(np.unique(out[0].round(12), axis=0)) == 8
+
+
 def test_fresh_model_per_device_side_restart():
     """The reference compiles a freshly randomised model at EVERY reset (base.py:183-185). 4096 Talos environments with restarts
     every 4 control steps: after 13 steps every environment is on its fifth model at least (one at set-up, one at reset(), one per
