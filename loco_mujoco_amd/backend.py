@@ -247,6 +247,22 @@ class HipBatch:
         every device-side restart; :meth:`compile_models` is the host-side reset."""
         ib = np.ascontiguousarray(program[0], dtype=np.int32)
         db = np.ascontiguousarray(program[1], dtype=np.float64)
+        # the library checks the program's sizes and where its gather / contact ops write; what its draws and drawn bodies index is
+        # checked here (the kernel's tables in LDS are sized by the header's counts)
+        if len(ib) < 16:
+            raise BackendError("model-compiler program: header missing")
+        nv, nrb, ngs, nd, nslot, nbody = int(ib[1]), int(ib[2]), int(ib[3]), int(ib[4]), int(ib[5]), int(ib[8])
+        if len(ib) < 16 + 4 * nd + 4 * nrb:
+            raise BackendError("model-compiler program: draw / body tables cut short")
+        draws = ib[16:16 + 4 * nd].reshape(nd, 4)
+        rb = ib[16 + 4 * nd:16 + 4 * nd + 4 * nrb].reshape(nrb, 4)
+        limit = {0: (nv, 1), 1: (nrb, 1), 2: (nrb, 3), 3: (nrb, 3), 4: (ngs, 3)}
+        for kind, target, idx, comp in draws:
+            if kind not in (1, 2, 3) or target not in limit or not (0 <= idx < limit[int(target)][0] and 0 <= comp < limit[int(target)][1]):
+                raise BackendError("model-compiler program: a draw outside its table (kind %d target %d index %d component %d)" % (kind, target, idx, comp))
+        for body, kind, slot, has_sv in rb:
+            if not (0 < body < nbody and kind in (1, 2) and 0 <= slot < nslot and has_sv in (0, 1)):
+                raise BackendError("model-compiler program: a drawn body outside the model (body %d kind %d slot %d)" % (body, kind, slot))
         rec, gt = _f32(nominal_tables[0], (len(nominal_tables[0]),)), _f32(nominal_tables[1], (len(nominal_tables[1]),))
         npair = len(nominal_tables[2])
         gpt = _f32(nominal_tables[2], (npair,)) if npair else None

@@ -946,3 +946,34 @@ def test_model_compiler_is_the_default_and_the_pool_an_option():
     assert not LocoEnv.make("Talos.walk", debug=True, n_envs=4)._use_model_compiler
     with pytest.raises(ValueError, match="do not compile their models on the device"):
         LocoEnv.make("Talos.walk", debug=True, n_envs=4).model_of_env(0)
+
+
+def test_model_compiler_program_is_checked_before_it_reaches_the_device():
+    """The binding refuses a program whose draws or drawn bodies index outside the tables the device kernel sizes from the header
+    (the library itself checks the sizes and every gather / contact op)."""
+    from loco_mujoco_amd import backend, lowering
+    from loco_mujoco_amd.utils.domain_randomization import JointRandomization
+    env = LocoEnv.make("Talos.walk", debug=True)
+    jr = JointRandomization(env._model, os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml"))
+    ib, db, _ = lowering.model_compiler_tables(env._model, env._device_task(), *jr.model_draw_ops())
+    nominal = env._chain_model()
+    tabs = lowering.variant_tables(nominal, nominal)
+
+    class Recorder:             # the wrapper up to the library call
+        n, _h, calls = 4, None, []
+
+        class _lib:
+            @staticmethod
+            def lm_set_model_compiler(*a):
+                Recorder.calls.append(a)
+                return 0
+
+    backend.HipBatch.set_model_compiler(Recorder, (ib, db), tabs, seed=1)
+    assert len(Recorder.calls) == 1 and Recorder.n_model_draws == int(ib[4]) and Recorder.n_variants == 4
+    nd = int(ib[4])
+    for at, value in ((lowering.MC_IH_SIZE + 2, 999), (lowering.MC_IH_SIZE + 1, 7), (lowering.MC_IH_SIZE + 4 * nd + 2, 99), (lowering.MC_IH_SIZE + 4 * nd, 0)):
+        bad = ib.copy()
+        bad[at] = value
+        with pytest.raises(backend.BackendError, match="model-compiler program"):
+            backend.HipBatch.set_model_compiler(Recorder, (bad, db), tabs, seed=1)
+    assert len(Recorder.calls) == 1
