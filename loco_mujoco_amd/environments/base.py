@@ -627,6 +627,9 @@ class LocoEnv:
             if self._blocks:
                 self._select_model(idx)
             b = self.backend
+            if self._pending_compile and getattr(self, "_compiler_reseed", False):
+                self._install_model_compiler()          # seed() since the last episode: the draws follow the new seed (before the
+                                                        # state and the joint parameters go up: it re-creates the batch's tables)
             b.set_state(qpos[envs], qvel[envs])
             if prm is not None:
                 b.set_dof_params(damping=prm[0][envs], stiffness=prm[1][envs], frictionloss=prm[2][envs])
@@ -636,8 +639,6 @@ class LocoEnv:
             if getattr(self, "_pending_variants", None) is not None:
                 b.set_variant_index(self._pending_variants[envs])
             if self._pending_compile:
-                if getattr(self, "_compiler_reseed", False):
-                    self._install_model_compiler()          # seed() since the last episode: the draws follow the new seed
                 b.compile_models()               # reset(): a freshly drawn model per environment (reference base.py:183-185)
             goal = self._goal_rows()
             if goal is not None:
