@@ -56,6 +56,13 @@ CLOCK_GHZ = 2.4
 PROFILE_ROUND = "r5"
 TOL = dict(qpos=1e-4, qvel=1e-2)
 
+# Tasks the bench can time but whose device-vs-oracle parity is not a gate: the robot's own golden rollouts are only partly reproducible
+# (the line says `"supported": false` and carries the sample's verdict; exit code 0)
+_H1 = ("UnitreeH1: 30 of the 58 rows of the reference's golden rollouts are not reproduced by ANY float64 restatement — 26 carry the flat cap of a "
+       "hip-yaw cylinder on a mesh hull (MPR picks its support points among equals: ill-conditioned in float64, tests/test_oracle_golden.py), 4 depend "
+       "on the engine's own hull graph; device and oracle inherit that class of states (DESIGN.md §2, §7)")
+PARITY_REPORTED_NOT_GATING = {"UnitreeH1.walk": _H1, "UnitreeH1.run": _H1, "UnitreeH1.carry": _H1}
+
 # BASELINE.json configs[2..4] as they run on ONE GPU (4 and 5 at their per-GPU share)
 SIDE_CONFIGS = [
     dict(key="HumanoidTorque.run", task="HumanoidTorque.run", envs=4096, dr=False, baseline_config=3),
@@ -70,71 +77,111 @@ def algorithmic_bytes_per_env_step(nq, nv, nu, nobs, na=0):
     return 4 * (2 * nq + 2 * nv + nu + nobs + 2) + 8 * nv + 8 * na
 
 
-def oracle_is_ill_conditioned(step_fn, q0, v0, qo, vo, probes=8, seed=0):
-    """The conditioning rule of tests/test_gpu_parity.py::test_4096_...: the fp64 oracle's OWN result moves by more than the
-    tolerance when its input moves by float32-sized rounding noise (<= 1.2e-7 relative) — a contact or limit switching on within a
-    hair of a substep boundary, MPR on a flat face (UnitreeH1's hip cylinders). Such a state cannot be compared."""
+def oracle_spread(step_fn, q0, v0, qo, vo, probes=8, seed=0):
+    """The conditioning probe of tests/test_gpu_parity.py::test_4096_...: how far the fp64 oracle's OWN result moves (qpos, qvel
+    L-infinity) when its input moves by float32-sized rounding noise (<= 1.2e-7 relative) — a contact or limit switching on within a
+    hair of a substep boundary, MPR on a flat face (UnitreeH1's hip cylinders)."""
     rs = np.random.RandomState(seed)
+    sq = sv = 0.0
     for _ in range(probes):
         q1 = q0 + 1.2e-7 * rs.uniform(-1, 1, q0.shape) * np.maximum(1.0, np.abs(q0))          # (as in _worker_oracle_steps of the GPU suite)
         v1 = v0 + 1.2e-7 * rs.uniform(-1, 1, v0.shape) * np.maximum(1.0, np.abs(v0))
         q2, v2 = step_fn(q1, v1)
-        if np.abs(q2 - qo).max() > TOL["qpos"] or np.abs(v2 - vo).max() > TOL["qvel"]:
-            return True
-    return False
+        sq, sv = max(sq, float(np.abs(q2 - qo).max())), max(sv, float(np.abs(v2 - vo).max()))
+    return sq, sv
 
 
-def parity_sample(env, hm, table, random_policy, n=64):
-    """Second half of the metric: qpos / qvel L-infinity of the device against the fp64 oracle port after one control step
-    from n dataset states under the workload's policy (checker only, outside the timed region). A state beyond the tolerance
-    whose ORACLE result is itself unstable under float32 input rounding is counted as ill-conditioned, not compared (the rule
-    of the GPU suite's 4096-state test)."""
+def excused_by_margin(dq, dv, sq, sv):
+    """THE MARGIN RULE (round 6; the GPU suite's 4096-state test applies the same one): a state beyond the tolerance is set aside as
+    ill-conditioned only if, in every component that is beyond it, the oracle's own spread under the probes is at least as large as
+    the DEVICE'S ERROR — not merely larger than the tolerance (rounds 4-5), which excused a device 50 x off beside an oracle that
+    moved by 1.1 x the tolerance."""
+    return (dq <= TOL["qpos"] or sq >= dq) and (dv <= TOL["qvel"] or sv >= dv)
+
+
+def parity_of_states(env, hm, q0, v0, act0, acts, what, dofprm=None):
+    """Second half of the metric: qpos / qvel L-infinity of the device against the fp64 oracle port after ONE control step from the
+    given states (float32 as the device holds them) under the given actions (checker only, outside every timed region).
+    `dofprm`: per-environment joint damping / stiffness / frictionloss (domain randomisation): the device steps with them, the
+    oracle is compiled from each state's own values."""
     from loco_mujoco_amd.backend import HipBatch
     from oracle.model_blob import pack_model
     from oracle.pyoracle import Oracle
     m = env._model
-    nv, na = m.nv, getattr(m, "na", 0)
+    nv, na, n = m.nv, getattr(m, "na", 0), len(q0)
     oracle = Oracle(pack_model(m))
-    rs = np.random.RandomState(5)
-    rows = table[rs.randint(0, len(table), n)]
-    nu = len(env._action_indices)
-    acts = rs.uniform(-1, 1, (n, nu)) if random_policy else np.zeros((n, nu))
     b = HipBatch(hm, n)
-    b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
-    if rows.shape[1] > 2 * nv:
-        b.set_goal(rows[:, 2 * nv:])
+    b.set_state(q0, v0)
+    if na:
+        b.set_activation(act0)
+    if dofprm is not None:
+        b.set_dof_params(damping=dofprm["damping"], stiffness=dofprm["stiffness"], frictionloss=dofprm["frictionloss"])
+    b.stats(reset=True)
     b.step(acts)
     q, v = b.get_state()
+    st = b.stats()
     b.close()
     eq = ev = 0.0
-    used = illc = 0
+    used = illc = nonfinite = 0
     for i in range(n):
         ctrl = np.zeros(m.nu)
         ctrl[env._action_indices] = env._preprocess_action(acts[i])
-        q0, v0 = rows[i, :nv].astype(np.float32).astype(np.float64), rows[i, nv:2 * nv].astype(np.float32).astype(np.float64)
+        qi, vi = q0[i].astype(np.float32).astype(np.float64), v0[i].astype(np.float32).astype(np.float64)
+        ai = act0[i].astype(np.float32).astype(np.float64) if na else None
+        if dofprm is not None:
+            import copy
+            mi = copy.copy(m)
+            mi.dof_damping, mi.jnt_stiffness, mi.dof_frictionloss = (np.array(dofprm[k][i].astype(np.float32), float) for k in ("damping", "stiffness", "frictionloss"))
+            oracle = Oracle(pack_model(mi))
 
         def step_fn(qa, va):
             if na:
-                r = oracle.step_act(qa, va, np.zeros(na), ctrl, 10)
+                r = oracle.step_act(qa, va, ai, ctrl, 10)
                 return r[0], r[1]
             r = oracle.step(qa, va, ctrl, 10)
             return r[0], r[1]
         if na:
-            qo, vo, _, _, st = oracle.step_act(q0, v0, np.zeros(na), ctrl, 10)
+            qo, vo, _, _, ost = oracle.step_act(qi, vi, ai, ctrl, 10)
         else:
-            qo, vo, _, st = oracle.step(q0, v0, ctrl, 10)
-        if st["unhandled_pairs"]:
+            qo, vo, _, ost = oracle.step(qi, vi, ctrl, 10)
+        if ost["unhandled_pairs"]:
             continue                                         # a collider-less geom within reach of the floor on either side
-        dq, dv = np.abs(q[i] - qo).max(), np.abs(v[i] - vo).max()
-        if (dq > TOL["qpos"] or dv > TOL["qvel"]) and oracle_is_ill_conditioned(step_fn, q0, v0, qo, vo, seed=i):
-            illc += 1
+        if not (np.isfinite(qo).all() and np.isfinite(vo).all() and np.isfinite(q[i]).all() and np.isfinite(v[i]).all()):
+            nonfinite += 1
             continue
+        dq, dv = float(np.abs(q[i] - qo).max()), float(np.abs(v[i] - vo).max())
+        if dq > TOL["qpos"] or dv > TOL["qvel"]:
+            sq, sv = oracle_spread(step_fn, qi, vi, qo, vo, seed=i)
+            if excused_by_margin(dq, dv, sq, sv):
+                illc += 1
+                continue
         used += 1
         eq, ev = max(eq, dq), max(ev, dv)
-    return dict(qpos_linf=eq, qvel_linf=ev, states=used, ill_conditioned=illc,
-                against="fp64 oracle port (CPU), one control step = 10 substeps, same (qpos, qvel, ctrl); ill_conditioned = beyond the "
-                        "tolerance AND the oracle's own result moves by more than the tolerance under float32-sized input noise (not compared)",
-                tolerance=TOL, within_tolerance=bool(used > 0 and eq <= TOL["qpos"] and ev <= TOL["qvel"]))
+    return dict(qpos_linf=eq, qvel_linf=ev, states=used, ill_conditioned=illc, non_finite=nonfinite, sample=what,
+                replayed_env_steps=st.get("replayed_env_steps", 0.0), own_manifold_contacts=st.get("own_manifold_contacts", 0.0),
+                against="fp64 oracle port (CPU), one control step = 10 substeps, same (qpos, qvel, act, ctrl); ill_conditioned = beyond the "
+                        "tolerance AND the oracle's own result moves by at least the device's error under float32-sized input noise "
+                        "(the margin rule; not compared)",
+                tolerance=TOL, within_tolerance=bool(used > 0 and nonfinite == 0 and eq <= TOL["qpos"] and ev <= TOL["qvel"]))
+
+
+def parity_sample(W, random_policy, n=64):
+    """The parity sample of a leg: n states OF THE ROLLOUT THE LEG JUST TIMED (lm_get_state behind the timed block: walking, stumbling,
+    folded and freshly restarted robots in the mixture the rate was measured on — rounds 1-5 took dataset states), one more control
+    step from each on a fresh batch and in the oracle."""
+    m = W.env._model
+    q, v = W.b.get_state()
+    act = W.b.get_activation() if getattr(m, "na", 0) else None
+    rs = np.random.RandomState(5)
+    pick = rs.choice(len(q), size=min(n, len(q)), replace=False)
+    nu = len(W.env._action_indices)
+    acts = rs.uniform(-1, 1, (len(pick), nu)) if random_policy else np.zeros((len(pick), nu))
+    prm = None
+    if W.dr:
+        got = W.b.get_dof_params()
+        prm = {k: got[k][pick] for k in ("damping", "stiffness", "frictionloss")}
+    return parity_of_states(W.env, W.hm, q[pick], v[pick], None if act is None else act[pick], acts,
+                            "%d states of the timed rollout (lm_get_state after the timed block)%s" % (len(pick), ", each with its own joint parameters" if W.dr else ""), prm)
 
 
 def leg_rate(envs_per_gpu, world, steps, seconds):
@@ -363,13 +410,17 @@ def roofline_block(W, kernel_ms_per_launch, lib_sha):
             except Exception as e:      # noqa: BLE001 - a malformed profile must not take the bench line down
                 note += " (unreadable: %s)" % e
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_env_step": per_env_step,
+           "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_env_step": per_env_step,
            "kernel_ms_per_launch": kernel_ms_per_launch, "profile": note, "lib_sha16": lib_sha,
            "note": "the HBM figure is the contract's; it does NOT bind (SURVEY.md 8d: %d algorithmic B per env-step). What binds is "
                    "`binding`: FP32 VALU issue at one wave per SIMD. traffic = PMC bytes per launch from the committed profile (same "
                    "command, separate rocprofv3 --pmc passes), null when that profile is not of this build" % per_env_step}
     if binding is not None:
+        # what binds is named as the bound, with ITS fraction as `frac` (round-5 review); the contract's HBM figure stays beside it
+        # (`achieved` / `peak` / `unit` / `hbm_frac`: algorithmic bytes per launch over the kernel time against the 8 TB/s peak)
         out["binding"] = binding
+        out["bound"] = "fp32-valu-issue"
+        out["frac"] = binding["valu_issue_frac"]
     return out
 
 
@@ -394,12 +445,40 @@ def side_config(cfg, rank, device, steps, warmup, lib_sha, with_cpu):
                      "own_manifold_contacts": st.get("own_manifold_contacts", 0.0),
                      "replayed_env_steps": st.get("replayed_env_steps", 0.0), "episodes": st["episodes"], "nan_resets": st["nan_resets"],
                      "newton_iters_per_forward_pass": st["solver_iters"] / max(st["env_steps"] * W.forwards_per_env_step(), 1)}}
-    out["parity"] = parity_sample(W.env, W.hm, W.table, True)
+    out["parity"] = parity_sample(W, True)
     if with_cpu:
         one = cpu_baseline(W.env, W.table, W.task, True, budget_s=2.0)
         out["cpu_baseline"] = dict(value=one["value"], unit="env-steps/s", cores=1, kind="port", sample=one["sample"])
     W.close()
     out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
+def python_surface_leg(device, n, steps, warmup):
+    """The surface the reference's users call (reference gymnasium.py:47-65 -> LocoEnv.step): `steps` calls of LocoEnv.step() at
+    n_envs = n with numpy actions in and numpy observation / reward / absorbing out — H2D of the action, the launch, D2H of the results,
+    dtype conversion — timed on the host clock. Reported beside `value` (which is the policy-free rollout with everything resident)."""
+    from loco_mujoco_amd import LocoEnv
+    np.random.seed(0)
+    env = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=n, device=device)
+    env.reset()
+    env.enable_auto_reset(seed=0)
+    act = np.zeros((n, 12))
+    for _ in range(warmup):
+        env.step(act)
+    env.backend.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, rew, absorbing, info = env.step(act)
+    dt = time.perf_counter() - t0
+    assert obs.shape == (n, 37) and obs.dtype == np.float64 and rew.shape == (n,) and absorbing.shape == (n,)
+    k0 = env.backend.stats()["kernel_ms"] if hasattr(env.backend, "stats") else None
+    out = dict(envs=n, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, value=n * steps / dt, unit="env-steps/s",
+               obs_dtype=str(obs.dtype), action_dtype=str(act.dtype),
+               note="LocoEnv.step(numpy float64 action) -> (obs float64, reward float64, absorbing bool, info): pinned staging buffers, one "
+                    "H2D + one D2H per call (lm_step_pinned), one float32->float64 conversion of the observation; UnitreeA1.simple, zero action, "
+                    "device-side auto-reset")
+    del k0
     return out
 
 
@@ -460,6 +539,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=25, help="control steps per launch of the extra fused-rollout leg (0/1 = skip)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="short legs of the other BASELINE configs "
                     "(HumanoidTorque.run, Atlas.walk --dr 2048, HumanoidMuscle.run 2048) under the `configs` key; auto = one rank, default task")
+    ap.add_argument("--surface-steps", type=int, default=200, help="calls of LocoEnv.step() of the `python_surface` leg (0 = skip; one rank, default task)")
     ap.add_argument("--config-steps", type=int, default=60)
     ap.add_argument("--config-warmup", type=int, default=20)
     args = ap.parse_args()
@@ -560,7 +640,8 @@ def main():
     roof["kernel"] = "step_kernel<3 links,6 slots,Euler,elliptic,self-collisions,4 replicas>" if W.default_task else "step_kernel"
     out = {
         "metric": baseline_metric(),
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # `steps` = the launches `value` / `ms_per_step` were measured over (the driver's --steps block is `burst`, with its own `steps`)
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": main_steps, "warmup": args.warmup,
         "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timed_steps": main_steps,
@@ -600,7 +681,7 @@ def main():
     out["sustained"] = {"steps": main_steps, "value": value, "unit": "env-steps/s", "ms_per_step": main_leg["ms_per_step"],
                         "note": "= `value`"}
     if world == 1 and not args.no_cpu_baseline:
-        out["parity"] = parity_sample(env, W.hm, W.table, not W.default_task)
+        out["parity"] = parity_sample(W, not W.default_task)
         one = cpu_baseline(env, W.table, args.task, not W.default_task, budget_s=6.0)
         allc = cpu_baseline_all_cores(args.task, not W.default_task, args.dr)
         # reported baseline = every host core running the fp64 port (falls back to the single-core sample)
@@ -615,9 +696,23 @@ def main():
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     # the other BASELINE configs, short legs (after the headline's timed legs and outside them)
     want_configs = args.configs == "on" or (args.configs == "auto" and world == 1 and W.default_task and n == 4096)
+    want_surface = args.surface_steps > 0 and world == 1 and W.default_task and not args.no_cpu_baseline
     parity_ok = "parity" not in out or out["parity"]["within_tolerance"]
-    if want_configs and world == 1:
+    if args.task in PARITY_REPORTED_NOT_GATING and "parity" in out:
+        # a robot whose parity is NOT pinned: the sample is reported with its verdict, the run does not fail on it
+        out["parity"]["gate"] = "reported, not gating: " + PARITY_REPORTED_NOT_GATING[args.task]
+        out["supported"] = False
+        parity_ok = True
+    if want_surface:
         W.close()
+        try:
+            out["python_surface"] = python_surface_leg(local_rank, n, args.surface_steps, 20)
+            out["python_surface"]["over_kernel_rate"] = out["python_surface"]["ms_per_step"] / (main_kernel_ms / main_steps)
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            out["python_surface"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if want_configs and world == 1:
+        if not want_surface:
+            W.close()
         out["configs"] = {}
         for cfg in SIDE_CONFIGS:
             try:

@@ -259,7 +259,12 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> 
   static constexpr int kQCap = kBig ? 128 : ((MC >= 5) ? 24 : 8);    // convex pairs per chain and pass
   static constexpr int kRCap = kBig ? 64 : ((NS < 8) ? NS : 8);      // contacts per chain and pass
   static constexpr int kLists = kBS + (PAIRS ? MC * 3 : 0);
-  static constexpr int kSize = kLists + ((PAIRS && kBig) ? kQCap + 8 * kRCap : 0);
+  // the ROOT twists of the kernels that build their inertias behind the pair pass (forward: DEFER): the root is replicated in the four
+  // chain lanes of an environment, so its 36 numbers are STRIPED over the four columns (element i in column i & 3, field i >> 2) —
+  // 9 floats per column outside the part of lane memory the pair pass's work lists overlay, written before the pass
+  static constexpr bool kStripe = PAIRS && MC >= 5;
+  static constexpr int kRootS = kLists + ((PAIRS && kBig) ? kQCap + 8 * kRCap : 0);
+  static constexpr int kSize = kRootS + (kStripe ? 9 : 0);
   // device layout: lanes are grouped by 16 ([field][16 lanes] per group, so every field offset is a compile-time
   // constant = an immediate in the ds_read/ds_write); kGroup = floats per group, its kSize part padded to 1 mod 4
   // so that the four groups of a wave start 16 banks apart
@@ -1203,13 +1208,29 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       s1 = dadd(dadd(pw[1], rot(*Rw[1], loc1)), dscl(hmg, dm));
       }
     };
-    // the portal: points 1..3 as (v, v1) in local arrays (dynamic index: private memory), point 0 in registers
+    // the portal: points 1..3 as (v, v1), point 0 = v0. Rounds 3-5 kept them in a local array indexed by the run-time point number of
+    // `expand` — private memory: 36 scratch dwords read and written in the innermost loops of the collider. Round 6: registers, the
+    // run-time index of `put` as selects (LM_MPR_PV_ARRAY: the array, for A/B builds)
     double PV[3][6];
     auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
     auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
+#ifdef LM_MPR_PV_ARRAY
     auto put = [&](int q, D3 v, D3 v1) {
       PV[q - 1][0] = v.x; PV[q - 1][1] = v.y; PV[q - 1][2] = v.z; PV[q - 1][3] = v1.x; PV[q - 1][4] = v1.y; PV[q - 1][5] = v1.z;
     };
+#else
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) PV[i][j] = 0.0;
+    auto put = [&](int q, D3 v, D3 v1) {
+      const double nw[6] = {v.x, v.y, v.z, v1.x, v1.y, v1.z};
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) PV[i][j] = (q - 1 == i) ? nw[j] : PV[i][j];
+    };
+#endif
     const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
     const D3 c1 = dadd(pw[0], rot(*Rw[0], d3(x1[LM_GX_CX], x1[LM_GX_CY], x1[LM_GX_CZ])));
     const D3 c2 = dadd(pw[1], rot(*Rw[1], d3(x2[LM_GX_CX], x2[LM_GX_CY], x2[LM_GX_CZ])));
@@ -1684,6 +1705,11 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // through it so that the compiler re-reads them from LDS where they are used instead of hoisting hundreds of
   // loop-invariant constants into registers across the Newton / line-search loops (that is what spilled).
   constexpr bool PAIRS = PM == 1 || PM == 2, NOMPR = PM == 2, DETECT = PM != 0, DETECT_ONLY = PM == 3;
+#ifdef LM_NO_DEFER
+  constexpr bool DEFER = false;
+#else
+  constexpr bool DEFER = PAIRS && MC >= 5;        // (the quadruped's kernel — three links, no scratch — keeps its kinematics in one loop)
+#endif
   // the link-pair lists: in the constant table (LDS) — the six-link kernels' in its global copy (Params::cmg)
 #define LPE(off, i, f) ((MC == 6) ? P.cmg[(off) + (i) * LM_LP_SIZE + (f)] : cm[oz + (off) + (i) * LM_LP_SIZE + (f)])
 #ifdef LM_A1_CAPBOX_INLINE
@@ -1756,20 +1782,50 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     else { Sr[k].w = v3(0, 0, 0); Sr[k].v = ru[k]; }
   }
   // root body inertia about O
-  SpI Iroot;
-  {
+  SpI Iroot = spi0();
+  auto root_inertia = [&]() {
     float Iw[6], Il[6] = {RBI(4), RBI(5), RBI(6), RBI(7), RBI(8), RBI(9)};
     rotate_inertia(R, Il, Iw);
     Iroot = make_spi(RBI(0), mul(R, v3(RBI(1), RBI(2), RBI(3))), Iw);
-  }
+  };
   // root velocity / acceleration recursion (replicated), base acceleration = -gravity
   Sp Vroot = sp0(), Aroot; Aroot.w = v3(0, 0, 0); Aroot.v = v3(-P.g.x, -P.g.y, -P.g.z);
+  using LMm = LaneMemFor<MC, NS, NM, PAIRS, CONE>;
+#define LMEM(i) lmem[(i) * ls]
+  if constexpr (!DEFER) {
+    root_inertia();
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    Sp Sd; Sd.w = cross(Vroot.w, Sr[k].w); Sd.v = cross(Vroot.w, Sr[k].v) + cross(Vroot.v, Sr[k].w);
-    Vroot = Vroot + vr[k] * Sr[k];
-    Aroot = Aroot + vr[k] * Sd;
+    for (int k = 0; k < 6; k++) {
+      Sp Sd; Sd.w = cross(Vroot.w, Sr[k].w); Sd.v = cross(Vroot.w, Sr[k].v) + cross(Vroot.v, Sr[k].w);
+      Vroot = Vroot + vr[k] * Sr[k];
+      Aroot = Aroot + vr[k] * Sd;
+    }
+  } else {
+    // DEFER: the root's twists go to lane memory here (striped, LaneMem::kRootS) and come back behind the pair pass, where the
+    // acceleration recursion and the root inertia are built; only the root velocity is needed by the collision passes
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      Vroot = Vroot + vr[k] * Sr[k];
+      const float s6[6] = {Sr[k].w.x, Sr[k].w.y, Sr[k].w.z, Sr[k].v.x, Sr[k].v.y, Sr[k].v.z};
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (((k * 6 + j) & 3) == c) LMEM(LMm::kRootS + ((k * 6 + j) >> 2)) = s6[j];
+    }
+    Q::quad_sync();
   }
+  // a root twist from lane memory: striped over the environment's four columns (DEFER), or this lane's own copy
+  auto ldSr = [&](int r) -> Sp {
+    Sp S;
+    if constexpr (DEFER) {
+      float s6[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) s6[j] = Q::peer(lmem, ls, LMm::kRootS + ((r * 6 + j) >> 2), ((r * 6 + j) & 3) - c);
+      S.w = v3(s6[0], s6[1], s6[2]); S.v = v3(s6[3], s6[4], s6[5]);
+    } else {
+      const int b_ = LMm::kSr + r * 6;
+      S.w = v3(LMEM(b_), LMEM(b_ + 1), LMEM(b_ + 2)); S.v = v3(LMEM(b_ + 3), LMEM(b_ + 4), LMEM(b_ + 5));
+    }
+    return S;
+  };
   // collider-less root geoms that reach the floor are counted, not simulated
   {
     int nu = (int)rb[LM_R_NUNSUP];
@@ -1783,7 +1839,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   // chain: kinematics + velocity recursion + link inertias; floor contacts are recorded into the slots.
   // Everything that must survive into the solver (M, twists) is parked in lane memory so that the Newton loop
   // keeps only small vectors in registers.
-  using LMm = LaneMemFor<MC, NS, NM, PAIRS, CONE>;
   // slot field offsets of THIS kernel's record layout (shadow the namespace-scope enumerators of the full layout)
   constexpr bool kCompactSlots = (CONE == 0);
   constexpr int SL_D = kCompactSlots ? (int)SLC_D : (int)lm::SL_D, SL_FR = kCompactSlots ? (int)SLC_AREF : (int)lm::SL_FR;
@@ -1794,7 +1849,6 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   constexpr int SL_PART = kCompactSlots ? (int)SLC_SIZE : (int)lm::SL_PART;
   constexpr int SL_NX = SL_PART + 1, SL_NY = SL_PART + 2, SL_NZ = SL_PART + 3;
   (void)SL_FR;
-#define LMEM(i) lmem[(i) * ls]
   float bias_c[MC], bias_r[6];
   float a0r[6], a0c[MC];
   float sm_r[6], sm_c[MC];
@@ -1825,17 +1879,22 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
           V3 al = v3(LK(k, LM_D_PX), LK(k, LM_D_PY), LK(k, LM_D_PZ));
           V3 aw = pk + mul(Rk, al);
           V3 uw = mul(Rk, v3(LK(k, LM_D_AX), LK(k, LM_D_AY), LK(k, LM_D_AZ)));
-          if (t != 0.0f) { rotate_world(Rk, uw, qc[k]); pk = aw - mul(Rk, al); Sc[k].w = uw; Sc[k].v = cross(uw, O - aw); }
-          else { pk = pk + qc[k] * uw; Sc[k].w = v3(0, 0, 0); Sc[k].v = uw; }
-          Sp Sd; Sd.w = cross(V.w, Sc[k].w); Sd.v = cross(V.w, Sc[k].v) + cross(V.v, Sc[k].w);
-          V = V + vc[k] * Sc[k];
-          A = A + vc[k] * Sd;
-          Vc[k] = V; Ac[k] = A;
-          float Il[6], Iw[6];
+          Sp Sk;
+          if (t != 0.0f) { rotate_world(Rk, uw, qc[k]); pk = aw - mul(Rk, al); Sk.w = uw; Sk.v = cross(uw, O - aw); }
+          else { pk = pk + qc[k] * uw; Sk.w = v3(0, 0, 0); Sk.v = uw; }
+          if constexpr (!DEFER) {
+            Sp Sd; Sd.w = cross(V.w, Sk.w); Sd.v = cross(V.w, Sk.v) + cross(V.v, Sk.w);
+            A = A + vc[k] * Sd;
+          }
+          V = V + vc[k] * Sk;
+          if constexpr (!DEFER) {
+            Sc[k] = Sk; Vc[k] = V; Ac[k] = A;
+            float Il[6], Iw[6];
 #pragma unroll
-          for (int i = 0; i < 6; i++) Il[i] = LXI(k, 4 + i);
-          rotate_inertia(Rk, Il, Iw);
-          Ic[k] = make_spi(LXI(k, 0), pk + mul(Rk, v3(LXI(k, 1), LXI(k, 2), LXI(k, 3))) - O, Iw);
+            for (int i = 0; i < 6; i++) Il[i] = LXI(k, 4 + i);
+            rotate_inertia(Rk, Il, Iw);
+            Ic[k] = make_spi(LXI(k, 0), pk + mul(Rk, v3(LXI(k, 1), LXI(k, 2), LXI(k, 3))) - O, Iw);
+          }
           LMEM(LMm::kFrame + k * 18 + 0) = pk.x; LMEM(LMm::kFrame + k * 18 + 1) = pk.y; LMEM(LMm::kFrame + k * 18 + 2) = pk.z;
 #pragma unroll
           for (int i = 0; i < 9; i++) LMEM(LMm::kFrame + k * 18 + 3 + i) = Rk.a[i];
@@ -1850,7 +1909,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             const V3 vcr = V.v - Vroot.v + cross(wr, cw - O);
             pair_speed = fmaxf(pair_speed, sqrtf(dot(vcr, vcr)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
           }
-        } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
+        } else if constexpr (!DEFER) { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
       }
       LM_TICK(11);     // kinematics, twists, link inertias
   // floor contacts of this chain's geoms (plane z = 0, normal +z), each in the frame of its link. The replicas of a
@@ -2680,6 +2739,50 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
     pair_mask_out = pair_mask;
     for (int s2 = 0; s2 < nslot; s2++) { if ((int)SL(s2, SL_LINK) < 0) nrootslot++; if (PAIRS && SL(s2, SL_PART) != 0.0f) npairslot++; }
 
+    // DEFER (the kernels with a pair pass): twists, velocity / acceleration recursion and link inertias are built HERE, behind the
+    // collision passes, from the link frames those passes read out of lane memory anyway — held in registers across the pair pass
+    // (140 values per lane for five links) they were what the compiler spilled around the float64 collider (round 6:
+    // tools/probes/r6/spill_flow.py — 146 of the kernel's 478 scratch dwords were stored in the kinematics loop and loaded here). A
+    // hinge leaves its own axis and anchor where they were, so both follow from the frame BEHIND the joint: u = R_k axis,
+    // a = p_k + R_k anchor.
+    if constexpr (DEFER) {
+      root_inertia();
+      {
+        Sp V = sp0();
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          Sr[k] = ldSr(k);
+          Sp Sd; Sd.w = cross(V.w, Sr[k].w); Sd.v = cross(V.w, Sr[k].v) + cross(V.v, Sr[k].w);
+          V = V + vr[k] * Sr[k];
+          Aroot = Aroot + vr[k] * Sd;
+        }
+      }
+      Sp V = Vroot, A = Aroot;
+#pragma unroll
+      for (int k = 0; k < MC; k++) {
+        if (k < nl) {
+          const int fb = LMm::kFrame + k * 18;
+          const V3 pk = v3(LMEM(fb), LMEM(fb + 1), LMEM(fb + 2));
+          M3 Rk;
+#pragma unroll
+          for (int i = 0; i < 9; i++) Rk.a[i] = LMEM(fb + 3 + i);
+          const V3 uw = mul(Rk, v3(LK(k, LM_D_AX), LK(k, LM_D_AY), LK(k, LM_D_AZ)));
+          if (LK(k, LM_D_TYPE) != 0.0f) {
+            const V3 aw = pk + mul(Rk, v3(LK(k, LM_D_PX), LK(k, LM_D_PY), LK(k, LM_D_PZ)));
+            Sc[k].w = uw; Sc[k].v = cross(uw, O - aw);
+          } else { Sc[k].w = v3(0, 0, 0); Sc[k].v = uw; }
+          Sp Sd; Sd.w = cross(V.w, Sc[k].w); Sd.v = cross(V.w, Sc[k].v) + cross(V.v, Sc[k].w);
+          A = A + vc[k] * Sd;
+          V.w = v3(LMEM(fb + 12), LMEM(fb + 13), LMEM(fb + 14)); V.v = v3(LMEM(fb + 15), LMEM(fb + 16), LMEM(fb + 17));      // = V + vc[k] S_k, as the kinematics loop left it
+          Vc[k] = V; Ac[k] = A;
+          float Il[6], Iw[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) Il[i] = LXI(k, 4 + i);
+          rotate_inertia(Rk, Il, Iw);
+          Ic[k] = make_spi(LXI(k, 0), pk + mul(Rk, v3(LXI(k, 1), LXI(k, 2), LXI(k, 3))) - O, Iw);
+        } else { Sc[k] = sp0(); Vc[k] = V; Ac[k] = A; Ic[k] = spi0(); }
+      }
+    }
     // ======== inertia matrix (composite rigid body about O) and bias (spatial Newton-Euler) ========
     SpI comp = spi0();
     Sp Fsuf = sp0();
@@ -2840,10 +2943,12 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       for (int r = 0; r < 6; r++) LMEM(LMm::kMcr + k * 6 + r) = Mcr[k][r];
 #pragma unroll
     for (int i = 0; i < 21; i++) LMEM(LMm::kMrr + i) = Mrr[i];
+    if constexpr (!DEFER) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      LMEM(LMm::kSr + i * 6 + 0) = Sr[i].w.x; LMEM(LMm::kSr + i * 6 + 1) = Sr[i].w.y; LMEM(LMm::kSr + i * 6 + 2) = Sr[i].w.z;
-      LMEM(LMm::kSr + i * 6 + 3) = Sr[i].v.x; LMEM(LMm::kSr + i * 6 + 4) = Sr[i].v.y; LMEM(LMm::kSr + i * 6 + 5) = Sr[i].v.z;
+      for (int i = 0; i < 6; i++) {
+        LMEM(LMm::kSr + i * 6 + 0) = Sr[i].w.x; LMEM(LMm::kSr + i * 6 + 1) = Sr[i].w.y; LMEM(LMm::kSr + i * 6 + 2) = Sr[i].w.z;
+        LMEM(LMm::kSr + i * 6 + 3) = Sr[i].v.x; LMEM(LMm::kSr + i * 6 + 4) = Sr[i].v.y; LMEM(LMm::kSr + i * 6 + 5) = Sr[i].v.z;
+      }
     }
 #pragma unroll
     for (int k = 0; k < MC; k++) {
@@ -2972,7 +3077,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   auto link_images = [&](const float* xr, const float* xc) {
     Sp A = sp0();
 #pragma unroll
-    for (int r = 0; r < 6; r++) A = A + xr[r] * ldS(LMm::kSr + r * 6);
+    for (int r = 0; r < 6; r++) A = A + xr[r] * ldSr(r);
     img_root = A;
 #pragma unroll
     for (int k = 0; k < MC; k++) {
@@ -3292,7 +3397,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       for (int k = 0; k < MC; k++) { gc[k] = Mac[k] - sm_c[k] - qf_c[k]; g2 = fmaf(gc[k], gc[k], g2); }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        qf_r[i] = fu_r[i] + ((P.ablate & 64) ? 0.0f : Q::sum(spdot(ldS(LMm::kSr + i * 6), Fsum)));
+        qf_r[i] = fu_r[i] + ((P.ablate & 64) ? 0.0f : Q::sum(spdot(ldSr(i), Fsum)));
         gr_[i] = Mar[i] - sm_r[i] - qf_r[i];
       }
       float gnorm2 = Q::sum(g2);
@@ -3385,7 +3490,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             }
           } else {
 #pragma unroll
-            for (int r = ROOT_XYZ ? 3 : 0; r < 6; r++) if (r >= 3 || !(MC >= 5 && P.root_xyz)) contact_rows(ldS(LMm::kSr + r * 6), rc, Jc[r]);
+            for (int r = ROOT_XYZ ? 3 : 0; r < 6; r++) if (r >= 3 || !(MC >= 5 && P.root_xyz)) contact_rows(ldSr(r), rc, Jc[r]);
 #pragma unroll
             for (int k = 0; k < MC; k++) {
               if (k <= link) contact_rows(ldS(LMm::kSc + k * 6), rc, Jc[6 + k]);

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
       }
       step_no = 0;
       zero_act = true;
-      if (DR == 2 && a.nvar > 1 && c == 0 && valid) {
+      if (DR == 2 && (a.vdirty || a.nvar > 1) && c == 0 && valid) {        // (model compiler: one slot per environment — a batch of ONE has nvar == 1)
         // new episode, new model variant (reference base.py:183-185: a freshly randomised model per reset)
         const unsigned long long rv = mix64(a.seed ^ mix64((unsigned long long)gid * 2ull + 1ull) ^ ((unsigned long long)ec << 32) ^ 0xA24BAED4963EE407ull);
         if (a.vdirty) a.vdirty[e] = 1;

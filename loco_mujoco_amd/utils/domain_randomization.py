@@ -116,6 +116,12 @@ class JointRandomization:
             for p, r in [pr for _, prs in grules for pr in prs]:
                 if p in ("mass", "density") and self._has_spread({p: r}) and not has_inertial:
                     raise NotImplementedError("geom %s randomisation on body %s, which has no <inertial> element" % (p, name))
+            # a body whose only spread is a geom mass / density rule draws nothing and changes nothing (its <inertial> element
+            # wins in the engine's compiler, sample_model_variant): it is NOT a model rule — with nothing else in the file the
+            # environment needs neither the model compiler nor a variant pool (an empty draw program is refused by the library)
+            if not (self._has_spread(dict(irules)) or
+                    any(self._has_spread({p: r}) for _, prs in grules for p, r in prs if p == "friction")):
+                continue
             self.body_rules.append((b, irules, grules))
 
     @staticmethod

@@ -279,6 +279,7 @@ typedef struct {
   int unhandled_pairs;
   int convex_contacts; double max_self_depth;     /* per forward pass: MPR contacts, deepest non-floor penetration */
   int native_contacts;                            /* per forward pass: contacts of the native box / cylinder colliders */
+  int own_contacts, own_face_contacts;            /* of those: capsule-box / box-box contacts (own constructions), and the box-box FACE case among them */
 } work;
 
 enum { ROW_FRICTION = 0, ROW_LIMIT = 1, ROW_CONTACT_PLAIN = 2, ROW_CONTACT_PYR = 3, ROW_CONTACT_ELL = 4 };
@@ -640,6 +641,10 @@ static int nat_capsule_box(const double* pc, const double* Rc, const double* sc,
   return n;
 }
 
+/* which branch the last nat_box_box call of this thread took: 1 = the incident face clipped against the reference face (the FACE case:
+   this repository's own construction, approximate), 0 = an edge pair (exact where the geometry leaves no choice) */
+static __thread int g_boxbox_face_case;
+
 /* box against box */
 static int nat_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
                        double margin, double (*out)[7]) {
@@ -665,6 +670,7 @@ static int nat_box_box(const double* p1, const double* R1, const double* s1, con
     const double pr = dot3(d, n), gap = fabs(pr) - rA - rB;
     if (gap > best_edge) { best_edge = gap; ei = i; ej = j; const double sg = pr >= 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) ne[k] = sg * n[k]; }
   }
+  g_boxbox_face_case = 0;
   if (best_face >= margin || best_edge >= margin) return 0;
   /* an edge pair decides only when it separates clearly better than every face (5 % + 1 um) */
   if (best_edge > best_face + 0.05 * fabs(best_face) + 1e-6) {
@@ -681,6 +687,7 @@ static int nat_box_box(const double* p1, const double* R1, const double* s1, con
     return 1;
   }
   /* face contact: the incident face of the other box clipped against the reference face */
+  g_boxbox_face_case = 1;
   const int ref1 = face < 3, kr = face % 3;
   const double *pr_ = ref1 ? p1 : p2, *sr = ref1 ? s1 : s2, *pi_ = ref1 ? p2 : p1, *si = ref1 ? s2 : s1;
   double (*Ar)[3] = ref1 ? A : B, (*Ai)[3] = ref1 ? B : A;
@@ -1115,7 +1122,7 @@ static void fix_normal(const cvx* A, const cvx* B, const double* pos, double* no
 }
 
 static void collide(const lmo_model* m, work* w) {
-  w->ncon = 0; w->unhandled_pairs = 0; w->convex_contacts = 0; w->max_self_depth = 0; w->native_contacts = 0;
+  w->ncon = 0; w->unhandled_pairs = 0; w->convex_contacts = 0; w->max_self_depth = 0; w->native_contacts = 0; w->own_contacts = 0; w->own_face_contacts = 0;
   for (int pi = 0; pi < m->npair; pi++) {
     int g1 = m->pair_g1[pi], g2 = m->pair_g2[pi];
     int t1 = IDX(m->geom_type, g1), t2 = IDX(m->geom_type, g2);
@@ -1296,6 +1303,12 @@ static void collide(const lmo_model* m, work* w) {
       const int nc = native_pair(t1, p1, R1, s1, t2, p2, R2, s2, margin, buf);
       for (int i = 0; i < nc; i++) add_contact(w, &tm, buf[i][0], buf[i] + 1, buf[i] + 4, NULL);
       w->native_contacts += nc > 0 ? nc : 0;
+      /* of those: contacts whose manifold is this repository's own construction, not the engine's case analysis (capsule-box, box-box),
+         and among them the box-box FACE case (the approximate one) */
+      if (nc > 0 && t2 == LM_GEOM_BOX && (t1 == LM_GEOM_BOX || t1 == LM_GEOM_CAPSULE)) {
+        w->own_contacts += nc;
+        if (t1 == LM_GEOM_BOX && g_boxbox_face_case) w->own_face_contacts += nc;
+      }
     } else if (m->skip_pair_counter) {
       /* timing runs: the pair has no collider here, and whether the engine would have a contact is not asked */
     } else if (t1 == LM_GEOM_MESH || t2 == LM_GEOM_MESH
@@ -1905,7 +1918,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
   for (int s = 0; s < nsub; s++) {
     if (m->integrator == LM_INT_EULER) {
       forward(m, qpos, qvel, ctrl, act, warmstart, w);
-      if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
+      if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; stats->own_contacts += w->own_contacts; stats->own_face_contacts += w->own_face_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
       if (warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
       euler(m, qpos, qvel, w);
       for (int i = 0; i < m->na; i++) act[i] += m->timestep * w->act_dot[i];      /* explicit Euler on activations */
@@ -1918,7 +1931,7 @@ static int step_impl(const lmo_model* m, double* qpos, double* qvel, double* act
       memcpy(X, q0, sizeof(double) * nv); memcpy(V, v0, sizeof(double) * nv);
       for (int st = 0; st < 4; st++) {
         forward(m, X, V, ctrl, NULL, warmstart, w);
-        if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
+        if (stats) { stats->convex_contacts += w->convex_contacts; stats->native_contacts += w->native_contacts; stats->own_contacts += w->own_contacts; stats->own_face_contacts += w->own_face_contacts; if (w->max_self_depth > stats->max_self_depth) stats->max_self_depth = w->max_self_depth; }
         if (st == 0 && warmstart) memcpy(warmstart, w->qacc, sizeof(double) * nv);
         for (int d = 0; d < nv; d++) { dq[d] += Bw[st] * V[d]; dv[d] += Bw[st] * w->qacc[d]; }
         if (st < 3) for (int d = 0; d < nv; d++) { double vn = v0[d] + h * A[st] * w->qacc[d]; X[d] = q0[d] + h * A[st] * V[d]; V[d] = vn; }

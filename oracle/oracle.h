@@ -30,6 +30,8 @@ typedef struct {
   int convex_contacts;        /* contacts from the convex-convex collider (MPR), summed over the forward passes */
   double max_self_depth;      /* deepest penetration (-dist) of a contact between two bodies of the robot over all forward passes */
   int native_contacts;        /* contacts of the native box / cylinder colliders (sphere-box, sphere-cylinder, capsule-box, box-box) */
+  int own_contacts;           /* of those: capsule-box and box-box contacts — this repository's own manifold constructions (oracle.c nat_*) */
+  int own_face_contacts;      /* of those: contacts of the box-box FACE case (incident face clipped against the reference face: approximate) */
 } lmo_stats;
 
 typedef struct {

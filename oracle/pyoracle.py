@@ -30,7 +30,8 @@ class Contact(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ncon", C.c_int), ("nefc", C.c_int), ("solver_iter_total", C.c_int),
                 ("solver_iter_max", C.c_int), ("unhandled_pairs", C.c_int), ("convex_contacts", C.c_int),
-                ("max_self_depth", C.c_double), ("native_contacts", C.c_int)]
+                ("max_self_depth", C.c_double), ("native_contacts", C.c_int),
+                ("own_contacts", C.c_int), ("own_face_contacts", C.c_int)]
 
 
 _DP = C.POINTER(C.c_double)

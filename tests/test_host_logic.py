@@ -720,6 +720,14 @@ def test_bench_leg_rate_identity_and_parity_flag():
     assert "within_tolerance" in src and "sys.exit(3)" in src
     # no rate is formed from a cumulative counter any more
     assert 'vals[13] / ' not in src and 'env_steps / elapsed' not in src
+    # the margin rule (round 6): a state beyond the tolerance is set aside only when the oracle's own spread under the probes reaches the
+    # DEVICE'S ERROR in every component that is beyond the tolerance — not when it merely exceeds the tolerance
+    assert bench.excused_by_margin(2e-4, 5e-3, 3e-4, 0.0)
+    assert not bench.excused_by_margin(2e-4, 5e-3, 1.5e-4, 1.0)       # the oracle moves by 1.5 x the tolerance, the device is 2 x off
+    assert not bench.excused_by_margin(5e-5, 0.5, 1.0, 0.02)          # qvel 50 x off beside an oracle that moves by 2 x the tolerance
+    assert bench.excused_by_margin(5e-5, 5e-3, 0.0, 0.0)              # (within the tolerance: nothing to excuse)
+    # the parity sample comes from the states of the timed rollout, and UnitreeH1 is reported, not gating
+    assert "lm_get_state after the timed block" in src and set(bench.PARITY_REPORTED_NOT_GATING) == {"UnitreeH1.walk", "UnitreeH1.run", "UnitreeH1.carry"}
 
 
 def test_model_rule_randomisation_with_several_models(tmp_path):
@@ -946,6 +954,21 @@ def test_model_compiler_is_the_default_and_the_pool_an_option():
     assert not LocoEnv.make("Talos.walk", debug=True, n_envs=4)._use_model_compiler
     with pytest.raises(ValueError, match="do not compile their models on the device"):
         LocoEnv.make("Talos.walk", debug=True, n_envs=4).model_of_env(0)
+
+
+def test_geom_mass_rule_on_a_body_with_inertial_is_no_model_rule(tmp_path):
+    """A geom `mass` / `density` rule on a body WITH an <inertial> element draws nothing and changes nothing (the engine's compiler
+    prefers the <inertial>): such a file must ask for neither the model compiler (an empty draw program is refused by the library)
+    nor a variant pool — and with a friction rule beside it only the friction is drawn."""
+    y = tmp_path / "dr.yaml"
+    y.write_text("Geoms:\n  trunk:\n    mass:\n      sigma: 0.3\n")
+    e = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=2, domain_randomization_config=str(y))
+    assert not e._domain_rand.has_model_rules and not e._use_model_compiler
+    assert e._domain_rand.model_draw_ops()[0] == []
+    y.write_text("Geoms:\n  trunk:\n    mass:\n      sigma: 0.3\n    friction:\n      sigma: [0.1, 0.0, 0.0]\n")
+    e = LocoEnv.make("UnitreeA1.simple", debug=True, n_envs=2, domain_randomization_config=str(y))
+    ops = e._domain_rand.model_draw_ops()[0]
+    assert e._use_model_compiler and len(ops) > 0 and all(op[3] == e._domain_rand.TARGET_FRICTION for op in ops)
 
 
 def test_model_compiler_program_is_checked_before_it_reaches_the_device():
