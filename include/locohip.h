@@ -184,6 +184,22 @@ int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t
    against that stream. */
 int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, void* stream, int sync);
 
+/* LocoEnv.step()'s host surface in ONE call (reference gymnasium.py:47-65 -> base.py step(): numpy float64 action in, float64
+   observation / reward and the absorbing flag out — the library's counterpart of the dtype conversions and copies the Python
+   layer did around lm_step, environments/base.py). The results land in PINNED host memory owned by the batch: a ring of
+   LM_PINNED_SLOTS result sets, so that what step t returned stays intact while steps t+1 .. t+LM_PINNED_SLOTS-1 run.
+     lm_pinned_slot   pointers to result set `slot` (allocated at the first call): obs [n_envs][nobs] float64 in the column order of
+                      lm_set_obs_order, reward [n_envs] float64, done [n_envs] (the done byte of lm_step)
+     lm_set_obs_order column j of the float64 observation = column perm[j] of the kernel's (the reference's observation order where
+                      it differs from the device's, base.py _obs_perm); NULL: the kernel's order
+     lm_step_pinned   one control step: the action (float64, pageable or not) is converted into a pinned staging buffer, which the step
+                      kernel reads itself; a small kernel behind it converts observation / reward to float64 (applying the order)
+                      straight into the pinned slot — no copy is queued on either side of the launch; synchronous */
+#define LM_PINNED_SLOTS 4
+int lm_pinned_slot(lm_batch* b, int slot, double** obs, double** reward, uint8_t** done);
+int lm_set_obs_order(lm_batch* b, const int32_t* perm, int n);
+int lm_step_pinned(lm_batch* b, const double* action, int slot);
+
 /* device-side episode handling: rows = [qpos(nq) | qvel(nv) | goal(ngoal)]; when enabled, an
    environment whose step ended absorbing (or reached `horizon` control steps, 0 = never) restarts
    from a row drawn with a counter-based RNG keyed by (seed, global env id, episode count) and the

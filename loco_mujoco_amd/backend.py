@@ -37,6 +37,7 @@ class ForwardOut(C.Structure):
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
+           "lm_pinned_slot", "lm_set_obs_order", "lm_step_pinned",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
            "lm_get_flags", "lm_set_model_variants", "lm_set_variant_index", "lm_get_variant_index", "lm_set_variant_rows",
            "lm_set_model_compiler", "lm_compile_models", "lm_get_model_draws", "lm_get_model_tables"]
@@ -79,6 +80,9 @@ def load_library():
     lib.lm_set_activation.argtypes = [C.c_void_p, _F, _U8]
     lib.lm_get_activation.argtypes = [C.c_void_p, _F]
     lib.lm_step.argtypes = [C.c_void_p, _F, _F, _F, _U8]
+    lib.lm_pinned_slot.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(_U8)]
+    lib.lm_set_obs_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+    lib.lm_step_pinned.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.lm_set_reset_table.argtypes = [C.c_void_p, _F, C.c_int, C.c_uint64, C.c_int64]
     lib.lm_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.lm_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(Stats)]
@@ -332,6 +336,42 @@ class HipBatch:
         _check(self._lib.lm_step(self._h, _fp(a), _fp(obs), _fp(rew), done.ctypes.data_as(_U8)))
         # done byte: bit 0 = absorbing state, bit 1 = the device ended the episode in this step (restarted it from the
         # reset table, or the horizon was reached)
+        self.last_restarted = (done & 2) != 0
+        return obs, rew, (done & 1) != 0
+
+    PINNED_SLOTS = 4
+
+    def set_obs_order(self, perm):
+        """Column order of the float64 observation of step_pinned (None: the kernel's own)."""
+        if perm is None:
+            _check(self._lib.lm_set_obs_order(self._h, None, 0))
+        else:
+            p = np.ascontiguousarray(perm, dtype=np.int32)
+            _check(self._lib.lm_set_obs_order(self._h, p.ctypes.data_as(C.POINTER(C.c_int32)), len(p)))
+
+    def _pinned_views(self):
+        views = []
+        for slot in range(self.PINNED_SLOTS):
+            o, r, d = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), _U8()
+            _check(self._lib.lm_pinned_slot(self._h, slot, C.byref(o), C.byref(r), C.byref(d)))
+            arrs = []
+            for ptr, ct, dt, shape in ((o, C.c_double, np.float64, (self.n, self.nobs)), (r, C.c_double, np.float64, (self.n,)), (d, C.c_uint8, np.uint8, (self.n,))):
+                buf = (ct * int(np.prod(shape))).from_address(C.addressof(ptr.contents))
+                buf._owner = self          # a view handed to the caller keeps the batch (and with it the pinned memory) alive
+                arrs.append(np.frombuffer(buf, dtype=dt).reshape(shape))
+            views.append(tuple(arrs))
+        return views
+
+    def step_pinned(self, action64):
+        """One control step through the library's float64 host surface (lm_step_pinned): ``action64`` is a C-contiguous float64
+        array [n, nu]; returns (obs float64 [n, nobs], reward float64 [n], absorbing bool [n]). obs and reward are VIEWS of a ring of
+        PINNED_SLOTS pinned result sets owned by the batch: what a call returned stays intact for the next PINNED_SLOTS - 1 calls."""
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = self._pinned_views()
+            self._slot = -1
+        self._slot = (self._slot + 1) % self.PINNED_SLOTS
+        _check(self._lib.lm_step_pinned(self._h, action64.ctypes.data_as(C.POINTER(C.c_double)), self._slot))
+        obs, rew, done = self._pinned[self._slot]
         self.last_restarted = (done & 2) != 0
         return obs, rew, (done & 1) != 0
 

@@ -33,6 +33,15 @@
 #ifndef LM_DEV_COLD
 #define LM_DEV_COLD LM_DEV    // the includer may make the rare, register-hungry helpers real functions (lm_step.h: noinline)
 #endif
+LM_DEV unsigned lm_f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+LM_DEV float lm_u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+#ifndef LM_GLD64
+// 64-bit words of the convex collider's warm-start cache (global memory, written by one lane of an environment in one forward pass and read
+// by another in the next): the step kernel (lm_step.h) makes them agent-scope relaxed atomics so that a read sees the last write, not a
+// stale line of the CU's L1; the emulator keeps the plain forms
+#define LM_GLD64(p) (*reinterpret_cast<const unsigned long long*>(p))
+#define LM_GST64(p, v) (*reinterpret_cast<unsigned long long*>(p) = (v))
+#endif
 #ifndef LM_LMEM_T
 #define LM_LMEM_T float       // element type of lane memory (A/B probe: `volatile float`)
 #endif
@@ -232,6 +241,8 @@ template <int MC> struct DofPrm {
                                                              // (twice per forward pass) — 22 registers fewer to carry through the solver
   const float* inr; const float* gt; const float* gpt;
   float rfl_r[6], rfl_c[MC];       // friction-loss regularisers of the variant (read inside the line search: kept in registers)
+  float* mprc;                     // the environment's warm-start cache of the convex collider: kMprCacheFloats floats per geom-pair record
+                                   // (mpr_convex_pair), or null (set by every caller, DR or not)
 };
 
 // lane-memory map: [NS slot records][Mcc, Mcr, Mrr][root twists 6x6][chain twists MCx6][link images MCx6][link frames MCx18][muscle act NM][muscle ctrl NM][link bounding-sphere centres MCx3 (PAIRS)]
@@ -707,10 +718,18 @@ LM_DEV void arrow_solve_x(const float* Lcc, const float (*W)[6], const float* Lr
 // coupled; quad-uniform, fill-in added here), so uncoupled pairs cost nothing. Afterwards every lane holds the Y blocks of ALL its
 // partners: the upper ones where their X was, a copy of the lower partner p's in slot NX - 1 - p, and the solve only exchanges
 // vectors. Exact for any coupling pattern (a folded-up humanoid couples all three of its chains); NX >= number of chains - 1.
+// The loops over lanes / cross-block slots: rolled (run-time slot indices: X lives in private memory = scratch) in the kernels with three
+// cross-block slots; UNROLLED for the humanoids' two (round 6: every index of X is a compile-time constant, the 50 floats are registers —
+// the cross blocks were 50 scratch dwords read and written inside the Hessian's slot loop and the factorisation of every coupled solve)
+#ifdef LM_ARROW_ROLLED
+#define LM_ARROW_LOOP _Pragma("nounroll")
+#else
+#define LM_ARROW_LOOP _Pragma("unroll (NX <= 2 ? 4 : 1)")
+#endif
 template <class Q, int MC, int NX>
 LM_DEV void arrow_factor_g(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, const float* Hrr_part, float* Lrr,
                            float (*X)[MC][MC], int c, int& adj) {
-#pragma nounroll
+LM_ARROW_LOOP
   for (int a = 0; a < NX + 1; a++) {
     const int row = (adj >> (4 * a)) & 15;
     if (c == a || (a == NX && c > NX)) {              // (a lane beyond the last one that can hold a cross block: plain factorisation)
@@ -757,7 +776,7 @@ LM_DEV void arrow_factor_g(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, co
     for (int k = 0; k < MC; k++)
 #pragma unroll
       for (int r = 0; r < 6; r++) Wa[k][r] = Q::quad_read(Hcr[k][r], a);
-#pragma nounroll
+LM_ARROW_LOOP
     for (int x1 = 0; x1 < NX; x1++) {
       const int b = a + 1 + x1;
       if (b > NX || !((row >> b) & 1)) continue;
@@ -790,7 +809,7 @@ LM_DEV void arrow_factor_g(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, co
 #pragma unroll
           for (int j = 0; j < MC; j++) X[NX - 1 - a][k][j] = Y1[k][j];
       }
-#pragma nounroll
+LM_ARROW_LOOP
       for (int x2 = x1 + 1; x2 < NX; x2++) {
         const int d = a + 1 + x2;
         if (d > NX || !((row >> d) & 1)) continue;
@@ -847,7 +866,7 @@ template <class Q, int MC, int NX>
 LM_DEV void arrow_solve_g(const float* Lcc, const float (*W)[6], const float* Lrr, const float (*Y)[MC][MC], int c, int adj,
                           float* xc, float* xr) {
   // forward, lanes in order: y_a = L_a^-1 g_a, then every coupled lane b above takes Y_ab^T y_a off its right-hand side
-#pragma nounroll
+LM_ARROW_LOOP
   for (int a = 0; a < NX + 1; a++) {
     if (c == a) {
 #pragma unroll
@@ -918,7 +937,7 @@ LM_DEV void arrow_solve_g(const float* Lcc, const float (*W)[6], const float* Lr
       xc[i] = tt / Lcc[tri(i, i)];
     }
   }
-#pragma nounroll
+LM_ARROW_LOOP
   for (int a = NX; a >= 0; a--) {
     if (c == a) {
 #pragma unroll
@@ -1011,8 +1030,24 @@ struct MprOut { float nx, ny, nz, px, py, pz, dist; int found; };
 #endif
 // mode 0: the one-direction separation test only (found = 1: not separated along it, the portal search has to decide);
 // mode 1: the portal search without that test (the caller ran it: stage A / stage B of the work queue).
+// WARM START (round 6). A forward pass meets nearly the configuration of the pass before it (RK4: four per substep), and the collider's
+// time is the number of DEPENDENT hull fetches of its slowest lane (2.5 hill steps per support, 6.7 supports per call; 46 % of the calls
+// end at the one-direction test, 12 % without contact behind the portal search). `ce` = this geom pair's record in the environment's
+// cache (global memory, kMprCacheFloats floats, null: none; zeroed = empty):
+//   [0..2] a direction that separated the two shapes when the pair was last seen, [3] 1 if there is one. Mode 0 tests IT first, then
+//          the direction between the bounding capsules; mode 1 leaves the direction its search ended without contact at. Any direction
+//          along which the inflated shapes are apart proves "no contact" (that is what the one-direction test rests on), and the test
+//          is evaluated on the CURRENT frames: what the cache holds decides how fast the answer comes, never which;
+//   [4 + 2 p, 5 + 2 p] the hull vertices (adjacency block + 1, 0 = none) at which the supports of the call's p-th direction ended:
+//          p = 0 the cached direction, 1 the capsule direction, 2.. the first directions of the portal search. The hill climb of the
+//          same direction one pass later starts there and usually ends there (one fetch instead of 2.5). A hull's support vertex does
+//          not depend on where the climb starts (greedy ascent on a convex vertex graph), so the results are those of the cold search.
+#ifndef LM_MPR_CACHE_HINTS
+#define LM_MPR_CACHE_HINTS 14
+#endif
+constexpr int kMprCacheHints = LM_MPR_CACHE_HINTS, kMprCacheFloats = 4 + 2 * kMprCacheHints;
 template <bool PAIRED>
-LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int mode LM_MPR_ARG) {
+LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool g1own, V3 po_, M3 Ro_, V3 pp_, M3 Rp_, V3 O, float pmargin, int mode, float* ce LM_MPR_ARG) {
   LM_MPR_COUNT(0, mode == 0 ? 1 : 0);
   MprOut out; out.nx = out.ny = out.nz = out.px = out.py = out.pz = out.dist = 0.0f; out.found = 0;
     // FLOAT64 inside: the portal search takes hundreds of sign decisions on differences of nearly equal support values; in
@@ -1111,7 +1146,7 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
     // block]...: one step = header + first eight neighbours, one 144-byte fetch). The two hulls climb IN THE SAME LOOP: the fetches of
     // a step of either are in flight together, so a support pair costs max(steps) memory round trips, not their sum (the loads are
     // unconditional — a hull that has arrived re-reads its block — to keep them out of divergent branches).
-    auto support_pair = [&](D3 d, D3* sp_) {
+    auto support_pair = [&](D3 d, D3* sp_, int ch0 = -1, int ch1 = -1) {
       if constexpr (!PAIRED) {
         // (the quadruped's kernel: its convex pairs are primitives; anything else in this function costs its bench rollout 2-3 % through
         // the register allocation of the kernel around it — this branch is the round's first version, untouched)
@@ -1155,8 +1190,11 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       if (!mesh0) loc0 = prim_support(rec + LM_GP_P1, xg0, type0, dl0);
       if (!mesh1) loc1 = prim_support(rec + LM_GP_P2, xg1, type1, dl1);
       if (mesh0 || mesh1) {
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+        const long long tc0_ = LM_CLOCK();
+#endif
         const F4* A = reinterpret_cast<const F4*>(meshadj);
-        int cur0 = mesh0 ? start_vertex(xg0, hint[0], dl0) : 0, cur1 = mesh1 ? start_vertex(xg1, hint[1], dl1) : 0;
+        int cur0 = mesh0 ? start_vertex(xg0, (ch0 >= 0) ? ch0 : hint[0], dl0) : 0, cur1 = mesh1 ? start_vertex(xg1, (ch1 >= 0) ? ch1 : hint[1], dl1) : 0;
         bool go0 = mesh0, go1 = mesh1;
         double best0 = -1.0e300, best1 = -1.0e300;
 #pragma nounroll
@@ -1203,18 +1241,21 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
         }
         if (mesh0) hint[0] = cur0;
         if (mesh1) hint[1] = cur1;
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+        if (mode == 1) mc[10] += LM_CLOCK() - tc0_;          // (probe: cycles in the hull climbs of the portal search; [13]: the search as a whole; [11] its support calls; [14] its directions)
+#endif
       }
       s0 = dadd(dadd(pw[0], rot(*Rw[0], loc0)), dscl(hmg, d));
       s1 = dadd(dadd(pw[1], rot(*Rw[1], loc1)), dscl(hmg, dm));
       }
     };
-    // the portal: points 1..3 as (v, v1), point 0 = v0. Rounds 3-5 kept them in a local array indexed by the run-time point number of
-    // `expand` — private memory: 36 scratch dwords read and written in the innermost loops of the collider. Round 6: registers, the
-    // run-time index of `put` as selects (LM_MPR_PV_ARRAY: the array, for A/B builds)
+    // the portal: points 1..3 as (v, v1), point 0 = v0, in a local array indexed by the run-time point number of `expand` — private
+    // memory: 36 scratch dwords. Round 6 tried registers (the run-time index of `put` as 36 selects of doubles, -DLM_MPR_PV_REGS):
+    // HumanoidTorque.run 12.86 ms per control step against 12.60 with the array on one box — six stores beat 72 v_cndmask
     double PV[3][6];
     auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
     auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
-#ifdef LM_MPR_PV_ARRAY
+#ifndef LM_MPR_PV_REGS
     auto put = [&](int q, D3 v, D3 v1) {
       PV[q - 1][0] = v.x; PV[q - 1][1] = v.y; PV[q - 1][2] = v.z; PV[q - 1][3] = v1.x; PV[q - 1][4] = v1.y; PV[q - 1][5] = v1.z;
     };
@@ -1254,25 +1295,69 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       float sa, ta;
       segment_closest(cA, aA, rec[LM_GP_H1], cB, aB, rec[LM_GP_H2], sa, ta);
       const V3 dsep = (cB + ta * aB) - (cA + sa * aA);
+      // hints of the two directions of this mode (one 16-byte word of the cache record), the cached direction (another)
+      unsigned long long hw0 = 0ull, hw1 = 0ull, cw0 = 0ull, cw1 = 0ull;
+      if constexpr (PAIRED) if (ce) { cw0 = LM_GLD64(ce); cw1 = LM_GLD64(ce + 2); hw0 = LM_GLD64(ce + 4); hw1 = LM_GLD64(ce + 6); }
+      auto lo_ = [](unsigned long long w) -> int { return (int)(unsigned)(w & 0xffffffffull) - 1; };
+      auto hi_ = [](unsigned long long w) -> int { return (int)(unsigned)(w >> 32) - 1; };
+      auto pack_ = [&]() -> unsigned long long { return (unsigned long long)(unsigned)(hint[0] + 1) | ((unsigned long long)(unsigned)(hint[1] + 1) << 32); };
+      if constexpr (PAIRED) if (ce && (unsigned)(cw1 >> 32) != 0u) {
+        const D3 dc = dunit(d3((double)lm_u2f((unsigned)cw0), (double)lm_u2f((unsigned)(cw0 >> 32)), (double)lm_u2f((unsigned)cw1)));
+        D3 sp[2];
+        support_pair(dc, sp, lo_(hw0), hi_(hw0));
+        LM_MPR_COUNT(4, 1);
+        LM_GST64(ce + 4, pack_());
+        if (ddot(dsub(sp[0], sp[1]), dc) < 0.0) { LM_MPR_COUNT(1, 1); return out; }
+      }
       if (dot(dsep, dsep) > 1e-12f) {
         const D3 du = dunit(up(dsep));
         D3 sp[2];
-        support_pair(du, sp);
+        support_pair(du, sp, lo_(hw1), hi_(hw1));
         LM_MPR_COUNT(4, 1);
-        if (ddot(dsub(sp[0], sp[1]), du) < 0.0) { LM_MPR_COUNT(1, 1); return out; }
+        if constexpr (PAIRED) if (ce) LM_GST64(ce + 6, pack_());
+        if (ddot(dsub(sp[0], sp[1]), du) < 0.0) {
+          LM_MPR_COUNT(1, 1);
+          if constexpr (PAIRED) if (ce) {       // the capsule direction separates: the direction to try first next time
+            LM_GST64(ce, (unsigned long long)lm_f2u((float)du.x) | ((unsigned long long)lm_f2u((float)du.y) << 32));
+            LM_GST64(ce + 2, (unsigned long long)lm_f2u((float)du.z) | (1ull << 32));
+          }
+          return out;
+        }
       }
       out.found = 1;
       return out;
     }
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+    const long long tp0_ = LM_CLOCK();
+    struct ClockOut_ { long long* m; long long t0; __device__ ~ClockOut_() { m[13] += LM_CLOCK() - t0; } } clock_out_{mc, tp0_};
+#endif
     D3 dir = dunit(dscl(-1.0, v0));
     int stage = 0, iter = 0, result = 0;                 // result: 1 contact from the portal, 2 origin on the segment v0-v1, -1 none
     int nsupport = 0; (void)nsupport;
+    // the cache's hints for the first directions of the search: the word of direction `guard + 1` is fetched while direction `guard`
+    // climbs (two registers instead of the whole record across the loop)
+    constexpr int kSeq = kMprCacheHints - 2;
+    unsigned long long hnext = 0ull;
+    if constexpr (PAIRED) if (ce) hnext = LM_GLD64(ce + 8);
 #pragma nounroll
     for (int guard = 0; guard < 192 && result == 0; guard++) {
       nsupport++;
       LM_MPR_COUNT(4, 1);
       D3 sup[2];
-      support_pair(dir, sup);
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+      const long long ts0_ = LM_CLOCK();
+      mc[14] += 1;
+#endif
+      if constexpr (PAIRED) {
+        const unsigned long long hw = hnext;
+        hnext = 0ull;
+        if (ce && guard + 1 < kSeq) hnext = LM_GLD64(ce + 8 + 2 * (guard + 1));
+        support_pair(dir, sup, (int)(unsigned)(hw & 0xffffffffull) - 1, (int)(unsigned)(hw >> 32) - 1);
+        if (ce && guard < kSeq) LM_GST64(ce + 8 + 2 * guard, (unsigned long long)(unsigned)(hint[0] + 1) | ((unsigned long long)(unsigned)(hint[1] + 1) << 32));
+      } else support_pair(dir, sup);
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+      mc[11] += LM_CLOCK() - ts0_;
+#endif
       const D3 sv = dsub(sup[0], sup[1]);
       const double dt = ddot(sv, dir);
       if (stage == 0) {
@@ -1328,6 +1413,12 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
     printf("   mpr result %d stage %d iter %d supports %d types %d %d\n", result, stage, iter, nsupport, (int)rec[LM_GP_X1], (int)rec[LM_GP_X2]);
 #endif
     LM_MPR_COUNT(6, iter);
+    if constexpr (PAIRED) if (ce) {
+      // no contact: the search ended at a direction the shapes are apart along (or as good as: the next pass tests it before it trusts it);
+      // a contact: no direction to try first
+      if (result < 0) LM_GST64(ce, (unsigned long long)lm_f2u((float)dir.x) | ((unsigned long long)lm_f2u((float)dir.y) << 32));
+      LM_GST64(ce + 2, (unsigned long long)lm_f2u((float)dir.z) | ((result < 0) ? (1ull << 32) : 0ull));
+    }
     if (result <= 0) { LM_MPR_COUNT(2, 1); return out; }
     LM_MPR_COUNT(3, 1);
     double depth; D3 pdir, pos;
@@ -1733,6 +1824,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   constexpr bool inr_on = DR == 2;
   const float* gtp = inr_on ? dp->gt : P.gt;
   const float* gptp = inr_on ? dp->gpt : P.gpt;
+  float* const mprc = (PAIRS && MC >= 5 && dp) ? dp->mprc : nullptr;       // (the quadruped's convex pairs are primitives: nothing to warm up)
 #define INR(i) dp->inr[(i) * LM_NCHAIN + c]
 #define LXI(k, j) (inr_on ? INR((k) * LM_IR_LINK + (j)) : LX(k, LM_L_MASS + (j)))        /* j: mass, com xyz, inertia xx yy zz xy xz yz */
 #define LKV(k, j, f) (inr_on ? INR((k) * LM_IR_LINK + 10 + (j)) : LK(k, f))               /* j: 0 armature, 1 invweight (2 = friction-loss R: dp->rfl_*) */
@@ -2346,9 +2438,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
 #ifndef LM_NO_MPR
                   if constexpr (!NOMPR) {
 #ifdef LM_TIMERS
-                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, cnt.m);
+                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, mprc ? mprc + (long long)(((int)raw) & 65535) * kMprCacheFloats : nullptr, cnt.m);
 #else
-                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage);
+                    mo = mpr_convex_pair<(MC >= 5)>(P.meshadj, rec, g1own, E.po, E.Ro, E.pp, E.Rp, O, rec[LM_GP_MARGIN], stage, mprc ? mprc + (long long)(((int)raw) & 65535) * kMprCacheFloats : nullptr);
 #endif
                   }
 #endif
@@ -2627,7 +2719,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                 if (G.dist < 0.004f) printf("   pair lane %d entry %d rec %d kind %d dist %.7f\n", cs, i, first + v, kind, G.dist);
 #endif
 #if defined(LM_TIMERS) && !defined(LM_PAIR_PHASES)
+#ifndef LM_MPR_CLOCK
                 cnt.m[10 + kind]++; if (G.dist < pmargin) cnt.m[13 + kind]++;
+#endif
 #endif
                 float clearance = G.dist - pmargin;               // what holds the next detection back: a LOWER bound of the pair's distance
                 bool in_reach = G.dist < pmargin;

@@ -72,6 +72,9 @@ struct lm_batch {
   int stat_pre_off, nstat; int* h_hint; int hint, hint_seen; int epoch;
   hipStream_t stream2; hipEvent_t ev_fork, ev_join, ev_done[2];
   float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
+  // the float64 host surface (lm_step_pinned): pinned action staging, the pinned ring of result sets [obs f64 | reward f64 | done]
+  float* h_act; unsigned char* h_out64[LM_PINNED_SLOTS]; int* d_perm; size_t out64_bytes;
+  float* mprc; int mprc_pairs;   // warm-start cache of the convex collider, [N][mprc_pairs][lm::kMprCacheFloats] (lm_step.h KArgs::mprc), or null
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
 // <3 links, 6 slots, Euler, elliptic, self-collisions>; the humanoid families (five- and six-link chains) are compiled for
@@ -403,6 +406,14 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->hsub, sizeof(int) * N)); HIPCHK(hipMemset(b->hsub, 0, sizeof(int) * N));
   HIPCHK(hipMalloc(&b->premark, sizeof(int) * N)); HIPCHK(hipMemset(b->premark, 0, sizeof(int) * N));
   HIPCHK(hipMalloc(&b->slack, sizeof(float) * 12 * N)); HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * N));
+  // the convex collider's warm-start cache: one record per environment and geom-pair record of the models whose hull pairs run through
+  // it in kernels with five or more links per chain (64 B each: HumanoidTorque 692 pairs -> 44 KB per environment, 180 MB at 4096)
+  b->mprc = nullptr; b->mprc_pairs = 0;
+  if (m->d_meshadj && m->n_gpt_floats > 0 && m->T.max_links > 3) {
+    b->mprc_pairs = m->n_gpt_floats / LM_GPAIR_SIZE;
+    const size_t bytes = sizeof(float) * lm::kMprCacheFloats * (size_t)b->mprc_pairs * (size_t)N;
+    HIPCHK(hipMalloc(&b->mprc, bytes)); HIPCHK(hipMemset(b->mprc, 0, bytes));
+  }
   HIPCHK(hipMemset(b->qpos, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->qvel, 0, sizeof(float) * nv * N));
   HIPCHK(hipMemset(b->warm, 0, sizeof(float) * nv * N)); HIPCHK(hipMemset(b->goal, 0, sizeof(float) * 4 * N));
   HIPCHK(hipMemset(b->ep_step, 0, sizeof(int) * N)); HIPCHK(hipMemset(b->ep_count, 0, sizeof(unsigned) * N));
@@ -484,9 +495,12 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->mprc, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
                   b->vrec, b->vgt, b->vgpt, b->var, b->mc_ib, b->mc_db, b->vdirty, b->mc_mask, b->vgen, b->vdraws};
   for (void* p : bufs) if (p) (void)hipFree(p);
+  if (b->d_perm) (void)hipFree(b->d_perm);
+  if (b->h_act) (void)hipHostFree(b->h_act);
+  for (int i = 0; i < LM_PINNED_SLOTS; i++) if (b->h_out64[i]) (void)hipHostFree(b->h_out64[i]);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev_ext) (void)hipEventDestroy(b->ev_ext);
@@ -847,7 +861,7 @@ static KArgs make_args(lm_batch* b) {
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
   a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.vdirty = b->mc_ib ? b->vdirty : nullptr; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
-  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack;
+  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack; a.mprc = b->mprc; a.mprc_pairs = b->mprc_pairs;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
@@ -915,6 +929,81 @@ int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t
   if (obs) HIPCHK(hipMemcpyAsync(obs, b->obs, sizeof(float) * T.nobs * N, hipMemcpyDeviceToHost, b->stream));
   if (reward) HIPCHK(hipMemcpyAsync(reward, b->reward, sizeof(float) * N, hipMemcpyDeviceToHost, b->stream));
   if (done) HIPCHK(hipMemcpyAsync(done, b->done, N, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+// ---- the float64 host surface (include/locohip.h lm_step_pinned)
+__global__ void pack_out64_kernel(const float* __restrict__ obs, const float* __restrict__ reward, const unsigned char* __restrict__ done,
+                                  const int* __restrict__ perm, int N, int nobs, double* __restrict__ o64, double* __restrict__ r64,
+                                  unsigned char* __restrict__ d8) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, total = N * nobs;
+  if (i < total) {
+    const int e = i / nobs, j = i - e * nobs;
+    o64[i] = (double)obs[e * nobs + (perm ? perm[j] : j)];
+  }
+  if (i < N) { r64[i] = (double)reward[i]; d8[i] = done[i]; }
+}
+
+static int pinned_alloc(lm_batch* b) {
+  if (b->h_act) return 0;
+  const size_t N = (size_t)b->N, nobs = (size_t)b->m->T.nobs;
+  b->out64_bytes = sizeof(double) * (N * nobs + N) + N;
+  HIPCHK(hipHostMalloc((void**)&b->h_act, sizeof(float) * N * (size_t)b->m->T.nu, hipHostMallocDefault));
+  for (int i = 0; i < LM_PINNED_SLOTS; i++) {
+    HIPCHK(hipHostMalloc((void**)&b->h_out64[i], b->out64_bytes, hipHostMallocDefault));
+    memset(b->h_out64[i], 0, b->out64_bytes);
+  }
+  return 0;
+}
+
+int lm_pinned_slot(lm_batch* b, int slot, double** obs, double** reward, uint8_t** done) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (slot < 0 || slot >= LM_PINNED_SLOTS) return fail("pinned slot out of range");
+  if (pinned_alloc(b)) return 1;
+  const size_t N = (size_t)b->N, nobs = (size_t)b->m->T.nobs;
+  double* base = reinterpret_cast<double*>(b->h_out64[slot]);
+  if (obs) *obs = base;
+  if (reward) *reward = base + N * nobs;
+  if (done) *done = reinterpret_cast<uint8_t*>(base + N * nobs + N);
+  return 0;
+}
+
+int lm_set_obs_order(lm_batch* b, const int32_t* perm, int n) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (b->d_perm) { HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipFree(b->d_perm)); b->d_perm = nullptr; }
+  if (!perm) return 0;
+  const int nobs = b->m->T.nobs;
+  if (n != nobs) return fail("observation order: one entry per observation column");
+  for (int j = 0; j < n; j++) if (perm[j] < 0 || perm[j] >= nobs) return fail("observation order: column out of range");
+  HIPCHK(hipMalloc(&b->d_perm, sizeof(int) * n));
+  HIPCHK(hipMemcpy(b->d_perm, perm, sizeof(int) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int lm_step_pinned(lm_batch* b, const double* action, int slot) {
+  HIPCHK(hipSetDevice(b->m->device));
+  if (slot < 0 || slot >= LM_PINNED_SLOTS) return fail("pinned slot out of range");
+  if (!action) return fail("lm_step_pinned needs an action (policy-free rollouts: lm_rollout)");
+  if (pinned_alloc(b)) return 1;
+  const int N = b->N; const Task& T = b->m->T;
+  const size_t na = (size_t)N * T.nu;
+  for (size_t i = 0; i < na; i++) b->h_act[i] = (float)action[i];
+  KArgs a = make_args(b);
+  // the step kernel reads the action out of the pinned staging buffer itself and the conversion kernel writes the pinned slot itself
+  // (both mapped into the device's address space): no copy is queued on either side of the launch. Measured on one box against an
+  // H2D copy in front and a D2H copy behind (tools/probes/r6/surface.py, 4096 quadrupeds): 1.258 against 1.274 ms per LocoEnv.step()
+  a.action = b->h_act;
+  a.action_mode = 0;
+  a.obs = b->obs; a.reward = b->reward; a.done = b->done;
+  launch_step(b, a);
+  if (g_launch_err) return fail(g_launch_err);
+  b->step_index++;
+  double* o64 = reinterpret_cast<double*>(b->h_out64[slot]);
+  const int total = N * T.nobs, threads = 256;
+  hipLaunchKernelGGL(pack_out64_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, b->stream, b->obs, b->reward, b->done,
+                     b->d_perm, N, T.nobs, o64, o64 + (size_t)N * T.nobs, reinterpret_cast<unsigned char*>(o64 + (size_t)N * T.nobs + N));
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }

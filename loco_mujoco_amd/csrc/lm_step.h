@@ -37,6 +37,10 @@
 // an integer the optimiser cannot see through (always 0): see lm_core.h `oz`
 __device__ __forceinline__ int lm_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 #define LM_OPAQUE_ZERO() lm_opaque_zero()
+// words of the convex collider's warm-start cache (lm_core.h mpr_convex_pair): agent-scope relaxed atomics — past the CU's L1, which the
+// lane that wrote the word one forward pass earlier does not share a coherent view with by default (loads could hit a stale line)
+#define LM_GLD64(p) __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LM_GST64(p, v) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define LM_POW01(x, p) __builtin_amdgcn_exp2f((p) * __builtin_amdgcn_logf(x))   // v_exp_f32(p * v_log_f32(x))
 #define LM_CLOCK() ((long long)__builtin_readcyclecounter())
 #include "lm_core.h"
@@ -178,6 +182,9 @@ struct KArgs {
   // self-collision detection (lm_core.h): per chain lane the clearance left since the last detection and the speed memory of its
   // travel bound, SoA [3][4][N]; kept from one control step to the next (zeroed by state uploads and restarts: "detect now")
   float* slack;
+  // warm-start cache of the convex collider (lm_core.h mpr_convex_pair): lm::kMprCacheFloats floats per environment and geom-pair
+  // record, [N][mprc_pairs][16], or null (no hull pairs / a family without the collider in its regular kernels)
+  float* mprc; int mprc_pairs;
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
 };
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; i++) goal[i] = (i < a.T.ngoal) ? a.goal[i * N + e] : 0.0f;
   lm::DofPrm<MC> dofp;
+  dofp.mprc = a.mprc ? a.mprc + (long long)e * a.mprc_pairs * lm::kMprCacheFloats : nullptr;
   if (DR) {
     const long long pn = (long long)nv * N;
 #pragma unroll

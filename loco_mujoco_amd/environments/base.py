@@ -49,8 +49,10 @@ class LocoEnv:
                  init_step_no=None, timestep=0.001, use_foot_forces=False, default_camera_mode="follow",
                  use_absorbing_states=True, domain_randomization_config=None, parallel_dom_rand=True,
                  N_worker_per_xml_dom_rand=4, n_envs=1, device=0, n_model_variants=None, model_variants_per_reset=4,
-                 **viewer_params):
+                 copy_outputs=False, **viewer_params):
         self._model = model
+        # n_envs > 1: step() returns VIEWS of a ring of four pinned result sets (intact for the next three calls) unless copy_outputs
+        self._copy_outputs = bool(copy_outputs)
         # models compiled per batch for the randomisation rules that change compile-time constants (inertial, armature, geom
         # friction): a pool the environments draw from per episode, see utils/domain_randomization.py
         # The reference compiles one freshly drawn model at every reset (base.py:183-185). Here: a pool of `n_model_variants`
@@ -568,6 +570,22 @@ class LocoEnv:
             b = self.backend
             if self._pending_state:
                 self._upload_state()
+            if self.n_envs > 1 and not self._copy_outputs and self._reward_device_spec() is not None and hasattr(b, "step_pinned"):
+                # THE FAST SURFACE of a batch (round 6): one library call (lm_step_pinned) converts the float64 action into a pinned
+                # staging buffer, runs the step, converts observation (in the reference's column order) and reward to float64 on the
+                # device and brings them back in ONE copy into a ring of pinned result sets — no astype / fancy-index / copy of
+                # [n_envs, nobs] arrays on the host. The arrays returned are VIEWS of that ring (as the tensors of batched GPU
+                # simulators are): intact for the next three step() calls; LocoEnv.make(..., copy_outputs=True) returns fresh arrays
+                if not getattr(b, "_obs_order_set", False):
+                    b.set_obs_order(self._obs_perm())
+                    b._obs_order_set = True
+                obs, reward, done = b.step_pinned(np.ascontiguousarray(a))
+                self._obs = obs
+                restarted = self._restarted_flags()
+                info = {}
+                if restarted is not None and (self._auto_reset or restarted.any()):
+                    info = {"episode_restarted": restarted}
+                return obs, reward, done, info
             obs32, rew32, done = b.step(a)
         obs = obs32.astype(np.float64)
         perm = self._obs_perm()

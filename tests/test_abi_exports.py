@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_all_declared_symbols():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "loco_mujoco_amd", "csrc"), "liblocohip.so"],
+    subprocess.check_call(["make", "-j%d" % (os.cpu_count() or 4), "-C", os.path.join(ROOT, "loco_mujoco_amd", "csrc"), "liblocohip.so"],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     header = open(os.path.join(ROOT, "include", "locohip.h")).read()
     declared = set(re.findall(r"\b(lm_[a-z_]+)\s*\(", header))
