@@ -226,6 +226,11 @@ int lm_get_flags(lm_batch* b, uint8_t* out);
 /* one forward-dynamics pass at the current state with `action`, without advancing it */
 int lm_forward_debug(lm_batch* b, const float* action, lm_forward_out* out);
 
+/* the compiler the library was built with and its optimisation level ("HIP version: ...;AMD clang version ... | -Os"), recorded by
+   csrc/Makefile: no counterpart in the reference; the kernels sit at the 512-register ceiling, where one code-generation defect of the
+   toolchain was met (csrc/Makefile) — a library built by another compiler should be re-validated (tests/test_abi_exports.py) */
+const char* lm_toolchain(void);
+
 int lm_get_stats(lm_batch* b, lm_stats* out, int reset);
 int lm_sync(lm_batch* b);
 

@@ -34,7 +34,7 @@ class ForwardOut(C.Structure):
                [("ncon", C.POINTER(C.c_int)), ("solver_iter", C.POINTER(C.c_int))]
 
 
-EXPORTS = ["lm_device_count", "lm_last_error", "lm_model_create", "lm_model_destroy", "lm_model_dims",
+EXPORTS = ["lm_device_count", "lm_last_error", "lm_toolchain", "lm_model_create", "lm_model_destroy", "lm_model_dims",
            "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_pinned_slot", "lm_set_obs_order", "lm_step_pinned",
@@ -60,6 +60,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.lm_device_count.restype = C.c_int
     lib.lm_last_error.restype = C.c_char_p
+    lib.lm_toolchain.restype = C.c_char_p
     lib.lm_model_create.argtypes = [_D, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     lib.lm_model_destroy.argtypes = [C.c_void_p]
     lib.lm_model_destroy.restype = None

@@ -915,6 +915,11 @@ static int drain_stats(lm_batch* b) {
   return 0;
 }
 
+#ifndef LM_TOOLCHAIN
+#define LM_TOOLCHAIN "unknown (built outside csrc/Makefile)"
+#endif
+const char* lm_toolchain(void) { return LM_TOOLCHAIN; }
+
 int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t* done) {
   HIPCHK(hipSetDevice(b->m->device));
   const int N = b->N; const Task& T = b->m->T;

@@ -25,6 +25,21 @@ def test_library_exports_all_declared_symbols():
     assert exported == declared, sorted(exported ^ declared)
 
 
+# the toolchain the GPU suite was last run green on (round 6): ROCm 7.2.0's hipcc, the library at -Os
+VALIDATED_TOOLCHAIN = ("HIP version: 7.2.26015-fc0010cf6a", "roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5", "| -Os")
+
+
+def test_library_records_the_toolchain_it_was_validated_on():
+    """The step kernels sit at the 512-register ceiling, where a code-generation defect of this toolchain was met and fenced by tests
+    (csrc/Makefile, profiles/r5_notes.md §5): the library says what built it, and a build by another compiler or at another optimisation
+    level fails HERE — re-run the GPU suite (bitwise fused-vs-single and replay-vs-regular tests, the -O2 guard) and update the strings."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "loco_mujoco_amd", "csrc", "liblocohip.so"))
+    lib.lm_toolchain.restype = ctypes.c_char_p
+    got = lib.lm_toolchain().decode()
+    for part in VALIDATED_TOOLCHAIN:
+        assert part in got, (part, got)
+
+
 def test_shipped_library_reads_no_environment_variable():
     """The A/B switches of the probe builds (LM_NO_PAIRS, LM_TOLERANCE, LM_ABLATE, LM_LS_*, LM_NO_REPLICAS, LM_GENERIC_KERNELS,
     LM_NO_XCD_MAP, LM_ENVS_PER_BLOCK) exist only under -DLM_PROBES: the default library does not import getenv at all."""

@@ -720,12 +720,15 @@ def test_bench_leg_rate_identity_and_parity_flag():
     assert "within_tolerance" in src and "sys.exit(3)" in src
     # no rate is formed from a cumulative counter any more
     assert 'vals[13] / ' not in src and 'env_steps / elapsed' not in src
-    # the margin rule (round 6): a state beyond the tolerance is set aside only when the oracle's own spread under the probes reaches the
-    # DEVICE'S ERROR in every component that is beyond the tolerance — not when it merely exceeds the tolerance
-    assert bench.excused_by_margin(2e-4, 5e-3, 3e-4, 0.0)
-    assert not bench.excused_by_margin(2e-4, 5e-3, 1.5e-4, 1.0)       # the oracle moves by 1.5 x the tolerance, the device is 2 x off
-    assert not bench.excused_by_margin(5e-5, 0.5, 1.0, 0.02)          # qvel 50 x off beside an oracle that moves by 2 x the tolerance
-    assert bench.excused_by_margin(5e-5, 5e-3, 0.0, 0.0)              # (within the tolerance: nothing to excuse)
+    # the neighbour rule (round 6): a state beyond the tolerance is set aside only when the oracle itself, for an input within one float32
+    # ulp, produces the DEVICE'S result to within the tolerance — not when its own result merely moves
+    q0, v0 = np.zeros(3), np.zeros(3)
+    jump = lambda qa, va: (qa + (0.5 if qa[0] > 0 else 0.0), va + (0.5 if qa[0] > 0 else 0.0))      # an oracle with a switch at q[0] = 0
+    assert bench.oracle_reaches(jump, q0, v0, q0 + 0.5, v0 + 0.5)[0]            # the device took the other branch: a probe gets there
+    reached, near = bench.oracle_reaches(jump, q0, v0, q0 + 5.0, v0 + 5.0)      # the device is 10 x further than the oracle ever jumps
+    assert not reached and near > 100
+    smooth = lambda qa, va: (qa, va)
+    assert not bench.oracle_reaches(smooth, q0, v0, q0 + 2e-4, v0)[0]           # a stable oracle excuses nothing
     # the parity sample comes from the states of the timed rollout, and UnitreeH1 is reported, not gating
     assert "lm_get_state after the timed block" in src and set(bench.PARITY_REPORTED_NOT_GATING) == {"UnitreeH1.walk", "UnitreeH1.run", "UnitreeH1.carry"}
 
