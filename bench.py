@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0
 FP32_VECTOR_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CUs x 128 FP32 FMA lanes x 2 flop x 2.4 GHz (packed FP32 counted)
 SIMDS = 1024
 CLOCK_GHZ = 2.4
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
 TOL = dict(qpos=1e-4, qvel=1e-2)
 
 # Tasks the bench can time but whose device-vs-oracle parity is not a gate: the robot's own golden rollouts are only partly reproducible
@@ -442,6 +442,18 @@ def side_config(cfg, rank, device, steps, warmup, lib_sha, with_cpu):
                      "replayed_env_steps": st.get("replayed_env_steps", 0.0), "episodes": st["episodes"], "nan_resets": st["nan_resets"],
                      "newton_iters_per_forward_pass": st["solver_iters"] / max(st["env_steps"] * W.forwards_per_env_step(), 1)}}
     out["parity"] = parity_sample(W, True)
+    # beside `value` (per-step launches: what a policy in the loop gets), never as it: the same rollout with 25 control steps per launch
+    # (lm_rollout_fused, bitwise the same states: no device-wide join behind every control step, so a launch no longer ends with the
+    # single hardest robot of EVERY step — the humanoids' per-step launches wait 2-3 x the mean wave's time for it)
+    try:
+        W.b.rollout(25, action_mode=W.action_mode, seed=13, steps_per_launch=25)
+        nf = max(25, (steps // 25) * 25)
+        dtf, stf = timed_leg(W, coll1, nf, 14, steps_per_launch=25)
+        fr = leg_rate(W.n, 1, nf, dtf)
+        out["rollout_fused"] = {"steps_per_launch": 25, "steps": nf, "value": fr["value"], "unit": "env-steps/s", "ms_per_step": fr["ms_per_step"],
+                                "overflow_contacts": stf["overflow_contacts"], "replayed_env_steps": stf.get("replayed_env_steps", 0.0)}
+    except Exception as e:      # noqa: BLE001 - reported in the line
+        out["rollout_fused"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if with_cpu:
         one = cpu_baseline(W.env, W.table, W.task, True, budget_s=2.0)
         out["cpu_baseline"] = dict(value=one["value"], unit="env-steps/s", cores=1, kind="port", sample=one["sample"])
@@ -471,9 +483,11 @@ def python_surface_leg(device, n, steps, warmup):
     k0 = env.backend.stats()["kernel_ms"] if hasattr(env.backend, "stats") else None
     out = dict(envs=n, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps, value=n * steps / dt, unit="env-steps/s",
                obs_dtype=str(obs.dtype), action_dtype=str(act.dtype),
-               note="LocoEnv.step(numpy float64 action) -> (obs float64, reward float64, absorbing bool, info): pinned staging buffers, one "
-                    "H2D + one D2H per call (lm_step_pinned), one float32->float64 conversion of the observation; UnitreeA1.simple, zero action, "
-                    "device-side auto-reset")
+               note="LocoEnv.step(numpy float64 action) -> (obs float64, reward float64, absorbing bool, info) through lm_step_pinned: the action "
+                    "is converted into a pinned staging buffer the step kernel reads itself, a conversion kernel writes float64 observation / "
+                    "reward / done straight into a pinned result set (a ring of 4: the arrays returned are views, intact for the next three "
+                    "calls; copy_outputs=True returns fresh arrays) — no copy queued on either side of the launch; UnitreeA1.simple, zero "
+                    "action, device-side auto-reset")
     del k0
     return out
 

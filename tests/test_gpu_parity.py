@@ -1490,7 +1490,8 @@ def test_bench_line_rates_are_their_own_legs():
     assert run.returncode == 0, run.stderr[-3000:]
     line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
     n = line["config"]["global_envs"]
-    assert n == 4096 and line["steps"] == 20 and line["warmup"] == 5
+    # `steps` = the launches `value` / `ms_per_step` were measured over (round 6: the sustained block), the driver's --steps block is `burst`
+    assert n == 4096 and line["steps"] == line["timed_steps"] == 200 and line["warmup"] == 5
     for leg in (line, line["rollout_fused"], line["sustained"], line["burst"]):
         assert abs(leg["value"] * leg["ms_per_step"] * 1e-3 / n - 1.0) < 1e-9, leg
     # `value` IS the sustained block (200 per-step launches) when the driver's --steps is shorter: the conservative headline; the
@@ -1525,6 +1526,9 @@ def test_bench_line_carries_the_other_baseline_configs():
         assert c["roofline"]["algorithmic_bytes_per_env_step"] == bytes_per and c["roofline"]["algorithmic_bytes_per_launch"] == bytes_per * envs
         assert c["parity"]["within_tolerance"] and c["parity"]["states"] >= 56
         assert c["stats"]["overflow_contacts"] == 0 and c["stats"]["nan_resets"] == 0 and c["stats"]["replayed_env_steps"] >= 0
+        # beside `value`: the same rollout with 25 control steps per launch (no join behind every control step), nothing dropped either
+        f = c["rollout_fused"]
+        assert "error" not in f and f["steps_per_launch"] == 25 and f["overflow_contacts"] == 0 and abs(f["value"] * f["ms_per_step"] * 1e-3 / envs - 1.0) < 1e-9
 
 
 @pytest.mark.parametrize("task", ["run", "walk"])
