@@ -184,6 +184,14 @@ int lm_step(lm_batch* b, const float* action, float* obs, float* reward, uint8_t
    against that stream. */
 int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, void* stream, int sync);
 
+/* ACTIVE LIST: from now on every step / rollout of this batch runs only the listed environments (ids in [0, n_envs), each at most
+   once; count 0: nothing runs), in one launch of ceil(count / environments per workgroup) workgroups; the others keep their state, and
+   what the step writes for them (observation, reward, done) is left as it was. NULL: all environments again. Host buffers keep their
+   [n_envs][...] shape — an environment keeps its row. For environments that share ids across several models and change model per
+   episode (the reference's MultiMuJoCo with models that differ in geometry, base.py:186-190: HumanoidTorque4Ages "all"): one batch per
+   model, each stepping the environments currently of its size. Random numbers stay keyed by the global environment id. */
+int lm_batch_set_active(lm_batch* b, const int32_t* env_ids, int count);
+
 /* LocoEnv.step()'s host surface in ONE call (reference gymnasium.py:47-65 -> base.py step(): numpy float64 action in, float64
    observation / reward and the absorbing flag out — the library's counterpart of the dtype conversions and copies the Python
    layer did around lm_step, environments/base.py). The results land in PINNED host memory owned by the batch: a ring of

@@ -35,7 +35,7 @@ class ForwardOut(C.Structure):
 
 
 EXPORTS = ["lm_device_count", "lm_last_error", "lm_toolchain", "lm_model_create", "lm_model_destroy", "lm_model_dims",
-           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
+           "lm_batch_create", "lm_batch_destroy", "lm_batch_set_layout", "lm_batch_set_replay", "lm_batch_set_active", "lm_get_replay_marks", "lm_set_state", "lm_get_state", "lm_set_activation", "lm_get_activation",
            "lm_set_dof_params", "lm_get_dof_params", "lm_set_dof_randomization", "lm_set_goal", "lm_step", "lm_step_device",
            "lm_pinned_slot", "lm_set_obs_order", "lm_step_pinned",
            "lm_set_reset_table", "lm_set_auto_reset", "lm_rollout", "lm_rollout_fused", "lm_forward_debug", "lm_get_stats", "lm_sync",
@@ -68,6 +68,7 @@ def load_library():
     lib.lm_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.lm_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.lm_batch_set_replay.argtypes = [C.c_void_p, C.c_int]
+    lib.lm_batch_set_active.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.lm_get_replay_marks.argtypes = [C.c_void_p, _U8, C.c_int]
     lib.lm_batch_destroy.argtypes = [C.c_void_p]
     lib.lm_batch_destroy.restype = None
@@ -339,6 +340,14 @@ class HipBatch:
         # reset table, or the horizon was reached)
         self.last_restarted = (done & 2) != 0
         return obs, rew, (done & 1) != 0
+
+    def set_active(self, env_ids):
+        """Run only the listed environments from now on (``lm_batch_set_active``); None: all of them again."""
+        if env_ids is None:
+            _check(self._lib.lm_batch_set_active(self._h, None, 0))
+            return
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32).reshape(-1)
+        _check(self._lib.lm_batch_set_active(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids)))
 
     PINNED_SLOTS = 4
 

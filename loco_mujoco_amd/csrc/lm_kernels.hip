@@ -74,6 +74,7 @@ struct lm_batch {
   float* slack;              // detection slack + speed memory of the self-collision pass, [3][4][N] (lm_step.h KArgs::slack)
   // the float64 host surface (lm_step_pinned): pinned action staging, the pinned ring of result sets [obs f64 | reward f64 | done]
   float* h_act; unsigned char* h_out64[LM_PINNED_SLOTS]; int* d_perm; size_t out64_bytes;
+  int* env_map; int n_active;    // active list (lm_batch_set_active): device copy of the environment ids, their number (N: all)
   float* mprc; int mprc_pairs;   // warm-start cache of the convex collider, [N][mprc_pairs][lm::kMprCacheFloats] (lm_step.h KArgs::mprc), or null
 };
 // which kernel family serves a model (lm_family.hip): the quadruped family gets a specialised step kernel
@@ -127,7 +128,8 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
       {lmk::launch_f10p0, lmk::launch_f10p1, lmk::launch_f10p2}};
   const int fam = family_of(b);
   if (fam < 0) { g_launch_err = "chains of six links are compiled for Euler, condim-3 pyramids, no muscles only"; return; }
-  const LaunchCtx L = {b->stream, b->N, b->epb};
+  const LaunchCtx L = {b->stream, b->n_active, b->epb};
+  if (b->n_active <= 0) return;            // an empty active list: nothing to run
   if (fam == 6) {
     if (b->m->T.na > 0) { g_launch_err = "muscle models need the <5 links, <=4 contacts per chain, Euler> family"; return; }
     if (b->dofprm) { g_launch_err = "per-environment joint parameters are not compiled for this model family"; return; }
@@ -145,7 +147,7 @@ static void launch_variant(lm_batch* b, const KArgs& a) {
   else kind = rep ? lmk::LMK_REP4 : lmk::LMK_REP1;
   const int big = b->nvar > 0 ? lmk::LMK_BIG_DRV : (b->dofprm ? lmk::LMK_BIG_DR : lmk::LMK_BIG);
   KArgs r = a;
-  r.reg_grid = (b->N + b->epb - 1) / b->epb; r.epoch = b->epoch; r.host_hint = b->h_hint;
+  r.reg_grid = (b->n_active + b->epb - 1) / b->epb; r.epoch = b->epoch; r.host_hint = b->h_hint;
   const bool replay = !FWD && a.replay_list;
   bool pollers = false;
   if (replay) {
@@ -434,7 +436,7 @@ int lm_batch_create(lm_model* m, int n_envs, lm_batch** out) {
   HIPCHK(hipSetDevice(m->device));
   lm_batch* b = new lm_batch();
   memset(b, 0, sizeof(*b));
-  b->m = m; b->N = n_envs;
+  b->m = m; b->N = n_envs; b->n_active = n_envs; b->env_map = nullptr;
   // Four environments per workgroup: with the replicated layout that is one full wave (4 envs x 4 replicas x 4 chains).
   // Larger batches simply run more workgroups back to back (wider workgroups without replicas were 30-50 % slower at
   // every size, profiles/r1_ab_probes.md); lm_batch_set_layout selects the plain layout.
@@ -495,7 +497,7 @@ void lm_batch_destroy(lm_batch* b) {
   hipSetDevice(b->m->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   void* bufs[] = {b->qpos, b->qvel, b->warm, b->goal, b->action, b->obs, b->reward, b->done, b->flags, b->ep_step, b->ep_count, b->stats,
-                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->mprc, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
+                  b->table, b->act, b->dofprm, b->drspec, b->timers, b->scr, b->scr_idx, b->replay_list, b->replay_ctl, b->stall, b->replay_mark, b->slack, b->mprc, b->env_map, b->hq, b->hv, b->hw, b->hsub, b->premark, b->tline,
                   b->vrec, b->vgt, b->vgpt, b->var, b->mc_ib, b->mc_db, b->vdirty, b->mc_mask, b->vgen, b->vdraws};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->d_perm) (void)hipFree(b->d_perm);
@@ -861,7 +863,7 @@ static KArgs make_args(lm_batch* b) {
   memset(&a, 0, sizeof(a));
   a.cm = b->m->d_cm; a.mt = b->m->d_mt; a.act = b->act; a.dofprm = b->dofprm; a.drspec = b->drspec;
   a.vrec = b->nvar > 0 ? b->vrec : nullptr; a.vgt = b->vgt; a.vgpt = b->vgpt; a.var = b->var; a.nvar = b->nvar; a.gpt_floats = b->gpt_floats; a.var_rows = b->var_rows; a.vdirty = b->mc_ib ? b->vdirty : nullptr; a.qpos = b->qpos; a.qvel = b->qvel; a.warm = b->warm; a.goal = b->goal;
-  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack; a.mprc = b->mprc; a.mprc_pairs = b->mprc_pairs;
+  a.ep_step = b->ep_step; a.ep_count = b->ep_count; a.flags = b->flags; a.slack = b->slack; a.mprc = b->mprc; a.mprc_pairs = b->mprc_pairs; a.env_map = b->env_map; a.n_active = b->n_active;
   a.table = b->table; a.table_rows = b->table_rows; a.seed = b->seed; a.env_offset = b->env_offset;
   a.auto_reset = b->auto_reset; a.horizon = b->horizon; a.step_index = b->step_index;
   a.N = b->N; a.P = b->m->P; a.T = b->m->T; a.stats = b->stats;
@@ -912,6 +914,23 @@ static int drain_stats(lm_batch* b) {
     b->acc.unhandled_geoms += x.unhandled; b->acc.linesearch_evals += x.ls_evals; b->acc.linesearch_capped += x.ls_capped; b->acc.steps_with_8plus_iters += x.it_ge8;
     b->acc.self_proximity += x.selfprox; b->acc.self_contacts += x.selfcon; b->acc.replayed_env_steps += x.replayed; b->acc.own_manifold_contacts += x.natown;
   }
+  return 0;
+}
+
+int lm_batch_set_active(lm_batch* b, const int32_t* env_ids, int count) {
+  HIPCHK(hipSetDevice(b->m->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (!env_ids) { b->n_active = b->N; if (b->env_map) { HIPCHK(hipFree(b->env_map)); b->env_map = nullptr; } return 0; }
+  if (count < 0 || count > b->N) return fail("active list: more entries than environments");
+  std::vector<char> seen((size_t)b->N, 0);
+  for (int i = 0; i < count; i++) {
+    if (env_ids[i] < 0 || env_ids[i] >= b->N) return fail("active list: environment id out of range");
+    if (seen[env_ids[i]]) return fail("active list: an environment is listed twice");
+    seen[env_ids[i]] = 1;
+  }
+  if (!b->env_map) HIPCHK(hipMalloc(&b->env_map, sizeof(int) * (size_t)b->N));
+  if (count > 0) HIPCHK(hipMemcpy(b->env_map, env_ids, sizeof(int) * (size_t)count, hipMemcpyHostToDevice));
+  b->n_active = count;
   return 0;
 }
 

@@ -185,6 +185,10 @@ struct KArgs {
   // warm-start cache of the convex collider (lm_core.h mpr_convex_pair): lm::kMprCacheFloats floats per environment and geom-pair
   // record, [N][mprc_pairs][16], or null (no hull pairs / a family without the collider in its regular kernels)
   float* mprc; int mprc_pairs;
+  // ACTIVE LIST (lm_batch_set_active): the launch runs `n_active` environments, slot s of the grid = environment env_map[s] (null:
+  // environment s; n_active = N for a batch without a list). N stays the stride of every state array: an environment keeps its place.
+  // Several models that share one set of environment ids (the humanoid's four sizes, a size drawn per episode) each step their own.
+  const int* env_map; int n_active;
   // debug (forward only)
   float* dM; float* dbias; float* dsmooth; float* dqacc_smooth; float* dqacc; float* dqfrc; int* dncon; int* diter;
 };
@@ -305,13 +309,16 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     const int nb = gridDim.x, x = wg & 7, per = nb >> 3, rem = nb & 7;
     wg = x * per + (x < rem ? x : rem) + (wg >> 3);
   }
-  int e_raw = wg * a.epb + e_local;
-  bool in_range = e_raw < a.N;
+  const int slot_ = wg * a.epb + e_local;
+  bool in_range = slot_ < a.n_active;
+  // (the padding quads of the last workgroup recompute the last active environment)
+  int e_raw = in_range ? slot_ : a.n_active - 1;
+  if (!REPLAY && a.env_map) e_raw = a.env_map[e_raw];
   int first_step = 0;               // REPLAY: the fused control step at which the environment left the regular kernel
   if (REPLAY) { in_range = true; e_raw = entry - 1; first_step = a.stall[e_raw]; }
-  // padding quads of the last workgroup recompute env N-1 (REPLAY: the last list entry); they and the replicas 1..REP-1 store nothing
+  // padding quads (REPLAY: none — the entry is the environment); they and the replicas 1..REP-1 store nothing
   const bool valid0 = in_range && QuadDpp::rep() == 0;
-  const int e = in_range ? e_raw : (REPLAY ? e_raw : a.N - 1);
+  const int e = e_raw;
   bool gone = false;                // this environment left the launch: abandoned here and handed to the replay kernel
   const int N = a.N, nv = a.T.nv;
   const float* rb = cm + LM_CM_ROOT;

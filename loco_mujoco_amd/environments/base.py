@@ -131,6 +131,8 @@ class LocoEnv:
         self._n_models = 1
         self._current_model_idx = 0
         self._blocks = False             # several models in one BATCH: contiguous blocks of environments, one per model
+        self._grouped = False            # ... blocks whose environments draw their model per episode (one batch per model over ALL ids)
+        self._redrawn = None
         self._pooled = False             # ... or ONE batch whose environments draw their model per episode (model variants)
         self._random_env_reset = True
 
@@ -177,7 +179,7 @@ class LocoEnv:
             from ..backend import HipBatch, HipModel
             nominal = self._chain_model(self._models[0] if self._pooled else None)
             self._hip_model = HipModel(nominal, self._device)
-            self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if self._blocks else self.n_envs)
+            self._backend = HipBatch(self._hip_model, len(self._model_envs(self._current_model_idx)) if (self._blocks and not self._grouped) else self.n_envs)
             if self._pooled:
                 from ..lowering import variant_tables
                 self._backend.set_model_variants([variant_tables(nominal, self._chain_model(m)) for m in self._models])
@@ -306,21 +308,45 @@ class LocoEnv:
         # e * n_models // n_envs for its whole life — the same mixture over the batch — `_blocks`.
         self._pooled = self.n_envs > 1 and self._n_models > 1 and self._models_differ_like_variants()
         self._blocks = self.n_envs > 1 and self._n_models > 1 and not self._pooled
-        if self._blocks and self.n_envs < self._n_models:
+        # GROUPED (round 6): models that differ in geometry AND are drawn per episode like the reference's (the humanoid's four sizes,
+        # base_humanoid_4_ages.py:106-135, base.py:186-190). Every model's device batch spans ALL environment ids; environment e is
+        # ACTIVE in the batch of the model it drew for this episode (lm_batch_set_active: one launch per model over its active list)
+        # and changes batch when an episode ends — at reset() on the host, and at a device-side restart through a host redraw keyed by
+        # (seed, global environment id, episodes so far), so that sharding a batch does not change what any environment draws.
+        # (rounds 2-5: `_blocks` alone — environment e kept model e * n_models // n_envs for its whole life.)
+        self._grouped = (self._blocks and self._models_regroup_per_episode()
+                         and not (self._domain_rand is not None and self._domain_rand.active))      # (with domain randomisation: blocks, as before)
+        if self._blocks and not self._grouped and self.n_envs < self._n_models:
             raise ValueError("n_envs=%d cannot hold %d models" % (self.n_envs, self._n_models))
         self._env_model = np.zeros(self.n_envs, dtype=np.int64)
         if self._blocks:
-            for i in range(self._n_models):
-                self._env_model[self._model_envs(i)] = i
+            n, m = self.n_envs, self._n_models
+            for i in range(m):
+                self._env_model[(i * n + m - 1) // m:((i + 1) * n + m - 1) // m] = i
+        self._active_version = [None] * self._n_models        # grouped: the active list each model's batch was last given
+        self._episodes = np.zeros(self.n_envs, dtype=np.int64)  # grouped: device-side restarts redrawn by the host, per environment
 
     def _models_differ_like_variants(self):
         """True if the models of this environment can live in one batch as model variants (``lowering.variant_tables``)."""
         return False
 
+    def _models_regroup_per_episode(self):
+        """True if a batch draws one of its (geometrically different) models per environment and episode (`_grouped`)."""
+        return False
+
     def _model_envs(self, idx):
-        """Environment indices of model ``idx``'s block."""
+        """Environment indices of model ``idx``: its block, or (grouped) the environments that drew it for their current episode."""
+        if self._grouped:
+            return np.nonzero(self._env_model == idx)[0]
         n, m = self.n_envs, self._n_models
         return np.arange((idx * n + m - 1) // m, ((idx + 1) * n + m - 1) // m)
+
+    def _activate(self, idx, envs):
+        """grouped: hand model ``idx``'s batch its active list (only when it changed)."""
+        key = envs.tobytes()
+        if self._active_version[idx] != key:
+            self.backend.set_active(envs)
+            self._active_version[idx] = key
 
     def _block_of(self, e):
         """Model of environment ``e`` in block mode."""
@@ -487,13 +513,13 @@ class LocoEnv:
         h = self._host[e]
         h.qpos[:] = self._model.qpos0          # mj_resetData
         h.qvel[:] = 0.0
-        if self._blocks:
+        if self._blocks and not self._grouped:
             self._select_model(self._block_of(e))
         elif self._random_env_reset:
             self._select_model(np.random.randint(0, self._n_models))
         elif self._n_models > 1:
             self._select_model((self._current_model_idx + 1) % self._n_models)
-        if self._pooled:
+        if self._pooled or self._grouped:
             self._env_model[e] = self._current_model_idx
         self._cur_env = e
         self.setup(obs)
@@ -561,11 +587,31 @@ class LocoEnv:
         if self._blocks:
             if self._pending_state:
                 self._upload_state()
-            parts = []
-            for idx in range(self._n_models):
-                self._select_model(idx)
-                parts.append(self.backend.step(a[self._model_envs(idx)]))
-            obs32, rew32, done = (np.concatenate([p[i] for p in parts]) for i in range(3))
+            if self._grouped:
+                obs32 = rew32 = done = None
+                restarted = np.zeros(self.n_envs, dtype=bool)
+                for idx in range(self._n_models):
+                    envs = self._model_envs(idx)
+                    if len(envs) == 0:
+                        continue
+                    self._select_model(idx)
+                    self._activate(idx, envs)
+                    o, r, d = self.backend.step(a)              # the launch runs `envs` only; the other rows come back as they were
+                    if obs32 is None:
+                        obs32, rew32, done = np.zeros_like(o), np.zeros_like(r), np.zeros_like(d)
+                    obs32[envs], rew32[envs], done[envs] = o[envs], r[envs], d[envs]
+                    restarted[envs] = self.backend.last_restarted[envs]
+                self._grouped_restarted = restarted
+                self._redrawn = None
+                if self._auto_reset and restarted.any():
+                    which = np.nonzero(restarted)[0]
+                    self._redrawn = (which, self._redraw_restarted(which))
+            else:
+                parts = []
+                for idx in range(self._n_models):
+                    self._select_model(idx)
+                    parts.append(self.backend.step(a[self._model_envs(idx)]))
+                obs32, rew32, done = (np.concatenate([p[i] for p in parts]) for i in range(3))
         else:
             b = self.backend
             if self._pending_state:
@@ -591,6 +637,8 @@ class LocoEnv:
         perm = self._obs_perm()
         if perm is not None:
             obs = obs[:, perm]
+        if self._grouped and self._redrawn is not None:
+            obs[self._redrawn[0]] = self._redrawn[1]          # the first observation of the episodes the host redrew (model + start row)
         if self._reward_device_spec() is None:
             # host-side functors (custom callbacks, ...) see what the reference's see (mushroom-rl MuJoCo.step ->
             # reward(cur_obs, action, obs, absorbing)): ONE environment's 1-D state and the UN-normalised action of
@@ -625,6 +673,8 @@ class LocoEnv:
 
     def _restarted_flags(self):
         """bit 1 of the device's done byte per environment (episode restarted / horizon reached in the last step)."""
+        if self._grouped:
+            return getattr(self, "_grouped_restarted", None)
         if self._blocks:
             flags = []
             for idx in range(self._n_models):
@@ -640,6 +690,13 @@ class LocoEnv:
         qpos = np.stack([h.qpos for h in self._host])
         qvel = np.stack([h.qvel for h in self._host])
         prm = getattr(self, "_pending_dof_params", None)
+        if self._grouped:
+            self._upload_grouped(qpos, qvel, np.arange(self.n_envs))
+            self._pending_dof_params = None
+            self._pending_variants = None
+            self._pending_compile = False
+            self._pending_state = False
+            return
         for idx in (range(self._n_models) if self._blocks else [self._current_model_idx]):
             envs = self._model_envs(idx) if self._blocks else np.arange(self.n_envs)
             if self._blocks:
@@ -666,6 +723,48 @@ class LocoEnv:
         self._pending_compile = False
         self._pending_state = False
 
+    def _upload_grouped(self, qpos, qvel, which):
+        """grouped: the states of the environments ``which`` (rows of the full-size arrays) go to the batch of the model each of them
+        is on — masked uploads; the batches keep what they hold for everybody else."""
+        if (self._domain_rand is not None and self._domain_rand.active) or getattr(self, "_pending_variants", None) is not None:
+            raise NotImplementedError("domain randomisation with a model drawn per episode among geometrically different models")
+        sel = np.zeros(self.n_envs, dtype=bool)
+        sel[which] = True
+        for idx in range(self._n_models):
+            mask = sel & (self._env_model == idx)
+            if not mask.any():
+                continue
+            self._select_model(idx)
+            b = self.backend
+            b.set_state(qpos, qvel, mask)
+            goal = self._goal_rows()
+            if goal is not None:
+                b.set_goal(goal, mask)
+
+    def _redraw_restarted(self, envs):
+        """grouped, device-side restarts: the step kernel restarted these environments on the model they had; the reference draws the
+        MODEL anew with every episode (base.py:186-190). The host redraws model and start row — counter-based, keyed by (seed, global
+        environment id, episodes so far): independent of batch size and sharding —, writes the row into the drawn model's batch and
+        returns the episodes' first observations (built on the host from the row as the device holds it, float32, like reset() does)."""
+        seed, off = self._auto_reset_seed
+        tabs = self._grouped_tables
+        nv = self._model.nv
+        qpos = np.zeros((self.n_envs, nv)); qvel = np.zeros((self.n_envs, nv))
+        rows = []
+        for e in envs:
+            self._episodes[e] += 1
+            rng = np.random.Generator(np.random.Philox(key=int(seed) & 0xFFFFFFFFFFFFFFFF, counter=[int(off) + int(e), int(self._episodes[e]), 0, 0]))
+            idx = int(rng.integers(self._n_models))
+            row = tabs[idx][int(rng.integers(len(tabs[idx])))]
+            self._env_model[e] = idx
+            qpos[e], qvel[e] = row[:nv].astype(np.float32), row[nv:2 * nv].astype(np.float32)
+            self._select_model(idx)
+            h = self._host[e]
+            h.qpos[:], h.qvel[:] = qpos[e], qvel[e]
+            rows.append(self._create_observation(self.obs_helper._build_obs(h)))
+        self._upload_grouped(qpos, qvel, envs)
+        return np.stack(rows)
+
     def _goal_rows(self):
         """(n_envs, n_goal) constants appended to the device observation, or None."""
         return None
@@ -682,7 +781,11 @@ class LocoEnv:
             if self._blocks:
                 self._select_model(idx)
             b = self.backend
-            first = int(self._model_envs(idx)[0]) if self._blocks else 0
+            first = int(self._model_envs(idx)[0]) if (self._blocks and not self._grouped) else 0
+            if self._grouped:
+                self._grouped_tables = getattr(self, "_grouped_tables", None) or [None] * self._n_models
+                self._grouped_tables[idx] = self._reset_table()
+                self._auto_reset_seed = (seed, global_env_offset)
             if self._pooled:
                 # one block of reset rows per model (the rows carry the model's constants, e.g. the weight): a device-side
                 # restart from row i puts the environment on model i // rows_per_model

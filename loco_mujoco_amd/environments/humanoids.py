@@ -300,6 +300,11 @@ class BaseHumanoid4Ages(BaseHumanoid):
         if len(self._models) > 1:
             self._init_models(self._models)
 
+    def _models_regroup_per_episode(self):
+        """The sizes differ in geometry (their own constant tables, hulls, datasets) and the reference draws one per episode: every
+        size's batch spans all environment ids and steps the environments currently of that size (``LocoEnv._grouped``)."""
+        return True
+
     def _select_model(self, idx):
         super()._select_model(idx)
         self._model_scale = float(self._scalings[self._current_model_idx])

@@ -23,15 +23,29 @@ class OracleBatch:
         self.goal = None
         self.prev_obs = None
         self.stats_log = []
+        self.active = None              # set_active: the environments a step runs (None: all)
+        self.last_restarted = np.zeros(self.n, dtype=bool)
+        self._last = None               # what the last step returned: rows of inactive environments come back as they were
+        self._stale = np.ones(self.n, dtype=bool)
+
+    def set_active(self, env_ids):
+        self.active = None if env_ids is None else np.array(env_ids, dtype=np.int64)
 
     def set_state(self, qpos, qvel, mask=None):
-        self.qpos[:] = qpos
-        self.qvel[:] = qvel
-        self.warm[:] = 0
-        self.act[:] = 0
+        m = slice(None) if mask is None else np.asarray(mask, dtype=bool)
+        self.qpos[m] = np.asarray(qpos)[m]
+        self.qvel[m] = np.asarray(qvel)[m]
+        self.warm[m] = 0
+        self.act[m] = 0
+        self._stale = np.ones(self.n, dtype=bool) if mask is None else (self._stale | m)      # their "previous observation" is the new state's
 
     def set_goal(self, goal, mask=None):
-        self.goal = np.array(goal, dtype=np.float64)
+        g = np.array(goal, dtype=np.float64)
+        if mask is None or self.goal is None:
+            self.goal = g
+        else:
+            m = np.asarray(mask, dtype=bool)
+            self.goal[m] = g[m]
 
     def _obs(self, e):
         env = self.env
@@ -44,16 +58,21 @@ class OracleBatch:
 
     def step(self, action):
         env = self.env
+        run = range(self.n) if self.active is None else [int(e) for e in self.active]
         if self.prev_obs is None:
             self.prev_obs = np.stack([self._obs(e) for e in range(self.n)])
-        obs, rew, done = [], [], []
-        for e in range(self.n):
+        for e in run:
+            if self._stale[e]:
+                self.prev_obs[e] = self._obs(e)
+                self._stale[e] = False
+        obs, rew, done = {}, {}, {}
+        for e in run:
             ctrl = np.zeros(env._model.nu)
             ctrl[env._action_indices] = env._preprocess_action(action[e])
             if env._use_foot_forces:
-                obs.append(self._step_with_foot_forces(e, ctrl))
-                done.append(bool(env.is_absorbing(obs[-1])))
-                rew.append(env.reward(self.prev_obs[e], action[e], obs[-1], done[-1]))
+                obs[e] = self._step_with_foot_forces(e, ctrl)
+                done[e] = bool(env.is_absorbing(obs[e]))
+                rew[e] = env.reward(self.prev_obs[e], action[e], obs[e], done[e])
                 continue
             if self.act.shape[1]:
                 q, v, a, w, st = self.oracle.step_act(self.qpos[e], self.qvel[e], self.act[e], ctrl, env._n_substeps, self.warm[e])
@@ -63,11 +82,16 @@ class OracleBatch:
             self.qpos[e], self.qvel[e], self.warm[e] = q, v, w
             self.stats_log.append(st)
             o = self._obs(e)
-            obs.append(o)
-            done.append(bool(env.is_absorbing(o)))
-            rew.append(env.reward(self.prev_obs[e], action[e], o, done[-1]))
-        self.prev_obs = np.stack(obs)
-        return np.stack(obs), np.array(rew, dtype=np.float64), np.array(done)
+            obs[e] = o
+            done[e] = bool(env.is_absorbing(o))
+            rew[e] = env.reward(self.prev_obs[e], action[e], o, done[e])
+        if self._last is None:
+            width = len(next(iter(obs.values()))) if obs else self.prev_obs.shape[1]
+            self._last = [np.zeros((self.n, width)), np.zeros(self.n), np.zeros(self.n, dtype=bool)]
+        for e in run:
+            self._last[0][e], self._last[1][e], self._last[2][e] = obs[e], rew[e], done[e]
+            self.prev_obs[e] = obs[e][:self.prev_obs.shape[1]]
+        return self._last[0].copy(), self._last[1].copy(), self._last[2].copy()
 
 
 def _grf_step(self, e, ctrl):
@@ -103,7 +127,7 @@ def attach(env):
         current = env._current_model_idx
         for idx in range(env._n_models):
             env._select_model(idx)
-            env._backend = OracleBatch(env, len(env._model_envs(idx)) if env._blocks else None)
+            env._backend = OracleBatch(env, len(env._model_envs(idx)) if (env._blocks and not getattr(env, "_grouped", False)) else None)
         env._select_model(current)
         return env
     env._backend = OracleBatch(env)

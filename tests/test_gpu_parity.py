@@ -1118,6 +1118,103 @@ def test_humanoid_4_ages_all_mode_env_rollout():
     assert sum(b is not None for b in env._model_backends) + (env._backend is not None and env._model_backends[env._current_model_idx] is None) >= 2
 
 
+def test_active_list_steps_only_the_listed_environments(setup):
+    """lm_batch_set_active: a launch over a list of environment ids runs exactly those — bitwise what they do in a full launch (results do
+    not depend on which environments share a wave) — and leaves everybody else's state, observation, reward and done byte untouched."""
+    env, hm, oracle, HipBatch = setup
+    n, nv = 200, env._model.nv
+    tab = env._reset_table()
+    rows = tab[np.random.RandomState(3).randint(0, len(tab), n)]
+    act = np.random.RandomState(4).uniform(-0.5, 0.5, (n, 12))
+    ids = np.random.RandomState(5).permutation(n)[:77].astype(np.int32)      # neither sorted nor a multiple of the workgroup's four
+    full = HipBatch(hm, n); part = HipBatch(hm, n)
+    for b in (full, part):
+        b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
+        b.set_goal(rows[:, 2 * nv:])
+    of, rf, df = full.step(act)
+    qf, vf = full.get_state()
+    part.set_active(ids)
+    op, rp, dp = part.step(act)
+    qp, vp = part.get_state()
+    rest = np.setdiff1d(np.arange(n), ids)
+    assert np.array_equal(qp[ids], qf[ids]) and np.array_equal(vp[ids], vf[ids]) and np.array_equal(op[ids], of[ids]) and np.array_equal(rp[ids], rf[ids])
+    assert np.array_equal(qp[rest], rows[rest, :nv].astype(np.float32)) and np.array_equal(vp[rest], rows[rest, nv:2 * nv].astype(np.float32))
+    assert part.stats()["env_steps"] == len(ids)
+    part.set_active(None)                                   # everybody again: the 123 catch up, the 77 take their second step
+    part.step(act)
+    full.step(act)                                          # (the full batch's second step: warm starts and all)
+    q2, _ = full.get_state()
+    qp2, _ = part.get_state()
+    assert np.array_equal(qp2[rest], qf[rest]) and np.array_equal(qp2[ids], q2[ids])
+    with pytest.raises(Exception):
+        part.set_active(np.array([1, 1], dtype=np.int32))
+    part.set_active(np.zeros(0, dtype=np.int32))            # an empty list: the step is a no-op
+    part.step(act)
+    assert np.array_equal(part.get_state()[0], qp2)
+
+
+def test_humanoid_4_ages_all_mode_draws_a_size_per_episode_in_a_batch():
+    """The reference draws one of the four sizes with EVERY episode (base.py:186-190, base_humanoid_4_ages.py:106-135). A batch of 64:
+    reset() draws a size per environment; with device-side restarts (horizon 4) every environment changes size from episode to
+    episode (the host redraws size and start row, keyed by seed, global id and episode count); the size bits of the observation, the
+    model the environment is stepped on and the dataset its start state comes from agree; the states are those of the size's own
+    model (one control step of 8 environments vs the oracle of their size); and two shards of 32 with global offsets reproduce the
+    batch of 64 bitwise."""
+    n, nu, K = 64, 13, 14
+    acts = np.random.RandomState(1).uniform(-0.3, 0.3, (K, n, nu))
+
+    def run(lo, hi, ref=None):
+        np.random.seed(0)
+        env = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=hi - lo)
+        env.reset()
+        if ref is not None:             # a shard starts from the whole batch's draws for its environments
+            env._env_model[:] = ref["model0"][lo:hi]
+            for e in range(hi - lo):
+                env._host[e].qpos[:], env._host[e].qvel[:] = ref["q0"][lo + e], ref["v0"][lo + e]
+            env._pending_state = True
+        model0 = env._env_model.copy()
+        q0 = np.stack([h.qpos for h in env._host]); v0 = np.stack([h.qvel for h in env._host])
+        env.enable_auto_reset(seed=7, horizon=4, global_env_offset=lo)
+        obs_log, model_log, restarts = [], [], 0
+        for k in range(K):
+            obs, rew, absorbing, info = env.step(acts[k, lo:hi])
+            obs_log.append(obs.copy()); model_log.append(env._env_model.copy())
+            restarts += int(info["episode_restarted"].sum())
+            bits = obs[:, -2:]
+            assert np.array_equal(bits[:, 0] * 2 + bits[:, 1], env._env_model.astype(float))        # the size bits follow the model in use
+        return dict(env=env, model0=model0, q0=q0, v0=v0, obs=np.array(obs_log), models=np.array(model_log), restarts=restarts)
+
+    whole = run(0, n)
+    assert np.isfinite(whole["obs"]).all() and whole["restarts"] >= 3 * n
+    assert len(np.unique(whole["model0"])) == 4                                # reset() drew all four sizes
+    changes = (np.diff(whole["models"], axis=0) != 0).sum(0)
+    assert (changes >= 1).mean() > 0.9 and np.all([len(np.unique(whole["models"][:, e])) >= 2 for e in range(n) if changes[e]])
+    # one more control step of 8 environments against the oracle OF THEIR SIZE
+    env = whole["env"]
+    states = {}
+    for idx in range(4):
+        env._select_model(idx)
+        q, v = env.backend.get_state()
+        for e in env._model_envs(idx)[:2]:
+            states[int(e)] = (idx, q[e].astype(np.float64), v[e].astype(np.float64))
+    a = np.random.RandomState(2).uniform(-0.3, 0.3, (n, nu))
+    for idx in range(4):
+        env._select_model(idx)
+        env.backend.set_auto_reset(False, horizon=1000)
+    env._auto_reset = False
+    env.step(a)
+    for e, (idx, q0, v0) in states.items():
+        env._select_model(idx)
+        q1, v1 = env.backend.get_state()
+        ctrl = np.zeros(env._model.nu); ctrl[env._action_indices] = env._preprocess_action(a[e])
+        qo, vo = Oracle(pack_model(env._model)).step(q0, v0, ctrl, nsub=10)[:2]
+        assert np.abs(q1[e] - qo).max() < QTOL and np.abs(v1[e] - vo).max() < VTOL, (e, idx)
+    # sharding: 64 = 32 + 32 with global offsets, bitwise — observations and the sizes drawn
+    lo_half, hi_half = run(0, 32, whole), run(32, 64, whole)
+    assert np.array_equal(np.concatenate([lo_half["models"], hi_half["models"]], axis=1), whole["models"])
+    assert np.array_equal(np.concatenate([lo_half["obs"], hi_half["obs"]], axis=1), whole["obs"])
+
+
 def test_step_on_device_buffers_matches_host_path():
     """lm_step_device: torch tensors in, torch tensors out, on torch's stream — same numbers as the host-buffer step."""
     import torch

@@ -198,33 +198,43 @@ def test_several_models_in_one_batch():
     tabs = [lowering.variant_tables(nominal, env._chain_model(m)) for m in env._models]      # what the backend uploads
     assert len(tabs) == 4 and all((tabs[0][0] != t[0]).any() for t in tabs[1:])
     assert not LocoEnv.make("Atlas.carry", debug=True, n_envs=4, weight_mass=5.0)._pooled
-    # blocks: every block is the single-model environment of that size on the same states and actions
+    # the humanoid's four sizes (round 6: GROUPED — a size per environment and episode, one batch per size over all environment ids,
+    # each stepping its active list): every size's environments are the single-model environment of that size on the same states / actions
     np.random.seed(0)
     env = attach(LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=6))
-    assert env._blocks and [list(env._model_envs(i)) for i in range(4)] == [[0, 1], [2], [3, 4], [5]]
+    assert env._blocks and env._grouped
     obs = env.reset()
+    drawn = env._env_model.copy()
+    assert len(set(drawn)) > 1 and np.array_equal(obs[:, -2] * 2 + obs[:, -1], drawn.astype(float))      # the size bits follow the draw
+    assert sorted(np.concatenate([env._model_envs(i) for i in range(4)])) == list(range(6))
     a = np.random.uniform(-0.2, 0.2, (6, 13))
     o1, r, d, _ = env.step(a)
     assert o1.shape == (6, 38) and np.array_equal(o1[:, -2:], obs[:, -2:]) and r.shape == (6,) and d.shape == (6,)
     for idx in range(4):
         envs = env._model_envs(idx)
+        if len(envs) == 0:
+            continue
         np.random.seed(1)
         one = attach(LocoEnv.make("HumanoidTorque4Ages.walk.%d" % (idx + 1), debug=True, n_envs=len(envs)))
         one.reset()
         for k, e in enumerate(envs):
             one._host[k].qpos[:], one._host[k].qvel[:] = obs_state(env, e)
         one._pending_state = True
-        o2, _, _, _ = one.step(a[envs])
-        assert np.abs(o2 - o1[envs]).max() < 1e-12
-    # the humanoid's four sizes: every block restarts from its own size's trajectories and shows its size bits
+        o2 = one.step(a[envs])[0]
+        assert np.abs(np.atleast_2d(o2) - o1[envs]).max() < 1e-12
+    env.reset()
+    assert (env._env_model != drawn).any()                       # a new draw per episode
+    # every size restarts from its own size's trajectories and shows its size bits
     np.random.seed(0)
     h = LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)
     oh = h.reset()
-    assert oh.shape == (8, 38) and oh[:, -2:].tolist() == [[0, 0]] * 2 + [[0, 1]] * 2 + [[1, 0]] * 2 + [[1, 1]] * 2
+    assert oh.shape == (8, 38) and np.array_equal(oh[:, -2] * 2 + oh[:, -1], h._env_model.astype(float))
     for idx in range(4):
         h._select_model(idx)
         tab = h._reset_table()
         assert len(tab) == 100 and np.all(tab[:, -2:] == h._env_id())
+    # with domain randomisation the sizes keep their contiguous blocks (one pool of model variants per block)
+    # (test_model_rule_randomisation_with_several_models)
 
 
 def obs_state(env, e):
@@ -520,7 +530,7 @@ def test_humanoid_4_ages_surface():
         lo, hi = a._scaling_trajectory_map[idx]
         assert lo <= a.trajectories.traj_no < hi                      # start state from the trajectories of that size
     assert len(seen) >= 3
-    assert LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)._blocks        # batches: one block per size
+    assert LocoEnv.make("HumanoidTorque4Ages.walk.all", debug=True, n_envs=8)._grouped       # batches: a size per environment and episode
     with pytest.raises(TypeError):
         e.reset(obs=np.zeros(38))
 
