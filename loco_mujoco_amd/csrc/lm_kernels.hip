@@ -409,7 +409,7 @@ static int batch_alloc(lm_batch* b) {
   HIPCHK(hipMalloc(&b->premark, sizeof(int) * N)); HIPCHK(hipMemset(b->premark, 0, sizeof(int) * N));
   HIPCHK(hipMalloc(&b->slack, sizeof(float) * 12 * N)); HIPCHK(hipMemset(b->slack, 0, sizeof(float) * 12 * N));
   // the convex collider's warm-start cache: one record per environment and geom-pair record of the models whose hull pairs run through
-  // it in kernels with five or more links per chain (64 B each: HumanoidTorque 692 pairs -> 44 KB per environment, 180 MB at 4096)
+  // it in kernels with five or more links per chain (128 B each: HumanoidTorque 692 pairs -> 88 KB per environment, 363 MB at 4096)
   b->mprc = nullptr; b->mprc_pairs = 0;
   if (m->d_meshadj && m->n_gpt_floats > 0 && m->T.max_links > 3) {
     b->mprc_pairs = m->n_gpt_floats / LM_GPAIR_SIZE;

@@ -43,8 +43,16 @@ def kernel_row(name):
 def short(name):
     return "step_kernel" + name.split("step_kernel")[1].split("(")[0]
 k = kernel_row(kname)
-summary = dict(kernel=short(kname), vgpr=k[0], agpr=k[1], sgpr=k[2], lds_bytes=k[3], scratch_bytes=k[4],
+# registers / spills: the COMPILER's analysis of the built kernel (tools/kernel_resources.py -> profiles/<round>_kernel_resources.json);
+# rocprofv3's vgpr_count / accum_vgpr_count columns do not describe these kernels (248 / 0 for one the compiler allocates 256 + 237 for)
+# and are kept only under their own names
+summary = dict(kernel=short(kname), rocprof_vgpr_count=k[0], rocprof_accum_vgpr_count=k[1], rocprof_sgpr_count=k[2], lds_bytes=k[3], scratch_bytes=k[4],
                workgroup=k[5], grid=k[6], duration_ns=dict(min=k[7], avg=k[8], max=k[9]), dispatches=k[10])
+_res = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", tag.split("_")[0] + "_kernel_resources.json")
+if os.path.exists(_res):
+    _r = json.load(open(_res))["kernels"].get(short(kname))
+    if _r:
+        summary["resources"] = dict(_r, source="profiles/%s (hipcc -Rpass-analysis=kernel-resource-usage)" % os.path.basename(_res))
 for other in names[1:]:
     o = kernel_row(other)
     summary.setdefault("other_step_kernels", []).append(dict(kernel=short(other), dispatches=o[10], duration_ns=dict(min=o[7], avg=o[8], max=o[9])))
