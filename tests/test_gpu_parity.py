@@ -581,15 +581,18 @@ def test_several_models_in_one_batch_on_the_device():
     # a fixed weight is a single model again
     one = LocoEnv.make("Talos.carry", debug=True, n_envs=4, weight_mass=5.0)
     assert not one._pooled and not one._blocks and np.allclose(one.reset()[:, -1], 5.0)
-    # the four sizes: blocks
+    # the four sizes (round 6: grouped — a size per environment and episode, one batch per size stepping its active list; the muscle
+    # humanoid: activation states travel with the environment's batch and start at zero with the episode)
     h = LocoEnv.make("HumanoidMuscle4Ages.run.all", debug=True, n_envs=12)
     oh = h.reset()
-    assert h._blocks and not h._pooled
-    bits = oh[:, -2:].copy()
+    assert h._blocks and h._grouped and not h._pooled
+    first = h._env_model.copy()
+    assert np.array_equal(oh[:, -2] * 2 + oh[:, -1], first.astype(float))
     h.enable_auto_reset(seed=1, horizon=5)
     for _ in range(8):
         oh, _, _, _ = h.step(rs.uniform(-1, 1, (12, 92)))
-        assert np.array_equal(oh[:, -2:], bits) and np.isfinite(oh).all()
+        assert np.array_equal(oh[:, -2] * 2 + oh[:, -1], h._env_model.astype(float)) and np.isfinite(oh).all()
+    assert (h._env_model != first).any()                    # the restart at the horizon drew new sizes
 
 
 # ---------------------------------------------------------------------------------------------------------------
