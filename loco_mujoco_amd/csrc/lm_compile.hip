@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64) void compile_models_kernel(Args a) {
     const int at = op[1], st = op[2], dim = op[3] & 15, mix = (op[3] >> 4) & 15, pair = (op[3] >> 8) & 1;
     const double* fa = fric + op[4] * 3; const double* fb = fric + op[5] * 3;
     double f3[3];
-    for (int k = 0; k < 3; k++) f3[k] = mix == 0 ? fmax(fa[k], fb[k]) : (mix == 1 ? fa[k] : fb[k]);
+    for (int k = 0; k < 3; k++) f3[k] = fmax(1e-5, mix == 0 ? fmax(fa[k], fb[k]) : (mix == 1 ? fa[k] : fb[k]));      // (mjMINMU: a friction drawn at exactly 0
+                                                                                                                  // would make rr = 0 / 0 below; lowering.py clamps alike)
     const double fr[5] = {f3[0], f3[0], f3[1], f3[2], f3[2]};
     const double tran = biw[op[6]] + biw[op[7]];
     double vt, vmu, rr[5];

@@ -765,11 +765,25 @@ int lm_set_model_compiler(lm_batch* b, const int32_t* index, long long n_index, 
         op[6] < 0 || op[6] >= nbody || op[7] < 0 || op[7] >= nbody)
       return fail("the model-compiler program writes outside the contact tables");
   }
-  // the tables: one slot per environment, every slot starts as the nominal model
-  if (lm_set_model_variants(b, nullptr, nullptr, nullptr, 0, 0)) return 1;
+  // what the draws and the drawn bodies index (the kernel sizes its LDS tables by the header's counts and indexes the body Jacobians by
+  // these numbers: a malformed program must not get past this point — round-5 advisor; the Python binding checks the same)
+  const int* draws = index + lmc::kIntHead;
+  for (int i = 0; i < nd; i++) {
+    const int kind = draws[4 * i], target = draws[4 * i + 1], idx = draws[4 * i + 2], comp = draws[4 * i + 3];
+    const int lim_i = target == 0 ? nv : (target >= 1 && target <= 3 ? nrb : (target == 4 ? ngs : -1)), lim_c = (target == 0 || target == 1) ? 1 : 3;
+    if (kind < 1 || kind > 3 || lim_i < 0 || idx < 0 || idx >= lim_i || comp < 0 || comp >= lim_c) return fail("the model-compiler program has a draw outside its table");
+  }
+  const int* rbody = draws + nd * lmc::kDrawInts;
+  for (int i = 0; i < nrb; i++) {
+    const int body = rbody[4 * i], kind = rbody[4 * i + 1], slot = rbody[4 * i + 2], has_sv = rbody[4 * i + 3];
+    if (body <= 0 || body >= nbody || kind < 1 || kind > 2 || slot < 0 || slot >= nslot || has_sv < 0 || has_sv > 1) return fail("the model-compiler program has a drawn body outside the model");
+  }
+  // ... and the nominal tables, BEFORE anything of the batch's current variant state is torn down
   if (!record || !geom_table) return fail("the model compiler needs the nominal inertial record and geom table");
   if ((pair_table != nullptr) != (b->m->n_gpt_floats > 0) || (pair_table && pair_floats != b->m->n_gpt_floats))
     return fail("the geom-pair table does not match the model's");
+  // the tables: one slot per environment, every slot starts as the nominal model
+  if (lm_set_model_variants(b, nullptr, nullptr, nullptr, 0, 0)) return 1;
   if (!b->dofprm) {
     if (lm_set_dof_params(b, nullptr, nullptr, nullptr, nullptr)) return 1;
     b->dofprm_of_variants = true;

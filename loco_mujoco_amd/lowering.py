@@ -105,6 +105,7 @@ GT_SIZE = MAXG * G_SIZE * NCHAIN
 
 GEOM_SUPPORTED = (mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_BOX, mjcf.GEOM_CYLINDER)     # + meshes that come with a convex hull
 MINIMP, MAXIMP, MINVAL = 1e-4, 0.9999, 1e-15
+MINMU = 1e-5          # mjMINMU: the engine's floor for a friction coefficient (applied when a contact is created)
 
 
 class UnsupportedModel(ValueError):
@@ -149,6 +150,8 @@ def _mix_with_floor(m, g, gf):
 def _fill_contact_params(blk, m, b, dim, fr):
     """cone-dependent floor-contact constants of a geom on body ``b`` (G_DIM, G_F*, G_MU, G_TRAN, G_RR*)."""
     tran = m.body_invweight0[b, 0] + m.body_invweight0[0, 0]
+    fr = np.maximum(np.asarray(fr, dtype=np.float64), MINMU)      # the engine clamps friction at contact creation (mjMINMU): a randomised friction
+                                                                  # drawn at exactly 0 would make rr = 0 / 0 below (csrc/lm_compile.hip does the same)
     blk[G_DIM] = dim
     blk[G_F0:G_F0 + 5] = fr
     if m.cone == mjcf.CONE_ELLIPTIC:
@@ -1070,6 +1073,7 @@ def _self_collision_tables(m, root, chains, kin, register_hull, hull_block, pair
                 rec[GP_K], rec[GP_B] = _kb(solref, solimp, m.timestep)
                 rec[GP_S0:GP_S0 + 5] = _clip_solimp(solimp)
                 tran = m.body_invweight0[m.geom_body[a], 0] + m.body_invweight0[m.geom_body[b], 0]
+                fr = np.maximum(np.asarray(fr, dtype=np.float64), MINMU)
                 rec[GP_F0:GP_F0 + 5] = fr
                 if pyramidal:
                     # condim 3: the four edges of the pyramid share R = 2 mu^2 (1 + mu^2) tran (like the floor contacts, G_TRAN).

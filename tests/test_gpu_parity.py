@@ -1890,6 +1890,40 @@ def test_device_model_compiler_writes_the_host_compilers_tables(task, tmp_path):
     print("%s: device-compiled tables vs the host compiler on the same draws: max relative difference %.1e" % (task, worst))
 
 
+def test_library_refuses_a_malformed_model_compiler_program_and_keeps_the_batch():
+    """The C entry point itself (not only the Python binding) checks what the draws and the drawn bodies of a program index, and it does
+    so BEFORE it tears the batch's current variant state down: a malformed program is refused with a message and the batch steps on."""
+    import ctypes as C
+    from loco_mujoco_amd import backend, lowering
+    from loco_mujoco_amd.backend import HipBatch, HipModel
+    from loco_mujoco_amd.utils.domain_randomization import JointRandomization
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    jr = JointRandomization(env._model, os.path.join(os.path.dirname(__file__), "golden", "dr_talos_inertial.yaml"))
+    ib, db, _ = lowering.model_compiler_tables(env._model, env._device_task(), *jr.model_draw_ops())
+    nominal = env._chain_model()
+    tabs = lowering.variant_tables(nominal, nominal)
+    b = HipBatch(HipModel(nominal), 8)
+    b.set_model_compiler((ib, db), tabs, seed=3)
+    tab = env._reset_table()
+    b.set_state(tab[:8, :env._model.nv], tab[:8, env._model.nv:2 * env._model.nv])
+    d0, g0 = b.get_model_draws()
+    lib = backend.load_library()
+    nd = int(ib[4])
+    rec, gt = np.ascontiguousarray(tabs[0], np.float32), np.ascontiguousarray(tabs[1], np.float32)
+    F = C.POINTER(C.c_float)
+    for at, value in ((lowering.MC_IH_SIZE + 2, 999), (lowering.MC_IH_SIZE + 1, 7), (lowering.MC_IH_SIZE + 4 * nd + 2, 99), (lowering.MC_IH_SIZE + 4 * nd, 0)):
+        bad = ib.astype(np.int32).copy()
+        bad[at] = value
+        rc = lib.lm_set_model_compiler(b._h, bad.ctypes.data_as(C.POINTER(C.c_int32)), len(bad), np.ascontiguousarray(db).ctypes.data_as(C.POINTER(C.c_double)), len(db),
+                                       rec.ctypes.data_as(F), gt.ctypes.data_as(F), None, 0, 1)
+        assert rc != 0 and b"model-compiler program" in lib.lm_last_error()
+    d1, g1 = b.get_model_draws()                     # the compiler that was installed is still there, with the models it had drawn
+    assert np.array_equal(d0, d1) and np.array_equal(g0, g1)
+    o, r, d = b.step(np.zeros((8, 12)))
+    assert np.isfinite(o).all()
+
+
 def test_device_model_compiler_follows_the_seed():
     """``env.seed(s)`` re-seeds the randomisation (reference: np.random.seed in the worker processes): the models the device draws
     at the following resets are a function of that seed again — same seed, same draws; another seed, other draws."""
