@@ -799,6 +799,11 @@ class LocoEnv:
                 b.set_reset_table(self._reset_table(), seed=seed, global_env_offset=global_env_offset + first)
             if self._domain_rand is not None and self._domain_rand.active:
                 b.set_dof_randomization(self._domain_rand.spec)
+            if self._use_model_compiler and global_env_offset + first != 0:
+                # the device compiler keys its draws by (seed, GLOBAL environment id, models had); the models it drew when it was installed
+                # were keyed with offset 0 — a rank of a sharded run redraws them under its own ids (round-5 advisor: ranks that share a
+                # seed started their first episodes on identical models)
+                b.compile_models()
             b.set_auto_reset(True, self.info.horizon if horizon is None else horizon)
         self._auto_reset = True
 
