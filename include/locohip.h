@@ -189,7 +189,8 @@ int lm_step_device(lm_batch* b, const float* d_action, float* d_obs, float* d_re
    what the step writes for them (observation, reward, done) is left as it was. NULL: all environments again. Host buffers keep their
    [n_envs][...] shape — an environment keeps its row. For environments that share ids across several models and change model per
    episode (the reference's MultiMuJoCo with models that differ in geometry, base.py:186-190: HumanoidTorque4Ages "all"): one batch per
-   model, each stepping the environments currently of its size. Random numbers stay keyed by the global environment id. */
+   model, each stepping the environments currently of its size. Random numbers stay keyed by the global environment id. Compiled into every
+   kernel family but the quadruped's (one model per batch there; the indirection costs its bench kernel 0.9 %): refused for it. */
 int lm_batch_set_active(lm_batch* b, const int32_t* env_ids, int count);
 
 /* LocoEnv.step()'s host surface in ONE call (reference gymnasium.py:47-65 -> base.py step(): numpy float64 action in, float64

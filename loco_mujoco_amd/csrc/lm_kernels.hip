@@ -935,6 +935,7 @@ int lm_batch_set_active(lm_batch* b, const int32_t* env_ids, int count) {
   HIPCHK(hipSetDevice(b->m->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (!env_ids) { b->n_active = b->N; if (b->env_map) { HIPCHK(hipFree(b->env_map)); b->env_map = nullptr; } return 0; }
+  if (family_of(b) == 0) return fail("active lists are not compiled into the quadruped's kernels (lm_step.h: the indirection costs the bench kernel 0.9 %)");
   if (count < 0 || count > b->N) return fail("active list: more entries than environments");
   std::vector<char> seen((size_t)b->N, 0);
   for (int i = 0; i < count; i++) {

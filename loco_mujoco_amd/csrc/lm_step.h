@@ -309,11 +309,19 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
     const int nb = gridDim.x, x = wg & 7, per = nb >> 3, rem = nb & 7;
     wg = x * per + (x < rem ? x : rem) + (wg >> 3);
   }
+  // (the quadruped's kernels — the bench line's — are compiled WITHOUT the active list: the indirection costs them 0.9 %, 1.212 against
+  // 1.200 ms per control step in four alternating runs on one box, and a quadruped batch has one model; lm_batch_set_active refuses it)
+#if defined(LM_NO_ENV_MAP) || (defined(LM_FAMILY) && LM_FAMILY == 0)
+  int e_raw = wg * a.epb + e_local;
+  bool in_range = e_raw < a.N;
+  if (!in_range) e_raw = a.N - 1;
+#else
   const int slot_ = wg * a.epb + e_local;
   bool in_range = slot_ < a.n_active;
   // (the padding quads of the last workgroup recompute the last active environment)
   int e_raw = in_range ? slot_ : a.n_active - 1;
   if (!REPLAY && a.env_map) e_raw = a.env_map[e_raw];
+#endif
   int first_step = 0;               // REPLAY: the fused control step at which the environment left the regular kernel
   if (REPLAY) { in_range = true; e_raw = entry - 1; first_step = a.stall[e_raw]; }
   // padding quads (REPLAY: none — the entry is the environment); they and the replicas 1..REP-1 store nothing

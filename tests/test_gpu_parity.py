@@ -1123,17 +1123,21 @@ def test_humanoid_4_ages_all_mode_env_rollout():
 
 def test_active_list_steps_only_the_listed_environments(setup):
     """lm_batch_set_active: a launch over a list of environment ids runs exactly those — bitwise what they do in a full launch (results do
-    not depend on which environments share a wave) — and leaves everybody else's state, observation, reward and done byte untouched."""
-    env, hm, oracle, HipBatch = setup
-    n, nv = 200, env._model.nv
+    not depend on which environments share a wave) — and leaves everybody else's state, observation, reward and done byte untouched.
+    (Talos: every kernel family but the quadruped's carries the indirection; the quadruped's batch refuses a list.)"""
+    from loco_mujoco_amd.backend import HipModel, BackendError
+    _, hm_a1, _, HipBatch = setup
+    np.random.seed(0)
+    env = LocoEnv.make("Talos.walk", debug=True)
+    hm = HipModel(env._chain_model())
+    n, nv, nu = 200, env._model.nv, len(env._action_indices)
     tab = env._reset_table()
     rows = tab[np.random.RandomState(3).randint(0, len(tab), n)]
-    act = np.random.RandomState(4).uniform(-0.5, 0.5, (n, 12))
+    act = np.random.RandomState(4).uniform(-0.5, 0.5, (n, nu))
     ids = np.random.RandomState(5).permutation(n)[:77].astype(np.int32)      # neither sorted nor a multiple of the workgroup's four
     full = HipBatch(hm, n); part = HipBatch(hm, n)
     for b in (full, part):
         b.set_state(rows[:, :nv], rows[:, nv:2 * nv])
-        b.set_goal(rows[:, 2 * nv:])
     of, rf, df = full.step(act)
     qf, vf = full.get_state()
     part.set_active(ids)
@@ -1154,6 +1158,8 @@ def test_active_list_steps_only_the_listed_environments(setup):
     part.set_active(np.zeros(0, dtype=np.int32))            # an empty list: the step is a no-op
     part.step(act)
     assert np.array_equal(part.get_state()[0], qp2)
+    with pytest.raises(BackendError, match="quadruped"):
+        HipBatch(hm_a1, 8).set_active(np.arange(4, dtype=np.int32))
 
 
 def test_humanoid_4_ages_all_mode_draws_a_size_per_episode_in_a_batch():
