@@ -724,7 +724,11 @@ LM_DEV void arrow_solve_x(const float* Lcc, const float (*W)[6], const float* Lr
 #ifdef LM_ARROW_ROLLED
 #define LM_ARROW_LOOP _Pragma("nounroll")
 #else
+#ifdef LM_ARROW_SIX_ROLLED          // (A/B probe: the six-link kernels' loops rolled, as before the end of round 6)
 #define LM_ARROW_LOOP _Pragma("unroll (NX <= 2 ? 4 : 1)")
+#else
+#define LM_ARROW_LOOP _Pragma("unroll ((NX <= 2 || MC == 6) ? 4 : 1)")
+#endif
 #endif
 template <class Q, int MC, int NX>
 LM_DEV void arrow_factor_g(float* Hcc, float (*Hcr)[6], const float* Hrr_rep, const float* Hrr_part, float* Lrr,
