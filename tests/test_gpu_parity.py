@@ -1422,7 +1422,11 @@ _R6_4096_CASES = [("UnitreeA1.simple", {}, "zero", 12, 0, 0, 1), ("UnitreeA1.sim
                   ("HumanoidTorque.run", {}, "random", 12, 0, 1, 1), ("HumanoidTorque.run", {}, "random", 3, 0, 1, 1),
                   ("Atlas.walk", {}, "random", 12, 0, 0, 1), ("HumanoidMuscle.run", {}, "random", 12, 0, 3, 1),
                   ("Talos.walk", {}, "random", 12, 0, 0, 1), ("UnitreeH1.walk", {}, "random", 3, 21, 292, 30),
-                  ("UnitreeG1.walk", {}, "random", 3, 0, 15, 1)]
+                  ("UnitreeG1.walk", {}, "random", 3, 0, 18, 1)]
+# UnitreeG1 15 -> 18 (end of round 6, said here as the rule above asks): the six-link family's coupled factorisation was compiled from
+# rolled loops over a private array and is now compiled from unrolled ones (lm_core.h LM_ARROW_LOOP: the same formulas, other fused
+# multiply-adds) — three more of the 4096 states sit on the other side of a contact switch, each reproduced by the oracle for an input
+# within one float32 ulp (set aside by the neighbour rule, none failing).
 
 
 @pytest.mark.parametrize("task,kw,policy,nroll,max_fail,max_illcond,far", _R6_4096_CASES)
