@@ -2434,7 +2434,13 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
                   else {
                     const NatGeom G1 = nat_geom(rec, false, g1own ? E.po : E.pp, g1own ? E.Ro : E.Rp, O);
                     const NatGeom G2 = nat_geom(rec, true, g1own ? E.pp : E.po, g1own ? E.Rp : E.Ro, O);
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+                    const long long tn0_ = LM_CLOCK();
+#endif
                     const NatOut no = native_contact<(MC >= 5), kCapBox>(G1, G2, rec[LM_GP_MARGIN], sub, ncon_item);
+#if defined(LM_TIMERS) && defined(LM_MPR_CLOCK)
+                    cnt.m[12] += LM_CLOCK() - tn0_; cnt.m[15] += 1;          // (probe: cycles / runs of the native colliders)
+#endif
                     mo.found = no.found ? 1 : 0; mo.dist = no.dist;
                     mo.nx = no.n.x; mo.ny = no.n.y; mo.nz = no.n.z; mo.px = no.p.x; mo.py = no.p.y; mo.pz = no.p.z;
                   }

@@ -60,5 +60,7 @@ if hasattr(lib, "lm_debug_mpr_counters"):
     if os.environ.get("LM_MPR_CLOCK"):      # -DLM_MPR_CLOCK builds: [10] cycles in the hull climbs, [13] cycles in the portal searches (lane sums)
         print("MPR clock probe: portal searches %.0f (contact or none), cycles per search %.0f, directions per search %.2f; per direction: %.0f cycles, of which the support call %.0f, of which the hull climbs %.0f" % (
             m[2] + m[3], m[13] / max(m[2] + m[3], 1), m[14] / max(m[2] + m[3], 1), m[13] / max(m[14], 1), m[11] / max(m[14], 1), m[10] / max(m[14], 1)))
+    if os.environ.get("LM_MPR_CLOCK"):
+        print("native colliders: %.0f runs, %.0f cycles each (lane sums); against the portal searches' %.0f x %.0f" % (m[15], m[12] / max(m[15], 1), m[2] + m[3], m[13] / max(m[2] + m[3], 1)))
     print("pair pass: detection ran in %.1f%% of the forward passes; geom pairs tested per detection (kind 0 / 1 / 2, all lanes and replicas): %.1f / %.1f / %.1f, "
           "of which within the margin: %.2f / %.2f / %.2f" % (100 * m[8] / max(m[9], 1), *(m[10:13] / max(m[8], 1)), *(m[13:16] / max(m[8], 1))))
