@@ -1253,9 +1253,13 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       s1 = dadd(dadd(pw[1], rot(*Rw[1], loc1)), dscl(hmg, dm));
       }
     };
-    // the portal: points 1..3 as (v, v1), point 0 = v0, in a local array indexed by the run-time point number of `expand` — private
-    // memory: 36 scratch dwords. Round 6 tried registers (the run-time index of `put` as 36 selects of doubles, -DLM_MPR_PV_REGS):
-    // HumanoidTorque.run 12.86 ms per control step against 12.60 with the array on one box — six stores beat 72 v_cndmask
+    // the portal: points 1..3 as (v, v1), point 0 = v0; `expand` replaces the point with a run-time number. One private array PV[3][6]
+    // (scratch: every direction of the search stores six doubles and loads eighteen). Round 6 measured the alternatives on
+    // HumanoidTorque.run, same box each: everything in registers (36 selects of doubles per `put`, -DLM_MPR_PV_REGS) 12.86 ms per control
+    // step against 12.60 with the array; the points v in nine double registers and only their witness points v1 in the array
+    // (-DLM_MPR_PV_SPLIT) 12.84 against 11.75 — 18 more live registers in the portal loop cost the kernel around it more than the
+    // loads they spare. The array stays.
+#if !defined(LM_MPR_PV_SPLIT)
     double PV[3][6];
     auto pv = [&](int q) -> D3 { return d3(PV[q - 1][0], PV[q - 1][1], PV[q - 1][2]); };
     auto pv1 = [&](int q) -> D3 { return d3(PV[q - 1][3], PV[q - 1][4], PV[q - 1][5]); };
@@ -1274,6 +1278,16 @@ LM_DEV_COLD MprOut mpr_convex_pair(const float* meshadj, const float* rec, bool 
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 6; j++) PV[i][j] = (q - 1 == i) ? nw[j] : PV[i][j];
+    };
+#endif
+#else
+    D3 PA = d3(0, 0, 0), PB = d3(0, 0, 0), PC = d3(0, 0, 0);
+    double PW[3][3];
+    auto pv = [&](int q) -> D3 { return (q == 1) ? PA : ((q == 2) ? PB : PC); };
+    auto pv1 = [&](int q) -> D3 { return d3(PW[q - 1][0], PW[q - 1][1], PW[q - 1][2]); };
+    auto put = [&](int q, D3 v, D3 v1) {
+      PA = (q == 1) ? v : PA; PB = (q == 2) ? v : PB; PC = (q == 3) ? v : PC;
+      PW[q - 1][0] = v1.x; PW[q - 1][1] = v1.y; PW[q - 1][2] = v1.z;
     };
 #endif
     const float* x1 = rec + LM_GP_X1; const float* x2 = rec + LM_GP_X2;
