@@ -424,7 +424,10 @@ __global__ __launch_bounds__(64) void step_kernel(KArgs a) {
 
   // ---- physics
   lm::Counters cnt = {};
-  using LMm = lm::LaneMemFor<MC, NS, NM, PAIRS, CONE>;
+  // (the lane memory of a DETECTION-ONLY kernel, PM == 3 — the -DLM_SIX_PAIRS=3 variant of the six-link family, lm_family.hip — is the
+  // layout without the pair extension: forward() has always used that one, this alias and the launcher now size the workgroup's LDS by it
+  // too, 59 floats per column less. The shipped six-link kernels carry the full pair pass, PM == 1: 42.7 KB per workgroup, three per CU)
+  using LMm = lm::LaneMemFor<MC, NS, NM, (PM == 1 || PM == 2), CONE>;
   const int lm_lane = e_local * 4 + c;                        // replicas share their environment's lane memory (same values)
   // REPLAY: ONE environment per workgroup and four lane-memory columns instead of sixteen — the whole LDS of the workgroup for one
   // robot's contact slots (128 per chain: more than the engine's own nconmax of 400 per robot, humanoid_torque.xml:19)
@@ -785,7 +788,7 @@ static void launch_one(K kernel, dim3 grid, dim3 block, size_t lane_floats, cons
 template <int MC, int NS, bool RK4, int CONE, int NM, int PART, int PM = 0>
 static bool launch_family(const LaunchCtx& L, const KArgs& a, int kind) {
   const dim3 grid((L.N + L.epb - 1) / L.epb);
-  using LMm = lm::LaneMemFor<MC, NS, NM, (PM != 0), CONE>;
+  using LMm = lm::LaneMemFor<MC, NS, NM, (PM == 1 || PM == 2), CONE>;       // (as the kernel's own alias: detection-only kernels carry no pair extension)
   const size_t plain = (size_t)LMm::kGroup * ((4 * L.epb + 15) / 16), rep = (size_t)LMm::kGroup;
   // the replay kernel: 128 contact slots per chain (one environment per workgroup: its whole LDS), the convex collider,
   // fused (it finishes the launch's control steps of its environments)
