@@ -269,7 +269,9 @@ template <int MC, int NS, int NM = 0, bool PAIRS = false, bool COMPACT = false> 
   static constexpr bool kBig = NS > 8;
   static constexpr int kQCap = kBig ? 128 : ((MC >= 5) ? 24 : 8);    // convex pairs per chain and pass
   static constexpr int kRCap = kBig ? 64 : ((NS < 8) ? NS : 8);      // contacts per chain and pass
-  static constexpr int kLists = kBS + (PAIRS ? MC * 3 : 0);
+  // (the six-link kernels compute the sphere centres from the link frames, like the detection-only ones: 18 floats per column that —
+  // with their prune records and link groups read from the table's copy in global memory — put the family back at FOUR workgroups per CU)
+  static constexpr int kLists = kBS + ((PAIRS && MC != 6) ? MC * 3 : 0);
   // the ROOT twists of the kernels that build their inertias behind the pair pass (forward: DEFER): the root is replicated in the four
   // chain lanes of an environment, so its 36 numbers are STRIPED over the four columns (element i in column i & 3, field i >> 2) —
   // 9 floats per column outside the part of lane memory the pair pass's work lists overlay, written before the pass
@@ -1851,7 +1853,9 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
   const float nscale = inr_on ? INR(LM_IR_SCALE) : P.scale;
 #define GE(g, f) gtp[((g) * LM_G_SIZE + (f)) * LM_NCHAIN + c]
   // the chain's tail lists (prune records, collider-less geoms, geom groups, link pairs): contiguous per chain, start in the chain block
-#define GP(g, f) cm[oz + (int)CH(LM_C_OFF_PRUNE) + (g) * LM_P_SIZE + (f)]
+// (six-link kernels: the prune records and the link groups are read from the constant table's copy in GLOBAL memory, like their link-pair
+// lists — lowering.py ends H_CM_USED in front of them: 1.8 KB of LDS that decide between three and four workgroups per CU)
+#define GP(g, f) ((MC == 6) ? P.cmg[(int)CH(LM_C_OFF_PRUNE) + (g) * LM_P_SIZE + (f)] : cm[oz + (int)CH(LM_C_OFF_PRUNE) + (g) * LM_P_SIZE + (f)])
 #define CU(i, f) cm[oz + (int)CH(LM_C_OFF_CUNSUP) + (i) * LM_U_SIZE + (f)]
 #define SL(s, f) lmem[((s) * LMm::kSlot + (f)) * ls]
 #define PEER(dl, i) Q::peer(lmem, ls, (i), (dl))
@@ -2014,7 +2018,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
             // self-collision broad phase: world centre of the link's bounding sphere, and the speed of the link's points
             // against the root body, |v_c| + |w| r with the twist relative to the root (the detection's travel bound)
             const V3 cw = pk + mul(Rk, v3(LX(k, LM_L_BSX), LX(k, LM_L_BSY), LX(k, LM_L_BSZ)));
-            if (PAIRS) { LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z; }      // (detection only: from the frames, bs_centre)
+            if (PAIRS && MC != 6) { LMEM(LMm::kBS + k * 3 + 0) = cw.x; LMEM(LMm::kBS + k * 3 + 1) = cw.y; LMEM(LMm::kBS + k * 3 + 2) = cw.z; }      // (detection only: from the frames, bs_centre)
             const V3 wr = V.w - Vroot.w;
             const V3 vcr = V.v - Vroot.v + cross(wr, cw - O);
             pair_speed = fmaxf(pair_speed, sqrtf(dot(vcr, vcr)) + sqrtf(dot(wr, wr)) * LX(k, LM_L_BSR));
@@ -2057,7 +2061,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // a link high above the floor costs one test per pass
       const int ngroups = (int)CH(LM_C_NLGROUP), off_lgroup_c = (int)CH(LM_C_OFF_LGROUP);
       for (int gi = 0; gi < ngroups; gi++) {
-#define LG(f) cm[oz + off_lgroup_c + gi * LM_LG_SIZE + (f)]
+#define LG(f) ((MC == 6) ? P.cmg[off_lgroup_c + gi * LM_LG_SIZE + (f)] : cm[oz + off_lgroup_c + gi * LM_LG_SIZE + (f)])
         const int glink = (int)LG(0), gfirst = (int)LG(1), gend = gfirst + (int)LG(2);
         {
           const int fbg = LMm::kFrame + (glink < 0 ? 0 : glink) * 18;
@@ -2576,7 +2580,7 @@ LM_DEV void forward(const float* cm, int c, const Params& P, float* qr, float* v
       // world centre of a link's bounding sphere: kept in lane memory by the kernels with the full pair pass, from the link frame
       // otherwise (detection only: no room for it beside the six-link lane memory)
       auto bs_centre = [&](int dl, int lane, int k) -> V3 {
-        if constexpr (PAIRS) return v3(PEER(dl, LMm::kBS + k * 3), PEER(dl, LMm::kBS + k * 3 + 1), PEER(dl, LMm::kBS + k * 3 + 2));
+        if constexpr (PAIRS && MC != 6) return v3(PEER(dl, LMm::kBS + k * 3), PEER(dl, LMm::kBS + k * 3 + 1), PEER(dl, LMm::kBS + k * 3 + 2));
         else {
           const int fb = LMm::kFrame + k * 18;
           M3 Rl;

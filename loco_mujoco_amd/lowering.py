@@ -808,9 +808,10 @@ def lower(m, task):
             max_contacts = 8                  # the pair families are compiled with eight slots per chain (floor + self-contacts)
             h[H_MAXCONTACTS] = max_contacts
     assert off <= CM_SIZE
-    # what a workgroup copies into its LDS: everything — but the six-link kernels read their link-pair lists (3 KB for UnitreeG1)
-    # from the table's copy in global memory, they do not fit beside that family's lane memory at four workgroups per CU
-    h[H_CM_USED] = off_before_lp if max_links > 5 else off
+    # what a workgroup copies into its LDS: everything — but the six-link kernels read their link-pair lists (3 KB for UnitreeG1) and, since
+    # the end of round 6, their prune records and link groups (1.8 KB) from the table's copy in global memory: with them in LDS the family
+    # sat at 42.7 KB per workgroup = THREE per CU, and a batch of 4096 ran its last quarter of workgroups behind the first finishers
+    h[H_CM_USED] = h[H_OFF_PRUNE] if max_links > 5 else off
     h[H_GT_SIZE] = GT_SIZE
     h[H_NGRF] = n_grf
     if max_groups_seen > 2 and max_links < MAXC:

@@ -691,7 +691,7 @@ def test_core_six_link_self_collisions_detect_and_replay(robot):
     m = env._model
     cmod, info = lowering.lower(m, env._device_task())
     assert info["max_links"] == 6 and info["self_collision_tables"]["convex"] > 100 and int(cmod[lowering.H_NGPAIR]) > 0
-    assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_LPAIR])          # the link-pair lists stay out of the LDS copy
+    assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_PRUNE]) < int(cmod[lowering.H_OFF_LPAIR])     # prune records, link groups and link-pair lists stay out of the LDS copy (round 6: four workgroups per CU)
     o = Oracle(pack_model(m))
     q0, v0, a0, spread = d[robot + "_qpos"], d[robot + "_qvel"], d[robot + "_action"], d[robot + "_oracle_spread"]
     pick = list(range(0, len(q0), 3 if robot == "g1" else 2)) + ([len(q0) - 1, len(q0) - 3] if robot == "g1" else [])       # (the GPU test runs all of them; the last four of g1: arm on arm)

@@ -799,7 +799,7 @@ def test_lowering_keeps_every_collider_and_builds_the_six_link_pair_tables():
         if info["max_links"] == 6:
             t = info["self_collision_tables"]
             assert t["convex"] > 100 and max(t["link_pairs"]) <= lowering.MAXLP and int(cmod[lowering.H_NGPAIR]) == t["closed_form"] + t["native"] + t["convex"]
-            assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_LPAIR])
+            assert int(cmod[lowering.H_CM_USED]) == int(cmod[lowering.H_OFF_PRUNE]) < int(cmod[lowering.H_OFF_LPAIR])      # (round 6: prune records and link groups stay out too)
         elif info.get("self_collision_tables"):
             assert max(info["self_collision_tables"]["link_pairs"]) <= 64 and int(cmod[lowering.H_CM_USED]) > int(cmod[lowering.H_OFF_LPAIR])
     # five-link humanoids without muscles run in the eight-slot families (a fifth contact on a leg must not abandon the control step)
